@@ -1,0 +1,138 @@
+/*
+ * mvmc.h -- C ABI of the MI355X (gfx950) hot path of multi-view motion capture:
+ * cross-view association -> multi-view DLT triangulation -> temporal IK.
+ *
+ * The reference (khanhha/multiview_motion_capture) is pure Python and has no
+ * FFI of its own; the boundary it offers is a set of Python callables
+ * (SURVEY.md section 8b).  Each entry point below is the batched device form
+ * of one of those callables and cites the reference function it replaces
+ * (file:line relative to the reference checkout).  The Python mirror in
+ * multiview_motion_capture_amd/ binds them with ctypes and keeps the
+ * reference's names and signatures.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in
+ *     `_host`; the caller owns all buffers, nothing is allocated or freed and
+ *     nothing synchronises inside a call (safe for hipGraph capture);
+ *   - `stream` is a hipStream_t (NULL = default stream);
+ *   - return value: MVMC_OK or an MVMC_ERR_* code, never an exception;
+ *   - tensors are dense row-major; shapes are written (d0,d1,...).
+ *   - a "pose" is 17 COCO joints x (x, y, score) in float64; poses of a batch
+ *     live in one array `kps17` of shape (F, C, P, 17, 3); pose index
+ *     q = (f*C + c)*P + p, so the camera of pose q is (q / P) % C.
+ */
+#ifndef MVMC_H
+#define MVMC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVMC_ABI_VERSION 1
+
+enum {
+    MVMC_OK = 0,
+    MVMC_ERR_ARG = 1,         /* bad shape / null pointer / unsupported size */
+    MVMC_ERR_LAUNCH = 2,      /* hipLaunch / runtime error */
+    MVMC_ERR_UNSUPPORTED = 3  /* size outside the compiled kernel variants */
+};
+
+enum { MVMC_F32 = 0, MVMC_F64 = 1 };
+
+#define MVMC_N_COCO 17
+#define MVMC_N_SKEL 18
+#define MVMC_N_SIDE 11
+#define MVMC_N_PARAM 68   /* root(3) + euler(18*3) + side bone lengths(11) */
+#define MVMC_MAX_NODES 64 /* max graph nodes (2-D poses + tracklets) per frame */
+
+typedef void* mvmcStream_t; /* hipStream_t */
+
+/* Skeleton constants (inverse_kinematics.py:94-117 Skeleton, :120-173 load_skeleton).
+ * Host struct, passed by pointer and copied into the kernel arguments. */
+typedef struct {
+    double bone_dirs[MVMC_N_SKEL][3]; /* ref_bone_dirs */
+    int32_t parents[MVMC_N_SKEL];     /* joint_parents (-1 for the root) */
+    int32_t side_map[MVMC_N_SKEL];    /* ref_side_to_full_bone_lens_map */
+    int32_t n_side;                   /* number of side lengths (11; 18 = identity map of the old pickle schema) */
+} mvmcSkeleton;
+
+int mvmc_abi_version(void);
+const char* mvmc_status_string(int status);
+
+/* Host helper: first `count` doubles of numpy.random.RandomState(0).rand()
+ * (MT19937, init_genrand(0), 53-bit doubles).  match_als seeds its factor with
+ * RandomState(0).rand(n, r) (mv_association.py:271) == table[i*r + j]. */
+int mvmc_als_seed_table(double* out_host, int count);
+
+/* IN-1 + IN-2: OpenPose-25 -> COCO-17 gather (pose_def.py:262-270,
+ * motion_capture.py:980-983) and filter_bad_pose(0.01, 4, 5)
+ * (motion_capture.py:1023-1043) with per-view compaction (order kept).
+ *   kps        (F,C,P,J_in,3) f32|f64, J_in = 25 (gathered) or 17 (copied)
+ *   counts_in  (F,C) people per view, or NULL = P everywhere
+ *   kps17      (F,C,P,17,3) f64 out (slots >= counts_out are zero)
+ *   counts_out (F,C) people kept per view */
+int mvmc_ingest(const void* kps, int dtype, int n_frames, int n_views, int p_max, int n_joints_in,
+                const int32_t* counts_in, double min_score, int min_valid, double min_bb_size,
+                double* kps17, int32_t* counts_out, mvmcStream_t stream);
+
+/* AS-1: calc_pairwise_f_mats (mv_math_util.py:267-285).  K (C,3,3), Rt (C,3,4) f64 -> F (C,C,3,3) f32. */
+int mvmc_fmats(const double* K, const double* Rt, int n_views, float* F, mvmcStream_t stream);
+
+/* AS-2 + AS-3: geometry_affinity (mv_math_util.py:320-351) with projected_distance (:288-317).
+ * Graph nodes of frame f = its poses in (view, person) order; n_f = sum_c counts[f,c].
+ *   D, S  (F,N,N) f32 out with N = C*P (only [0:n_f,0:n_f] is meaningful, rest 0); either may be NULL */
+int mvmc_affinity(const double* kps17, const int32_t* counts, const float* Fmats, int n_frames, int n_views,
+                  int p_max, float* D, float* S, mvmcStream_t stream);
+
+/* AS-4 + AS-5 + AS-6: match_als (mv_association.py:222-318), transform_closure (:99-121) and the
+ * cluster rule of parse_match_result (motion_capture.py:417-425).
+ *   W            (F,N,N) f32|f64 affinity in compact node order (leading dimension N)
+ *   group_counts (F,G) nodes per group (views; for match_spatial_time group 0 = tracklets)
+ *   g_max        upper bound of any group's node count (rank <= min(n, 2*g_max) selects the kernel variant)
+ *   seed_table   first seed_len doubles of RandomState(0).rand() (mvmc_als_seed_table)
+ *   x_bin, match_mat  (F,N,N) u8 out, may be NULL
+ *   labels       (F,N) i32 out: cluster ordinal of each node, -1 = in no cluster of >= 2 members
+ *   n_clusters   (F) i32 out (kept columns); iters (F) i32 out (ALS iterations run) */
+int mvmc_als_associate(const void* W, int w_dtype, const int32_t* group_counts, int n_frames, int n_groups,
+                       int n_max, int g_max, const double* seed_table, int seed_len, uint8_t* x_bin, uint8_t* match_mat,
+                       int32_t* labels, int32_t* n_clusters, int32_t* iters, mvmcStream_t stream);
+
+/* Turns labels into member lists: members (F,K,V) pose index q (ascending node order, -1 padded),
+ * n_members (F,K).  Clusters beyond K or members beyond V are dropped (n_members still counts them). */
+int mvmc_cluster_members(const int32_t* labels, const int32_t* counts, int n_frames, int n_views, int p_max,
+                         int k_max, int v_max, int32_t* members, int32_t* n_members, mvmcStream_t stream);
+
+/* TR-1 + TR-2: triangulate_point_groups_from_multiple_views_linear(post_optimize=False)
+ * (mv_math_util.py:152-187, :215-240).  One problem = one member list.
+ *   kps17   (n_poses,17,3) f64; Pmats (C,3,4) f64; members (B,V) pose indices (-1 = unused slot)
+ *   out     (B,17,4) f64: x, y, z, mean score of the views used; problems with < 1 member give NaN */
+int mvmc_dlt(const double* kps17, const double* Pmats, const int32_t* members, int n_problems, int v_max,
+             int n_views, int p_max, double min_score, double* out, mvmcStream_t stream);
+
+/* FK-1 + FK-2: foward_kinematics (inverse_kinematics.py:176-199) with Quaternions.from_euler /
+ * transforms (Quaternions.py:449-462, :335-366).
+ *   params (B,3+54+n_side) f64 = root, euler(18,3), bone lengths
+ *   joints (B,18,3) out; G (B,18,4,4) out or NULL */
+int mvmc_fk(const mvmcSkeleton* skel_host, const double* params, int n_problems, double* joints, double* G,
+            mvmcStream_t stream);
+
+/* IK-1..IK-4: PoseSolver.solve (inverse_kinematics.py:351-433) = two trust-region-reflective
+ * least-squares stages (solve_pose_reproj :202-238, solve_pose_bone_lens_reproj :241-277; SciPy
+ * least_squares defaults, max_nfev evaluations each).
+ *   members      (B,V) pose indices into kps17 (-1 padded)
+ *   init_params  (B,68) warm-start parameters, ignored where cold[b] != 0
+ *   cold         (B) u8: 1 = cold start (DLT root, zero angles, reference lengths, max_nfev_cold),
+ *                0 = warm (max_nfev_warm); NULL = all cold
+ *   params_out   (B,68); joints_out (B,18,3); info_out (B,8) f64 =
+ *                {cost1, nfev1, status1, cost2, nfev2, status2, njev1, njev2} or NULL */
+int mvmc_ik_solve(const mvmcSkeleton* skel_host, const double* kps17, const double* Pmats,
+                  const int32_t* members, int n_problems, int v_max, int n_views, int p_max,
+                  const double* init_params, const uint8_t* cold, int max_nfev_cold, int max_nfev_warm,
+                  double* params_out, double* joints_out, double* info_out, mvmcStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVMC_H */

@@ -1,0 +1,80 @@
+"""ctypes binding of the C ABI in include/mvmc.h (libmvmc_hip.so, gfx950).
+
+The product path has no CPU fallback: if the HIP library is missing or a call
+fails, this module raises.  Build the library with ``python -c "import
+__graft_entry__ as g; g.build()"`` or ``make -C multiview_motion_capture_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmvmc_hip.so")
+_lib = None
+
+MVMC_OK = 0
+MVMC_F32, MVMC_F64 = 0, 1
+N_PARAM = 68
+MAX_NODES = 64
+
+# every symbol declared in include/mvmc.h
+SYMBOLS = (
+    "mvmc_abi_version", "mvmc_status_string", "mvmc_als_seed_table", "mvmc_ingest", "mvmc_fmats",
+    "mvmc_affinity", "mvmc_als_associate", "mvmc_cluster_members", "mvmc_dlt", "mvmc_fk", "mvmc_ik_solve",
+)
+
+
+class MvmcSkeleton(C.Structure):
+    """mvmcSkeleton of include/mvmc.h."""
+    _fields_ = [("bone_dirs", (C.c_double * 3) * 18), ("parents", C.c_int32 * 18),
+                ("side_map", C.c_int32 * 18), ("n_side", C.c_int32)]
+
+
+class MvmcError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load libmvmc_hip.so (once) and declare the argument types."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise MvmcError(
+            f"HIP extension not built: {_LIB_PATH} is missing. There is no CPU fallback; "
+            "run __graft_entry__.build() (or make -C multiview_motion_capture_amd/csrc).")
+    lib = C.CDLL(_LIB_PATH)
+    vp, i32, f64 = C.c_void_p, C.c_int, C.c_double
+    lib.mvmc_abi_version.restype = C.c_int
+    lib.mvmc_status_string.restype = C.c_char_p
+    lib.mvmc_status_string.argtypes = [C.c_int]
+    lib.mvmc_als_seed_table.argtypes = [vp, i32]
+    lib.mvmc_ingest.argtypes = [vp, i32, i32, i32, i32, i32, vp, f64, i32, f64, vp, vp, vp]
+    lib.mvmc_fmats.argtypes = [vp, vp, i32, vp, vp]
+    lib.mvmc_affinity.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.mvmc_als_associate.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp]
+    lib.mvmc_cluster_members.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
+    lib.mvmc_dlt.argtypes = [vp, vp, vp, i32, i32, i32, i32, f64, vp, vp]
+    lib.mvmc_fk.argtypes = [C.POINTER(MvmcSkeleton), vp, i32, vp, vp, vp]
+    lib.mvmc_ik_solve.argtypes = [C.POINTER(MvmcSkeleton), vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, i32,
+                                  vp, vp, vp, vp]
+    for name in SYMBOLS:
+        getattr(lib, name)  # AttributeError if the library does not export it
+        if name not in ("mvmc_status_string",):
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str):
+    """Status -> exception (the reference raises Python exceptions, motion_capture.py:112)."""
+    if status == MVMC_OK:
+        return
+    msg = load().mvmc_status_string(status).decode()
+    if status == 1:
+        raise ValueError(f"{what}: {msg}")
+    raise MvmcError(f"{what}: {msg} (status {status})")

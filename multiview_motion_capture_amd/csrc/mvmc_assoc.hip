@@ -1,0 +1,637 @@
+// Cross-view association kernels for gfx950 (wave64):
+//   ingest     IN-1/IN-2  OpenPose-25 -> COCO-17 gather + filter_bad_pose + per-view compaction
+//   fmats      AS-1       pairwise fundamental matrices (f64 math, f32 store)
+//   affinity   AS-2/AS-3  epipolar point-line distance blocks + f32 z-score sigmoid
+//   als        AS-4/5/6   low-rank ADMM/ALS matching, closure, cluster labels
+//   members               labels -> per-cluster member lists
+// One frame per workgroup; the frame's whole working set lives in LDS / VGPRs, HBM is touched
+// once on the way in and once on the way out (the path is ALU/latency bound).
+#include "mvmc_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// ingest
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+ingest_kernel(const T* __restrict__ kps, int C, int P, int J_in, const int32_t* __restrict__ counts_in,
+              double min_score, int min_valid, double min_bb, double* __restrict__ kps17,
+              int32_t* __restrict__ counts_out) {
+    extern __shared__ double sm[];
+    const int f = blockIdx.x;
+    const int nq = C * P;
+    double* pose = sm;                                // [nq][17][3]
+    int* keep = reinterpret_cast<int*>(sm + nq * 51);  // [nq]
+    int* src_of = keep + nq;                          // [nq] destination slot -> source pose
+    const T* src = kps + (size_t)f * nq * J_in * 3;
+    for (int e = threadIdx.x; e < nq * 51; e += blockDim.x) {
+        int q = e / 51, r = e - q * 51, j = r / 3, k = r - j * 3;
+        int js = (J_in == 25) ? kOp25ToCoco17[j] : j;
+        pose[e] = (double)src[(q * J_in + js) * 3 + k];
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < nq; q += blockDim.x) {
+        int c = q / P, p = q - c * P;
+        int cnt = counts_in ? counts_in[f * C + c] : P;
+        int ok = 0;
+        if (p < cnt) {
+            int nv = 0;
+            double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+            for (int j = 0; j < 17; ++j) {
+                const double* kp = pose + q * 51 + j * 3;
+                if (kp[2] > min_score) {
+                    ++nv;
+                    x0 = fmin(x0, kp[0]); x1 = fmax(x1, kp[0]);
+                    y0 = fmin(y0, kp[1]); y1 = fmax(y1, kp[1]);
+                }
+            }
+            ok = (nv >= min_valid) && !((x1 - x0) < min_bb || (y1 - y0) < min_bb);
+        }
+        keep[q] = ok;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        int k = 0;
+        for (int p = 0; p < P; ++p)
+            if (keep[c * P + p]) src_of[c * P + k++] = c * P + p;
+        counts_out[f * C + c] = k;
+        for (; k < P; ++k) src_of[c * P + k] = -1;
+    }
+    __syncthreads();
+    double* out = kps17 + (size_t)f * nq * 51;
+    for (int e = threadIdx.x; e < nq * 51; e += blockDim.x) {
+        int d = e / 51, r = e - d * 51;
+        int q = src_of[d];
+        out[e] = q >= 0 ? pose[q * 51 + r] : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fundamental matrices
+// ------------------------------------------------------------------------------------------------
+__device__ inline void m3mul(const double* A, const double* B, double* O) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += A[i * 3 + k] * B[k * 3 + j];
+            O[i * 3 + j] = s;
+        }
+}
+__device__ inline void m3t(const double* A, double* O) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) O[i * 3 + j] = A[j * 3 + i];
+}
+__device__ inline void m3v(const double* A, const double* x, double* o) {
+    for (int i = 0; i < 3; ++i) o[i] = A[i * 3] * x[0] + A[i * 3 + 1] * x[1] + A[i * 3 + 2] * x[2];
+}
+__device__ inline void m3inv(const double* A, double* O) {
+    double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+    double det = A[0] * c00 + A[1] * c01 + A[2] * c02, id = 1.0 / det;
+    O[0] = c00 * id; O[1] = (A[2] * A[7] - A[1] * A[8]) * id; O[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+    O[3] = c01 * id; O[4] = (A[0] * A[8] - A[2] * A[6]) * id; O[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+    O[6] = c02 * id; O[7] = (A[1] * A[6] - A[0] * A[7]) * id; O[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+}
+
+// F_ij = inv(K_i)^T (R_i R_j^T) K_j^T [K_j R_j R_i^T (t_i - R_i R_j^T t_j)]_x   (mv_math_util.py:268-283)
+__global__ void fmats_kernel(const double* __restrict__ K, const double* __restrict__ Rt, int C,
+                             float* __restrict__ F) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= C * C) return;
+    int i = idx / C, j = idx - i * C;
+    double K0[9], K1[9], R0[9], R1[9], T0[3], T1[3];
+    for (int a = 0; a < 9; ++a) { K0[a] = K[i * 9 + a]; K1[a] = K[j * 9 + a]; }
+    for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) { R0[a * 3 + b] = Rt[i * 12 + a * 4 + b]; R1[a * 3 + b] = Rt[j * 12 + a * 4 + b]; }
+        T0[a] = Rt[i * 12 + a * 4 + 3]; T1[a] = Rt[j * 12 + a * 4 + 3];
+    }
+    double Ki[9], KiT[9], R1T[9], R0T[9], K1T[9], R01[9], A[9], B[9], Cm[9], D[9], v[3], w[3], u[3];
+    m3inv(K0, Ki); m3t(Ki, KiT); m3t(R1, R1T); m3t(R0, R0T); m3t(K1, K1T);
+    m3mul(R0, R1T, R01);
+    m3mul(KiT, R01, A);   // inv(K0)^T R01
+    m3mul(A, K1T, B);     // ... K1^T
+    m3mul(K1, R1, Cm);    // K1 R1
+    m3mul(Cm, R0T, D);    // K1 R1 R0^T
+    m3v(R01, T1, w);
+    for (int a = 0; a < 3; ++a) u[a] = T0[a] - w[a];
+    m3v(D, u, v);
+    double S[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0}, Fd[9];
+    m3mul(B, S, Fd);
+    float f32[9], sum = 0.f;
+    for (int a = 0; a < 9; ++a) { f32[a] = (float)Fd[a]; sum = faddr(sum, f32[a]); }
+    for (int a = 0; a < 9; ++a) F[idx * 9 + a] = (sum == 0.f) ? faddr(f32[a], 1e-12f) : f32[a];
+}
+
+// ------------------------------------------------------------------------------------------------
+// affinity
+// ------------------------------------------------------------------------------------------------
+// NumPy's float32 pairwise summation (loops_utils.h.src, PW_BLOCKSIZE = 128), same operation order.
+__device__ __noinline__ float np_pairwise_leaf_f32(const float* a, int n) {
+    if (n < 8) {
+        float r = -0.0f;
+        for (int i = 0; i < n; ++i) r = faddr(r, a[i]);
+        return r;
+    }
+    float r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+        r0 = faddr(r0, a[i]); r1 = faddr(r1, a[i + 1]); r2 = faddr(r2, a[i + 2]); r3 = faddr(r3, a[i + 3]);
+        r4 = faddr(r4, a[i + 4]); r5 = faddr(r5, a[i + 5]); r6 = faddr(r6, a[i + 6]); r7 = faddr(r7, a[i + 7]);
+    }
+    float res = faddr(faddr(faddr(r0, r1), faddr(r2, r3)), faddr(faddr(r4, r5), faddr(r6, r7)));
+    for (; i < n; ++i) res = faddr(res, a[i]);
+    return res;
+}
+__device__ __noinline__ float np_pairwise_sum_f32(const float* a, int n) {
+    int s_[16], n_[16], st_[16];
+    float left_[16];
+    int sp = 0;
+    s_[0] = 0; n_[0] = n; st_[0] = 0;
+    float ret = 0.f;
+    while (sp >= 0) {
+        int s = s_[sp], m = n_[sp];
+        if (st_[sp] == 0) {
+            if (m <= 128) { ret = np_pairwise_leaf_f32(a + s, m); --sp; continue; }
+            int n2 = m / 2; n2 -= n2 % 8;
+            st_[sp] = 1;
+            ++sp; s_[sp] = s; n_[sp] = n2; st_[sp] = 0;
+        } else if (st_[sp] == 1) {
+            int n2 = m / 2; n2 -= n2 % 8;
+            left_[sp] = ret; st_[sp] = 2;
+            ++sp; s_[sp] = s + n2; n_[sp] = m - n2; st_[sp] = 0;
+        } else {
+            ret = faddr(left_[sp], ret);
+            --sp;
+        }
+    }
+    return ret;
+}
+
+// mean_j |line_j . x_j| over 17 joints in NumPy's reduction order (8 accumulators + tail)
+__device__ inline double mean17(const double* d) {
+    double r[8];
+    for (int k = 0; k < 8; ++k) r[k] = dadd(d[k], d[8 + k]);
+    double res = dadd(dadd(dadd(r[0], r[1]), dadd(r[2], r[3])), dadd(dadd(r[4], r[5]), dadd(r[6], r[7])));
+    res = dadd(res, d[16]);
+    return res / 17.0;
+}
+
+// distance of pose b's joints to the epipolar lines of pose a's joints:
+// line = normalise(F^T [x_a, 1]) (computeCorrespondEpilines(pts, 2, F)); mv_math_util.py:307-315
+__device__ __noinline__ double proj_dist(const double* pa, const double* pb, const float* F) {
+    double f[9];
+    for (int k = 0; k < 9; ++k) f[k] = (double)F[k];
+    double d[17];
+    for (int j = 0; j < 17; ++j) {
+        double x = pa[j * 3], y = pa[j * 3 + 1];
+        double a = dadd(dadd(dmul(f[0], x), dmul(f[3], y)), f[6]);
+        double b = dadd(dadd(dmul(f[1], x), dmul(f[4], y)), f[7]);
+        double c = dadd(dadd(dmul(f[2], x), dmul(f[5], y)), f[8]);
+        double nu = dadd(dmul(a, a), dmul(b, b));
+        double sc = (nu != 0.0) ? 1.0 / sqrt(nu) : 1.0;
+        a = dmul(a, sc); b = dmul(b, sc); c = dmul(c, sc);
+        double v = dadd(dadd(dmul(a, pb[j * 3]), dmul(b, pb[j * 3 + 1])), c);
+        d[j] = fabs(v);
+    }
+    return mean17(d);
+}
+
+__global__ void __launch_bounds__(64)
+affinity_kernel(const double* __restrict__ kps17, const int32_t* __restrict__ counts, const float* __restrict__ Fm,
+                int C, int P, float* __restrict__ Dg, float* __restrict__ Sg) {
+    extern __shared__ double sm[];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int N = C * P;
+    double* pts = sm;                                   // [N][17][3] compact node order
+    float* D = reinterpret_cast<float*>(pts + N * 51);  // [n*n] contiguous (ld = n)
+    float* tmp = D + N * N;                             // [n*n]
+    int* node_q = reinterpret_cast<int*>(tmp + N * N);  // [N] node -> local pose index c*P+p
+    int* node_v = node_q + N;                           // [N] node -> view
+    __shared__ int s_n;
+    __shared__ float s_mean, s_std;
+    if (tid == 0) {
+        int n = 0;
+        for (int c = 0; c < C; ++c) {
+            int cnt = counts[f * C + c];
+            cnt = cnt < 0 ? 0 : (cnt > P ? P : cnt);
+            for (int p = 0; p < cnt; ++p) { node_q[n] = c * P + p; node_v[n] = c; ++n; }
+        }
+        s_n = n;
+    }
+    __syncthreads();
+    const int n = s_n;
+    const double* src = kps17 + (size_t)f * N * 51;
+    for (int e = tid; e < n * 51; e += 64) {
+        int i = e / 51, r = e - i * 51;
+        pts[e] = src[node_q[i] * 51 + r];
+    }
+    for (int e = tid; e < n * n; e += 64) {
+        int i = e / n, j = e - i * n;
+        D[e] = (i == j) ? 0.f : 50.f;
+    }
+    __syncthreads();
+    // every unordered node pair of different views
+    for (int e = tid; e < n * n; e += 64) {
+        int i = e / n, j = e - i * n;
+        if (j <= i) continue;
+        int a = node_v[i], b = node_v[j];
+        if (a == b) continue;
+        double d_ab = proj_dist(pts + i * 51, pts + j * 51, Fm + (a * C + b) * 9);
+        double d_ba = proj_dist(pts + j * 51, pts + i * 51, Fm + (b * C + a) * 9);
+        float v = (float)dmul(0.5, dadd(d_ab, d_ba));
+        D[i * n + j] = v;
+        D[j * n + i] = v;
+    }
+    __syncthreads();
+    // float32 statistics in NumPy's order (mv_math_util.py:348): mean, population std
+    const int nn = n * n;
+    if (tid == 0 && nn > 0) s_mean = np_pairwise_sum_f32(D, nn) / (float)nn;
+    __syncthreads();
+    for (int e = tid; e < nn; e += 64) {
+        float x = D[e] - s_mean;
+        tmp[e] = fmulr(x, x);
+    }
+    __syncthreads();
+    if (tid == 0 && nn > 0) s_std = sqrtf(np_pairwise_sum_f32(tmp, nn) / (float)nn);
+    __syncthreads();
+    float* Do = Dg ? Dg + (size_t)f * N * N : nullptr;
+    float* So = Sg ? Sg + (size_t)f * N * N : nullptr;
+    for (int e = tid; e < N * N; e += 64) {
+        int i = e / N, j = e - i * N;
+        float d = 0.f, s = 0.f;
+        if (i < n && j < n) {
+            d = D[i * n + j];
+            float a = -(d - s_mean) / s_std;
+            float t = fmulr(-5.f, a);
+            float ex = (float)exp((double)t);  // correctly-rounded f32 exp (NumPy's SIMD expf is <1 ulp)
+            s = 1.f / faddr(1.f, ex);
+        }
+        if (Do) Do[e] = d;
+        if (So) So[e] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ALS matching + closure + cluster labels
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__device__ inline double block_sum(double v, double* red) {
+    v = wave_sum(v);
+    if constexpr (NT > 64) {
+        const int w = threadIdx.x >> 6;
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[w] = v;
+        __syncthreads();
+        v = 0;
+        for (int k = 0; k < NT / 64; ++k) v += red[k];
+    }
+    return v;
+}
+
+// In-place Gauss-Jordan on M (r x ld, ld = r + n): left block SPD (G + ridge), right block RHS.
+// After the sweep row a holds diag * solution; no pivoting is needed for an SPD system.
+template <int NT>
+__device__ inline void gauss_jordan(double* M, int r, int ld) {
+    for (int p = 0; p < r; ++p) {
+        const double inv = 1.0 / M[p * ld + p];
+        const int w = ld - p - 1;
+        for (int idx = threadIdx.x; idx < (r - 1) * w; idx += NT) {
+            int a = idx / w, b = p + 1 + (idx - a * w);
+            if (a >= p) ++a;
+            M[a * ld + b] -= M[a * ld + p] * (M[p * ld + b] * inv);
+        }
+        __syncthreads();
+    }
+}
+
+template <typename TW, int NMAX, int RMAX, int NT>
+__global__ void __launch_bounds__(NT)
+als_kernel(const TW* __restrict__ W, const int32_t* __restrict__ gcounts, int G, int ldw,
+           const double* __restrict__ seed, int seed_len, uint8_t* __restrict__ x_bin,
+           uint8_t* __restrict__ match_mat, int32_t* __restrict__ labels, int32_t* __restrict__ n_clusters,
+           int32_t* __restrict__ iters_out) {
+    constexpr int T = (NMAX * NMAX + NT - 1) / NT;
+    __shared__ double sX[NMAX * NMAX];
+    __shared__ double sA[NMAX * RMAX];
+    __shared__ double sB[NMAX * RMAX];
+    __shared__ double sM[RMAX * (RMAX + NMAX)];
+    __shared__ double sRed[NT / 64 + 1];
+    __shared__ int sGid[NMAX];
+    __shared__ uint8_t sVis[NMAX];
+    __shared__ int sKeep[NMAX];
+    __shared__ int s_n, s_r;
+
+    const int f = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        int n = 0, total = 0, gmax = 0;
+        for (int g = 0; g < G; ++g) {
+            int c = gcounts[f * G + g];
+            c = c < 0 ? 0 : c;
+            total += c;
+            for (int k = 0; k < c && n < NMAX; ++k) sGid[n++] = g;
+            if (c > gmax) gmax = c;
+        }
+        s_n = total;
+        int r = 2 * gmax;
+        s_r = r < total ? r : total;
+    }
+    __syncthreads();
+    const int n = s_n, r = s_r;
+    int32_t* lab = labels + (size_t)f * ldw;
+    if (n == 0 || n > NMAX || n > ldw || r > RMAX || n * r > seed_len) {
+        for (int i = tid; i < ldw; i += NT) lab[i] = -1;
+        if (tid == 0) { n_clusters[f] = 0; iters_out[f] = (n == 0) ? 0 : -1; }
+        return;
+    }
+
+    // ---- per-thread element state (registers): W, Z, Y, previous X ----
+    int ei[T], ej[T];
+    double w[T], z[T], y[T], xp[T];
+    float w32[T];
+    const TW* Wf = W + (size_t)f * ldw * ldw;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        int e = t * NT + tid;
+        bool ok = e < n * n;
+        int i = ok ? e / n : 0, j = ok ? e - i * n : 0;
+        ei[t] = ok ? i : -1; ej[t] = j;
+        if constexpr (sizeof(TW) == 4) {
+            float a = ok ? (float)Wf[i * ldw + j] : 0.f, b = ok ? (float)Wf[j * ldw + i] : 0.f;
+            w32[t] = fmulr(0.5f, faddr(a, b));
+            w[t] = (double)w32[t];
+        } else {
+            double a = ok ? (double)Wf[i * ldw + j] : 0., b = ok ? (double)Wf[j * ldw + i] : 0.;
+            w[t] = 0.5 * (a + b);
+            w32[t] = 0.f;
+        }
+        z[t] = w[t]; xp[t] = w[t]; y[t] = 0.0;
+    }
+    for (int e = tid; e < n * r; e += NT) sA[e] = seed[e];
+    __syncthreads();
+
+    double mu = 64.0;
+    const int ld = r + n;
+    int iters = 1000;
+    for (int it = 0; it < 1000; ++it) {
+        // X1 = Z - (Y - W + beta) / mu      (float32 arithmetic on iteration 1 when W is f32)
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if (ei[t] < 0) continue;
+            double x1;
+            if (sizeof(TW) == 4 && it == 0) {
+                float q = faddr(-w32[t], 0.1f) / 64.f;
+                x1 = (double)(w32[t] - q);
+            } else {
+                x1 = z[t] - ((y[t] - w[t]) + 0.1) / mu;
+            }
+            sX[t * NT + tid] = x1;
+        }
+        __syncthreads();
+        const double ridge = 50.0 / mu;
+        // M = [A^T A + ridge I | A^T X1]
+        for (int idx = tid; idx < r * ld; idx += NT) {
+            int a = idx / ld, b = idx - a * ld;
+            double s = 0;
+            if (b < r) {
+                for (int k = 0; k < n; ++k) s += sA[k * r + a] * sA[k * r + b];
+                if (a == b) s += ridge;
+            } else {
+                for (int k = 0; k < n; ++k) s += sA[k * r + a] * sX[k * n + (b - r)];
+            }
+            sM[idx] = s;
+        }
+        __syncthreads();
+        gauss_jordan<NT>(sM, r, ld);
+        for (int idx = tid; idx < n * r; idx += NT) {
+            int j = idx / r, a = idx - j * r;
+            sB[idx] = sM[a * ld + r + j] / sM[a * ld + a];
+        }
+        __syncthreads();
+        // M = [B^T B + ridge I | B^T X1^T]
+        for (int idx = tid; idx < r * ld; idx += NT) {
+            int a = idx / ld, b = idx - a * ld;
+            double s = 0;
+            if (b < r) {
+                for (int k = 0; k < n; ++k) s += sB[k * r + a] * sB[k * r + b];
+                if (a == b) s += ridge;
+            } else {
+                for (int k = 0; k < n; ++k) s += sB[k * r + a] * sX[(b - r) * n + k];
+            }
+            sM[idx] = s;
+        }
+        __syncthreads();
+        gauss_jordan<NT>(sM, r, ld);
+        for (int idx = tid; idx < n * r; idx += NT) {
+            int j = idx / r, a = idx - j * r;
+            sA[idx] = sM[a * ld + r + j] / sM[a * ld + a];
+        }
+        __syncthreads();
+        // X = A B^T ; Z ; Y ; residuals
+        double acc_p = 0, acc_d = 0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if (ei[t] < 0) continue;
+            const int i = ei[t], j = ej[t];
+            double x = 0;
+            for (int a = 0; a < r; ++a) x += sA[i * r + a] * sB[j * r + a];
+            double zz = x + y[t] / mu;
+            if (sGid[i] == sGid[j]) zz = 0.0;
+            if (i == j) zz = 1.0;
+            zz = zz < 0.0 ? 0.0 : (zz > 1.0 ? 1.0 : zz);
+            const double dz = x - zz, dx = x - xp[t];
+            y[t] = y[t] + mu * dz;
+            z[t] = zz;
+            xp[t] = x;
+            acc_p += dz * dz;
+            acc_d += dx * dx;
+        }
+        const double p_res = sqrt(block_sum<NT>(acc_p, sRed)) / n;
+        const double d_res = mu * sqrt(block_sum<NT>(acc_d, sRed)) / n;
+        if (p_res < 1e-4 && d_res < 1e-4) { iters = it + 1; break; }
+        if (p_res > 10 * d_res) mu = 2 * mu;
+        else if (d_res > 10 * p_res) mu = mu / 2;
+    }
+
+    // ---- X_bin = (X + X^T)/2 > 0.5 ----  (sA / sB are free now: reuse them for the byte matrices)
+    static_assert(NMAX * NMAX <= NMAX * RMAX * 8, "byte matrices must fit the factor buffers");
+    uint8_t* sBin = reinterpret_cast<uint8_t*>(sA);
+    uint8_t* sOut = reinterpret_cast<uint8_t*>(sB);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+        if (ei[t] >= 0) sX[t * NT + tid] = xp[t];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+        if (ei[t] >= 0) sBin[t * NT + tid] = (0.5 * (sX[ei[t] * n + ej[t]] + sX[ej[t] * n + ei[t]])) > 0.5;
+    __syncthreads();
+    // ---- transform_closure: only k = n-1 survives (mv_association.py:105-110) ----
+    for (int e = tid; e < n * n; e += NT) {
+        int i = e / n, j = e - i * n;
+        sOut[e] = 0;
+        // reuse the upper bits of sBin for temp to save LDS: bit0 = x_bin, bit1 = temp
+        uint8_t xb = sBin[e] & 1;
+        uint8_t tmpv = xb | ((sBin[i * n + (n - 1)] & 1) & (sBin[(n - 1) * n + j] & 1));
+        sX[e] = (double)tmpv;  // temp kept in sX (free now)
+    }
+    for (int i = tid; i < n; i += NT) sVis[i] = 0;
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+        const bool skip = sVis[i] != 0;
+        __syncthreads();
+        if (!skip)
+            for (int j = tid; j < n; j += NT)
+                if (sX[i * n + j] != 0.0) { sVis[j] = 1; sOut[j * n + i] = 1; }
+        __syncthreads();
+    }
+    // ---- parse_match_result rule: keep columns with >= 2 members, first kept column wins ----
+    for (int c = tid; c < n; c += NT) {
+        int s = 0;
+        for (int j = 0; j < n; ++j) s += sOut[j * n + c];
+        sKeep[c] = s >= 2;
+    }
+    __syncthreads();
+    for (int row = tid; row < ldw; row += NT) {
+        int label = -1;
+        if (row < n) {
+            int ord = 0;
+            for (int c = 0; c < n; ++c) {
+                if (!sKeep[c]) continue;
+                if (sOut[row * n + c]) { label = ord; break; }
+                ++ord;
+            }
+        }
+        lab[row] = label;
+    }
+    if (tid == 0) {
+        int k = 0;
+        for (int c = 0; c < n; ++c) k += sKeep[c];
+        n_clusters[f] = k;
+        iters_out[f] = iters;
+    }
+    if (x_bin || match_mat) {
+        for (int e = tid; e < ldw * ldw; e += NT) {
+            int i = e / ldw, j = e - i * ldw;
+            bool in = i < n && j < n;
+            if (x_bin) x_bin[(size_t)f * ldw * ldw + e] = in ? (sBin[i * n + j] & 1) : 0;
+            if (match_mat) match_mat[(size_t)f * ldw * ldw + e] = in ? sOut[i * n + j] : 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// labels -> member lists
+// ------------------------------------------------------------------------------------------------
+__global__ void members_kernel(const int32_t* __restrict__ labels, const int32_t* __restrict__ counts, int F, int C,
+                               int P, int K, int V, int32_t* __restrict__ members, int32_t* __restrict__ n_members) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const int N = C * P;
+    int32_t* mem = members + (size_t)f * K * V;
+    int32_t* nm = n_members + (size_t)f * K;
+    for (int k = 0; k < K; ++k) nm[k] = 0;
+    for (int e = 0; e < K * V; ++e) mem[e] = -1;
+    int node = 0;
+    for (int c = 0; c < C; ++c) {
+        int cnt = counts[f * C + c];
+        cnt = cnt < 0 ? 0 : (cnt > P ? P : cnt);
+        for (int p = 0; p < cnt; ++p, ++node) {
+            int l = labels[(size_t)f * N + node];
+            if (l < 0 || l >= K) continue;
+            int m = nm[l]++;
+            if (m < V) mem[l * V + m] = (f * C + c) * P + p;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" int mvmc_ingest(const void* kps, int dtype, int n_frames, int n_views, int p_max, int n_joints_in,
+                           const int32_t* counts_in, double min_score, int min_valid, double min_bb_size,
+                           double* kps17, int32_t* counts_out, mvmcStream_t stream) {
+    if (!kps || !kps17 || !counts_out || n_frames < 0 || n_views <= 0 || p_max <= 0) return MVMC_ERR_ARG;
+    if (n_joints_in != 25 && n_joints_in != 17) return MVMC_ERR_ARG;
+    if (dtype != MVMC_F32 && dtype != MVMC_F64) return MVMC_ERR_ARG;
+    if (n_frames == 0) return MVMC_OK;
+    const int nq = n_views * p_max;
+    size_t shm = (size_t)nq * 51 * sizeof(double) + (size_t)nq * 2 * sizeof(int);
+    if (shm > 64 * 1024) return MVMC_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MVMC_F32)
+        hipLaunchKernelGGL(ingest_kernel<float>, dim3(n_frames), dim3(256), shm, s, (const float*)kps, n_views, p_max,
+                           n_joints_in, counts_in, min_score, min_valid, min_bb_size, kps17, counts_out);
+    else
+        hipLaunchKernelGGL(ingest_kernel<double>, dim3(n_frames), dim3(256), shm, s, (const double*)kps, n_views,
+                           p_max, n_joints_in, counts_in, min_score, min_valid, min_bb_size, kps17, counts_out);
+    MVMC_CHECK_LAUNCH();
+    return MVMC_OK;
+}
+
+extern "C" int mvmc_fmats(const double* K, const double* Rt, int n_views, float* F, mvmcStream_t stream) {
+    if (!K || !Rt || !F || n_views <= 0) return MVMC_ERR_ARG;
+    int n = n_views * n_views;
+    hipLaunchKernelGGL(fmats_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, K, Rt, n_views, F);
+    MVMC_CHECK_LAUNCH();
+    return MVMC_OK;
+}
+
+extern "C" int mvmc_affinity(const double* kps17, const int32_t* counts, const float* Fmats, int n_frames,
+                             int n_views, int p_max, float* D, float* S, mvmcStream_t stream) {
+    if (!kps17 || !counts || !Fmats || n_frames < 0 || n_views <= 0 || p_max <= 0) return MVMC_ERR_ARG;
+    const int N = n_views * p_max;
+    if (N > MVMC_MAX_NODES) return MVMC_ERR_UNSUPPORTED;
+    if (n_frames == 0) return MVMC_OK;
+    size_t shm = (size_t)N * 51 * sizeof(double) + (size_t)2 * N * N * sizeof(float) + (size_t)2 * N * sizeof(int);
+    hipLaunchKernelGGL(affinity_kernel, dim3(n_frames), dim3(64), shm, (hipStream_t)stream, kps17, counts, Fmats,
+                       n_views, p_max, D, S);
+    MVMC_CHECK_LAUNCH();
+    return MVMC_OK;
+}
+
+template <typename TW>
+static int launch_als(const TW* W, const int32_t* gc, int F, int G, int n_max, int r_max, const double* seed,
+                      int seed_len, uint8_t* xb, uint8_t* mm, int32_t* lab, int32_t* nc, int32_t* it, hipStream_t s) {
+#define MVMC_ALS(NM, RM, NT)                                                                              \
+    hipLaunchKernelGGL((als_kernel<TW, NM, RM, NT>), dim3(F), dim3(NT), 0, s, W, gc, G, n_max, seed,    \
+                       seed_len, xb, mm, lab, nc, it)
+    if (n_max <= 16) MVMC_ALS(16, 16, 64);
+    else if (n_max <= 24) MVMC_ALS(24, 24, 64);
+    else if (n_max <= 32 && r_max <= 16) MVMC_ALS(32, 16, 64);
+    else if (n_max <= 32) MVMC_ALS(32, 32, 128);
+    else if (n_max <= 64 && r_max <= 16) MVMC_ALS(64, 16, 256);
+    else return MVMC_ERR_UNSUPPORTED;
+#undef MVMC_ALS
+    return MVMC_OK;
+}
+
+extern "C" int mvmc_als_associate(const void* W, int w_dtype, const int32_t* group_counts, int n_frames,
+                                  int n_groups, int n_max, int g_max, const double* seed_table, int seed_len, uint8_t* x_bin,
+                                  uint8_t* match_mat, int32_t* labels, int32_t* n_clusters, int32_t* iters,
+                                  mvmcStream_t stream) {
+    if (!W || !group_counts || !seed_table || !labels || !n_clusters || !iters) return MVMC_ERR_ARG;
+    if (n_frames < 0 || n_groups <= 0 || n_max <= 0 || n_max > MVMC_MAX_NODES) return MVMC_ERR_ARG;
+    if (w_dtype != MVMC_F32 && w_dtype != MVMC_F64) return MVMC_ERR_ARG;
+    if (n_frames == 0) return MVMC_OK;
+    if (g_max <= 0) return MVMC_ERR_ARG;
+    int r_max = 2 * g_max < n_max ? 2 * g_max : n_max;  // rank = min(n, 2 * largest group)
+    hipStream_t s = (hipStream_t)stream;
+    int st = (w_dtype == MVMC_F32)
+                 ? launch_als<float>((const float*)W, group_counts, n_frames, n_groups, n_max, r_max, seed_table,
+                                     seed_len, x_bin, match_mat, labels, n_clusters, iters, s)
+                 : launch_als<double>((const double*)W, group_counts, n_frames, n_groups, n_max, r_max, seed_table,
+                                      seed_len, x_bin, match_mat, labels, n_clusters, iters, s);
+    if (st != MVMC_OK) return st;
+    MVMC_CHECK_LAUNCH();
+    return MVMC_OK;
+}
+
+extern "C" int mvmc_cluster_members(const int32_t* labels, const int32_t* counts, int n_frames, int n_views,
+                                    int p_max, int k_max, int v_max, int32_t* members, int32_t* n_members,
+                                    mvmcStream_t stream) {
+    if (!labels || !counts || !members || !n_members || n_views <= 0 || p_max <= 0 || k_max <= 0 || v_max <= 0)
+        return MVMC_ERR_ARG;
+    if (n_frames <= 0) return n_frames == 0 ? MVMC_OK : MVMC_ERR_ARG;
+    hipLaunchKernelGGL(members_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, (hipStream_t)stream, labels, counts,
+                       n_frames, n_views, p_max, k_max, v_max, members, n_members);
+    MVMC_CHECK_LAUNCH();
+    return MVMC_OK;
+}

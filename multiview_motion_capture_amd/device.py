@@ -1,0 +1,219 @@
+"""Batched device entry points: torch CUDA tensors in, torch CUDA tensors out.
+
+Thin, allocation-only wrappers over the C ABI (include/mvmc.h).  PyTorch is the
+device-memory container and the stream provider; all arithmetic happens in the
+hand-written gfx950 kernels.  Every function launches on the current torch
+stream and does not synchronise.
+
+Shapes use F frames, C views, P max people per view, N = C*P graph nodes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _cabi
+from ._cabi import MvmcSkeleton, check
+
+_SEED_CACHE = {}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _req(t: torch.Tensor, dtype, name: str, shape=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError(f"{name}: expected a CUDA tensor")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous tensor")
+    if shape is not None:
+        if t.dim() != len(shape) or any(s is not None and int(d) != int(s) for d, s in zip(t.shape, shape)):
+            raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+# ----------------------------------------------------------------------------
+# skeleton constants (inverse_kinematics.py:120-173) -- data, restated
+# ----------------------------------------------------------------------------
+SKEL_OFFSETS = np.array([
+    [0, 0, 0], [0.15, 0, 0], [0, 0, -0.5], [0, 0, -0.5], [-0.15, 0, 0], [0, 0, -0.5],
+    [0, 0, -0.5], [0, 0, 0.3], [0, 0, 0.3], [0.2, 0, 0], [0.3, 0, 0], [0.3, 0, 0],
+    [-0.2, 0, 0], [-0.3, 0, 0], [-0.3, 0, 0], [0, -0.02, 0.15], [0.07, 0.02, 0.1],
+    [-0.07, 0.02, 0.1]], dtype=np.float64)
+SKEL_PARENTS = np.array([-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 9, 10, 8, 12, 13, 8, 15, 15], dtype=np.int32)
+SKEL_SIDE_MAP = np.array([7, 0, 1, 2, 0, 1, 2, 8, 9, 3, 4, 5, 3, 4, 5, 10, 6, 6], dtype=np.int32)
+SKEL_SIDE_JOINTS = np.array([1, 2, 3, 9, 10, 11, 16, 0, 7, 8, 15])
+
+
+def skeleton_arrays():
+    """(ref_bone_dirs[18,3], ref_side_bone_lens[11])."""
+    lens = np.linalg.norm(SKEL_OFFSETS, axis=-1)
+    dirs = SKEL_OFFSETS.copy()
+    dirs[1:] = dirs[1:] / lens[1:, None]
+    return dirs, lens[SKEL_SIDE_JOINTS].copy()
+
+
+def make_skeleton(bone_dirs=None, parents=None, side_map=None, n_side=11) -> MvmcSkeleton:
+    sk = MvmcSkeleton()
+    bd = skeleton_arrays()[0] if bone_dirs is None else np.asarray(bone_dirs, np.float64)
+    pa = SKEL_PARENTS if parents is None else np.asarray(parents, np.int32)
+    sm = SKEL_SIDE_MAP if side_map is None else np.asarray(side_map, np.int32)
+    for j in range(18):
+        for k in range(3):
+            sk.bone_dirs[j][k] = float(bd[j, k])
+        sk.parents[j] = int(pa[j])
+        sk.side_map[j] = int(sm[j])
+    sk.n_side = int(n_side)
+    return sk
+
+
+# ----------------------------------------------------------------------------
+def als_seed_table(count: int, device) -> torch.Tensor:
+    """First ``count`` doubles of RandomState(0).rand() (host MT19937 in the library), on ``device``."""
+    key = (str(device), int(count))
+    hit = _SEED_CACHE.get(key)
+    if hit is not None:
+        return hit
+    buf = (C.c_double * count)()
+    check(_cabi.load().mvmc_als_seed_table(C.cast(buf, C.c_void_p), count), "mvmc_als_seed_table")
+    t = torch.from_numpy(np.frombuffer(buf, dtype=np.float64).copy()).to(device)
+    _SEED_CACHE[key] = t
+    return t
+
+
+def ingest(kps: torch.Tensor, counts: Optional[torch.Tensor] = None, min_score=0.01, min_valid=4, min_bb=5.0):
+    """IN-1/IN-2.  kps (F,C,P,25|17,3) f32|f64 -> (kps17 (F,C,P,17,3) f64, counts (F,C) i32)."""
+    if kps.dtype not in (torch.float32, torch.float64):
+        raise ValueError("ingest: kps must be float32 or float64")
+    _req(kps, kps.dtype, "kps")
+    if kps.dim() != 5 or kps.shape[3] not in (17, 25) or kps.shape[4] != 3:
+        raise ValueError(f"ingest: expected (F,C,P,25|17,3), got {tuple(kps.shape)}")
+    F, Cn, P, J, _ = kps.shape
+    if counts is not None:
+        _req(counts, torch.int32, "counts", (F, Cn))
+    out = torch.empty((F, Cn, P, 17, 3), dtype=torch.float64, device=kps.device)
+    cnt = torch.empty((F, Cn), dtype=torch.int32, device=kps.device)
+    dt = _cabi.MVMC_F32 if kps.dtype == torch.float32 else _cabi.MVMC_F64
+    check(_cabi.load().mvmc_ingest(_p(kps), dt, F, Cn, P, J, _p(counts), float(min_score), int(min_valid),
+                                   float(min_bb), _p(out), _p(cnt), _stream()), "mvmc_ingest")
+    return out, cnt
+
+
+def fmats(K: torch.Tensor, Rt: torch.Tensor) -> torch.Tensor:
+    """AS-1.  K (C,3,3), Rt (C,3,4) f64 -> F (C,C,3,3) f32."""
+    Cn = K.shape[0]
+    _req(K, torch.float64, "K", (Cn, 3, 3))
+    _req(Rt, torch.float64, "Rt", (Cn, 3, 4))
+    F = torch.empty((Cn, Cn, 3, 3), dtype=torch.float32, device=K.device)
+    check(_cabi.load().mvmc_fmats(_p(K), _p(Rt), Cn, _p(F), _stream()), "mvmc_fmats")
+    return F
+
+
+def affinity(kps17: torch.Tensor, counts: torch.Tensor, Fm: torch.Tensor, want_D=True):
+    """AS-2/AS-3.  -> (D, S) each (F,N,N) f32 in compact node order."""
+    F, Cn, P = kps17.shape[:3]
+    _req(kps17, torch.float64, "kps17", (F, Cn, P, 17, 3))
+    _req(counts, torch.int32, "counts", (F, Cn))
+    _req(Fm, torch.float32, "Fm", (Cn, Cn, 3, 3))
+    N = Cn * P
+    D = torch.empty((F, N, N), dtype=torch.float32, device=kps17.device) if want_D else None
+    S = torch.empty((F, N, N), dtype=torch.float32, device=kps17.device)
+    check(_cabi.load().mvmc_affinity(_p(kps17), _p(counts), _p(Fm), F, Cn, P, _p(D), _p(S), _stream()),
+          "mvmc_affinity")
+    return D, S
+
+
+def als_associate(W: torch.Tensor, group_counts: torch.Tensor, g_max: int, want_mats=False):
+    """AS-4/5/6.  W (F,N,N) f32|f64, group_counts (F,G) i32 -> dict(labels (F,N), n_clusters, iters[, x_bin, match_mat])."""
+    if W.dtype not in (torch.float32, torch.float64):
+        raise ValueError("als_associate: W must be float32 or float64")
+    F, N, N2 = W.shape
+    _req(W, W.dtype, "W", (F, N, N))
+    G = group_counts.shape[1]
+    _req(group_counts, torch.int32, "group_counts", (F, G))
+    dev = W.device
+    seed = als_seed_table(_cabi.MAX_NODES * _cabi.MAX_NODES, dev)
+    labels = torch.empty((F, N), dtype=torch.int32, device=dev)
+    ncl = torch.empty((F,), dtype=torch.int32, device=dev)
+    iters = torch.empty((F,), dtype=torch.int32, device=dev)
+    xb = torch.empty((F, N, N), dtype=torch.uint8, device=dev) if want_mats else None
+    mm = torch.empty((F, N, N), dtype=torch.uint8, device=dev) if want_mats else None
+    dt = _cabi.MVMC_F32 if W.dtype == torch.float32 else _cabi.MVMC_F64
+    check(_cabi.load().mvmc_als_associate(_p(W), dt, _p(group_counts), F, G, N, int(g_max), _p(seed),
+                                          seed.numel(), _p(xb), _p(mm), _p(labels), _p(ncl), _p(iters), _stream()),
+          "mvmc_als_associate")
+    return dict(labels=labels, n_clusters=ncl, iters=iters, x_bin=xb, match_mat=mm)
+
+
+def cluster_members(labels: torch.Tensor, counts: torch.Tensor, p_max: int, k_max: int, v_max: int):
+    """labels (F,N), counts (F,C) -> members (F,K,V) pose indices (-1 padded), n_members (F,K)."""
+    F, Cn = counts.shape
+    _req(counts, torch.int32, "counts")
+    _req(labels, torch.int32, "labels", (F, Cn * p_max))
+    mem = torch.empty((F, k_max, v_max), dtype=torch.int32, device=labels.device)
+    nm = torch.empty((F, k_max), dtype=torch.int32, device=labels.device)
+    check(_cabi.load().mvmc_cluster_members(_p(labels), _p(counts), F, Cn, p_max, k_max, v_max, _p(mem), _p(nm),
+                                            _stream()), "mvmc_cluster_members")
+    return mem, nm
+
+
+def dlt(kps17: torch.Tensor, Pmats: torch.Tensor, members: torch.Tensor, min_score=0.01) -> torch.Tensor:
+    """TR-1/TR-2.  kps17 (F,C,P,17,3); Pmats (C,3,4); members (B,V) pose indices -> (B,17,4)."""
+    F, Cn, P = kps17.shape[:3]
+    _req(kps17, torch.float64, "kps17", (F, Cn, P, 17, 3))
+    _req(Pmats, torch.float64, "Pmats", (Cn, 3, 4))
+    _req(members, torch.int32, "members")
+    mem = members.reshape(-1, members.shape[-1])
+    B, V = mem.shape
+    out = torch.empty((B, 17, 4), dtype=torch.float64, device=kps17.device)
+    check(_cabi.load().mvmc_dlt(_p(kps17), _p(Pmats), _p(mem), B, V, Cn, P, float(min_score), _p(out), _stream()),
+          "mvmc_dlt")
+    return out.reshape(members.shape[:-1] + (17, 4))
+
+
+def fk(params: torch.Tensor, skeleton: Optional[MvmcSkeleton] = None, want_G=False):
+    """FK-1/FK-2.  params (B, 57+n_side) f64 -> joints (B,18,3)[, G (B,18,4,4)]."""
+    sk = skeleton if skeleton is not None else make_skeleton()
+    B = params.shape[0]
+    _req(params, torch.float64, "params", (B, 57 + sk.n_side))
+    joints = torch.empty((B, 18, 3), dtype=torch.float64, device=params.device)
+    G = torch.empty((B, 18, 4, 4), dtype=torch.float64, device=params.device) if want_G else None
+    check(_cabi.load().mvmc_fk(C.byref(sk), _p(params), B, _p(joints), _p(G), _stream()), "mvmc_fk")
+    return (joints, G) if want_G else joints
+
+
+def ik_solve(kps17: torch.Tensor, Pmats: torch.Tensor, members: torch.Tensor,
+             init_params: Optional[torch.Tensor] = None, cold: Optional[torch.Tensor] = None,
+             max_nfev_cold=50, max_nfev_warm=5, skeleton: Optional[MvmcSkeleton] = None, want_info=True):
+    """IK-1..IK-4.  members (B,V) -> params (B,68), joints (B,18,3), info (B,8)."""
+    sk = skeleton if skeleton is not None else make_skeleton()
+    F, Cn, P = kps17.shape[:3]
+    _req(kps17, torch.float64, "kps17", (F, Cn, P, 17, 3))
+    _req(Pmats, torch.float64, "Pmats", (Cn, 3, 4))
+    _req(members, torch.int32, "members")
+    B, V = members.shape
+    dev = kps17.device
+    if init_params is not None:
+        _req(init_params, torch.float64, "init_params", (B, 68))
+    if cold is not None:
+        _req(cold, torch.uint8, "cold", (B,))
+    if init_params is None and cold is not None:
+        raise ValueError("ik_solve: warm problems need init_params")
+    params = torch.empty((B, 68), dtype=torch.float64, device=dev)
+    joints = torch.empty((B, 18, 3), dtype=torch.float64, device=dev)
+    info = torch.empty((B, 8), dtype=torch.float64, device=dev) if want_info else None
+    check(_cabi.load().mvmc_ik_solve(C.byref(sk), _p(kps17), _p(Pmats), _p(members), B, V, Cn, P, _p(init_params),
+                                     _p(cold if init_params is not None else None), int(max_nfev_cold),
+                                     int(max_nfev_warm), _p(params), _p(joints), _p(info), _stream()),
+          "mvmc_ik_solve")
+    return params, joints, info

@@ -1,0 +1,43 @@
+"""CPU checks of the C-ABI library: it loads without a GPU, exports every symbol that
+include/mvmc.h declares, and its host-side MT19937 table equals NumPy's RandomState(0)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mvmc.h")).read()
+    return sorted(set(re.findall(r"\b(mvmc_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_exported():
+    from multiview_motion_capture_amd import _cabi
+    lib = _cabi.load()
+    declared = _declared_symbols()
+    assert set(declared) == set(_cabi.SYMBOLS), (declared, _cabi.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.mvmc_abi_version() == 1
+
+
+def test_seed_table_is_numpy_randomstate0():
+    from multiview_motion_capture_amd import _cabi
+    lib = _cabi.load()
+    n = 64 * 64
+    buf = (ctypes.c_double * n)()
+    assert lib.mvmc_als_seed_table(ctypes.cast(buf, ctypes.c_void_p), n) == 0
+    assert np.array_equal(np.frombuffer(buf, dtype=np.float64), np.random.RandomState(0).rand(n))
+    # rand(n, r) is the row-major prefix of the same stream (mv_association.py:271)
+    assert np.array_equal(np.frombuffer(buf, dtype=np.float64)[:20 * 8].reshape(20, 8),
+                          np.random.RandomState(0).rand(20, 8))
+
+
+def test_bad_arguments_are_reported_not_raised_in_c():
+    from multiview_motion_capture_amd import _cabi
+    lib = _cabi.load()
+    assert lib.mvmc_fmats(None, None, 5, None, None) == 1
+    assert lib.mvmc_status_string(1).decode() == "invalid argument"
