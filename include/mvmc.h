@@ -56,6 +56,7 @@ typedef struct {
     int32_t parents[MVMC_N_SKEL];     /* joint_parents (-1 for the root) */
     int32_t side_map[MVMC_N_SKEL];    /* ref_side_to_full_bone_lens_map */
     int32_t n_side;                   /* number of side lengths (11; 18 = identity map of the old pickle schema) */
+    double ref_side_lens[MVMC_N_SKEL]; /* ref_side_bone_lens (first n_side entries): cold-start lengths */
 } mvmcSkeleton;
 
 int mvmc_abi_version(void);

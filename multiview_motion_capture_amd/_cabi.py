@@ -27,7 +27,7 @@ SYMBOLS = (
 class MvmcSkeleton(C.Structure):
     """mvmcSkeleton of include/mvmc.h."""
     _fields_ = [("bone_dirs", (C.c_double * 3) * 18), ("parents", C.c_int32 * 18),
-                ("side_map", C.c_int32 * 18), ("n_side", C.c_int32)]
+                ("side_map", C.c_int32 * 18), ("n_side", C.c_int32), ("ref_side_lens", C.c_double * 18)]
 
 
 class MvmcError(RuntimeError):

@@ -28,3 +28,56 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+
+// ---- skeleton + rotation helpers shared by the FK and IK kernels ----
+struct SkelDev {
+    double dirs[18][3];
+    int parents[18];
+    int side_map[18];
+    int n_side;
+    double ref_side[18];
+};
+
+__device__ inline void quat_mul(const double* q, const double* r, double* o) {
+    o[0] = r[0] * q[0] - r[1] * q[1] - r[2] * q[2] - r[3] * q[3];
+    o[1] = r[0] * q[1] + r[1] * q[0] - r[2] * q[3] + r[3] * q[2];
+    o[2] = r[0] * q[2] + r[1] * q[3] + r[2] * q[0] - r[3] * q[1];
+    o[3] = r[0] * q[3] - r[1] * q[2] + r[2] * q[1] + r[3] * q[0];
+}
+
+__device__ inline void euler_to_rot(const double* e, double* R) {
+    const double inv = 1.0 / (1.0 + 1e-10);
+    double sx, cx, sy, cy, sz, cz;
+    sincos(e[0] / 2.0, &sx, &cx);
+    sincos(e[1] / 2.0, &sy, &cy);
+    sincos(e[2] / 2.0, &sz, &cz);
+    const double q0[4] = {cx, inv * sx, 0.0, 0.0};
+    const double q1[4] = {cy, 0.0, inv * sy, 0.0};
+    const double q2[4] = {cz, 0.0, 0.0, inv * sz};
+    double q12[4], q[4];
+    quat_mul(q1, q2, q12);
+    quat_mul(q0, q12, q);
+    const double qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+    const double x2 = qx + qx, y2 = qy + qy, z2 = qz + qz;
+    const double xx = qx * x2, yy = qy * y2, wx = qw * x2;
+    const double xy = qx * y2, yz = qy * z2, wy = qw * y2;
+    const double xz = qx * z2, zz = qz * z2, wz = qw * z2;
+    R[0] = 1.0 - (yy + zz); R[1] = xy - wz; R[2] = xz + wy;
+    R[3] = xy + wz; R[4] = 1.0 - (xx + zz); R[5] = yz - wx;
+    R[6] = xz - wy; R[7] = yz + wx; R[8] = 1.0 - (xx + yy);
+}
+
+// host mvmcSkeleton -> kernel argument; false if the tables are inconsistent
+static inline bool skel_to_dev(const mvmcSkeleton* h, SkelDev* sk) {
+    if (h->n_side <= 0 || h->n_side > 18) return false;
+    for (int j = 0; j < 18; ++j) {
+        for (int k = 0; k < 3; ++k) sk->dirs[j][k] = h->bone_dirs[j][k];
+        sk->parents[j] = h->parents[j];
+        sk->side_map[j] = h->side_map[j];
+        sk->ref_side[j] = h->ref_side_lens[j];
+        if (sk->side_map[j] < 0 || sk->side_map[j] >= h->n_side) return false;
+        if (j == 0 ? (sk->parents[j] != -1) : (sk->parents[j] < 0 || sk->parents[j] >= j)) return false;
+    }
+    sk->n_side = h->n_side;
+    return true;
+}

@@ -107,42 +107,6 @@ dlt_kernel(const double* __restrict__ kps17, const double* __restrict__ Pm, cons
 // FK: R_j = Rx Ry Rz through the reference's quaternion path (axis scaled by 1/(1+1e-10),
 // Quaternions.py:444), chained 4x4 products in index order (parents precede children).
 // ------------------------------------------------------------------------------------------------
-struct SkelDev {
-    double dirs[18][3];
-    int parents[18];
-    int side_map[18];
-    int n_side;
-};
-
-__device__ inline void quat_mul(const double* q, const double* r, double* o) {
-    o[0] = r[0] * q[0] - r[1] * q[1] - r[2] * q[2] - r[3] * q[3];
-    o[1] = r[0] * q[1] + r[1] * q[0] - r[2] * q[3] + r[3] * q[2];
-    o[2] = r[0] * q[2] + r[1] * q[3] + r[2] * q[0] - r[3] * q[1];
-    o[3] = r[0] * q[3] - r[1] * q[2] + r[2] * q[1] + r[3] * q[0];
-}
-
-__device__ inline void euler_to_rot(const double* e, double* R) {
-    const double inv = 1.0 / (1.0 + 1e-10);
-    double sx, cx, sy, cy, sz, cz;
-    sincos(e[0] / 2.0, &sx, &cx);
-    sincos(e[1] / 2.0, &sy, &cy);
-    sincos(e[2] / 2.0, &sz, &cz);
-    const double q0[4] = {cx, inv * sx, 0.0, 0.0};
-    const double q1[4] = {cy, 0.0, inv * sy, 0.0};
-    const double q2[4] = {cz, 0.0, 0.0, inv * sz};
-    double q12[4], q[4];
-    quat_mul(q1, q2, q12);
-    quat_mul(q0, q12, q);
-    const double qw = q[0], qx = q[1], qy = q[2], qz = q[3];
-    const double x2 = qx + qx, y2 = qy + qy, z2 = qz + qz;
-    const double xx = qx * x2, yy = qy * y2, wx = qw * x2;
-    const double xy = qx * y2, yz = qy * z2, wy = qw * y2;
-    const double xz = qx * z2, zz = qz * z2, wz = qw * z2;
-    R[0] = 1.0 - (yy + zz); R[1] = xy - wz; R[2] = xz + wy;
-    R[3] = xy + wz; R[4] = 1.0 - (xx + zz); R[5] = yz - wx;
-    R[6] = xz - wy; R[7] = yz + wx; R[8] = 1.0 - (xx + yy);
-}
-
 __global__ void __launch_bounds__(64)
 fk_kernel(SkelDev sk, const double* __restrict__ params, int B, double* __restrict__ joints, double* __restrict__ Gout) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -200,17 +164,9 @@ extern "C" int mvmc_dlt(const double* kps17, const double* Pmats, const int32_t*
 extern "C" int mvmc_fk(const mvmcSkeleton* skel_host, const double* params, int n_problems, double* joints,
                        double* G, mvmcStream_t stream) {
     if (!skel_host || !params || !joints) return MVMC_ERR_ARG;
-    if (skel_host->n_side <= 0 || skel_host->n_side > 18) return MVMC_ERR_ARG;
     if (n_problems <= 0) return n_problems == 0 ? MVMC_OK : MVMC_ERR_ARG;
     SkelDev sk;
-    for (int j = 0; j < 18; ++j) {
-        for (int k = 0; k < 3; ++k) sk.dirs[j][k] = skel_host->bone_dirs[j][k];
-        sk.parents[j] = skel_host->parents[j];
-        sk.side_map[j] = skel_host->side_map[j];
-        if (sk.side_map[j] < 0 || sk.side_map[j] >= skel_host->n_side) return MVMC_ERR_ARG;
-        if (j > 0 && (sk.parents[j] < 0 || sk.parents[j] >= j)) return MVMC_ERR_ARG;
-    }
-    sk.n_side = skel_host->n_side;
+    if (!skel_to_dev(skel_host, &sk)) return MVMC_ERR_ARG;
     hipLaunchKernelGGL(fk_kernel, dim3((n_problems + 63) / 64), dim3(64), 0, (hipStream_t)stream, sk, params,
                        n_problems, joints, G);
     MVMC_CHECK_LAUNCH();

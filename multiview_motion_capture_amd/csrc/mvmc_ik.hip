@@ -1,6 +1,609 @@
-// Temporary placeholder so the library links while the IK kernel is being written.
+// Temporal inverse kinematics for gfx950: PoseSolver.solve (inverse_kinematics.py:351-433).
+//
+// One 256-thread workgroup (4 waves) solves one person-frame; the whole solver state lives in LDS.
+// Two trust-region stages, each a restatement of SciPy's trf_no_bounds / solve_lsq_trust_region as the
+// reference reaches them through least_squares(fun, x0, max_nfev=k) (trf.py:401-560, common.py:57-168):
+//   stage 1  x = [root, euler(18x3)]                (57 parameters, 39 structurally non-null)
+//   stage 2  x = [root, euler, side bone lengths]   (68 parameters, 49 structurally non-null)
+// Differences from the reference that are deliberate (DESIGN.md "IK parity"):
+//   * analytic Jacobian of the FK chain instead of 2-point finite differences;
+//   * the trust-region sub-problem is solved from the normal equations: with J^T J = V L V^T,
+//     s^2 = L and s*(U^T f) = V^T g, so p(alpha) = -V (V^T g / (L + alpha)); J^T J is assembled from the
+//     per-joint 3x3 image-space blocks (J^T J = D^T W D, D = d pos / d x is 48 x n) and diagonalised by a
+//     parallel cyclic Jacobi in LDS;
+//   * columns that are identically zero for every input (leaf-joint angles, the root's bone length) are
+//     removed from the eigenproblem -- SciPy gives them s = 0 and a zero step, which is what they get here.
 #include "mvmc_common.h"
-extern "C" int mvmc_ik_solve(const mvmcSkeleton*, const double*, const double*, const int32_t*, int, int, int, int,
-                             const double*, const uint8_t*, int, int, double*, double*, double*, mvmcStream_t) {
-    return MVMC_ERR_UNSUPPORTED;
+
+namespace {
+
+constexpr int NT = 256;    // threads per problem
+constexpr int NA = 50;     // max active parameters (even)
+constexpr int LD = 51;     // odd leading dimension: conflict-free column walks on 8-byte elements
+constexpr int VMAX = 8;    // max views per person
+constexpr int NOBS = 16;   // observed joints per view
+
+// skeleton joint <-> observed keypoint (COCO-17 + synthetic mid-spine at 17); inverse_kinematics.py:366-378
+__device__ __constant__ const int kIkSkel[NOBS] = {1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17};
+__device__ __constant__ const int kIkObs[NOBS] = {11, 13, 15, 12, 14, 16, 17, 5, 7, 9, 6, 8, 10, 0, 3, 4};
+
+struct IkShared {
+    double bufA[NA * LD];  // D (48 x LD)  | eigenvectors V (NA x LD)
+    double bufB[NA * LD];  // per-(view,joint) scratch | Y = W D (48 x LD) | J^T J -> diag(L) (NA x LD)
+    double x[68], xn[68];
+    double side[18];       // side bone lengths used by stage 1 (fixed)
+    double g[NA], lam[NA], suf[NA], cv[NA], step[NA];
+    double rc[NA / 2], rs[NA / 2];
+    double obs[VMAX * NOBS * 3], Pm[VMAX * 12];
+    double Rl[18 * 9], Rg[18 * 9], pos[18 * 3], bvec[18 * 3], off[18 * 3], axes[18 * 9];
+    double Wk[NOBS * 6], tk[NOBS * 3];
+    double red[8];
+    double sc[8];          // broadcast scalars
+    int act[2][NA], inv_act[2][68], na[2];
+    int colkind[2][NA], cola[2][NA], colc[2][NA];
+    int anc[18], depth[18], maxdepth, nviews;
+    int pp[NA / 2], qq[NA / 2];
+};
+
+__device__ inline double block_sum256(double v, double* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// FK + residual (+ per-joint normal-equation blocks when want_jac).  Returns the cost 0.5*|f|^2.
+// ---------------------------------------------------------------------------------------------
+__device__ double ik_eval(IkShared& S, const SkelDev& sk, const double* xs, int stage, bool want_jac) {
+    const int tid = threadIdx.x;
+    if (tid < 18) {
+        euler_to_rot(xs + 3 + 3 * tid, &S.Rl[tid * 9]);
+        double len = 0.0;
+        if (tid > 0) len = (stage == 0) ? S.side[sk.side_map[tid]] : xs[57 + sk.side_map[tid]];
+        for (int k = 0; k < 3; ++k) S.off[tid * 3 + k] = sk.dirs[tid][k] * len;
+    }
+    __syncthreads();
+    if (tid < 9) S.Rg[tid] = S.Rl[tid];
+    if (tid < 3) S.pos[tid] = xs[tid];
+    __syncthreads();
+    for (int lev = 1; lev <= S.maxdepth; ++lev) {
+        if (tid < 162) {
+            const int j = tid / 9, e = tid - j * 9;
+            if (S.depth[j] == lev) {
+                const int p = sk.parents[j], r = e / 3, c = e - r * 3;
+                const double* Gp = &S.Rg[p * 9];
+                const double* Rj = &S.Rl[j * 9];
+                S.Rg[j * 9 + e] = Gp[r * 3] * Rj[c] + Gp[r * 3 + 1] * Rj[3 + c] + Gp[r * 3 + 2] * Rj[6 + c];
+                if (e < 3) {
+                    S.pos[j * 3 + e] = Gp[e * 3] * S.off[j * 3] + Gp[e * 3 + 1] * S.off[j * 3 + 1] +
+                                       Gp[e * 3 + 2] * S.off[j * 3 + 2] + S.pos[p * 3 + e];
+                    S.bvec[j * 3 + e] = Gp[e * 3] * sk.dirs[j][0] + Gp[e * 3 + 1] * sk.dirs[j][1] +
+                                        Gp[e * 3 + 2] * sk.dirs[j][2];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // residuals: one thread per (view, observed joint)
+    double f2 = 0.0;
+    const int nvk = S.nviews * NOBS;
+    if (tid < nvk) {
+        const int v = tid / NOBS, k = tid - v * NOBS;
+        const double* X = &S.pos[kIkSkel[k] * 3];
+        const double* P = &S.Pm[v * 12];
+        const double h0 = P[0] * X[0] + P[1] * X[1] + P[2] * X[2] + P[3];
+        const double h1 = P[4] * X[0] + P[5] * X[1] + P[6] * X[2] + P[7];
+        const double h2 = P[8] * X[0] + P[9] * X[1] + P[10] * X[2] + P[11];
+        const double w = 1e-5 + h2, iw = 1.0 / w;
+        const double u = h0 / w, vv = h1 / w;
+        const double* ob = &S.obs[tid * 3];
+        const double s = ob[2];
+        const double fu = (u - ob[0]) * s, fv = (vv - ob[1]) * s;
+        f2 = fu * fu + fv * fv;
+        if (want_jac) {
+            double du[3], dv[3];
+            for (int c = 0; c < 3; ++c) {
+                du[c] = (P[c] - u * P[8 + c]) * iw;
+                dv[c] = (P[4 + c] - vv * P[8 + c]) * iw;
+            }
+            const double s2 = s * s;
+            double* o = &S.bufB[tid * 10];
+            o[0] = s2 * (du[0] * du[0] + dv[0] * dv[0]);
+            o[1] = s2 * (du[0] * du[1] + dv[0] * dv[1]);
+            o[2] = s2 * (du[0] * du[2] + dv[0] * dv[2]);
+            o[3] = s2 * (du[1] * du[1] + dv[1] * dv[1]);
+            o[4] = s2 * (du[1] * du[2] + dv[1] * dv[2]);
+            o[5] = s2 * (du[2] * du[2] + dv[2] * dv[2]);
+            o[6] = s * (du[0] * fu + dv[0] * fv);
+            o[7] = s * (du[1] * fu + dv[1] * fv);
+            o[8] = s * (du[2] * fu + dv[2] * fv);
+        }
+    }
+    return 0.5 * block_sum256(f2, S.red);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Jacobian blocks -> J^T J (into bufB), g = J^T f, V = I (into bufA).  Needs ik_eval(want_jac) state.
+// ---------------------------------------------------------------------------------------------
+__device__ void ik_normal_equations(IkShared& S, const SkelDev& sk, const double* xs, int stage) {
+    const int tid = threadIdx.x;
+    const int na = S.na[stage], nap = (na + 1) & ~1;
+    // per-joint blocks: W_k = sum_v s^2 (du du^T + dv dv^T), t_k = sum_v s (du fu + dv fv)
+    if (tid < NOBS * 9) {
+        const int k = tid / 9, e = tid - k * 9;
+        double a = 0.0;
+        for (int v = 0; v < S.nviews; ++v) a += S.bufB[(v * NOBS + k) * 10 + e];
+        if (e < 6) S.Wk[k * 6 + e] = a; else S.tk[k * 3 + (e - 6)] = a;
+    }
+    // rotation axes in the world frame: R_a = Rx Ry Rz inside the parent's frame
+    if (tid >= 192 && tid < 192 + 54) {
+        const int t = tid - 192, a = t / 3, c = t - a * 3;
+        const double* e = xs + 3 + 3 * a;
+        double l[3];
+        if (c == 0) { l[0] = 1; l[1] = 0; l[2] = 0; }
+        else if (c == 1) { double s0, c0; sincos(e[0], &s0, &c0); l[0] = 0; l[1] = c0; l[2] = s0; }
+        else {
+            double s0, c0, s1, c1;
+            sincos(e[0], &s0, &c0); sincos(e[1], &s1, &c1);
+            l[0] = s1; l[1] = -s0 * c1; l[2] = c0 * c1;
+        }
+        if (a == 0) {
+            for (int r = 0; r < 3; ++r) S.axes[t * 3 + r] = l[r];
+        } else {
+            const double* Gp = &S.Rg[sk.parents[a] * 9];
+            for (int r = 0; r < 3; ++r) S.axes[t * 3 + r] = Gp[r * 3] * l[0] + Gp[r * 3 + 1] * l[1] + Gp[r * 3 + 2] * l[2];
+        }
+    }
+    __syncthreads();
+    // D[row = 3k + c3][col] = d pos_K[c3] / d x_col
+    for (int idx = tid; idx < 48 * nap; idx += NT) {
+        const int row = idx / nap, col = idx - row * nap;
+        const int k = row / 3, c3 = row - k * 3, K = kIkSkel[k];
+        double d = 0.0;
+        if (col < na) {
+            const int kind = S.colkind[stage][col], a = S.cola[stage][col], c = S.colc[stage][col];
+            if (kind == 0) {
+                d = (c3 == c) ? 1.0 : 0.0;
+            } else if (kind == 1) {
+                if ((S.anc[K] >> a) & 1) {
+                    const double* ax = &S.axes[(a * 3 + c) * 3];
+                    const double r0 = S.pos[K * 3] - S.pos[a * 3], r1 = S.pos[K * 3 + 1] - S.pos[a * 3 + 1],
+                                 r2 = S.pos[K * 3 + 2] - S.pos[a * 3 + 2];
+                    d = (c3 == 0) ? ax[1] * r2 - ax[2] * r1 : (c3 == 1) ? ax[2] * r0 - ax[0] * r2 : ax[0] * r1 - ax[1] * r0;
+                }
+            } else {
+                for (int j = K; j > 0; j = sk.parents[j])
+                    if (sk.side_map[j] == a) d += S.bvec[j * 3 + c3];
+            }
+        }
+        S.bufA[row * LD + col] = d;
+    }
+    __syncthreads();
+    // Y = W D  (bufB; the per-(view,joint) scratch is dead now)
+    for (int idx = tid; idx < 48 * nap; idx += NT) {
+        const int row = idx / nap, col = idx - row * nap;
+        const int k = row / 3, c3 = row - k * 3;
+        const double* W = &S.Wk[k * 6];
+        const double w0 = (c3 == 0) ? W[0] : (c3 == 1) ? W[1] : W[2];
+        const double w1 = (c3 == 0) ? W[1] : (c3 == 1) ? W[3] : W[4];
+        const double w2 = (c3 == 0) ? W[2] : (c3 == 1) ? W[4] : W[5];
+        S.bufB[row * LD + col] = w0 * S.bufA[(3 * k) * LD + col] + w1 * S.bufA[(3 * k + 1) * LD + col] +
+                                 w2 * S.bufA[(3 * k + 2) * LD + col];
+    }
+    __syncthreads();
+    // J^T J = D^T Y (registers first: the result overwrites Y), g = D^T t
+    constexpr int EPT = (NA * NA + NT - 1) / NT;
+    double acc[EPT];
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) {
+        const int idx = t * NT + tid;
+        double a = 0.0;
+        if (idx < nap * nap) {
+            const int i = idx / nap, j = idx - i * nap;
+            for (int row = 0; row < 48; ++row) a += S.bufA[row * LD + i] * S.bufB[row * LD + j];
+        }
+        acc[t] = a;
+    }
+    if (tid < nap) {
+        double a = 0.0;
+        for (int row = 0; row < 48; ++row) a += S.bufA[row * LD + tid] * S.tk[row];
+        S.g[tid] = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) {
+        const int idx = t * NT + tid;
+        if (idx < nap * nap) {
+            const int i = idx / nap, j = idx - i * nap;
+            S.bufB[i * LD + j] = acc[t];
+            S.bufA[i * LD + j] = (i == j) ? 1.0 : 0.0;
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Parallel cyclic Jacobi (round-robin pairs): bufB -> diag(lam), bufA -> eigenvectors (columns).
+// ---------------------------------------------------------------------------------------------
+__device__ void ik_eigh(IkShared& S, int nap) {
+    const int tid = threadIdx.x;
+    double* A = S.bufB;
+    double* V = S.bufA;
+    const int half = nap / 2;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0, dg = 0.0;
+        for (int idx = tid; idx < nap * nap; idx += NT) {
+            const int i = idx / nap, j = idx - i * nap;
+            const double a = A[i * LD + j];
+            if (i == j) dg += a * a; else off += a * a;
+        }
+        off = block_sum256(off, S.red);
+        dg = block_sum256(dg, S.red);
+        if (off <= 1e-30 * (dg + off) || off == 0.0) break;
+        for (int s = 0; s < nap - 1; ++s) {
+            if (tid < half) {
+                int p, q;
+                if (tid == 0) { p = nap - 1; q = s; }
+                else { p = (s + tid) % (nap - 1); q = (s - tid + (nap - 1)) % (nap - 1); }
+                if (p > q) { const int t = p; p = q; q = t; }
+                const double apq = A[p * LD + q], app = A[p * LD + p], aqq = A[q * LD + q];
+                double c = 1.0, sn = 0.0;
+                if (fabs(apq) > 1e-300 && fabs(apq) > 1e-19 * sqrt(fabs(app * aqq))) {
+                    const double theta = (aqq - app) / (2.0 * apq);
+                    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    c = 1.0 / sqrt(t * t + 1.0);
+                    sn = t * c;
+                }
+                S.rc[tid] = c; S.rs[tid] = sn; S.pp[tid] = p; S.qq[tid] = q;
+            }
+            __syncthreads();
+            // A <- A J and V <- V J (column pairs)
+            for (int idx = tid; idx < 2 * half * nap; idx += NT) {
+                const int m = idx / (half * nap), rem = idx - m * half * nap;
+                const int i = rem / nap, r = rem - i * nap;
+                double* M = m ? V : A;
+                const double c = S.rc[i], sn = S.rs[i];
+                const int p = S.pp[i], q = S.qq[i];
+                const double a = M[r * LD + p], b = M[r * LD + q];
+                M[r * LD + p] = c * a - sn * b;
+                M[r * LD + q] = sn * a + c * b;
+            }
+            __syncthreads();
+            // A <- J^T A (row pairs)
+            for (int idx = tid; idx < half * nap; idx += NT) {
+                const int i = idx / nap, k = idx - i * nap;
+                const double c = S.rc[i], sn = S.rs[i];
+                const int p = S.pp[i], q = S.qq[i];
+                const double a = A[p * LD + k], b = A[q * LD + k];
+                A[p * LD + k] = c * a - sn * b;
+                A[q * LD + k] = sn * a + c * b;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// solve_lsq_trust_region (common.py:57-168), rank-deficient branch (structurally null columns
+// exist, so SciPy's full-rank Gauss-Newton shortcut never fires).  Wave 0 only; writes cv[] and
+// returns alpha; *pred receives the predicted reduction, all lanes hold the same scalars.
+// ---------------------------------------------------------------------------------------------
+__device__ double ik_tr_solve(IkShared& S, int nap, double Delta, double alpha0, double* pred) {
+    const int lane = threadIdx.x;
+    const bool on = lane < nap;
+    const double lam = on ? S.lam[lane] : 1.0, suf = on ? S.suf[lane] : 0.0;
+    double alpha_upper = sqrt(wave_sum(suf * suf)) / Delta;
+    double alpha_lower = 0.0;
+    double alpha = (alpha0 == 0.0) ? fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper)) : alpha0;
+    for (int it = 0; it < 10; ++it) {
+        if (alpha < alpha_lower || alpha > alpha_upper)
+            alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+        const double denom = lam + alpha;
+        const double t = suf / denom;
+        const double p_norm = sqrt(wave_sum(t * t));
+        const double phi = p_norm - Delta;
+        const double phi_prime = -wave_sum(suf * suf / (denom * denom * denom)) / p_norm;
+        if (phi < 0) alpha_upper = alpha;
+        const double ratio = phi / phi_prime;
+        alpha_lower = fmax(alpha_lower, alpha - ratio);
+        alpha -= (phi + Delta) * ratio / Delta;
+        if (fabs(phi) < 0.01 * Delta) break;
+    }
+    double c = -suf / (lam + alpha);
+    if (!on) c = 0.0;
+    const double pn = sqrt(wave_sum(c * c));
+    c *= Delta / pn;
+    if (on) S.cv[lane] = c;
+    *pred = -(0.5 * wave_sum(lam * c * c) + wave_sum(suf * c));
+    return alpha;
+}
+
+// ---------------------------------------------------------------------------------------------
+// trf_no_bounds (trf.py:401-560) with x_scale = 1, linear loss, ftol = xtol = gtol = 1e-8.
+// ---------------------------------------------------------------------------------------------
+__device__ void ik_trf(IkShared& S, const SkelDev& sk, int stage, int max_nfev, double* cost_out, int* nfev_out,
+                       int* njev_out, int* status_out) {
+    const int tid = threadIdx.x;
+    const int nfull = (stage == 0) ? 57 : 57 + sk.n_side;
+    const int na = S.na[stage], nap = (na + 1) & ~1;
+    const double ftol = 1e-8, xtol = 1e-8, gtol = 1e-8;
+
+    double cost = ik_eval(S, sk, S.x, stage, true);
+    ik_normal_equations(S, sk, S.x, stage);
+    int nfev = 1, njev = 1, status = -1;
+    double xx = (tid < nfull) ? S.x[tid] * S.x[tid] : 0.0;
+    double Delta = sqrt(block_sum256(xx, S.red));
+    if (Delta == 0.0) Delta = 1.0;
+    double alpha = 0.0;
+
+    while (true) {
+        // |g|_inf over the active set (null columns have g = 0)
+        if (tid == 0) {
+            double gm = 0.0;
+            for (int i = 0; i < na; ++i) gm = fmax(gm, fabs(S.g[i]));
+            S.sc[0] = gm;
+        }
+        __syncthreads();
+        if (S.sc[0] < gtol) status = 1;
+        if (status != -1 || nfev == max_nfev) break;
+
+        ik_eigh(S, nap);
+        if (tid < nap) {
+            const double l = S.bufB[tid * LD + tid];
+            S.lam[tid] = l > 0.0 ? l : 0.0;
+            double a = 0.0;
+            for (int i = 0; i < nap; ++i) a += S.bufA[i * LD + tid] * S.g[i];
+            S.suf[tid] = a;
+        }
+        __syncthreads();
+
+        double actual = -1.0, cost_new = cost;
+        while (actual <= 0.0 && nfev < max_nfev) {
+            if (tid < 64) {
+                double pred;
+                const double al = ik_tr_solve(S, nap, Delta, alpha, &pred);
+                if (tid == 0) { S.sc[1] = al; S.sc[2] = pred; }
+            }
+            __syncthreads();
+            alpha = S.sc[1];
+            const double pred = S.sc[2];
+            if (tid < nap) {
+                double a = 0.0;
+                for (int j = 0; j < nap; ++j) a += S.bufA[tid * LD + j] * S.cv[j];
+                S.step[tid] = a;
+            }
+            __syncthreads();
+            double sq = (tid < na) ? S.step[tid] * S.step[tid] : 0.0;
+            const double step_norm = sqrt(block_sum256(sq, S.red));
+            xx = (tid < nfull) ? S.x[tid] * S.x[tid] : 0.0;
+            const double x_norm = sqrt(block_sum256(xx, S.red));
+            if (tid < nfull) {
+                const int ia = S.inv_act[stage][tid];
+                S.xn[tid] = S.x[tid] + (ia >= 0 ? S.step[ia] : 0.0);
+            }
+            __syncthreads();
+            cost_new = ik_eval(S, sk, S.xn, stage, true);
+            ++nfev;
+            if (!isfinite(cost_new)) { Delta = 0.25 * step_norm; continue; }
+            actual = cost - cost_new;
+            // update_tr_radius (common.py:222-245)
+            double ratio;
+            if (pred > 0.0) ratio = actual / pred;
+            else if (pred == 0.0 && actual == 0.0) ratio = 1.0;
+            else ratio = 0.0;
+            double Delta_new = Delta;
+            if (ratio < 0.25) Delta_new = 0.25 * step_norm;
+            else if (ratio > 0.75 && step_norm > 0.95 * Delta) Delta_new = Delta * 2.0;
+            // check_termination (common.py:705-717)
+            const bool f_ok = (actual < ftol * cost) && (ratio > 0.25);
+            const bool x_ok = step_norm < xtol * (xtol + x_norm);
+            if (f_ok && x_ok) status = 4; else if (f_ok) status = 2; else if (x_ok) status = 3;
+            if (status != -1) break;
+            alpha *= Delta / Delta_new;
+            Delta = Delta_new;
+        }
+        if (actual > 0.0) {
+            __syncthreads();
+            if (tid < nfull) S.x[tid] = S.xn[tid];
+            __syncthreads();
+            cost = cost_new;
+            if (status == -1 && nfev < max_nfev) {
+                // the accepted point's FK / residual blocks are still in LDS (last ik_eval was at xn)
+                ik_normal_equations(S, sk, S.x, stage);
+                ++njev;
+            }
+        } else if (status == -1 && nfev < max_nfev) {
+            // not reachable: the inner loop only ends on acceptance, termination or the nfev cap
+        }
+    }
+    if (status == -1) status = 0;
+    *cost_out = cost; *nfev_out = nfev; *njev_out = njev; *status_out = status;
+}
+
+// 4x4 symmetric Jacobi for the cold-start DLT of one joint (same scheme as mvmc_geom.hip)
+template <int P, int Q>
+__device__ __forceinline__ void rot4(double (&a)[4][4], double (&v)[4][4]) {
+    const double apq = a[P][Q];
+    if (fabs(apq) < 1e-300) return;
+    const double theta = (a[Q][Q] - a[P][P]) / (2.0 * apq);
+    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const double x = a[k][P], y = a[k][Q]; a[k][P] = c * x - s * y; a[k][Q] = s * x + c * y; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const double x = a[P][k], y = a[Q][k]; a[P][k] = c * x - s * y; a[Q][k] = s * x + c * y; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const double x = v[k][P], y = v[k][Q]; v[k][P] = c * x - s * y; v[k][Q] = s * x + c * y; }
+}
+
+// DLT of one observed keypoint (index into the 18-row pose: 17 = mid-spine) over the problem's views
+__device__ void dlt_obs_point(const double* pose18 /*[V][18][3]*/, const double* Pm, int nv, int jo, double min_score,
+                              double* X) {
+    int n_ok = 0;
+    for (int v = 0; v < nv; ++v) n_ok += pose18[(v * 18 + jo) * 3 + 2] >= min_score;
+    const bool use_all = n_ok < 2;
+    double a[4][4], vv[4][4];
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { a[r][c] = 0.0; vv[r][c] = (r == c) ? 1.0 : 0.0; }
+    for (int v = 0; v < nv; ++v) {
+        const double* kp = &pose18[(v * 18 + jo) * 3];
+        if (!use_all && !(kp[2] >= min_score)) continue;
+        const double* P = &Pm[v * 12];
+        double r1[4], r2[4];
+        for (int k = 0; k < 4; ++k) { r1[k] = kp[0] * P[8 + k] - P[k]; r2[k] = kp[1] * P[8 + k] - P[4 + k]; }
+        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) a[r][c] += r1[r] * r1[c] + r2[r] * r2[c];
+    }
+    const double tr = a[0][0] + a[1][1] + a[2][2] + a[3][3];
+    for (int sweep = 0; sweep < 16; ++sweep) {
+        const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[0][3] * a[0][3] + a[1][2] * a[1][2] +
+                           a[1][3] * a[1][3] + a[2][3] * a[2][3];
+        if (off <= 1e-36 * tr * tr) break;
+        rot4<0, 1>(a, vv); rot4<0, 2>(a, vv); rot4<0, 3>(a, vv); rot4<1, 2>(a, vv); rot4<1, 3>(a, vv); rot4<2, 3>(a, vv);
+    }
+    int m = 0;
+    for (int k = 1; k < 4; ++k) if (a[k][k] < a[m][m]) m = k;
+    double e[4];
+    for (int r = 0; r < 4; ++r) e[r] = (m == 0) ? vv[r][0] : (m == 1) ? vv[r][1] : (m == 2) ? vv[r][2] : vv[r][3];
+    X[0] = e[0] / e[3]; X[1] = e[1] / e[3]; X[2] = e[2] / e[3];
+}
+
+__global__ void __launch_bounds__(NT)
+ik_kernel(SkelDev sk, const double* __restrict__ kps17, const double* __restrict__ Pmats,
+          const int32_t* __restrict__ members, int B, int V, int C, int Pmax, const double* __restrict__ init,
+          const uint8_t* __restrict__ cold, int nfev_cold, int nfev_warm, double* __restrict__ params_out,
+          double* __restrict__ joints_out, double* __restrict__ info_out) {
+    __shared__ IkShared S;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n_side = sk.n_side;
+
+    // ---- static tables: depth, ancestor masks, active columns of both stages ----
+    if (tid == 0) {
+        int md = 0;
+        for (int j = 0; j < 18; ++j) {
+            int d = 0, m = 0;
+            for (int a = sk.parents[j]; a >= 0; a = sk.parents[a]) { ++d; m |= 1 << a; }
+            S.depth[j] = d; S.anc[j] = m;
+            if (d > md) md = d;
+        }
+        S.maxdepth = md;
+        int moved = 0, lens = 0;  // joints whose rotation moves an observed joint; used length slots
+        for (int k = 0; k < NOBS; ++k) {
+            const int K = kIkSkel[k];
+            moved |= S.anc[K];
+            for (int j = K; j > 0; j = sk.parents[j]) {
+                const double* d = sk.dirs[j];
+                if (d[0] != 0.0 || d[1] != 0.0 || d[2] != 0.0) lens |= 1 << sk.side_map[j];
+            }
+        }
+        for (int st = 0; st < 2; ++st) {
+            int n = 0;
+            for (int i = 0; i < 68; ++i) S.inv_act[st][i] = -1;
+            for (int c = 0; c < 3; ++c) { S.act[st][n] = c; S.colkind[st][n] = 0; S.cola[st][n] = 0; S.colc[st][n] = c; ++n; }
+            for (int a = 0; a < 18; ++a)
+                if ((moved >> a) & 1)
+                    for (int c = 0; c < 3 && n < NA; ++c) {
+                        S.act[st][n] = 3 + 3 * a + c; S.colkind[st][n] = 1; S.cola[st][n] = a; S.colc[st][n] = c; ++n;
+                    }
+            if (st == 1)
+                for (int s = 0; s < n_side && n < NA; ++s)
+                    if ((lens >> s) & 1) { S.act[st][n] = 57 + s; S.colkind[st][n] = 2; S.cola[st][n] = s; S.colc[st][n] = 0; ++n; }
+            S.na[st] = n;
+            for (int i = 0; i < n; ++i) S.inv_act[st][S.act[st][i]] = i;
+        }
+        int nv = 0;
+        for (int v = 0; v < V && nv < VMAX; ++v) nv += members[(size_t)b * V + v] >= 0;
+        S.nviews = nv;
+    }
+    __syncthreads();
+    const int nv = S.nviews;
+    double* info = info_out ? info_out + (size_t)b * 8 : nullptr;
+    if (nv < 1) {
+        const double nan = __longlong_as_double(0x7ff8000000000000LL);
+        for (int i = tid; i < 68; i += NT) params_out[(size_t)b * 68 + i] = nan;
+        for (int i = tid; i < 54; i += NT) joints_out[(size_t)b * 54 + i] = nan;
+        if (info && tid < 8) info[tid] = nan;
+        return;
+    }
+
+    // ---- gather observations: 17 COCO rows + synthetic mid-spine (inverse_kinematics.py:339-348) ----
+    double* pose18 = S.bufA;  // [nv][18][3] scratch
+    if (tid < nv) {
+        int seen = 0, q = -1;
+        for (int v = 0; v < V; ++v) {
+            const int m = members[(size_t)b * V + v];
+            if (m >= 0) { if (seen == tid) { q = m; break; } ++seen; }
+        }
+        const double* kp = kps17 + (size_t)q * 51;
+        double* dst = pose18 + tid * 54;
+        for (int e = 0; e < 51; ++e) dst[e] = kp[e];
+        // COCO: L_Shoulder 5, R_Shoulder 6, L_Hip 11, R_Hip 12
+        for (int c = 0; c < 2; ++c) {
+            const double mid_sh = 0.5 * (kp[5 * 3 + c] + kp[6 * 3 + c]);
+            const double mid_hip = 0.5 * (kp[11 * 3 + c] + kp[12 * 3 + c]);
+            dst[51 + c] = 0.5 * (mid_sh + mid_hip);
+        }
+        double sc = kp[5 * 3 + 2] * kp[6 * 3 + 2];
+        sc *= kp[11 * 3 + 2] * kp[12 * 3 + 2];
+        dst[53] = sc;
+        const double* Pc = Pmats + (size_t)((q / Pmax) % C) * 12;
+        for (int e = 0; e < 12; ++e) S.Pm[tid * 12 + e] = Pc[e];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < nv * NOBS * 3; idx += NT) {
+        const int v = idx / (NOBS * 3), r = idx - v * NOBS * 3, k = r / 3, c = r - k * 3;
+        S.obs[idx] = pose18[(v * 18 + kIkObs[k]) * 3 + c];
+    }
+    // ---- initial parameters ----
+    const bool is_cold = (cold == nullptr) || cold[b] != 0;
+    if (is_cold) {
+        // root = midpoint of the triangulated hips; zero angles; reference lengths (:390-396)
+        if (tid < 2) dlt_obs_point(pose18, S.Pm, nv, 11 + tid, 0.01, &S.xn[tid * 3]);
+        for (int i = tid; i < 54; i += NT) S.x[3 + i] = 0.0;
+        if (tid < n_side) { S.side[tid] = sk.ref_side[tid]; S.x[57 + tid] = sk.ref_side[tid]; }
+        __syncthreads();
+        if (tid < 3) S.x[tid] = 0.5 * (S.xn[tid] + S.xn[3 + tid]);
+    } else {
+        const double* p0 = init + (size_t)b * 68;
+        for (int i = tid; i < 57 + n_side; i += NT) S.x[i] = p0[i];
+        if (tid < n_side) S.side[tid] = p0[57 + tid];
+    }
+    __syncthreads();
+
+    const int max_nfev = is_cold ? nfev_cold : nfev_warm;
+    double cost1, cost2;
+    int nf1, nj1, st1, nf2, nj2, st2;
+    ik_trf(S, sk, 0, max_nfev, &cost1, &nf1, &nj1, &st1);
+    __syncthreads();
+    ik_trf(S, sk, 1, max_nfev, &cost2, &nf2, &nj2, &st2);
+    __syncthreads();
+    // final FK at the solution
+    ik_eval(S, sk, S.x, 1, false);
+    __syncthreads();
+    for (int i = tid; i < 57 + n_side; i += NT) params_out[(size_t)b * 68 + i] = S.x[i];
+    for (int i = tid; i < 54; i += NT) joints_out[(size_t)b * 54 + i] = S.pos[i];
+    if (info && tid == 0) {
+        info[0] = cost1; info[1] = nf1; info[2] = st1; info[3] = cost2; info[4] = nf2; info[5] = st2;
+        info[6] = nj1; info[7] = nj2;
+    }
+}
+
+}  // namespace
+
+extern "C" int mvmc_ik_solve(const mvmcSkeleton* skel_host, const double* kps17, const double* Pmats,
+                             const int32_t* members, int n_problems, int v_max, int n_views, int p_max,
+                             const double* init_params, const uint8_t* cold, int max_nfev_cold, int max_nfev_warm,
+                             double* params_out, double* joints_out, double* info_out, mvmcStream_t stream) {
+    if (!skel_host || !kps17 || !Pmats || !members || !params_out || !joints_out) return MVMC_ERR_ARG;
+    if (v_max <= 0 || n_views <= 0 || p_max <= 0 || max_nfev_cold < 1 || max_nfev_warm < 1) return MVMC_ERR_ARG;
+    if (cold && !init_params) return MVMC_ERR_ARG;
+    if (n_problems <= 0) return n_problems == 0 ? MVMC_OK : MVMC_ERR_ARG;
+    SkelDev sk;
+    if (!skel_to_dev(skel_host, &sk)) return MVMC_ERR_ARG;
+    if (sk.n_side != MVMC_N_SIDE) return MVMC_ERR_UNSUPPORTED;  // the solver is sized for 57 + 11 parameters
+    hipLaunchKernelGGL(ik_kernel, dim3(n_problems), dim3(NT), 0, (hipStream_t)stream, sk, kps17, Pmats, members,
+                       n_problems, v_max, n_views, p_max, init_params, init_params ? cold : nullptr, max_nfev_cold,
+                       max_nfev_warm, params_out, joints_out, info_out);
+    MVMC_CHECK_LAUNCH();
+    return MVMC_OK;
 }

@@ -63,8 +63,11 @@ def skeleton_arrays():
     return dirs, lens[SKEL_SIDE_JOINTS].copy()
 
 
-def make_skeleton(bone_dirs=None, parents=None, side_map=None, n_side=11) -> MvmcSkeleton:
+def make_skeleton(bone_dirs=None, parents=None, side_map=None, n_side=11, ref_side_lens=None) -> MvmcSkeleton:
     sk = MvmcSkeleton()
+    rl = skeleton_arrays()[1] if ref_side_lens is None else np.asarray(ref_side_lens, np.float64)
+    for k in range(18):
+        sk.ref_side_lens[k] = float(rl[k]) if k < len(rl) else 0.0
     bd = skeleton_arrays()[0] if bone_dirs is None else np.asarray(bone_dirs, np.float64)
     pa = SKEL_PARENTS if parents is None else np.asarray(parents, np.int32)
     sm = SKEL_SIDE_MAP if side_map is None else np.asarray(side_map, np.int32)

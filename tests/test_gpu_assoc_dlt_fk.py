@@ -118,7 +118,7 @@ def test_members_and_dlt(dev, shelf):
     _, S = dev.affinity(shelf["kps17"], shelf["cnt"], torch.from_numpy(F_o).to(d), want_D=False)
     P = shelf["kps17"].shape[2]
     res = dev.als_associate(S, shelf["cnt"], g_max=P)
-    K_MAX, V_MAX = 12, 8
+    K_MAX, V_MAX = 12, 40  # V_MAX = C*P: a (wrong) cluster may hold every node
     mem, nm = dev.cluster_members(res["labels"], shelf["cnt"], P, K_MAX, V_MAX)
     pts3d = dev.dlt(shelf["kps17"], torch.from_numpy(shelf["P"]).to(d), mem.reshape(-1, V_MAX)).cpu().numpy()
     pts3d = pts3d.reshape(len(FRAMES), K_MAX, 17, 4)
