@@ -1,0 +1,181 @@
+"""Benchmark of the hot path (BASELINE.json metric): frames/s for association + triangulation + IK
+on synthetic (F frames x C views x P people x 25 joints) keypoints, one process per GPU.
+
+    python bench.py [--gpus N --steps K --warmup W] [--frames F --views C --people P --workload full]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the whole hot path over this rank's F frames (inputs resident in HBM before
+the timed region).  Frames shard across ranks (weak scaling: F per GPU is fixed); each step ends
+with one RCCL all-gather of the per-frame results.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_FRAME = lambda C, P, J=25: 12 * C * P * J + 4 * C * P + 16 * P * J + 488 * P
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+FP64_PEAK_TFLOPS = 78.6  # vector fp64
+
+
+def cpu_baseline(data, n_frames, max_nfev):
+    """Oracle (NumPy/SciPy restatement of the reference, 1 thread) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_np as o
+    kps25, K, Rt, P = data["kps25"].astype(np.float64), data["K"], data["Rt"], data["P"]
+    C, Pn = kps25.shape[1:3]
+    t0 = time.perf_counter()
+    Fm = o.pairwise_f_mats(K, Rt)
+    n_solved = 0
+    for f in range(n_frames):
+        pts, poses, cam, dim = [], [], [], [0]
+        for c in range(C):
+            k = 0
+            for p in range(Pn):
+                k17 = o.openpose25_to_coco17(kps25[f, c, p])
+                if o.pose_is_good(k17):
+                    pts.append(k17[:, :2]); poses.append(k17); cam.append(c); k += 1
+            dim.append(dim[-1] + k)
+        D, S = o.geometry_affinity(np.array(pts), Fm, dim)
+        mm, _ = o.match_als(S, dim)
+        lab = o.cluster_labels(mm, len(pts))
+        for k in range(lab.max() + 1):
+            nodes = np.nonzero(lab == k)[0]
+            if len(nodes) < 2:
+                continue
+            o.triangulate_groups(P[[cam[i] for i in nodes]], [poses[i] for i in nodes], 0.01, False)
+            # PoseSolver.solve() cold start (DLT + 2 TRF stages)
+            o.pose_solver_solve([poses[i] for i in nodes], [P[cam[i]] for i in nodes], None)
+            n_solved += 1
+    dt = time.perf_counter() - t0
+    return dict(value=n_frames / dt, unit="frames/s", cores=1, kind="port",
+                sample=f"{n_frames} frame(s) of the same synthetic workload ({n_solved} cold IK solves), "
+                       f"oracle/oracle_np.py (NumPy + SciPy least_squares), {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=10000, help="frames per GPU")
+    ap.add_argument("--views", type=int, default=5)
+    ap.add_argument("--people", type=int, default=4)
+    ap.add_argument("--workload", default="full", choices=["full", "assoc_dlt"])
+    ap.add_argument("--nfev-cold", type=int, default=50)
+    ap.add_argument("--cpu-frames", type=int, default=1, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--seed", type=int, default=20260103)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    d = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=d)
+
+    from multiview_motion_capture_amd import synth
+    from multiview_motion_capture_amd.pipeline import HotPath
+    from multiview_motion_capture_amd.parallel import gather_results
+
+    F, C, Pn = args.frames, args.views, args.people
+    # same cameras on every rank (seed), a different frame shard per rank (frame_seed)
+    data = synth.generate(F, C, Pn, args.seed, frame_seed=args.seed + 1000 * rank)
+    hp = HotPath(data["K"], data["Rt"], device=d)
+    kps = torch.from_numpy(data["kps25"]).to(d)
+    counts = torch.from_numpy(data["counts"]).to(d)
+    with_ik = args.workload == "full"
+
+    ev = {k: [] for k in ("assoc", "tri", "ik")}
+
+    def step(timed):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
+        if timed: e[0].record()
+        assoc = hp.associate(kps, counts)
+        if timed: e[1].record()
+        tri = hp.triangulate(assoc)
+        if timed: e[2].record()
+        out = dict(labels=assoc["labels"], pts3d=tri["pts3d"])
+        if with_ik:
+            out.update(hp.solve_cold(assoc, tri, args.nfev_cold))
+        if timed: e[3].record()
+        if world > 1:
+            out = gather_results(out, world)
+        if timed:
+            ev["assoc"].append((e[0], e[1])); ev["tri"].append((e[1], e[2])); ev["ik"].append((e[2], e[3]))
+        return out
+
+    for _ in range(args.warmup):
+        step(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=d)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    stage_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
+    if rank == 0:
+        frames_total = F * world * args.steps
+        value = frames_total / dt
+        bpf = BYTES_PER_FRAME(C, Pn)
+        dom = "ik" if with_ik else "assoc"
+        dom_ms = stage_ms[dom]
+        achieved = bpf * F / (dom_ms * 1e-3) / 1e9
+        info = out.get("info")
+        extra = {}
+        if with_ik and world == 1:
+            inf = info.reshape(-1, 8)
+            ok = ~torch.isnan(inf[:, 0])
+            extra = dict(ik_solves_per_step=int(ok.sum()), mean_nfev=float((inf[ok, 1] + inf[ok, 4]).mean()),
+                         mean_njev=float(inf[ok, 6].mean()), mean_jacobi_sweeps=float(inf[ok, 7].mean()))
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tp):
+            rec = json.load(open(tp))
+            key = f"{dom}:{F}x{C}x{Pn}"
+            traffic = rec.get(key)
+        res = {
+            "metric": "frames/s (assoc+triangulate+IK) at C=5,P=4,J=25" if with_ik else "frames/s (assoc+triangulate)",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"synthetic {F} frames/GPU, C={C}, P={Pn}, J=25: affinity+ALS+DLT" +
+                                   ("+IK, every frame cold-started (chain length 1, max_nfev 50+50)" if with_ik else ""),
+                       "frames_per_gpu": F, "views": C, "people": Pn, "seed": args.seed, "parallelism": f"frames x{world}",
+                       **extra},
+            "stages_ms": stage_ms,
+            "roofline": {"bound": "hbm", "kernel": "ik_kernel" if with_ik else "als_kernel",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "bytes_per_frame": bpf,
+                         "note": "path is fp64-ALU/latency bound, not HBM bound (SURVEY.md F6); see DESIGN.md"},
+        }
+        if args.cpu_frames > 0 and world == 1:
+            res["cpu_baseline"] = cpu_baseline(data, args.cpu_frames, args.nfev_cold)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -127,7 +127,7 @@ int mvmc_fk(const mvmcSkeleton* skel_host, const double* params, int n_problems,
  *   cold         (B) u8: 1 = cold start (DLT root, zero angles, reference lengths, max_nfev_cold),
  *                0 = warm (max_nfev_warm); NULL = all cold
  *   params_out   (B,68); joints_out (B,18,3); info_out (B,8) f64 =
- *                {cost1, nfev1, status1, cost2, nfev2, status2, njev1, njev2} or NULL */
+ *                {cost1, nfev1, status1, cost2, nfev2, status2, njev1+njev2, Jacobi sweeps} or NULL */
 int mvmc_ik_solve(const mvmcSkeleton* skel_host, const double* kps17, const double* Pmats,
                   const int32_t* members, int n_problems, int v_max, int n_views, int p_max,
                   const double* init_params, const uint8_t* cold, int max_nfev_cold, int max_nfev_warm,

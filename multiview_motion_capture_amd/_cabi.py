@@ -9,7 +9,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmvmc_hip.so")
+_LIB_PATH = os.environ.get("MVMC_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                                                           "libmvmc_hip.so")
 _lib = None
 
 MVMC_OK = 0

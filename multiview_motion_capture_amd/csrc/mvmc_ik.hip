@@ -17,6 +17,14 @@
 
 namespace {
 
+#ifdef MVMC_IK_PROFILE
+#define PROF_T0 const long long _t0 = clock64();
+#define PROF_ADD(S, k) if (threadIdx.x == 0) (S).prof[k] += clock64() - _t0;
+#else
+#define PROF_T0
+#define PROF_ADD(S, k)
+#endif
+
 constexpr int NT = 256;    // threads per problem
 constexpr int NA = 50;     // max active parameters (even)
 constexpr int LD = 51;     // odd leading dimension: conflict-free column walks on 8-byte elements
@@ -28,8 +36,9 @@ __device__ __constant__ const int kIkSkel[NOBS] = {1, 2, 3, 4, 5, 6, 7, 9, 10, 1
 __device__ __constant__ const int kIkObs[NOBS] = {11, 13, 15, 12, 14, 16, 17, 5, 7, 9, 6, 8, 10, 0, 3, 4};
 
 struct IkShared {
-    double bufA[NA * LD];  // D (48 x LD)  | eigenvectors V (NA x LD)
+    double bufA[NA * LD];  // D (48 x LD)  | T = (J^T J) V for the basis change
     double bufB[NA * LD];  // per-(view,joint) scratch | Y = W D (48 x LD) | J^T J -> diag(L) (NA x LD)
+    double bufC[NA * LD];  // eigenvector basis V, kept across the iterations of a solve (warm-started Jacobi)
     double x[68], xn[68];
     double side[18];       // side bone lengths used by stage 1 (fixed)
     double g[NA], lam[NA], suf[NA], cv[NA], step[NA];
@@ -43,6 +52,20 @@ struct IkShared {
     int colkind[2][NA], cola[2][NA], colc[2][NA];
     int anc[18], depth[18], maxdepth, nviews;
     int pp[NA / 2], qq[NA / 2];
+    // skeleton tables (copied from the kernel argument once: dynamic indexing of by-value kernel
+    // arguments costs SGPR spills and scratch)
+    double dirs[18 * 3], ref_side[18];
+    int parents[18], side_map[18], n_side;
+#ifdef MVMC_IK_PROFILE
+    long long prof[4];
+#endif
+};
+
+struct SkelRef {  // what the solver routines see
+    const double (*dirs)[3];
+    const int* parents;
+    const int* side_map;
+    int n_side;
 };
 
 __device__ inline double block_sum256(double v, double* red) {
@@ -56,7 +79,7 @@ __device__ inline double block_sum256(double v, double* red) {
 // ---------------------------------------------------------------------------------------------
 // FK + residual (+ per-joint normal-equation blocks when want_jac).  Returns the cost 0.5*|f|^2.
 // ---------------------------------------------------------------------------------------------
-__device__ double ik_eval(IkShared& S, const SkelDev& sk, const double* xs, int stage, bool want_jac) {
+__device__ double ik_eval(IkShared& S, const SkelRef& sk, const double* xs, int stage, bool want_jac) {
     const int tid = threadIdx.x;
     if (tid < 18) {
         euler_to_rot(xs + 3 + 3 * tid, &S.Rl[tid * 9]);
@@ -125,9 +148,9 @@ __device__ double ik_eval(IkShared& S, const SkelDev& sk, const double* xs, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Jacobian blocks -> J^T J (into bufB), g = J^T f, V = I (into bufA).  Needs ik_eval(want_jac) state.
+// Jacobian blocks -> J^T J (into bufB), g = J^T f.  Needs ik_eval(want_jac) state.
 // ---------------------------------------------------------------------------------------------
-__device__ void ik_normal_equations(IkShared& S, const SkelDev& sk, const double* xs, int stage) {
+__device__ void ik_normal_equations(IkShared& S, const SkelRef& sk, const double* xs, int stage) {
     const int tid = threadIdx.x;
     const int na = S.na[stage], nap = (na + 1) & ~1;
     // per-joint blocks: W_k = sum_v s^2 (du du^T + dv dv^T), t_k = sum_v s (du fu + dv fv)
@@ -218,39 +241,104 @@ __device__ void ik_normal_equations(IkShared& S, const SkelDev& sk, const double
         if (idx < nap * nap) {
             const int i = idx / nap, j = idx - i * nap;
             S.bufB[i * LD + j] = acc[t];
-            S.bufA[i * LD + j] = (i == j) ? 1.0 : 0.0;
         }
     }
     __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------
-// Parallel cyclic Jacobi (round-robin pairs): bufB -> diag(lam), bufA -> eigenvectors (columns).
+// Symmetric eigensolver of the trust-region step
 // ---------------------------------------------------------------------------------------------
-__device__ void ik_eigh(IkShared& S, int nap) {
+// out (bufA) = M1 * M2 or M1^T * M2 on nap x nap LDS matrices, 1 x 5 register tiles
+template <bool TRANS1>
+__device__ inline void ik_matmul(const double* M1, const double* M2, double* out, int nap) {
+    const int jb = nap / 5;  // nap is 40 or 50
+    for (int tile = threadIdx.x; tile < nap * jb; tile += NT) {
+        const int i = tile / jb, j0 = (tile - i * jb) * 5;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+        for (int k = 0; k < nap; ++k) {
+            const double m = TRANS1 ? M1[k * LD + i] : M1[i * LD + k];
+            const double* r = &M2[k * LD + j0];
+            a0 += m * r[0]; a1 += m * r[1]; a2 += m * r[2]; a3 += m * r[3]; a4 += m * r[4];
+        }
+        double* o = &out[i * LD + j0];
+        o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4;
+    }
+}
+
+// Parallel cyclic Jacobi (round-robin pairs).  On entry bufB = J^T J and bufC = an orthonormal basis V0
+// (identity, or the eigenvectors of the previous iterate's J^T J); the matrix is first moved into that
+// basis (A' = V0^T A V0, nearly diagonal when J changed little), then rotated to diag(lam) while the
+// rotations accumulate into bufC, which ends as the eigenvector matrix (columns).
+__device__ int ik_eigh(IkShared& S, int nap, bool have_basis) {
     const int tid = threadIdx.x;
     double* A = S.bufB;
-    double* V = S.bufA;
+    double* V = S.bufC;
+    if (have_basis && (nap % 5) == 0) {
+        ik_matmul<false>(S.bufB, S.bufC, S.bufA, nap);  // T = A V0
+        __syncthreads();
+        ik_matmul<true>(S.bufC, S.bufA, S.bufB, nap);   // A' = V0^T T
+        __syncthreads();
+    } else {
+        for (int idx = tid; idx < nap * LD; idx += NT) {
+            const int i = idx / LD, j = idx - i * LD;
+            V[idx] = (i == j) ? 1.0 : 0.0;
+        }
+        __syncthreads();
+    }
     const int half = nap / 2;
+    // Work items (fixed for the whole call, so no integer division inside the sweeps):
+    //   A: one 2x2 block per pair-of-pairs (i <= j): B' = L_i B R_j, mirrored into (j, i) -- the
+    //      two-sided update in ONE pass over the upper block triangle
+    //   V: one row of one column pair: V <- V J
+    constexpr int HM = NA / 2;
+    constexpr int IBK = (HM * (HM + 1) / 2 + NT - 1) / NT;
+    constexpr int IV = (HM * NA + NT - 1) / NT;
+    short bi[IBK], bj[IBK], vi[IV], vr[IV];
+#pragma unroll
+    for (int t = 0; t < IBK; ++t) {
+        int idx = t * NT + tid;
+        bi[t] = -1; bj[t] = 0;
+        if (idx < half * (half + 1) / 2) {
+            int i = 0;
+            while (idx >= half - i) { idx -= half - i; ++i; }
+            bi[t] = (short)i; bj[t] = (short)(i + idx);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < IV; ++t) {
+        const int idx = t * NT + tid;
+        if (idx < half * nap) { vi[t] = (short)(idx / nap); vr[t] = (short)(idx % nap); }
+        else { vi[t] = -1; vr[t] = 0; }
+    }
+    int sweeps = 0;
     for (int sweep = 0; sweep < 30; ++sweep) {
         double off = 0.0, dg = 0.0;
-        for (int idx = tid; idx < nap * nap; idx += NT) {
-            const int i = idx / nap, j = idx - i * nap;
-            const double a = A[i * LD + j];
-            if (i == j) dg += a * a; else off += a * a;
+        for (int idx = tid; idx < nap * LD; idx += NT) {
+            const int i = idx / LD, j = idx - i * LD;
+            if (j < nap) {
+                const double a = A[idx];
+                if (i == j) dg += a * a; else off += a * a;
+            }
         }
         off = block_sum256(off, S.red);
         dg = block_sum256(dg, S.red);
-        if (off <= 1e-30 * (dg + off) || off == 0.0) break;
+        // off-diagonal mass below (1e-14 |A|_F)^2: eigenvalues are converged to ~1e-14 lambda_max
+        if (off <= 1e-28 * (dg + off)) break;
+        ++sweeps;
+        const double tiny = 1e-17 * sqrt(dg + off);  // entries below this are rounding noise of the null space
         for (int s = 0; s < nap - 1; ++s) {
             if (tid < half) {
                 int p, q;
                 if (tid == 0) { p = nap - 1; q = s; }
-                else { p = (s + tid) % (nap - 1); q = (s - tid + (nap - 1)) % (nap - 1); }
+                else {
+                    p = s + tid; if (p >= nap - 1) p -= nap - 1;
+                    q = s - tid; if (q < 0) q += nap - 1;
+                }
                 if (p > q) { const int t = p; p = q; q = t; }
                 const double apq = A[p * LD + q], app = A[p * LD + p], aqq = A[q * LD + q];
                 double c = 1.0, sn = 0.0;
-                if (fabs(apq) > 1e-300 && fabs(apq) > 1e-19 * sqrt(fabs(app * aqq))) {
+                if (fabs(apq) > tiny) {
                     const double theta = (aqq - app) / (2.0 * apq);
                     const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                     c = 1.0 / sqrt(t * t + 1.0);
@@ -259,30 +347,50 @@ __device__ void ik_eigh(IkShared& S, int nap) {
                 S.rc[tid] = c; S.rs[tid] = sn; S.pp[tid] = p; S.qq[tid] = q;
             }
             __syncthreads();
-            // A <- A J and V <- V J (column pairs)
-            for (int idx = tid; idx < 2 * half * nap; idx += NT) {
-                const int m = idx / (half * nap), rem = idx - m * half * nap;
-                const int i = rem / nap, r = rem - i * nap;
-                double* M = m ? V : A;
-                const double c = S.rc[i], sn = S.rs[i];
-                const int p = S.pp[i], q = S.qq[i];
-                const double a = M[r * LD + p], b = M[r * LD + q];
-                M[r * LD + p] = c * a - sn * b;
-                M[r * LD + q] = sn * a + c * b;
+            // all loads first, then all stores (LDS stores would otherwise serialise the items)
+            double b00[IBK], b01[IBK], b10[IBK], b11[IBK], ci[IBK], si[IBK], cj[IBK], sj[IBK];
+            int pi_[IBK], qi_[IBK], pj_[IBK], qj_[IBK];
+#pragma unroll
+            for (int t = 0; t < IBK; ++t) {
+                const int i = bi[t] < 0 ? 0 : bi[t], j = bj[t];
+                ci[t] = S.rc[i]; si[t] = S.rs[i]; cj[t] = S.rc[j]; sj[t] = S.rs[j];
+                pi_[t] = S.pp[i]; qi_[t] = S.qq[i]; pj_[t] = S.pp[j]; qj_[t] = S.qq[j];
+                b00[t] = A[pi_[t] * LD + pj_[t]]; b01[t] = A[pi_[t] * LD + qj_[t]];
+                b10[t] = A[qi_[t] * LD + pj_[t]]; b11[t] = A[qi_[t] * LD + qj_[t]];
             }
-            __syncthreads();
-            // A <- J^T A (row pairs)
-            for (int idx = tid; idx < half * nap; idx += NT) {
-                const int i = idx / nap, k = idx - i * nap;
-                const double c = S.rc[i], sn = S.rs[i];
-                const int p = S.pp[i], q = S.qq[i];
-                const double a = A[p * LD + k], b = A[q * LD + k];
-                A[p * LD + k] = c * a - sn * b;
-                A[q * LD + k] = sn * a + c * b;
+            double va[IV], vb[IV], vc[IV], vs[IV];
+            int ia[IV], ib[IV];
+#pragma unroll
+            for (int t = 0; t < IV; ++t) {
+                const int i = vi[t] < 0 ? 0 : vi[t];
+                vc[t] = S.rc[i]; vs[t] = S.rs[i];
+                ia[t] = vr[t] * LD + S.pp[i]; ib[t] = vr[t] * LD + S.qq[i];
+                va[t] = V[ia[t]]; vb[t] = V[ib[t]];
+            }
+#pragma unroll
+            for (int t = 0; t < IBK; ++t) {
+                if (bi[t] < 0) continue;
+                const double t00 = cj[t] * b00[t] - sj[t] * b01[t], t01 = sj[t] * b00[t] + cj[t] * b01[t];
+                const double t10 = cj[t] * b10[t] - sj[t] * b11[t], t11 = sj[t] * b10[t] + cj[t] * b11[t];
+                const double n00 = ci[t] * t00 - si[t] * t10, n01 = ci[t] * t01 - si[t] * t11;
+                const double n10 = si[t] * t00 + ci[t] * t10, n11 = si[t] * t01 + ci[t] * t11;
+                A[pi_[t] * LD + pj_[t]] = n00; A[pi_[t] * LD + qj_[t]] = n01;
+                A[qi_[t] * LD + pj_[t]] = n10; A[qi_[t] * LD + qj_[t]] = n11;
+                if (bi[t] != bj[t]) {  // mirror: block (j, i) = block (i, j)^T
+                    A[pj_[t] * LD + pi_[t]] = n00; A[qj_[t] * LD + pi_[t]] = n01;
+                    A[pj_[t] * LD + qi_[t]] = n10; A[qj_[t] * LD + qi_[t]] = n11;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < IV; ++t) {
+                if (vi[t] < 0) continue;
+                V[ia[t]] = vc[t] * va[t] - vs[t] * vb[t];
+                V[ib[t]] = vs[t] * va[t] + vc[t] * vb[t];
             }
             __syncthreads();
         }
     }
+    return sweeps;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -323,16 +431,18 @@ __device__ double ik_tr_solve(IkShared& S, int nap, double Delta, double alpha0,
 // ---------------------------------------------------------------------------------------------
 // trf_no_bounds (trf.py:401-560) with x_scale = 1, linear loss, ftol = xtol = gtol = 1e-8.
 // ---------------------------------------------------------------------------------------------
-__device__ void ik_trf(IkShared& S, const SkelDev& sk, int stage, int max_nfev, double* cost_out, int* nfev_out,
-                       int* njev_out, int* status_out) {
+__device__ void ik_trf(IkShared& S, const SkelRef& sk, int stage, int max_nfev, double* cost_out, int* nfev_out,
+                       int* njev_out, int* status_out, int* sweeps_out, bool basis_in, bool* basis_out) {
     const int tid = threadIdx.x;
     const int nfull = (stage == 0) ? 57 : 57 + sk.n_side;
     const int na = S.na[stage], nap = (na + 1) & ~1;
     const double ftol = 1e-8, xtol = 1e-8, gtol = 1e-8;
 
-    double cost = ik_eval(S, sk, S.x, stage, true);
-    ik_normal_equations(S, sk, S.x, stage);
+    double cost;
+    { PROF_T0 cost = ik_eval(S, sk, S.x, stage, true); PROF_ADD(S, 0) }
+    { PROF_T0 ik_normal_equations(S, sk, S.x, stage); PROF_ADD(S, 1) }
     int nfev = 1, njev = 1, status = -1;
+    bool have_basis = basis_in;
     double xx = (tid < nfull) ? S.x[tid] * S.x[tid] : 0.0;
     double Delta = sqrt(block_sum256(xx, S.red));
     if (Delta == 0.0) Delta = 1.0;
@@ -349,12 +459,13 @@ __device__ void ik_trf(IkShared& S, const SkelDev& sk, int stage, int max_nfev, 
         if (S.sc[0] < gtol) status = 1;
         if (status != -1 || nfev == max_nfev) break;
 
-        ik_eigh(S, nap);
+        { PROF_T0 *sweeps_out += ik_eigh(S, nap, have_basis); PROF_ADD(S, 2) }
+        have_basis = true;
         if (tid < nap) {
             const double l = S.bufB[tid * LD + tid];
             S.lam[tid] = l > 0.0 ? l : 0.0;
             double a = 0.0;
-            for (int i = 0; i < nap; ++i) a += S.bufA[i * LD + tid] * S.g[i];
+            for (int i = 0; i < nap; ++i) a += S.bufC[i * LD + tid] * S.g[i];
             S.suf[tid] = a;
         }
         __syncthreads();
@@ -371,7 +482,7 @@ __device__ void ik_trf(IkShared& S, const SkelDev& sk, int stage, int max_nfev, 
             const double pred = S.sc[2];
             if (tid < nap) {
                 double a = 0.0;
-                for (int j = 0; j < nap; ++j) a += S.bufA[tid * LD + j] * S.cv[j];
+                for (int j = 0; j < nap; ++j) a += S.bufC[tid * LD + j] * S.cv[j];
                 S.step[tid] = a;
             }
             __syncthreads();
@@ -384,7 +495,7 @@ __device__ void ik_trf(IkShared& S, const SkelDev& sk, int stage, int max_nfev, 
                 S.xn[tid] = S.x[tid] + (ia >= 0 ? S.step[ia] : 0.0);
             }
             __syncthreads();
-            cost_new = ik_eval(S, sk, S.xn, stage, true);
+            { PROF_T0 cost_new = ik_eval(S, sk, S.xn, stage, true); PROF_ADD(S, 0) }
             ++nfev;
             if (!isfinite(cost_new)) { Delta = 0.25 * step_norm; continue; }
             actual = cost - cost_new;
@@ -411,7 +522,7 @@ __device__ void ik_trf(IkShared& S, const SkelDev& sk, int stage, int max_nfev, 
             cost = cost_new;
             if (status == -1 && nfev < max_nfev) {
                 // the accepted point's FK / residual blocks are still in LDS (last ik_eval was at xn)
-                ik_normal_equations(S, sk, S.x, stage);
+                { PROF_T0 ik_normal_equations(S, sk, S.x, stage); PROF_ADD(S, 1) }
                 ++njev;
             }
         } else if (status == -1 && nfev < max_nfev) {
@@ -420,6 +531,7 @@ __device__ void ik_trf(IkShared& S, const SkelDev& sk, int stage, int max_nfev, 
     }
     if (status == -1) status = 0;
     *cost_out = cost; *nfev_out = nfev; *njev_out = njev; *status_out = status;
+    *basis_out = have_basis;
 }
 
 // 4x4 symmetric Jacobi for the cold-start DLT of one joint (same scheme as mvmc_geom.hip)
@@ -468,14 +580,26 @@ __device__ void dlt_obs_point(const double* pose18 /*[V][18][3]*/, const double*
     X[0] = e[0] / e[3]; X[1] = e[1] / e[3]; X[2] = e[2] / e[3];
 }
 
-__global__ void __launch_bounds__(NT)
-ik_kernel(SkelDev sk, const double* __restrict__ kps17, const double* __restrict__ Pmats,
+__global__ void __launch_bounds__(NT, 2)
+ik_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restrict__ Pmats,
           const int32_t* __restrict__ members, int B, int V, int C, int Pmax, const double* __restrict__ init,
           const uint8_t* __restrict__ cold, int nfev_cold, int nfev_warm, double* __restrict__ params_out,
           double* __restrict__ joints_out, double* __restrict__ info_out) {
     __shared__ IkShared S;
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int n_side = sk.n_side;
+    const int n_side = skarg.n_side;
+    if (tid < 18) {
+        for (int k = 0; k < 3; ++k) S.dirs[tid * 3 + k] = skarg.dirs[tid][k];
+        S.parents[tid] = skarg.parents[tid];
+        S.side_map[tid] = skarg.side_map[tid];
+        S.ref_side[tid] = skarg.ref_side[tid];
+    }
+    __syncthreads();
+    SkelRef sk;
+    sk.dirs = reinterpret_cast<const double(*)[3]>(S.dirs);
+    sk.parents = S.parents;
+    sk.side_map = S.side_map;
+    sk.n_side = n_side;
 
     // ---- static tables: depth, ancestor masks, active columns of both stages ----
     if (tid == 0) {
@@ -518,7 +642,7 @@ ik_kernel(SkelDev sk, const double* __restrict__ kps17, const double* __restrict
     __syncthreads();
     const int nv = S.nviews;
     double* info = info_out ? info_out + (size_t)b * 8 : nullptr;
-    if (nv < 1) {
+    if (nv < 2) {  // the reference only solves clusters with >= 2 views (motion_capture.py:927,940)
         const double nan = __longlong_as_double(0x7ff8000000000000LL);
         for (int i = tid; i < 68; i += NT) params_out[(size_t)b * 68 + i] = nan;
         for (int i = tid; i < 54; i += NT) joints_out[(size_t)b * 54 + i] = nan;
@@ -560,7 +684,7 @@ ik_kernel(SkelDev sk, const double* __restrict__ kps17, const double* __restrict
         // root = midpoint of the triangulated hips; zero angles; reference lengths (:390-396)
         if (tid < 2) dlt_obs_point(pose18, S.Pm, nv, 11 + tid, 0.01, &S.xn[tid * 3]);
         for (int i = tid; i < 54; i += NT) S.x[3 + i] = 0.0;
-        if (tid < n_side) { S.side[tid] = sk.ref_side[tid]; S.x[57 + tid] = sk.ref_side[tid]; }
+        if (tid < n_side) { S.side[tid] = S.ref_side[tid]; S.x[57 + tid] = S.ref_side[tid]; }
         __syncthreads();
         if (tid < 3) S.x[tid] = 0.5 * (S.xn[tid] + S.xn[3 + tid]);
     } else {
@@ -571,11 +695,27 @@ ik_kernel(SkelDev sk, const double* __restrict__ kps17, const double* __restrict
     __syncthreads();
 
     const int max_nfev = is_cold ? nfev_cold : nfev_warm;
-    double cost1, cost2;
-    int nf1, nj1, st1, nf2, nj2, st2;
-    ik_trf(S, sk, 0, max_nfev, &cost1, &nf1, &nj1, &st1);
+#ifdef MVMC_IK_PROFILE
+    if (tid < 4) S.prof[tid] = 0;
+    const long long t_all = clock64();
     __syncthreads();
-    ik_trf(S, sk, 1, max_nfev, &cost2, &nf2, &nj2, &st2);
+#endif
+    double cost1, cost2;
+    int nf1, nj1, st1, nf2, nj2, st2, sweeps = 0;
+    bool basis = false;
+    ik_trf(S, sk, 0, max_nfev, &cost1, &nf1, &nj1, &st1, &sweeps, false, &basis);
+    __syncthreads();
+    if (basis) {
+        // stage 2 appends the bone-length columns to stage 1's active set: embed the stage-1
+        // eigenvectors as [[V1, 0], [0, I]]
+        const int n1 = (S.na[0] + 1) & ~1, n2 = (S.na[1] + 1) & ~1;
+        for (int idx = tid; idx < n2 * LD; idx += NT) {
+            const int i = idx / LD, j = idx - i * LD;
+            if (i >= n1 || j >= n1) S.bufC[idx] = (i == j) ? 1.0 : 0.0;
+        }
+        __syncthreads();
+    }
+    ik_trf(S, sk, 1, max_nfev, &cost2, &nf2, &nj2, &st2, &sweeps, basis, &basis);
     __syncthreads();
     // final FK at the solution
     ik_eval(S, sk, S.x, 1, false);
@@ -584,7 +724,12 @@ ik_kernel(SkelDev sk, const double* __restrict__ kps17, const double* __restrict
     for (int i = tid; i < 54; i += NT) joints_out[(size_t)b * 54 + i] = S.pos[i];
     if (info && tid == 0) {
         info[0] = cost1; info[1] = nf1; info[2] = st1; info[3] = cost2; info[4] = nf2; info[5] = st2;
-        info[6] = nj1; info[7] = nj2;
+        info[6] = nj1 + nj2; info[7] = sweeps;
+#ifdef MVMC_IK_PROFILE
+        // diagnostic build only: cycle shares instead of the costs
+        info[0] = (double)S.prof[0]; info[3] = (double)S.prof[1]; info[2] = (double)S.prof[2];
+        info[5] = (double)(clock64() - t_all);
+#endif
     }
 }
 

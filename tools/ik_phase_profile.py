@@ -1,0 +1,35 @@
+"""Diagnostic: cycle shares of the IK kernel's phases (needs the -DMVMC_IK_PROFILE build:
+MVMC_LIB_PATH=multiview_motion_capture_amd/lib/libmvmc_prof.so python tools/ik_phase_profile.py).
+Shares only -- the instrumented build's run time is not quoted anywhere."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multiview_motion_capture_amd import synth  # noqa: E402
+from multiview_motion_capture_amd.pipeline import HotPath  # noqa: E402
+
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+data = synth.generate(F, 5, 4, 20260103)
+hp = HotPath(data["K"], data["Rt"])
+kps = torch.from_numpy(data["kps25"]).cuda()
+cnt = torch.from_numpy(data["counts"]).cuda()
+assoc = hp.associate(kps, cnt)
+tri = hp.triangulate(assoc)
+out = hp.solve_cold(assoc, tri)
+torch.cuda.synchronize()
+inf = out["info"].reshape(-1, 8).cpu().numpy()
+ok = ~np.isnan(inf[:, 1])
+inf = inf[ok]
+tot = inf[:, 5].sum()
+print("solves", len(inf), "mean nfev", (inf[:, 1] + inf[:, 4]).mean(), "njev", inf[:, 6].mean(), "sweeps", inf[:, 7].mean())
+print("cycles per solve (mean): total %.0f  eval %.0f  normal-eq %.0f  eigh %.0f" %
+      (inf[:, 5].mean(), inf[:, 0].mean(), inf[:, 3].mean(), inf[:, 2].mean()))
+print("shares: eval %.3f normal-eq %.3f eigh %.3f other %.3f" %
+      (inf[:, 0].sum() / tot, inf[:, 3].sum() / tot, inf[:, 2].sum() / tot,
+       1 - (inf[:, 0].sum() + inf[:, 3].sum() + inf[:, 2].sum()) / tot))
+print("cycles per eval %.0f ; per normal-eq %.0f ; per sweep %.0f ; per jacobi step %.0f" %
+      (inf[:, 0].sum() / (inf[:, 1] + inf[:, 4]).sum(), inf[:, 3].sum() / inf[:, 6].sum(),
+       inf[:, 2].sum() / inf[:, 7].sum(), inf[:, 2].sum() / inf[:, 7].sum() / 49))
