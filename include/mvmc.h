@@ -100,6 +100,12 @@ int mvmc_als_associate(const void* W, int w_dtype, const int32_t* group_counts, 
                        int n_max, int g_max, const double* seed_table, int seed_len, uint8_t* x_bin, uint8_t* match_mat,
                        int32_t* labels, int32_t* n_clusters, int32_t* iters, mvmcStream_t stream);
 
+/* AS-5 + AS-6 alone: transform_closure (mv_association.py:99-121) and the cluster rule of
+ * parse_match_result (motion_capture.py:419-425) on a caller-supplied binary matrix.
+ *   x_bin (F,N,N) u8, n_nodes (F) i32 -> match_mat (F,N,N) u8 (may be NULL), labels (F,N), n_clusters (F) */
+int mvmc_closure_labels(const uint8_t* x_bin, const int32_t* n_nodes, int n_frames, int n_max, uint8_t* match_mat,
+                        int32_t* labels, int32_t* n_clusters, mvmcStream_t stream);
+
 /* Turns labels into member lists: members (F,K,V) pose index q (ascending node order, -1 padded),
  * n_members (F,K).  Clusters beyond K or members beyond V are dropped (n_members still counts them). */
 int mvmc_cluster_members(const int32_t* labels, const int32_t* counts, int n_frames, int n_views, int p_max,
@@ -107,10 +113,11 @@ int mvmc_cluster_members(const int32_t* labels, const int32_t* counts, int n_fra
 
 /* TR-1 + TR-2: triangulate_point_groups_from_multiple_views_linear(post_optimize=False)
  * (mv_math_util.py:152-187, :215-240).  One problem = one member list.
- *   kps17   (n_poses,17,3) f64; Pmats (C,3,4) f64; members (B,V) pose indices (-1 = unused slot)
- *   out     (B,17,4) f64: x, y, z, mean score of the views used; problems with < 1 member give NaN */
-int mvmc_dlt(const double* kps17, const double* Pmats, const int32_t* members, int n_problems, int v_max,
-             int n_views, int p_max, double min_score, double* out, mvmcStream_t stream);
+ *   kps     (n_poses,J,3) f64 (J = n_joints; 17 on the batched path, 18 with the synthetic mid-spine);
+ *   Pmats (C,3,4) f64; members (B,V) pose indices (-1 = unused slot)
+ *   out     (B,J,4) f64: x, y, z, mean score of the views used; problems with < 1 member give NaN */
+int mvmc_dlt(const double* kps, const double* Pmats, const int32_t* members, int n_problems, int v_max,
+             int n_views, int p_max, int n_joints, double min_score, double* out, mvmcStream_t stream);
 
 /* FK-1 + FK-2: foward_kinematics (inverse_kinematics.py:176-199) with Quaternions.from_euler /
  * transforms (Quaternions.py:449-462, :335-366).

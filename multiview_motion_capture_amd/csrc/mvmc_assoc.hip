@@ -518,6 +518,66 @@ als_kernel(const TW* __restrict__ W, const int32_t* __restrict__ gcounts, int G,
 }
 
 // ------------------------------------------------------------------------------------------------
+// standalone closure + labelling (transform_closure, mv_association.py:99-121; the cluster rule of
+// parse_match_result, motion_capture.py:419-425) for callers that bring their own binary matrix
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+closure_kernel(const uint8_t* __restrict__ x_bin, const int32_t* __restrict__ n_nodes, int ld,
+               uint8_t* __restrict__ match_mat, int32_t* __restrict__ labels, int32_t* __restrict__ n_clusters) {
+    __shared__ uint8_t sT[MVMC_MAX_NODES * MVMC_MAX_NODES];
+    __shared__ uint8_t sO[MVMC_MAX_NODES * MVMC_MAX_NODES];
+    __shared__ uint8_t sVis[MVMC_MAX_NODES];
+    __shared__ int sKeep[MVMC_MAX_NODES];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    int n = n_nodes[f];
+    n = n < 0 ? 0 : (n > ld ? ld : n);
+    const uint8_t* xb = x_bin + (size_t)f * ld * ld;
+    for (int e = tid; e < n * n; e += 64) {
+        const int i = e / n, j = e - i * n;
+        sT[e] = (xb[i * ld + j] != 0) | ((xb[i * ld + (n - 1)] != 0) & (xb[(n - 1) * ld + j] != 0));
+        sO[e] = 0;
+    }
+    for (int i = tid; i < n; i += 64) sVis[i] = 0;
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+        const bool skip = sVis[i] != 0;
+        __syncthreads();
+        if (!skip)
+            for (int j = tid; j < n; j += 64)
+                if (sT[i * n + j]) { sVis[j] = 1; sO[j * n + i] = 1; }
+        __syncthreads();
+    }
+    for (int c = tid; c < n; c += 64) {
+        int s = 0;
+        for (int j = 0; j < n; ++j) s += sO[j * n + c];
+        sKeep[c] = s >= 2;
+    }
+    __syncthreads();
+    for (int row = tid; row < ld; row += 64) {
+        int label = -1;
+        if (row < n) {
+            int ord = 0;
+            for (int c = 0; c < n; ++c) {
+                if (!sKeep[c]) continue;
+                if (sO[row * n + c]) { label = ord; break; }
+                ++ord;
+            }
+        }
+        labels[(size_t)f * ld + row] = label;
+    }
+    if (tid == 0) {
+        int k = 0;
+        for (int c = 0; c < n; ++c) k += sKeep[c];
+        n_clusters[f] = k;
+    }
+    if (match_mat)
+        for (int e = tid; e < ld * ld; e += 64) {
+            const int i = e / ld, j = e - i * ld;
+            match_mat[(size_t)f * ld * ld + e] = (i < n && j < n) ? sO[i * n + j] : 0;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // labels -> member lists
 // ------------------------------------------------------------------------------------------------
 __global__ void members_kernel(const int32_t* __restrict__ labels, const int32_t* __restrict__ counts, int F, int C,
@@ -632,6 +692,16 @@ extern "C" int mvmc_cluster_members(const int32_t* labels, const int32_t* counts
     if (n_frames <= 0) return n_frames == 0 ? MVMC_OK : MVMC_ERR_ARG;
     hipLaunchKernelGGL(members_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, (hipStream_t)stream, labels, counts,
                        n_frames, n_views, p_max, k_max, v_max, members, n_members);
+    MVMC_CHECK_LAUNCH();
+    return MVMC_OK;
+}
+
+extern "C" int mvmc_closure_labels(const uint8_t* x_bin, const int32_t* n_nodes, int n_frames, int n_max,
+                                   uint8_t* match_mat, int32_t* labels, int32_t* n_clusters, mvmcStream_t stream) {
+    if (!x_bin || !n_nodes || !labels || !n_clusters || n_max <= 0 || n_max > MVMC_MAX_NODES) return MVMC_ERR_ARG;
+    if (n_frames <= 0) return n_frames == 0 ? MVMC_OK : MVMC_ERR_ARG;
+    hipLaunchKernelGGL(closure_kernel, dim3(n_frames), dim3(64), 0, (hipStream_t)stream, x_bin, n_nodes, n_max,
+                       match_mat, labels, n_clusters);
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;
 }

@@ -35,17 +35,18 @@ __device__ __forceinline__ void jacobi_rot4(double (&a)[4][4], double (&v)[4][4]
 
 __global__ void __launch_bounds__(256)
 dlt_kernel(const double* __restrict__ kps17, const double* __restrict__ Pm, const int32_t* __restrict__ members,
-           int B, int V, int C, int Pmax, double min_score, double* __restrict__ out) {
+           int B, int V, int C, int Pmax, int J, double min_score, double* __restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * 17) return;
-    const int b = idx / 17, j = idx - b * 17;
+    if (idx >= B * J) return;
+    const int b = idx / J, j = idx - b * J;
+    const int ps = J * 3;  // pose stride
     const int32_t* mem = members + (size_t)b * V;
     int n_all = 0, n_ok = 0;
     for (int v = 0; v < V; ++v) {
         const int q = mem[v];
         if (q < 0) continue;
         ++n_all;
-        if (kps17[(size_t)q * 51 + j * 3 + 2] >= min_score) ++n_ok;
+        if (kps17[(size_t)q * ps + j * 3 + 2] >= min_score) ++n_ok;
     }
     double* o = out + (size_t)idx * 4;
     if (n_all == 0) {
@@ -64,7 +65,7 @@ dlt_kernel(const double* __restrict__ kps17, const double* __restrict__ Pm, cons
     for (int v = 0; v < V; ++v) {
         const int q = mem[v];
         if (q < 0) continue;
-        const double* kp = kps17 + (size_t)q * 51 + j * 3;
+        const double* kp = kps17 + (size_t)q * ps + j * 3;
         const double x = kp[0], y = kp[1], sc = kp[2];
         if (!use_all && !(sc >= min_score)) continue;
         const double* Pc = Pm + (size_t)((q / Pmax) % C) * 12;
@@ -151,12 +152,14 @@ fk_kernel(SkelDev sk, const double* __restrict__ params, int B, double* __restri
 // C ABI
 // ------------------------------------------------------------------------------------------------
 extern "C" int mvmc_dlt(const double* kps17, const double* Pmats, const int32_t* members, int n_problems,
-                        int v_max, int n_views, int p_max, double min_score, double* out, mvmcStream_t stream) {
-    if (!kps17 || !Pmats || !members || !out || v_max <= 0 || n_views <= 0 || p_max <= 0) return MVMC_ERR_ARG;
+                        int v_max, int n_views, int p_max, int n_joints, double min_score, double* out,
+                        mvmcStream_t stream) {
+    if (!kps17 || !Pmats || !members || !out || v_max <= 0 || n_views <= 0 || p_max <= 0 || n_joints <= 0)
+        return MVMC_ERR_ARG;
     if (n_problems <= 0) return n_problems == 0 ? MVMC_OK : MVMC_ERR_ARG;
-    const int total = n_problems * 17;
+    const int total = n_problems * n_joints;
     hipLaunchKernelGGL(dlt_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, kps17, Pmats, members,
-                       n_problems, v_max, n_views, p_max, min_score, out);
+                       n_problems, v_max, n_views, p_max, n_joints, min_score, out);
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;
 }

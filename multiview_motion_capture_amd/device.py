@@ -158,6 +158,19 @@ def als_associate(W: torch.Tensor, group_counts: torch.Tensor, g_max: int, want_
     return dict(labels=labels, n_clusters=ncl, iters=iters, x_bin=xb, match_mat=mm)
 
 
+def closure_labels(x_bin: torch.Tensor, n_nodes: torch.Tensor, want_mat=True):
+    """AS-5/AS-6 alone.  x_bin (F,N,N) u8, n_nodes (F) i32 -> (match_mat (F,N,N) u8 | None, labels (F,N), n_clusters (F))."""
+    F, N, _ = x_bin.shape
+    _req(x_bin, torch.uint8, "x_bin", (F, N, N))
+    _req(n_nodes, torch.int32, "n_nodes", (F,))
+    mm = torch.empty((F, N, N), dtype=torch.uint8, device=x_bin.device) if want_mat else None
+    labels = torch.empty((F, N), dtype=torch.int32, device=x_bin.device)
+    ncl = torch.empty((F,), dtype=torch.int32, device=x_bin.device)
+    check(_cabi.load().mvmc_closure_labels(_p(x_bin), _p(n_nodes), F, N, _p(mm), _p(labels), _p(ncl), _stream()),
+          "mvmc_closure_labels")
+    return mm, labels, ncl
+
+
 def cluster_members(labels: torch.Tensor, counts: torch.Tensor, p_max: int, k_max: int, v_max: int):
     """labels (F,N), counts (F,C) -> members (F,K,V) pose indices (-1 padded), n_members (F,K)."""
     F, Cn = counts.shape
@@ -170,18 +183,18 @@ def cluster_members(labels: torch.Tensor, counts: torch.Tensor, p_max: int, k_ma
     return mem, nm
 
 
-def dlt(kps17: torch.Tensor, Pmats: torch.Tensor, members: torch.Tensor, min_score=0.01) -> torch.Tensor:
-    """TR-1/TR-2.  kps17 (F,C,P,17,3); Pmats (C,3,4); members (B,V) pose indices -> (B,17,4)."""
-    F, Cn, P = kps17.shape[:3]
-    _req(kps17, torch.float64, "kps17", (F, Cn, P, 17, 3))
+def dlt(kps: torch.Tensor, Pmats: torch.Tensor, members: torch.Tensor, min_score=0.01) -> torch.Tensor:
+    """TR-1/TR-2.  kps (F,C,P,J,3); Pmats (C,3,4); members (...,V) pose indices -> (...,J,4)."""
+    F, Cn, P, J = kps.shape[:4]
+    _req(kps, torch.float64, "kps", (F, Cn, P, J, 3))
     _req(Pmats, torch.float64, "Pmats", (Cn, 3, 4))
     _req(members, torch.int32, "members")
     mem = members.reshape(-1, members.shape[-1])
     B, V = mem.shape
-    out = torch.empty((B, 17, 4), dtype=torch.float64, device=kps17.device)
-    check(_cabi.load().mvmc_dlt(_p(kps17), _p(Pmats), _p(mem), B, V, Cn, P, float(min_score), _p(out), _stream()),
+    out = torch.empty((B, J, 4), dtype=torch.float64, device=kps.device)
+    check(_cabi.load().mvmc_dlt(_p(kps), _p(Pmats), _p(mem), B, V, Cn, P, J, float(min_score), _p(out), _stream()),
           "mvmc_dlt")
-    return out.reshape(members.shape[:-1] + (17, 4))
+    return out.reshape(members.shape[:-1] + (J, 4))
 
 
 def fk(params: torch.Tensor, skeleton: Optional[MvmcSkeleton] = None, want_G=False):

@@ -1,0 +1,99 @@
+"""GPU parity through the reference-named Python call surface: the same calls
+motion_capture.py makes, compared against golden vectors captured from the reference."""
+import numpy as np
+import pytest
+
+import oracle_np as o
+from conftest import SPATIAL_FRAMES, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    import multiview_motion_capture_amd.common as common
+    import multiview_motion_capture_amd.inverse_kinematics as ik
+    import multiview_motion_capture_amd.motion_capture as mc
+    import multiview_motion_capture_amd.mv_association as assoc
+    import multiview_motion_capture_amd.mv_math_util as mu
+    import multiview_motion_capture_amd.pose_def as pose_def
+    si = load_golden("shelf_inputs.npz")
+    calibs = [common.Calib.from_k_rt(si["K"][c], si["Rt"][c], (1032, 776)) for c in range(5)]
+    return dict(common=common, ik=ik, mc=mc, assoc=assoc, mu=mu, pose_def=pose_def, calibs=calibs, si=si)
+
+
+def _frames(api, fi):
+    pd, common, mc, si = api["pose_def"], api["common"], api["mc"], api["si"]
+    frames = []
+    for c in range(5):
+        poses = {}
+        for p in range(int(si["counts"][fi, c])):
+            coco = pd.conversion_openpose_25_to_coco(si["kps25"][fi, c, p])
+            poses[p] = pd.Pose(pd.KpsFormat.COCO, coco[:, :2], coco[:, 2:], None)
+        frames.append(mc.filter_bad_pose(common.FrameData(fi, poses, api["calibs"][c], c + 1), 0.01, 4, 5))
+    return frames
+
+
+@pytest.mark.parametrize("fi", SPATIAL_FRAMES)
+def test_match_spatial_call_chain(api, fi):
+    g = load_golden("shelf_spatial.npz")
+    mu, assoc, mc = api["mu"], api["assoc"], api["mc"]
+    frames = _frames(api, fi)
+    pts = np.array([frm.poses[k].keypoints for frm in frames for k in frm.poses])
+    assert np.array_equal(pts, g[f"f{fi}_points"])
+    dim = g[f"f{fi}_dim"].tolist()
+    F = mu.calc_pairwise_f_mats(api["calibs"])
+    assert F.dtype == np.float32 and F.shape == (5, 5, 3, 3)
+    D, S = mu.geometry_affinity(pts, g[f"f{fi}_F"], dim)
+    assert np.array_equal(D, g[f"f{fi}_D"])
+    assert np.abs(S.astype(np.float64) - g[f"f{fi}_S"]).max() < 1e-6
+    mm, xb = assoc.match_als(g[f"f{fi}_S"], dim)
+    assert np.array_equal(xb, g[f"f{fi}_x_bin"])
+    assert np.array_equal(mm.astype(np.uint8), g[f"f{fi}_match_mat"])
+    assert np.array_equal(assoc.transform_closure(g[f"f{fi}_x_bin"]).astype(np.uint8), g[f"f{fi}_match_mat"])
+    clusters = mc.parse_match_result(mm, len(mm), dim)
+    assert len(clusters) == int(g[f"f{fi}_n_clusters"])
+    for ci, cl in enumerate(clusters):
+        assert np.array_equal(np.array(cl), g[f"f{fi}_cl{ci}"])
+    # whole chain, own F and S
+    st = mc.match_spatial(frames)
+    assert len(st.spatial_matches) == len(clusters)
+    for m, cl in zip(st.spatial_matches, clusters):
+        assert m.view_idxs == [c for c, _, _ in cl]
+    # triangulation of every cluster
+    for ci, cl in enumerate(clusters):
+        if len(cl) < 2:
+            continue
+        projs = [api["calibs"][c].P for c, _, _ in cl]
+        grps = [np.concatenate([g[f"f{fi}_points"][gi], g[f"f{fi}_scores"][gi]], axis=1) for _, _, gi in cl]
+        out = mu.triangulate_point_groups_from_multiple_views_linear(np.array(projs), grps, 0.01, False)
+        ref = g[f"f{fi}_cl{ci}_dlt"]
+        seen = np.array([sum(gr[j, 2] >= 0.01 for gr in grps) >= 2 for j in range(17)])
+        rel = np.linalg.norm(out[seen, :3] - ref[seen, :3], axis=1) / np.linalg.norm(ref[seen, :3], axis=1)
+        assert rel.max() < 1e-4 and np.allclose(out[:, 3], ref[:, 3], rtol=1e-14)
+
+
+def test_pose_solver_and_fk(api):
+    ik, pd = api["ik"], api["pose_def"]
+    g = load_golden("ik_cases.npz")
+    skel = ik.load_skeleton()
+    cold = [i for i in np.nonzero(g["cold"])[0] if g["n_views"][i] >= 3 and g["s2_status"][i] > 0][:2]
+    for i in cold:
+        v = int(g["n_views"][i])
+        solver = ik.PoseSolver(skel, None, list(g["poses"][i, :v]), list(g["projs"][i, :v]), cam_calibs=None,
+                               obs_kps_format=pd.KpsFormat.COCO)
+        param, pose = solver.solve()
+        assert pose.pose_type == pd.KpsFormat.BASIC_18 and pose.keypoints.shape == (18, 3)
+        assert abs(solver.last_info[3] - g["s2_cost"][i]) / g["s2_cost"][i] < 1e-4
+        pos, G = ik.foward_kinematics(skel, param)
+        assert np.abs(pos - pose.keypoints).max() < 1e-12
+        ref_pos, ref_G = o.forward_kinematics(param.root, param.euler_angles, param.bone_lens)
+        assert np.abs(pos - ref_pos).max() < 1e-12 and np.abs(G - ref_G).max() < 1e-12
+    i = int(np.nonzero(~g["cold"])[0][0])
+    v = int(g["n_views"][i])
+    init = ik.PoseShapeParam(g["init_root"][i], g["init_euler"][i], g["init_blens"][i])
+    param, pose = ik.PoseSolver(skel, init, list(g["poses"][i, :v]), list(g["projs"][i, :v]),
+                                obs_kps_format=pd.KpsFormat.COCO).solve()
+    assert np.isfinite(pose.keypoints).all() and param.bone_lens.shape == (11,)
+    with pytest.raises(ValueError):
+        ik.PoseSolver(skel, None, list(g["poses"][i, :1]), list(g["projs"][i, :1]), obs_kps_format=pd.KpsFormat.COCO)
