@@ -140,6 +140,43 @@ int mvmc_ik_solve(const mvmcSkeleton* skel_host, const double* kps17, const doub
                   const double* init_params, const uint8_t* cold, int max_nfev_cold, int max_nfev_warm,
                   double* params_out, double* joints_out, double* info_out, mvmcStream_t stream);
 
+/* ---- temporal layer: match_spatial_time + tracker, batched over independent chains (sub-sequences) ---- */
+
+/* AS-8 helper: get_fundamental_matrix(P_i, P_j) (mv_math_util.py:57-77) for every view pair.
+ * Pmats (C,3,4) f64 -> F2 (C,C,3,3) f64 with x_j^T F2[i][j] x_i = 0. */
+int mvmc_fmats_from_projections(const double* Pmats, int n_views, double* F2, mvmcStream_t stream);
+
+/* AS-7/8/9: node graph of match_spatial_time (motion_capture.py:651-756) for one frame of every chain.
+ * Nodes of chain b = its n_tracks[b] live tracklets (last FK joints), then the 2-D poses of frame
+ * frame_idx[b] by view.  2D-2D different views: calc_epipolar_error (mv_math_util.py:80-115, score product
+ * > 0.1); 2D-3D: reprojection_error (motion_capture.py:403-414); same view / 3D-3D: NaN -> nanmax + 1;
+ * S = 1/(1+exp(5 (D-15)/30)) clamped (S < 1e-3 -> 0).  Chains with n_tracks == 0 get an empty graph (they
+ * take the match_spatial path).
+ *   track_joints (B,T,18,3) f64; W (B,NS,NS) f64 out, NS = T + C*P; D (B,NS,NS) out or NULL;
+ *   group_counts (B,C+1) i32 out = {n_tracks, people per view} */
+int mvmc_st_affinity(const double* kps17, const int32_t* counts, const int32_t* frame_idx,
+                     const double* track_joints, const int32_t* n_tracks, const double* Pmats, const double* F2,
+                     int n_chains, int n_views, int p_max, int t_max, double* W, double* D, int32_t* group_counts,
+                     mvmcStream_t stream);
+
+/* TK-1, first half (motion_capture.py:763-808 and :618-626): cluster labels -> IK problems of the frame.
+ * Chains without tracklets read labels_sp (B,C*P) (match_spatial, every member kept); the others read
+ * labels_st (B,T+C*P) (tracklet-anchored clusters, one pose per view, first wins).
+ *   members (B,T+K,V) pose indices; cold (B,T+K) u8; init_params (B,T+K,68);
+ *   status (B,T) i32: 0 unmatched (dies), 1 one view (kept, not updated), 2 updated; n_new (B) new tracklets */
+int mvmc_track_assign(const int32_t* labels_sp, const int32_t* ncl_sp, const int32_t* labels_st,
+                      const int32_t* ncl_st, const int32_t* counts, const int32_t* frame_idx,
+                      const int32_t* n_tracks, const double* track_params, int n_chains, int n_views, int p_max,
+                      int t_max, int k_max, int v_max, int32_t* members, uint8_t* cold, double* init_params,
+                      int32_t* status, int32_t* n_new, mvmcStream_t stream);
+
+/* TK-1, second half (MvTracklet.update / mark_missed / __init__, motion_capture.py:352-391, :924-963):
+ * applies the frame's IK results to the tracklet table (order kept, survivors first, new ones appended).
+ *   meta (B,T,4) i32 = {id, state (1 tentative, 2 confirmed), hits, length}; n_inits = 3 in the reference */
+int mvmc_track_commit(const int32_t* status, const int32_t* n_new, const double* ik_params, const double* ik_joints,
+                      int n_chains, int t_max, int k_max, int n_inits, double* track_params, double* track_joints,
+                      int32_t* meta, int32_t* n_tracks, int32_t* next_id, int32_t* n_dead, mvmcStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

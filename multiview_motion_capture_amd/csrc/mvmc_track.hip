@@ -1,0 +1,339 @@
+// Temporal layer for gfx950: match_spatial_time's node graph (AS-7/8/9) and the tracker state machine
+// (TK-1) for a batch of independent chains (sub-sequences), one chain per workgroup / thread.
+//   fmats_p     get_fundamental_matrix(P_i, P_j) for every view pair        mv_math_util.py:57-77
+//   st_affinity distance / affinity of [tracklets | 2-D poses by view]       motion_capture.py:651-756
+//               2D-2D: calc_epipolar_error (mv_math_util.py:80-115), 2D-3D: reprojection_error (:403-414)
+//   assign      clusters -> IK problems (one pose per view, first wins)      motion_capture.py:763-808, :618-626
+//   commit      MvTracklet.update / mark_missed / new tracklets              motion_capture.py:352-391, :924-963
+#include "mvmc_common.h"
+
+namespace {
+
+// common joints BASIC_18 -> COCO used by reprojection_error (pose_def.py:278-288)
+__device__ __constant__ const int kRpSkel[15] = {1, 2, 3, 4, 5, 6, 9, 10, 11, 12, 13, 14, 15, 16, 17};
+__device__ __constant__ const int kRpCoco[15] = {11, 13, 15, 12, 14, 16, 5, 7, 9, 6, 8, 10, 0, 3, 4};
+
+__device__ inline double det4(const double* r0, const double* r1, const double* r2, const double* r3) {
+    // Laplace expansion along the first two rows
+    const double s0 = r0[0] * r1[1] - r0[1] * r1[0], s1 = r0[0] * r1[2] - r0[2] * r1[0];
+    const double s2 = r0[0] * r1[3] - r0[3] * r1[0], s3 = r0[1] * r1[2] - r0[2] * r1[1];
+    const double s4 = r0[1] * r1[3] - r0[3] * r1[1], s5 = r0[2] * r1[3] - r0[3] * r1[2];
+    const double c5 = r2[2] * r3[3] - r2[3] * r3[2], c4 = r2[1] * r3[3] - r2[3] * r3[1];
+    const double c3 = r2[1] * r3[2] - r2[2] * r3[1], c2 = r2[0] * r3[3] - r2[3] * r3[0];
+    const double c1 = r2[0] * r3[2] - r2[2] * r3[0], c0 = r2[0] * r3[1] - r2[1] * r3[0];
+    return s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+}
+
+// F[i][j] = det([X_j; Y_i]) with X, Y the row-pair stacks of P1, P2 (x2^T F x1 = 0)
+__global__ void fmats_p_kernel(const double* __restrict__ Pm, int C, double* __restrict__ F2) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= C * C) return;
+    const int a = idx / C, b = idx - a * C;
+    const double* P1 = Pm + a * 12;
+    const double* P2 = Pm + b * 12;
+    const int rp[3][2] = {{1, 2}, {2, 0}, {0, 1}};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            F2[idx * 9 + i * 3 + j] = det4(P1 + rp[j][0] * 4, P1 + rp[j][1] * 4, P2 + rp[i][0] * 4, P2 + rp[i][1] * 4);
+}
+
+// mean over valid joints of the symmetric point-to-epiline distance; NaN if none is valid
+__device__ __noinline__ double epipolar_error(const double* F, const double* k1, const double* k2, double min_score) {
+    double total = 0.0;
+    int cnt = 0;
+    for (int j = 0; j < 17; ++j) {
+        const double x1 = k1[j * 3], y1 = k1[j * 3 + 1], x2 = k2[j * 3], y2 = k2[j * 3 + 1];
+        if (!(k1[j * 3 + 2] * k2[j * 3 + 2] > min_score)) continue;
+        // image 1 -> line in image 2: l = F x1
+        double a = F[0] * x1 + F[1] * y1 + F[2], b = F[3] * x1 + F[4] * y1 + F[5], c = F[6] * x1 + F[7] * y1 + F[8];
+        double nu = a * a + b * b, sc = nu != 0.0 ? 1.0 / sqrt(nu) : 1.0;
+        a *= sc; b *= sc; c *= sc;
+        const double d1 = fabs(a * x2 + b * y2 + c) / sqrt(a * a + b * b);
+        // image 2 -> line in image 1: l = F^T x2
+        a = F[0] * x2 + F[3] * y2 + F[6]; b = F[1] * x2 + F[4] * y2 + F[7]; c = F[2] * x2 + F[5] * y2 + F[8];
+        nu = a * a + b * b; sc = nu != 0.0 ? 1.0 / sqrt(nu) : 1.0;
+        a *= sc; b *= sc; c *= sc;
+        const double d2 = fabs(a * x1 + b * y1 + c) / sqrt(a * a + b * b);
+        total = total + 0.5 * (d1 + d2);
+        ++cnt;
+    }
+    return cnt ? total / cnt : __longlong_as_double(0x7ff8000000000000LL);
+}
+
+__device__ __noinline__ double reproj_error(const double* joints, const double* k2, const double* P, double min_score) {
+    double total = 0.0;
+    int cnt = 0;
+    for (int m = 0; m < 15; ++m) {
+        const double* X = joints + kRpSkel[m] * 3;
+        const double* kp = k2 + kRpCoco[m] * 3;
+        if (!(kp[2] > min_score)) continue;  // 3-D scores are ones
+        const double h0 = P[0] * X[0] + P[1] * X[1] + P[2] * X[2] + P[3];
+        const double h1 = P[4] * X[0] + P[5] * X[1] + P[6] * X[2] + P[7];
+        const double h2 = P[8] * X[0] + P[9] * X[1] + P[10] * X[2] + P[11];
+        const double du = h0 / (1e-5 + h2) - kp[0], dv = h1 / (1e-5 + h2) - kp[1];
+        total += sqrt(du * du + dv * dv);
+        ++cnt;
+    }
+    return cnt ? total / cnt : __longlong_as_double(0x7ff8000000000000LL);
+}
+
+__global__ void __launch_bounds__(64)
+st_affinity_kernel(const double* __restrict__ kps17, const int32_t* __restrict__ counts,
+                   const int32_t* __restrict__ frame_idx, const double* __restrict__ track_joints,
+                   const int32_t* __restrict__ n_tracks, const double* __restrict__ Pm, const double* __restrict__ F2,
+                   int C, int P, int T, double* __restrict__ W, double* __restrict__ Dout,
+                   int32_t* __restrict__ group_counts) {
+    extern __shared__ double sm[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int NS = T + C * P;
+    double* D = sm;                       // [NS*NS]
+    int* nview = reinterpret_cast<int*>(D + NS * NS);  // node -> view (-1 = tracklet)
+    int* nidx = nview + NS;               // node -> tracklet slot or local pose index c*P+p
+    __shared__ int s_n;
+    __shared__ double s_max;
+    const int f = frame_idx[b];
+    int nt = n_tracks[b];
+    nt = nt < 0 ? 0 : (nt > T ? T : nt);
+    if (tid == 0) {
+        int n = 0;
+        for (int t = 0; t < nt; ++t) { nview[n] = -1; nidx[n] = t; ++n; }
+        group_counts[b * (C + 1)] = nt;
+        for (int c = 0; c < C; ++c) {
+            int cnt = counts[f * C + c];
+            cnt = cnt < 0 ? 0 : (cnt > P ? P : cnt);
+            if (nt == 0) cnt = 0;  // chains without tracklets take the match_spatial path
+            group_counts[b * (C + 1) + 1 + c] = cnt;
+            for (int p = 0; p < cnt; ++p) { nview[n] = c; nidx[n] = c * P + p; ++n; }
+        }
+        s_n = n;
+    }
+    __syncthreads();
+    const int n = s_n;
+    const double* kf = kps17 + (size_t)f * C * P * 51;
+    const double* tj = track_joints + (size_t)b * T * 54;
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    for (int e = tid; e < n * n; e += 64) {
+        const int i = e / n, j = e - i * n;
+        double d;
+        if (i == j) d = 0.0;
+        else {
+            const int vi = nview[i], vj = nview[j];
+            if (vi >= 0 && vi == vj) d = nan;
+            else if (vi >= 0 && vj >= 0) d = epipolar_error(F2 + (vi * C + vj) * 9, kf + nidx[i] * 51, kf + nidx[j] * 51, 0.1);
+            else if (vi >= 0) d = reproj_error(tj + nidx[j] * 54, kf + nidx[i] * 51, Pm + vi * 12, 0.1);
+            else if (vj >= 0) d = reproj_error(tj + nidx[i] * 54, kf + nidx[j] * 51, Pm + vj * 12, 0.1);
+            else d = nan;
+        }
+        D[e] = d;
+    }
+    __syncthreads();
+    // nanmax, NaN -> max + 1 (motion_capture.py:744-745)
+    double m = -1e300;
+    for (int e = tid; e < n * n; e += 64) { const double d = D[e]; if (d == d && d > m) m = d; }
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+    if (tid == 0) s_max = m;
+    __syncthreads();
+    double* Wb = W + (size_t)b * NS * NS;
+    double* Db = Dout ? Dout + (size_t)b * NS * NS : nullptr;
+    for (int e = tid; e < NS * NS; e += 64) {
+        const int i = e / NS, j = e - i * NS;
+        double d = 0.0, s = 0.0;
+        if (i < n && j < n) {
+            d = D[i * n + j];
+            if (!(d == d)) d = s_max + 1.0;
+            s = 1.0 / (1.0 + exp(5.0 * ((d - 15.0) / 30.0)));
+            if (s < 1e-3) s = 0.0;
+            if (s > 1.0) s = 1.0;
+        }
+        Wb[e] = s;
+        if (Db) Db[e] = d;
+    }
+}
+
+// One thread per chain: cluster labels -> IK problem descriptors.
+//   slots [0,T): live tracklets (warm, init = their parameters) -- status 0 unmatched, 1 one view, 2 update
+//   slots [T,T+K): new tracklets from 2-D-only clusters with >= 2 views (cold)
+__global__ void assign_kernel(const int32_t* __restrict__ labels_sp, const int32_t* __restrict__ ncl_sp,
+                              const int32_t* __restrict__ labels_st, const int32_t* __restrict__ ncl_st,
+                              const int32_t* __restrict__ counts, const int32_t* __restrict__ frame_idx,
+                              const int32_t* __restrict__ n_tracks, const double* __restrict__ track_params, int B,
+                              int C, int P, int T, int K, int V, int32_t* __restrict__ members,
+                              uint8_t* __restrict__ cold, double* __restrict__ init, int32_t* __restrict__ status,
+                              int32_t* __restrict__ n_new) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int f = frame_idx[b];
+    int nt = n_tracks[b];
+    nt = nt < 0 ? 0 : (nt > T ? T : nt);
+    const int NP = T + K;
+    int32_t* mem = members + (size_t)b * NP * V;
+    for (int e = 0; e < NP * V; ++e) mem[e] = -1;
+    for (int s = 0; s < NP; ++s) cold[(size_t)b * NP + s] = s >= T;
+    for (int s = 0; s < T; ++s) {
+        status[(size_t)b * T + s] = 0;
+        const double* src = track_params + ((size_t)b * T + s) * 68;
+        double* dst = init + ((size_t)b * NP + s) * 68;
+        for (int e = 0; e < 68; ++e) dst[e] = s < nt ? src[e] : 0.0;
+    }
+    int cnt[16];
+    for (int c = 0; c < C && c < 16; ++c) {
+        int k = counts[f * C + c];
+        cnt[c] = k < 0 ? 0 : (k > P ? P : k);
+    }
+    int created = 0;
+    if (nt == 0) {
+        // match_spatial path: node order = 2-D poses by view; every member is kept (motion_capture.py:621-626)
+        const int32_t* lab = labels_sp + (size_t)b * C * P;
+        const int nc = ncl_sp[b];
+        for (int k = 0; k < nc; ++k) {
+            int m = 0, node = 0;
+            int32_t tmp[64];
+            for (int c = 0; c < C; ++c)
+                for (int p = 0; p < cnt[c]; ++p, ++node)
+                    if (lab[node] == k && m < 64) tmp[m++] = (f * C + c) * P + p;
+            if (m >= 2 && created < K) {
+                for (int v = 0; v < m && v < V; ++v) mem[(T + created) * V + v] = tmp[v];
+                ++created;
+            }
+        }
+    } else {
+        const int NS = T + C * P;
+        const int32_t* lab = labels_st + (size_t)b * NS;
+        const int nc = ncl_st[b];
+        for (int k = 0; k < nc; ++k) {
+            int tracklet = -1;
+            for (int t = 0; t < nt; ++t)
+                if (lab[t] == k) { tracklet = t; break; }
+            int m = 0, node = nt;
+            int32_t tmp[16];
+            for (int c = 0; c < C; ++c) {
+                bool used = false;
+                for (int p = 0; p < cnt[c]; ++p, ++node)
+                    if (lab[node] == k && !used && m < 16) { tmp[m++] = (f * C + c) * P + p; used = true; }
+            }
+            if (tracklet >= 0) {
+                if (m > 0) {
+                    status[(size_t)b * T + tracklet] = m >= 2 ? 2 : 1;
+                    if (m >= 2)
+                        for (int v = 0; v < m && v < V; ++v) mem[tracklet * V + v] = tmp[v];
+                }
+            } else if (m >= 2 && created < K) {
+                for (int v = 0; v < m && v < V; ++v) mem[(T + created) * V + v] = tmp[v];
+                ++created;
+            }
+        }
+    }
+    n_new[b] = created;
+}
+
+// One thread per chain: tracklet table after the frame's IK solves.
+// meta[b][slot] = {id, state (1 tentative, 2 confirmed), hits, length}
+__global__ void commit_kernel(const int32_t* __restrict__ status, const int32_t* __restrict__ n_new,
+                              const double* __restrict__ ik_params, const double* __restrict__ ik_joints, int B, int T,
+                              int K, int n_inits, double* __restrict__ track_params, double* __restrict__ track_joints,
+                              int32_t* __restrict__ meta, int32_t* __restrict__ n_tracks, int32_t* __restrict__ next_id,
+                              int32_t* __restrict__ n_dead) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int NP = T + K;
+    int nt = n_tracks[b];
+    nt = nt < 0 ? 0 : (nt > T ? T : nt);
+    double* tp = track_params + (size_t)b * T * 68;
+    double* tj = track_joints + (size_t)b * T * 54;
+    int32_t* mt = meta + (size_t)b * T * 4;
+    int w = 0, dead = 0;
+    for (int s = 0; s < nt; ++s) {
+        const int st = status[(size_t)b * T + s];
+        if (st == 0) { ++dead; continue; }  // mark_missed: max_age = 0, any miss kills
+        int id = mt[s * 4], state = mt[s * 4 + 1], hits = mt[s * 4 + 2], len = mt[s * 4 + 3];
+        const double* sp = tp + s * 68;
+        const double* sj = tj + s * 54;
+        if (st == 2) {
+            sp = ik_params + ((size_t)b * NP + s) * 68;
+            sj = ik_joints + ((size_t)b * NP + s) * 54;
+            ++hits; ++len;
+            if (state == 1 && hits >= n_inits) state = 2;
+        }
+        // compaction only moves entries to lower slots (w <= s), and slot s's IK result is read from the
+        // separate IK buffers, so the in-place copy is safe
+        for (int e = 0; e < 68; ++e) tp[w * 68 + e] = sp[e];
+        for (int e = 0; e < 54; ++e) tj[w * 54 + e] = sj[e];
+        mt[w * 4] = id; mt[w * 4 + 1] = state; mt[w * 4 + 2] = hits; mt[w * 4 + 3] = len;
+        ++w;
+    }
+    int id = next_id[b];
+    const int nn = n_new[b];
+    for (int k = 0; k < nn; ++k) {
+        if (w >= T) break;  // table full: the tracklet is dropped (sized so that this does not happen)
+        const double* sp = ik_params + ((size_t)b * NP + T + k) * 68;
+        const double* sj = ik_joints + ((size_t)b * NP + T + k) * 54;
+        for (int e = 0; e < 68; ++e) tp[w * 68 + e] = sp[e];
+        for (int e = 0; e < 54; ++e) tj[w * 54 + e] = sj[e];
+        mt[w * 4] = id++; mt[w * 4 + 1] = 1; mt[w * 4 + 2] = 1; mt[w * 4 + 3] = 1;
+        ++w;
+    }
+    next_id[b] = id;
+    n_tracks[b] = w;
+    n_dead[b] += dead;
+}
+
+}  // namespace
+
+extern "C" int mvmc_fmats_from_projections(const double* Pmats, int n_views, double* F2, mvmcStream_t stream) {
+    if (!Pmats || !F2 || n_views <= 0) return MVMC_ERR_ARG;
+    const int n = n_views * n_views;
+    hipLaunchKernelGGL(fmats_p_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, Pmats, n_views, F2);
+    MVMC_CHECK_LAUNCH();
+    return MVMC_OK;
+}
+
+extern "C" int mvmc_st_affinity(const double* kps17, const int32_t* counts, const int32_t* frame_idx,
+                                const double* track_joints, const int32_t* n_tracks, const double* Pmats,
+                                const double* F2, int n_chains, int n_views, int p_max, int t_max, double* W,
+                                double* D, int32_t* group_counts, mvmcStream_t stream) {
+    if (!kps17 || !counts || !frame_idx || !track_joints || !n_tracks || !Pmats || !F2 || !W || !group_counts)
+        return MVMC_ERR_ARG;
+    if (n_views <= 0 || p_max <= 0 || t_max <= 0) return MVMC_ERR_ARG;
+    const int NS = t_max + n_views * p_max;
+    if (NS > MVMC_MAX_NODES) return MVMC_ERR_UNSUPPORTED;
+    if (n_chains <= 0) return n_chains == 0 ? MVMC_OK : MVMC_ERR_ARG;
+    const size_t shm = (size_t)NS * NS * sizeof(double) + (size_t)2 * NS * sizeof(int);
+    hipLaunchKernelGGL(st_affinity_kernel, dim3(n_chains), dim3(64), shm, (hipStream_t)stream, kps17, counts, frame_idx,
+                       track_joints, n_tracks, Pmats, F2, n_views, p_max, t_max, W, D, group_counts);
+    MVMC_CHECK_LAUNCH();
+    return MVMC_OK;
+}
+
+extern "C" int mvmc_track_assign(const int32_t* labels_sp, const int32_t* ncl_sp, const int32_t* labels_st,
+                                 const int32_t* ncl_st, const int32_t* counts, const int32_t* frame_idx,
+                                 const int32_t* n_tracks, const double* track_params, int n_chains, int n_views,
+                                 int p_max, int t_max, int k_max, int v_max, int32_t* members, uint8_t* cold,
+                                 double* init_params, int32_t* status, int32_t* n_new, mvmcStream_t stream) {
+    if (!labels_sp || !ncl_sp || !labels_st || !ncl_st || !counts || !frame_idx || !n_tracks || !track_params ||
+        !members || !cold || !init_params || !status || !n_new)
+        return MVMC_ERR_ARG;
+    if (n_views <= 0 || n_views > 16 || p_max <= 0 || t_max <= 0 || k_max <= 0 || v_max <= 0) return MVMC_ERR_ARG;
+    if (n_views * p_max > MVMC_MAX_NODES) return MVMC_ERR_UNSUPPORTED;
+    if (n_chains <= 0) return n_chains == 0 ? MVMC_OK : MVMC_ERR_ARG;
+    hipLaunchKernelGGL(assign_kernel, dim3((n_chains + 63) / 64), dim3(64), 0, (hipStream_t)stream, labels_sp, ncl_sp,
+                       labels_st, ncl_st, counts, frame_idx, n_tracks, track_params, n_chains, n_views, p_max, t_max,
+                       k_max, v_max, members, cold, init_params, status, n_new);
+    MVMC_CHECK_LAUNCH();
+    return MVMC_OK;
+}
+
+extern "C" int mvmc_track_commit(const int32_t* status, const int32_t* n_new, const double* ik_params,
+                                 const double* ik_joints, int n_chains, int t_max, int k_max, int n_inits,
+                                 double* track_params, double* track_joints, int32_t* meta, int32_t* n_tracks,
+                                 int32_t* next_id, int32_t* n_dead, mvmcStream_t stream) {
+    if (!status || !n_new || !ik_params || !ik_joints || !track_params || !track_joints || !meta || !n_tracks ||
+        !next_id || !n_dead)
+        return MVMC_ERR_ARG;
+    if (t_max <= 0 || k_max <= 0) return MVMC_ERR_ARG;
+    if (n_chains <= 0) return n_chains == 0 ? MVMC_OK : MVMC_ERR_ARG;
+    hipLaunchKernelGGL(commit_kernel, dim3((n_chains + 63) / 64), dim3(64), 0, (hipStream_t)stream, status, n_new,
+                       ik_params, ik_joints, n_chains, t_max, k_max, n_inits, track_params, track_joints, meta,
+                       n_tracks, next_id, n_dead);
+    MVMC_CHECK_LAUNCH();
+    return MVMC_OK;
+}

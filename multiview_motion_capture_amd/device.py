@@ -233,3 +233,67 @@ def ik_solve(kps17: torch.Tensor, Pmats: torch.Tensor, members: torch.Tensor,
                                      int(max_nfev_warm), _p(params), _p(joints), _p(info), _stream()),
           "mvmc_ik_solve")
     return params, joints, info
+
+
+# ----------------------------------------------------------------------------
+# temporal layer (match_spatial_time + tracker), batched over chains
+# ----------------------------------------------------------------------------
+def fmats_from_projections(Pmats: torch.Tensor) -> torch.Tensor:
+    """AS-8 helper.  Pmats (C,3,4) f64 -> F2 (C,C,3,3) f64."""
+    Cn = Pmats.shape[0]
+    _req(Pmats, torch.float64, "Pmats", (Cn, 3, 4))
+    F2 = torch.empty((Cn, Cn, 3, 3), dtype=torch.float64, device=Pmats.device)
+    check(_cabi.load().mvmc_fmats_from_projections(_p(Pmats), Cn, _p(F2), _stream()), "mvmc_fmats_from_projections")
+    return F2
+
+
+def st_affinity(kps17, counts, frame_idx, track_joints, n_tracks, Pmats, F2, want_D=False):
+    """AS-7/8/9.  -> (W (B,NS,NS) f64, D | None, group_counts (B,C+1) i32)."""
+    F, Cn, P = kps17.shape[:3]
+    B, T = track_joints.shape[:2]
+    _req(kps17, torch.float64, "kps17", (F, Cn, P, 17, 3))
+    _req(counts, torch.int32, "counts", (F, Cn))
+    _req(frame_idx, torch.int32, "frame_idx", (B,))
+    _req(track_joints, torch.float64, "track_joints", (B, T, 18, 3))
+    _req(n_tracks, torch.int32, "n_tracks", (B,))
+    _req(Pmats, torch.float64, "Pmats", (Cn, 3, 4))
+    _req(F2, torch.float64, "F2", (Cn, Cn, 3, 3))
+    NS = T + Cn * P
+    W = torch.empty((B, NS, NS), dtype=torch.float64, device=kps17.device)
+    D = torch.empty((B, NS, NS), dtype=torch.float64, device=kps17.device) if want_D else None
+    gc = torch.empty((B, Cn + 1), dtype=torch.int32, device=kps17.device)
+    check(_cabi.load().mvmc_st_affinity(_p(kps17), _p(counts), _p(frame_idx), _p(track_joints), _p(n_tracks), _p(Pmats),
+                                        _p(F2), B, Cn, P, T, _p(W), _p(D), _p(gc), _stream()), "mvmc_st_affinity")
+    return W, D, gc
+
+
+def track_assign(labels_sp, ncl_sp, labels_st, ncl_st, counts, frame_idx, n_tracks, track_params, p_max, k_max, v_max):
+    """TK-1 first half -> members (B,T+K,V), cold (B,T+K), init (B,T+K,68), status (B,T), n_new (B)."""
+    B, T = track_params.shape[:2]
+    Cn = counts.shape[1]
+    dev_ = track_params.device
+    _req(labels_sp, torch.int32, "labels_sp", (B, Cn * p_max))
+    _req(labels_st, torch.int32, "labels_st", (B, T + Cn * p_max))
+    _req(track_params, torch.float64, "track_params", (B, T, 68))
+    NP = T + k_max
+    mem = torch.empty((B, NP, v_max), dtype=torch.int32, device=dev_)
+    cold = torch.empty((B, NP), dtype=torch.uint8, device=dev_)
+    init = torch.empty((B, NP, 68), dtype=torch.float64, device=dev_)
+    status = torch.empty((B, T), dtype=torch.int32, device=dev_)
+    n_new = torch.empty((B,), dtype=torch.int32, device=dev_)
+    check(_cabi.load().mvmc_track_assign(_p(labels_sp), _p(ncl_sp), _p(labels_st), _p(ncl_st), _p(counts), _p(frame_idx),
+                                         _p(n_tracks), _p(track_params), B, Cn, p_max, T, k_max, v_max, _p(mem), _p(cold),
+                                         _p(init), _p(status), _p(n_new), _stream()), "mvmc_track_assign")
+    return mem, cold, init, status, n_new
+
+
+def track_commit(status, n_new, ik_params, ik_joints, track_params, track_joints, meta, n_tracks, next_id, n_dead,
+                 k_max, n_inits=3):
+    """TK-1 second half: updates the tracklet table tensors in place."""
+    B, T = track_params.shape[:2]
+    _req(ik_params, torch.float64, "ik_params", (B, T + k_max, 68))
+    _req(ik_joints, torch.float64, "ik_joints", (B, T + k_max, 18, 3))
+    _req(meta, torch.int32, "meta", (B, T, 4))
+    check(_cabi.load().mvmc_track_commit(_p(status), _p(n_new), _p(ik_params), _p(ik_joints), B, T, k_max, n_inits,
+                                         _p(track_params), _p(track_joints), _p(meta), _p(n_tracks), _p(next_id),
+                                         _p(n_dead), _stream()), "mvmc_track_commit")

@@ -1,0 +1,89 @@
+"""Temporal hot path: MvTracker.update_4d (motion_capture.py:873-963) for a batch of independent
+chains (sub-sequences), every stage on the GPU and no host synchronisation inside a step.
+
+Per step and chain: live tracklets + the frame's 2-D poses -> match_spatial_time graph -> ALS ->
+tracklet-anchored clusters (warm IK from the previous parameters) and 2-D-only clusters (new tracklets,
+cold IK); chains without live tracklets take the match_spatial path, exactly as
+associate_tracking does (motion_capture.py:829-835).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import device as dev
+from .pipeline import HotPath
+
+
+class ChainTracker:
+    def __init__(self, hp: HotPath, n_chains: int, p_max: int, t_max: int = 8, k_max: Optional[int] = None,
+                 v_max: Optional[int] = None, nfev_cold=50, nfev_warm=5):
+        d = hp.device
+        self.hp, self.B, self.P, self.T = hp, n_chains, p_max, t_max
+        C = hp.K.shape[0]
+        self.C = C
+        self.K = k_max or p_max + 2
+        self.V = v_max or min(C + 1, 8)
+        self.nfev_cold, self.nfev_warm = nfev_cold, nfev_warm
+        self.F2 = dev.fmats_from_projections(hp.P)
+        B, T = n_chains, t_max
+        self.params = torch.zeros((B, T, 68), dtype=torch.float64, device=d)
+        self.joints = torch.zeros((B, T, 18, 3), dtype=torch.float64, device=d)
+        self.meta = torch.zeros((B, T, 4), dtype=torch.int32, device=d)
+        self.n_tracks = torch.zeros((B,), dtype=torch.int32, device=d)
+        self.next_id = torch.zeros((B,), dtype=torch.int32, device=d)
+        self.n_dead = torch.zeros((B,), dtype=torch.int32, device=d)
+        self.frame_idx = torch.arange(B, dtype=torch.int32, device=d)
+
+    def step(self, kps17: torch.Tensor, counts: torch.Tensor, want_debug=False):
+        """kps17 (B,C,P,17,3) f64 + counts (B,C) i32 of the current frame of every chain."""
+        B, C, P, T, K, V = self.B, self.C, self.P, self.T, self.K, self.V
+        hp = self.hp
+        has = (self.n_tracks > 0)
+        # chains without tracklets: match_spatial (f32 affinity); the others get zero people there
+        cnt_sp = torch.where(has[:, None], torch.zeros_like(counts), counts)
+        _, S = dev.affinity(kps17, cnt_sp, hp.F, want_D=False)
+        sp = dev.als_associate(S, cnt_sp, g_max=P)
+        # chains with tracklets: match_spatial_time graph
+        W, D, gc = dev.st_affinity(kps17, counts, self.frame_idx, self.joints, self.n_tracks, hp.P, self.F2,
+                                   want_D=want_debug)
+        st = dev.als_associate(W, gc, g_max=max(P, T), want_mats=want_debug)
+        mem, cold, init, status, n_new = dev.track_assign(sp["labels"], sp["n_clusters"], st["labels"],
+                                                          st["n_clusters"], counts, self.frame_idx, self.n_tracks,
+                                                          self.params, P, K, V)
+        NP = T + K
+        p, j, info = dev.ik_solve(kps17, hp.P, mem.reshape(B * NP, V), init.reshape(B * NP, 68),
+                                  cold.reshape(B * NP), self.nfev_cold, self.nfev_warm, hp.skeleton)
+        p, j = p.reshape(B, NP, 68), j.reshape(B, NP, 18, 3)
+        dev.track_commit(status, n_new, p, j, self.params, self.joints, self.meta, self.n_tracks, self.next_id,
+                         self.n_dead, K)
+        out = dict(members=mem, status=status, n_new=n_new, ik_params=p, ik_joints=j, ik_info=info.reshape(B, NP, 8))
+        if want_debug:
+            out.update(D=D, W=W, st=st, sp=sp, group_counts=gc)
+        return out
+
+
+def run_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], chain_len: int, t_max=8,
+               nfev_cold=50, nfev_warm=5):
+    """Whole shard: frames [c*L, (c+1)*L) form chain c (F must be a multiple of L).  Returns per-frame
+    tracklet tables: params (F,T,68), joints (F,T,18,3), meta (F,T,4), n_tracks (F)."""
+    F, C, P = kps.shape[:3]
+    L = chain_len
+    if F % L:
+        raise ValueError("run_chains: the frame count must be a multiple of the chain length")
+    B = F // L
+    kps17, cnt = dev.ingest(kps, counts)
+    k4 = kps17.view(B, L, C, P, 17, 3)
+    c4 = cnt.view(B, L, C)
+    tr = ChainTracker(hp, B, P, t_max, nfev_cold=nfev_cold, nfev_warm=nfev_warm)
+    d = kps.device
+    out_p = torch.empty((B, L, t_max, 68), dtype=torch.float64, device=d)
+    out_j = torch.empty((B, L, t_max, 18, 3), dtype=torch.float64, device=d)
+    out_m = torch.empty((B, L, t_max, 4), dtype=torch.int32, device=d)
+    out_n = torch.empty((B, L), dtype=torch.int32, device=d)
+    for t in range(L):
+        tr.step(k4[:, t].contiguous(), c4[:, t].contiguous())
+        out_p[:, t], out_j[:, t], out_m[:, t], out_n[:, t] = tr.params, tr.joints, tr.meta, tr.n_tracks
+    return dict(params=out_p.view(F, t_max, 68), joints=out_j.view(F, t_max, 18, 3), meta=out_m.view(F, t_max, 4),
+                n_tracks=out_n.view(F), n_dead=tr.n_dead)

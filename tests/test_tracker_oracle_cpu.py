@@ -1,0 +1,60 @@
+"""CPU: (1) the oracle of the temporal layer (oracle/tracker_np.py: match_spatial_time + tracker state
+machine + IK) reproduces the reference's Shelf log exactly; (2) evidence that the log is not
+reproducible beyond ~90 frames by the reference itself once its residual is re-ordered in a
+float-equivalent way (the bar used for the device tracker in tests/test_gpu_tracker.py)."""
+import numpy as np
+
+import oracle_np as o
+import tracker_np as tk
+from conftest import load_golden
+from helpers import oracle_ingest
+
+
+def _run(n_frames, residual=None):
+    si, g = load_golden("shelf_inputs.npz"), load_golden("shelf_tracker.npz")
+    k17, cnt = oracle_ingest(si["kps25"][:n_frames + 1], si["counts"][:n_frames + 1].astype(np.int32))
+    orig = o.ik_residual
+    if residual is not None:
+        o.ik_residual = residual
+    try:
+        tr = tk.OracleTracker(si["K"], si["Rt"], si["P"])
+        same, first = 0, None
+        for fi in range(1, n_frames + 1):
+            views = [[k17[fi, c, p] for p in range(cnt[fi, c])] for c in range(5)]
+            n0 = len(tr.solves)
+            tr.update(fi, views)
+            exp = [tuple(int(v) for v in r) for r in g["alive_after"][fi - 1] if r[0] >= 0]
+            got = [(t.tid, t.state, t.hits, t.length) for t in tr.tracklets]
+            ok = got == exp and tr.n_dead == g["n_dead"][fi - 1] and len(tr.solves) - n0 == g["n_solves"][fi - 1]
+            same += int(ok)
+            if not ok and first is None:
+                first = fi
+    finally:
+        o.ik_residual = orig
+    return tr, same, first, g
+
+
+def test_oracle_tracker_reproduces_reference_log_exactly():
+    n = 60
+    tr, same, first, g = _run(n)
+    assert same == n and first is None
+    roots = np.array([s[3][0] for s in tr.solves])
+    joints = np.array([s[4] for s in tr.solves])
+    assert np.array_equal(roots, g["solves"][:len(roots), 3:6])     # bit-exact IK trajectories
+    assert np.array_equal(joints, g["solve_joints"][:len(joints)])
+    assert [int(s[1]) for s in tr.solves] == [int(c) for c in g["solves"][:len(roots), 1]]
+
+
+def _residual_einsum(root, euler, side_blens, obs, projs, bone_dirs=None):
+    pos, _ = o.forward_kinematics(root, euler, side_blens, bone_dirs)
+    X = pos[o.IK_SKEL_IDX]
+    h = np.einsum('vik,jk->vji', projs, np.concatenate([X, np.ones((len(X), 1))], axis=1))
+    uv = h[..., :2] / (1e-5 + h[..., 2:3])
+    return ((uv - obs[..., :2]) * obs[..., 2:3]).ravel()
+
+
+def test_reference_log_is_not_reproducible_under_float_reordering():
+    n = 100
+    _, same, first, _ = _run(n, _residual_einsum)
+    print("reference vs float-equivalent reference: identical tracker state on", same, "of", n, "frames; first divergence", first)
+    assert first is not None and 60 <= first <= n  # observed: frame 92
