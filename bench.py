@@ -60,6 +60,28 @@ def cpu_baseline(data, n_frames, max_nfev):
                        f"oracle/oracle_np.py (NumPy + SciPy least_squares), {dt:.1f} s")
 
 
+def cpu_baseline_chain(data, L):
+    """Oracle tracker (oracle/tracker_np.py: the reference's update_4d restated) over ONE chain of L frames."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_np as o
+    import tracker_np as tk
+    kps25 = data["kps25"][:L].astype(np.float64)
+    C, Pn = kps25.shape[1:3]
+    t0 = time.perf_counter()
+    tr = tk.OracleTracker(data["K"], data["Rt"], data["P"])
+    for f in range(L):
+        views = []
+        for c in range(C):
+            poses = [o.openpose25_to_coco17(kps25[f, c, p]) for p in range(Pn)]
+            views.append([p for p in poses if o.pose_is_good(p)])
+        tr.update(f, views)
+    dt = time.perf_counter() - t0
+    n_cold = sum(1 for s in tr.solves if s[1])
+    return dict(value=L / dt, unit="frames/s", cores=1, kind="port",
+                sample=f"one chain of {L} frames of the same synthetic workload ({n_cold} cold + {len(tr.solves) - n_cold} warm "
+                       f"IK solves), oracle/tracker_np.py + oracle_np.py (NumPy + SciPy least_squares), {dt:.1f} s")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,6 +92,9 @@ def main():
     ap.add_argument("--people", type=int, default=4)
     ap.add_argument("--workload", default="full", choices=["full", "assoc_dlt"])
     ap.add_argument("--nfev-cold", type=int, default=50)
+    ap.add_argument("--nfev-warm", type=int, default=5)
+    ap.add_argument("--chain-len", type=int, default=16,
+                    help="frames per temporal chain (cold start at the head, warm after); 1 = every frame cold")
     ap.add_argument("--cpu-frames", type=int, default=1, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--seed", type=int, default=20260103)
     args = ap.parse_args()
@@ -89,18 +114,38 @@ def main():
     from multiview_motion_capture_amd import synth
     from multiview_motion_capture_amd.pipeline import HotPath
     from multiview_motion_capture_amd.parallel import gather_results
+    from multiview_motion_capture_amd.tracker import run_chains
 
     F, C, Pn = args.frames, args.views, args.people
     # same cameras on every rank (seed), a different frame shard per rank (frame_seed)
-    data = synth.generate(F, C, Pn, args.seed, frame_seed=args.seed + 1000 * rank)
+    L = args.chain_len
+    if F % L:
+        raise SystemExit("--frames must be a multiple of --chain-len")
+    data = synth.generate(F, C, Pn, args.seed, chain_len=L, frame_seed=args.seed + 1000 * rank)
     hp = HotPath(data["K"], data["Rt"], device=d)
     kps = torch.from_numpy(data["kps25"]).to(d)
     counts = torch.from_numpy(data["counts"]).to(d)
     with_ik = args.workload == "full"
 
-    ev = {k: [] for k in ("assoc", "tri", "ik")}
+    ev = {k: [] for k in ("assoc", "tri", "ik", "total")}
+
+    ik_events = []
 
     def step(timed):
+        if with_ik and L > 1:
+            # temporal protocol: chains of L frames, MvTracker.update_4d semantics
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if timed else None
+            if timed: e[0].record()
+            out = run_chains(hp, kps, counts, L, nfev_cold=args.nfev_cold, nfev_warm=args.nfev_warm,
+                             events=ik_events if timed else None, want_info=timed)
+            if timed:
+                e[1].record()
+                ev["total"].append((e[0], e[1]))
+            info = out.pop("ik_info", None)
+            if world > 1:
+                out = gather_results({k: v for k, v in out.items() if k != "n_dead"}, world)
+            out["info"] = info
+            return out
         e = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
         if timed: e[0].record()
         assoc = hp.associate(kps, counts)
@@ -134,19 +179,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    stage_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
+    stage_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items() if v}
+    chain = with_ik and L > 1
+    if chain:
+        ik_launch_ms = [a.elapsed_time(b) for a, b in ik_events]
+        stage_ms["ik"] = float(np.sum(ik_launch_ms) / args.steps)     # all IK launches of one step
+        stage_ms["assoc_tracker_other"] = stage_ms["total"] - stage_ms["ik"]
     if rank == 0:
         frames_total = F * world * args.steps
         value = frames_total / dt
         bpf = BYTES_PER_FRAME(C, Pn)
         dom = "ik" if with_ik else "assoc"
-        dom_ms = stage_ms[dom]
-        achieved = bpf * F / (dom_ms * 1e-3) / 1e9
+        if chain:
+            # dominant kernel: ik_kernel, launched once per time step over all chains; one launch serves F/L frames
+            launch_ms = float(np.mean(ik_launch_ms))
+            achieved = bpf * (F // L) / (launch_ms * 1e-3) / 1e9
+        else:
+            launch_ms = stage_ms[dom]
+            achieved = bpf * F / (launch_ms * 1e-3) / 1e9
         info = out.get("info")
         extra = {}
-        if with_ik and world == 1:
+        if with_ik and info is not None:
             inf = info.reshape(-1, 8)
-            ok = ~torch.isnan(inf[:, 0])
+            ok = ~torch.isnan(inf[:, 1])
             extra = dict(ik_solves_per_step=int(ok.sum()), mean_nfev=float((inf[ok, 1] + inf[ok, 4]).mean()),
                          mean_njev=float(inf[ok, 6].mean()), mean_jacobi_sweeps=float(inf[ok, 7].mean()))
         traffic = None
@@ -161,17 +216,21 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"synthetic {F} frames/GPU, C={C}, P={Pn}, J=25: affinity+ALS+DLT" +
-                                   ("+IK, every frame cold-started (chain length 1, max_nfev 50+50)" if with_ik else ""),
-                       "frames_per_gpu": F, "views": C, "people": Pn, "seed": args.seed, "parallelism": f"frames x{world}",
+                                   ((f"+IK, temporal chains of {L} frames (match_spatial_time + tracker; cold 50+50 nfev at the head, "
+                                     f"warm 5+5 after)" if L > 1 else "+IK, every frame cold-started (chain length 1, max_nfev 50+50)")
+                                    if with_ik else ""),
+                       "frames_per_gpu": F, "views": C, "people": Pn, "chain_len": L, "seed": args.seed, "parallelism": f"frames x{world}",
                        **extra},
             "stages_ms": stage_ms,
             "roofline": {"bound": "hbm", "kernel": "ik_kernel" if with_ik else "als_kernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "launch_ms": launch_ms,
                          "traffic": traffic, "bytes_per_frame": bpf,
                          "note": "path is fp64-ALU/latency bound, not HBM bound (SURVEY.md F6); see DESIGN.md"},
         }
         if args.cpu_frames > 0 and world == 1:
-            res["cpu_baseline"] = cpu_baseline(data, args.cpu_frames, args.nfev_cold)
+            res["cpu_baseline"] = (cpu_baseline_chain(data, L) if chain else
+                                   cpu_baseline(data, args.cpu_frames, args.nfev_cold))
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -518,6 +518,305 @@ als_kernel(const TW* __restrict__ W, const int32_t* __restrict__ gcounts, int G,
 }
 
 // ------------------------------------------------------------------------------------------------
+// ALS, latency-oriented variant for n <= 32 nodes (one wave per frame).
+// Lane (i = lane & 31, h = lane >> 5) owns row i, column half h of W/Z/Y/X in registers.  Both factor
+// updates are "R x R normal matrix + one right-hand side per lane": the normal matrix is eliminated once
+// by lanes that hold its rows in registers (pivot rows broadcast with shuffles, no LDS round trips), and
+// every lane then applies the stored multipliers to its own right-hand side.  All inner loops have
+// compile-time bounds (nodes are padded to NMAX with exact zeros, which changes no sum).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = r * (2.0 - x * r);
+    r = r * (2.0 - x * r);
+    return r;
+}
+
+// Gauss-Jordan elimination of the R x R matrix whose row (lane % R) sits in g[]; writes the multipliers
+// mul[p][a] (row a, pivot p) and the reciprocal pivots dinv[a].
+template <int R>
+__device__ __forceinline__ void gj_chain(double (&g)[R], double* __restrict__ mul, double* __restrict__ dinv) {
+    const int lane = threadIdx.x, a = lane % R;
+#pragma unroll
+    for (int p = 0; p < R; ++p) {
+        double piv[R];
+#pragma unroll
+        for (int b = p; b < R; ++b) piv[b] = __shfl(g[b], p, 64);
+        const double m = (a == p) ? 0.0 : g[p] * fast_rcp(piv[p]);
+#pragma unroll
+        for (int b = p + 1; b < R; ++b) g[b] -= m * piv[b];
+        if (lane < R) mul[p * R + a] = m;
+    }
+    if (lane < R) dinv[a] = 1.0 / g[a];
+}
+
+template <int R>
+__device__ __forceinline__ void gj_apply(double (&hv)[R], const double* __restrict__ mul, const double* __restrict__ dinv) {
+#pragma unroll
+    for (int p = 0; p < R; ++p) {
+        const double hp = hv[p];
+#pragma unroll
+        for (int a = 0; a < R; ++a) hv[a] -= mul[p * R + a] * hp;  // mul[p][p] == 0
+        hv[p] = hp;
+    }
+#pragma unroll
+    for (int a = 0; a < R; ++a) hv[a] *= dinv[a];
+}
+
+template <typename TW, int NMAX, int R>
+__device__ __forceinline__ int als2_iterate(const TW* __restrict__ Wf, int ldw, int n, int r, const int* sGid,
+                                            const double* __restrict__ seed, double* sX, double* sA, double* sB,
+                                            double* sG, double* sMul, double* sDinv) {
+    constexpr int NH = NMAX / 2, LDX = NMAX + 1;
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    const bool row_ok = i < n;
+    double w[NH], z[NH], y[NH], xp[NH], x1[NH];
+    float w32[NH];
+    unsigned valid = 0, same = 0;
+#pragma unroll
+    for (int c = 0; c < NH; ++c) {
+        const int j = h * NH + c;
+        const bool ok = row_ok && j < n;
+        if (ok) valid |= 1u << c;
+        if (ok && sGid[i] == sGid[j]) same |= 1u << c;
+        if constexpr (sizeof(TW) == 4) {
+            const float a = ok ? (float)Wf[i * ldw + j] : 0.f, b = ok ? (float)Wf[j * ldw + i] : 0.f;
+            w32[c] = fmulr(0.5f, faddr(a, b));
+            w[c] = (double)w32[c];
+        } else {
+            const double a = ok ? (double)Wf[i * ldw + j] : 0., b = ok ? (double)Wf[j * ldw + i] : 0.;
+            w[c] = 0.5 * (a + b);
+            w32[c] = 0.f;
+        }
+        z[c] = w[c]; xp[c] = w[c]; y[c] = 0.0;
+    }
+    // factor A (rows in LDS, read by every lane)
+    for (int e = lane; e < NMAX * R; e += 64) {
+        const int k = e / R, a = e - k * R;
+        sA[e] = (k < n && a < r) ? seed[k * r + a] : 0.0;
+    }
+    __syncthreads();
+    double mu = 64.0;
+    int iters = 1000;
+    for (int it = 0; it < 1000; ++it) {
+        // ---- X1 = Z - (Y - W + beta)/mu ; own row half in registers, whole matrix in LDS ----
+#pragma unroll
+        for (int c = 0; c < NH; ++c) {
+            double v = 0.0;
+            if ((valid >> c) & 1) {
+                if (sizeof(TW) == 4 && it == 0) v = (double)(w32[c] - faddr(-w32[c], 0.1f) / 64.f);
+                else v = z[c] - ((y[c] - w[c]) + 0.1) / mu;
+            }
+            x1[c] = v;
+            if (i < NMAX) sX[i * LDX + h * NH + c] = v;
+        }
+        __syncthreads();
+        const double ridge = 50.0 / mu;
+        double hv[R];
+        // ---- B update: G = A^T A + ridge I ; H[:, j] = A^T X1[:, j] ----
+        for (int e = lane; e < R * R; e += 64) {
+            const int a = e / R, b = e - a * R;
+            double g = (a == b) ? ridge : 0.0;
+#pragma unroll 8
+            for (int k = 0; k < NMAX; ++k) g += sA[k * R + a] * sA[k * R + b];
+            sG[e] = g;
+        }
+#pragma unroll
+        for (int a = 0; a < R; ++a) hv[a] = 0.0;
+        if (i < NMAX) {
+#pragma unroll 4
+            for (int kk = 0; kk < NH; ++kk) {
+                const int k = h * NH + kk;
+                const double xv = sX[k * LDX + i];
+#pragma unroll
+                for (int a = 0; a < R; ++a) hv[a] += sA[k * R + a] * xv;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < R; ++a) hv[a] += __shfl_xor(hv[a], 32, 64);
+        __syncthreads();
+        {
+            double g[R];
+#pragma unroll
+            for (int b = 0; b < R; ++b) g[b] = sG[(lane % R) * R + b];
+            gj_chain<R>(g, sMul, sDinv);
+        }
+        __syncthreads();
+        gj_apply<R>(hv, sMul, sDinv);  // hv = B[i][:]
+        if (h == 0 && i < NMAX)
+#pragma unroll
+            for (int a = 0; a < R; ++a) sB[i * R + a] = hv[a];
+        __syncthreads();
+        // ---- A update: G = B^T B + ridge I ; H[:, i] = B^T X1[i, :]^T (own row, registers) ----
+        for (int e = lane; e < R * R; e += 64) {
+            const int a = e / R, b = e - a * R;
+            double g = (a == b) ? ridge : 0.0;
+#pragma unroll 8
+            for (int k = 0; k < NMAX; ++k) g += sB[k * R + a] * sB[k * R + b];
+            sG[e] = g;
+        }
+        double av[R];
+#pragma unroll
+        for (int a = 0; a < R; ++a) av[a] = 0.0;
+#pragma unroll
+        for (int c = 0; c < NH; ++c) {
+            const double xv = x1[c];
+#pragma unroll
+            for (int a = 0; a < R; ++a) av[a] += sB[(h * NH + c) * R + a] * xv;
+        }
+#pragma unroll
+        for (int a = 0; a < R; ++a) av[a] += __shfl_xor(av[a], 32, 64);
+        __syncthreads();
+        {
+            double g[R];
+#pragma unroll
+            for (int b = 0; b < R; ++b) g[b] = sG[(lane % R) * R + b];
+            gj_chain<R>(g, sMul, sDinv);
+        }
+        __syncthreads();
+        gj_apply<R>(av, sMul, sDinv);  // av = A[i][:]
+        if (h == 0 && i < NMAX)
+#pragma unroll
+            for (int a = 0; a < R; ++a) sA[i * R + a] = av[a];
+        // ---- X = A B^T, Z, Y, residuals ----
+        double acc_p = 0.0, acc_d = 0.0;
+#pragma unroll
+        for (int c = 0; c < NH; ++c) {
+            const int j = h * NH + c;
+            double x = 0.0;
+#pragma unroll
+            for (int a = 0; a < R; ++a) x += av[a] * sB[j * R + a];
+            if ((valid >> c) & 1) {
+                double zz = x + y[c] / mu;
+                if ((same >> c) & 1) zz = 0.0;
+                if (i == j) zz = 1.0;
+                zz = zz < 0.0 ? 0.0 : (zz > 1.0 ? 1.0 : zz);
+                const double dz = x - zz, dx = x - xp[c];
+                y[c] = y[c] + mu * dz;
+                z[c] = zz;
+                xp[c] = x;
+                acc_p += dz * dz;
+                acc_d += dx * dx;
+            }
+        }
+        const double p_res = sqrt(wave_sum(acc_p)) / n;
+        const double d_res = mu * sqrt(wave_sum(acc_d)) / n;
+        __syncthreads();  // sA complete before the next iteration reads it
+        if (p_res < 1e-4 && d_res < 1e-4) { iters = it + 1; break; }
+        if (p_res > 10 * d_res) mu = 2 * mu;
+        else if (d_res > 10 * p_res) mu = mu / 2;
+    }
+    // final X (dense n x n, leading dimension n) for the symmetrise / binarise tail
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NH; ++c)
+        if ((valid >> c) & 1) sX[i * n + h * NH + c] = xp[c];
+    __syncthreads();
+    return iters;
+}
+
+template <typename TW, int NMAX>
+__global__ void __launch_bounds__(64)
+als2_kernel(const TW* __restrict__ W, const int32_t* __restrict__ gcounts, int G, int ldw,
+            const double* __restrict__ seed, int seed_len, uint8_t* __restrict__ x_bin,
+            uint8_t* __restrict__ match_mat, int32_t* __restrict__ labels, int32_t* __restrict__ n_clusters,
+            int32_t* __restrict__ iters_out) {
+    constexpr int RMAX = 16;
+    __shared__ double sX[NMAX * (NMAX + 1)];
+    __shared__ double sA[NMAX * RMAX];
+    __shared__ double sB[NMAX * RMAX];
+    __shared__ double sG[RMAX * RMAX];
+    __shared__ double sMul[RMAX * RMAX];
+    __shared__ double sDinv[RMAX];
+    __shared__ int sGid[NMAX];
+    __shared__ uint8_t sVis[NMAX];
+    __shared__ int sKeep[NMAX];
+    __shared__ int s_n, s_r;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        int n = 0, total = 0, gmax = 0;
+        for (int g = 0; g < G; ++g) {
+            int c = gcounts[f * G + g];
+            c = c < 0 ? 0 : c;
+            total += c;
+            for (int k = 0; k < c && n < NMAX; ++k) sGid[n++] = g;
+            if (c > gmax) gmax = c;
+        }
+        s_n = total;
+        const int r = 2 * gmax;
+        s_r = r < total ? r : total;
+    }
+    __syncthreads();
+    const int n = s_n, r = s_r;
+    int32_t* lab = labels + (size_t)f * ldw;
+    if (n == 0 || n > NMAX || n > ldw || r > RMAX || n * r > seed_len) {
+        for (int i = tid; i < ldw; i += 64) lab[i] = -1;
+        if (tid == 0) { n_clusters[f] = 0; iters_out[f] = (n == 0) ? 0 : -1; }
+        return;
+    }
+    const TW* Wf = W + (size_t)f * ldw * ldw;
+    const int iters = (r <= 8) ? als2_iterate<TW, NMAX, 8>(Wf, ldw, n, r, sGid, seed, sX, sA, sB, sG, sMul, sDinv)
+                               : als2_iterate<TW, NMAX, 16>(Wf, ldw, n, r, sGid, seed, sX, sA, sB, sG, sMul, sDinv);
+    // ---- tail: X_bin, closure (k = n-1 only), labels -- same rules as als_kernel ----
+    uint8_t* sBin = reinterpret_cast<uint8_t*>(sA);
+    uint8_t* sOut = reinterpret_cast<uint8_t*>(sB);
+    uint8_t* sTmp = reinterpret_cast<uint8_t*>(sG);
+    static_assert(NMAX * NMAX <= NMAX * RMAX * 8 && NMAX * NMAX <= RMAX * RMAX * 8, "byte matrices must fit");
+    for (int e = tid; e < n * n; e += 64) {
+        const int i = e / n, j = e - i * n;
+        sBin[e] = (0.5 * (sX[i * n + j] + sX[j * n + i])) > 0.5;
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 64) {
+        const int i = e / n, j = e - i * n;
+        sOut[e] = 0;
+        sTmp[e] = sBin[e] | (sBin[i * n + (n - 1)] & sBin[(n - 1) * n + j]);
+    }
+    for (int i = tid; i < n; i += 64) sVis[i] = 0;
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+        const bool skip = sVis[i] != 0;
+        __syncthreads();
+        if (!skip)
+            for (int j = tid; j < n; j += 64)
+                if (sTmp[i * n + j]) { sVis[j] = 1; sOut[j * n + i] = 1; }
+        __syncthreads();
+    }
+    for (int c = tid; c < n; c += 64) {
+        int s = 0;
+        for (int j = 0; j < n; ++j) s += sOut[j * n + c];
+        sKeep[c] = s >= 2;
+    }
+    __syncthreads();
+    for (int row = tid; row < ldw; row += 64) {
+        int label = -1;
+        if (row < n) {
+            int ord = 0;
+            for (int c = 0; c < n; ++c) {
+                if (!sKeep[c]) continue;
+                if (sOut[row * n + c]) { label = ord; break; }
+                ++ord;
+            }
+        }
+        lab[row] = label;
+    }
+    if (tid == 0) {
+        int k = 0;
+        for (int c = 0; c < n; ++c) k += sKeep[c];
+        n_clusters[f] = k;
+        iters_out[f] = iters;
+    }
+    if (x_bin || match_mat) {
+        for (int e = tid; e < ldw * ldw; e += 64) {
+            const int i = e / ldw, j = e - i * ldw;
+            const bool in = i < n && j < n;
+            if (x_bin) x_bin[(size_t)f * ldw * ldw + e] = in ? sBin[i * n + j] : 0;
+            if (match_mat) match_mat[(size_t)f * ldw * ldw + e] = in ? sOut[i * n + j] : 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // standalone closure + labelling (transform_closure, mv_association.py:99-121; the cluster rule of
 // parse_match_result, motion_capture.py:419-425) for callers that bring their own binary matrix
 // ------------------------------------------------------------------------------------------------
@@ -653,13 +952,17 @@ static int launch_als(const TW* W, const int32_t* gc, int F, int G, int n_max, i
 #define MVMC_ALS(NM, RM, NT)                                                                              \
     hipLaunchKernelGGL((als_kernel<TW, NM, RM, NT>), dim3(F), dim3(NT), 0, s, W, gc, G, n_max, seed,    \
                        seed_len, xb, mm, lab, nc, it)
-    if (n_max <= 16) MVMC_ALS(16, 16, 64);
+#define MVMC_ALS2(NM)                                                                                     \
+    hipLaunchKernelGGL((als2_kernel<TW, NM>), dim3(F), dim3(64), 0, s, W, gc, G, n_max, seed, seed_len, xb, mm, \
+                       lab, nc, it)
+    if (n_max <= 24 && r_max <= 16) MVMC_ALS2(24);
+    else if (n_max <= 32 && r_max <= 16) MVMC_ALS2(32);
     else if (n_max <= 24) MVMC_ALS(24, 24, 64);
-    else if (n_max <= 32 && r_max <= 16) MVMC_ALS(32, 16, 64);
     else if (n_max <= 32) MVMC_ALS(32, 32, 128);
     else if (n_max <= 64 && r_max <= 16) MVMC_ALS(64, 16, 256);
     else return MVMC_ERR_UNSUPPORTED;
 #undef MVMC_ALS
+#undef MVMC_ALS2
     return MVMC_OK;
 }
 

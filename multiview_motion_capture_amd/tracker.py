@@ -35,6 +35,7 @@ class ChainTracker:
         self.next_id = torch.zeros((B,), dtype=torch.int32, device=d)
         self.n_dead = torch.zeros((B,), dtype=torch.int32, device=d)
         self.frame_idx = torch.arange(B, dtype=torch.int32, device=d)
+        self.events = None  # set to a list to collect (start, end) CUDA events around every IK launch
 
     def step(self, kps17: torch.Tensor, counts: torch.Tensor, want_debug=False):
         """kps17 (B,C,P,17,3) f64 + counts (B,C) i32 of the current frame of every chain."""
@@ -53,8 +54,14 @@ class ChainTracker:
                                                           st["n_clusters"], counts, self.frame_idx, self.n_tracks,
                                                           self.params, P, K, V)
         NP = T + K
+        if self.events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         p, j, info = dev.ik_solve(kps17, hp.P, mem.reshape(B * NP, V), init.reshape(B * NP, 68),
                                   cold.reshape(B * NP), self.nfev_cold, self.nfev_warm, hp.skeleton)
+        if self.events is not None:
+            e1.record()
+            self.events.append((e0, e1))
         p, j = p.reshape(B, NP, 68), j.reshape(B, NP, 18, 3)
         dev.track_commit(status, n_new, p, j, self.params, self.joints, self.meta, self.n_tracks, self.next_id,
                          self.n_dead, K)
@@ -65,7 +72,7 @@ class ChainTracker:
 
 
 def run_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], chain_len: int, t_max=8,
-               nfev_cold=50, nfev_warm=5):
+               nfev_cold=50, nfev_warm=5, events=None, want_info=False):
     """Whole shard: frames [c*L, (c+1)*L) form chain c (F must be a multiple of L).  Returns per-frame
     tracklet tables: params (F,T,68), joints (F,T,18,3), meta (F,T,4), n_tracks (F)."""
     F, C, P = kps.shape[:3]
@@ -77,13 +84,17 @@ def run_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], c
     k4 = kps17.view(B, L, C, P, 17, 3)
     c4 = cnt.view(B, L, C)
     tr = ChainTracker(hp, B, P, t_max, nfev_cold=nfev_cold, nfev_warm=nfev_warm)
+    tr.events = events
+    infos = []
     d = kps.device
     out_p = torch.empty((B, L, t_max, 68), dtype=torch.float64, device=d)
     out_j = torch.empty((B, L, t_max, 18, 3), dtype=torch.float64, device=d)
     out_m = torch.empty((B, L, t_max, 4), dtype=torch.int32, device=d)
     out_n = torch.empty((B, L), dtype=torch.int32, device=d)
     for t in range(L):
-        tr.step(k4[:, t].contiguous(), c4[:, t].contiguous())
+        o = tr.step(k4[:, t].contiguous(), c4[:, t].contiguous())
+        if want_info:
+            infos.append(o["ik_info"])
         out_p[:, t], out_j[:, t], out_m[:, t], out_n[:, t] = tr.params, tr.joints, tr.meta, tr.n_tracks
     return dict(params=out_p.view(F, t_max, 68), joints=out_j.view(F, t_max, 18, 3), meta=out_m.view(F, t_max, 4),
-                n_tracks=out_n.view(F), n_dead=tr.n_dead)
+                n_tracks=out_n.view(F), n_dead=tr.n_dead, **({"ik_info": torch.stack(infos, 1)} if want_info else {}))
