@@ -28,6 +28,7 @@ namespace {
 constexpr int NT = 256;    // threads per problem
 constexpr int NA = 50;     // max active parameters (even)
 constexpr int LD = 51;     // odd leading dimension: conflict-free column walks on 8-byte elements
+constexpr int LDV = 52;    // leading dimension of the transposed eigenvector matrix (even: 16-byte aligned row pairs)
 constexpr int VMAX = 8;    // max views per person
 constexpr int NOBS = 16;   // observed joints per view
 
@@ -38,11 +39,11 @@ __device__ __constant__ const int kIkObs[NOBS] = {11, 13, 15, 12, 14, 16, 17, 5,
 struct IkShared {
     double bufA[NA * LD];  // D (48 x LD)  | T = (J^T J) V for the basis change
     double bufB[NA * LD];  // per-(view,joint) scratch | Y = W D (48 x LD) | J^T J -> diag(L) (NA x LD)
-    double bufC[NA * LD];  // eigenvector basis V, kept across the iterations of a solve (warm-started Jacobi)
+    double bufC[NA * LDV]; // eigenvector basis, TRANSPOSED (row = eigenvector), kept across the iterations of a solve
     double x[68], xn[68];
     double side[18];       // side bone lengths used by stage 1 (fixed)
     double g[NA], lam[NA], suf[NA], cv[NA], step[NA];
-    double rc[NA / 2], rs[NA / 2];
+    double2 rcs[NA / 2];   // (cos, sin) of the step's rotations
     double obs[VMAX * NOBS * 3], Pm[VMAX * 12];
     double Rl[18 * 9], Rg[18 * 9], pos[18 * 3], bvec[18 * 3], off[18 * 3], axes[18 * 9];
     double Wk[NOBS * 6], tk[NOBS * 3];
@@ -51,7 +52,7 @@ struct IkShared {
     int act[2][NA], inv_act[2][68], na[2];
     int colkind[2][NA], cola[2][NA], colc[2][NA];
     int anc[18], depth[18], maxdepth, nviews;
-    int pp[NA / 2], qq[NA / 2];
+    int pq[NA / 2];        // p | q << 8
     // skeleton tables (copied from the kernel argument once: dynamic indexing of by-value kernel
     // arguments costs SGPR spills and scratch)
     double dirs[18 * 3], ref_side[18];
@@ -249,51 +250,55 @@ __device__ void ik_normal_equations(IkShared& S, const SkelRef& sk, const double
 // ---------------------------------------------------------------------------------------------
 // Symmetric eigensolver of the trust-region step
 // ---------------------------------------------------------------------------------------------
-// out (bufA) = M1 * M2 or M1^T * M2 on nap x nap LDS matrices, 1 x 5 register tiles
-template <bool TRANS1>
-__device__ inline void ik_matmul(const double* M1, const double* M2, double* out, int nap) {
+// out = M1 * M2 (TRANSB = false) or M1 * M2^T (TRANSB = true) on nap x nap LDS matrices with leading
+// dimensions l1, l2, lo; 1 x 5 register tiles
+template <bool TRANSB>
+__device__ inline void ik_matmul(const double* M1, int l1, const double* M2, int l2, double* out, int lo, int nap) {
     const int jb = nap / 5;  // nap is 40 or 50
     for (int tile = threadIdx.x; tile < nap * jb; tile += NT) {
         const int i = tile / jb, j0 = (tile - i * jb) * 5;
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
         for (int k = 0; k < nap; ++k) {
-            const double m = TRANS1 ? M1[k * LD + i] : M1[i * LD + k];
-            const double* r = &M2[k * LD + j0];
-            a0 += m * r[0]; a1 += m * r[1]; a2 += m * r[2]; a3 += m * r[3]; a4 += m * r[4];
+            const double m = M1[i * l1 + k];
+            if (TRANSB) {
+                a0 += m * M2[(j0 + 0) * l2 + k]; a1 += m * M2[(j0 + 1) * l2 + k]; a2 += m * M2[(j0 + 2) * l2 + k];
+                a3 += m * M2[(j0 + 3) * l2 + k]; a4 += m * M2[(j0 + 4) * l2 + k];
+            } else {
+                const double* r = &M2[k * l2 + j0];
+                a0 += m * r[0]; a1 += m * r[1]; a2 += m * r[2]; a3 += m * r[3]; a4 += m * r[4];
+            }
         }
-        double* o = &out[i * LD + j0];
+        double* o = &out[i * lo + j0];
         o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4;
     }
 }
 
-// Parallel cyclic Jacobi (round-robin pairs).  On entry bufB = J^T J and bufC = an orthonormal basis V0
-// (identity, or the eigenvectors of the previous iterate's J^T J); the matrix is first moved into that
-// basis (A' = V0^T A V0, nearly diagonal when J changed little), then rotated to diag(lam) while the
-// rotations accumulate into bufC, which ends as the eigenvector matrix (columns).
+// Parallel cyclic Jacobi (round-robin pairs).  On entry bufB = J^T J (full symmetric) and bufC = an
+// orthonormal basis, transposed (Vt: one eigenvector per row; identity or the previous iterate's).
+// The matrix is first moved into that basis (A' = Vt A Vt^T, nearly diagonal when J changed little), then
+// rotated to diag(lam); only the UPPER triangle of A is kept current during the sweeps.  Per step, the
+// two-sided update is one pass over the 2x2 blocks of the pair-of-pairs with i <= j (B' = L_i B R_j) and Vt
+// takes the same rotations on row pairs (two adjacent columns per 16-byte access).
 __device__ int ik_eigh(IkShared& S, int nap, bool have_basis) {
     const int tid = threadIdx.x;
     double* A = S.bufB;
-    double* V = S.bufC;
+    double* Vt = S.bufC;
     if (have_basis && (nap % 5) == 0) {
-        ik_matmul<false>(S.bufB, S.bufC, S.bufA, nap);  // T = A V0
+        ik_matmul<false>(S.bufC, LDV, S.bufB, LD, S.bufA, LD, nap);  // T = Vt A
         __syncthreads();
-        ik_matmul<true>(S.bufC, S.bufA, S.bufB, nap);   // A' = V0^T T
+        ik_matmul<true>(S.bufA, LD, S.bufC, LDV, S.bufB, LD, nap);   // A' = T Vt^T
         __syncthreads();
     } else {
-        for (int idx = tid; idx < nap * LD; idx += NT) {
-            const int i = idx / LD, j = idx - i * LD;
-            V[idx] = (i == j) ? 1.0 : 0.0;
+        for (int idx = tid; idx < nap * LDV; idx += NT) {
+            const int i = idx / LDV, j = idx - i * LDV;
+            Vt[idx] = (i == j) ? 1.0 : 0.0;
         }
         __syncthreads();
     }
     const int half = nap / 2;
-    // Work items (fixed for the whole call, so no integer division inside the sweeps):
-    //   A: one 2x2 block per pair-of-pairs (i <= j): B' = L_i B R_j, mirrored into (j, i) -- the
-    //      two-sided update in ONE pass over the upper block triangle
-    //   V: one row of one column pair: V <- V J
     constexpr int HM = NA / 2;
-    constexpr int IBK = (HM * (HM + 1) / 2 + NT - 1) / NT;
-    constexpr int IV = (HM * NA + NT - 1) / NT;
+    constexpr int IBK = (HM * (HM + 1) / 2 + NT - 1) / NT;   // 2x2 blocks per thread
+    constexpr int IV = (HM * (NA / 2) + NT - 1) / NT;        // (pair, two adjacent columns of Vt) per thread
     short bi[IBK], bj[IBK], vi[IV], vr[IV];
 #pragma unroll
     for (int t = 0; t < IBK; ++t) {
@@ -308,7 +313,7 @@ __device__ int ik_eigh(IkShared& S, int nap, bool have_basis) {
 #pragma unroll
     for (int t = 0; t < IV; ++t) {
         const int idx = t * NT + tid;
-        if (idx < half * nap) { vi[t] = (short)(idx / nap); vr[t] = (short)(idx % nap); }
+        if (idx < half * half) { vi[t] = (short)(idx / half); vr[t] = (short)(2 * (idx % half)); }
         else { vi[t] = -1; vr[t] = 0; }
     }
     int sweeps = 0;
@@ -316,9 +321,9 @@ __device__ int ik_eigh(IkShared& S, int nap, bool have_basis) {
         double off = 0.0, dg = 0.0;
         for (int idx = tid; idx < nap * LD; idx += NT) {
             const int i = idx / LD, j = idx - i * LD;
-            if (j < nap) {
+            if (j < nap && j >= i) {
                 const double a = A[idx];
-                if (i == j) dg += a * a; else off += a * a;
+                if (i == j) dg += a * a; else off += 2.0 * a * a;
             }
         }
         off = block_sum256(off, S.red);
@@ -328,6 +333,9 @@ __device__ int ik_eigh(IkShared& S, int nap, bool have_basis) {
         ++sweeps;
         const double tiny = 1e-17 * sqrt(dg + off);  // entries below this are rounding noise of the null space
         for (int s = 0; s < nap - 1; ++s) {
+#ifdef MVMC_IK_PROFILE
+            const long long _ts0 = clock64();
+#endif
             if (tid < half) {
                 int p, q;
                 if (tid == 0) { p = nap - 1; q = s; }
@@ -339,53 +347,79 @@ __device__ int ik_eigh(IkShared& S, int nap, bool have_basis) {
                 const double apq = A[p * LD + q], app = A[p * LD + p], aqq = A[q * LD + q];
                 double c = 1.0, sn = 0.0;
                 if (fabs(apq) > tiny) {
-                    const double theta = (aqq - app) / (2.0 * apq);
-                    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                    c = 1.0 / sqrt(t * t + 1.0);
-                    sn = t * c;
+                    // t = sgn(d) apq / (|d| + sqrt(d^2 + apq^2)), c = 1/sqrt(1 + t^2), s = t c, with
+                    // Newton-refined v_rsq/v_rcp instead of IEEE sqrt/div sequences (this scalar chain is
+                    // on the critical path of every Jacobi step)
+                    const double d = 0.5 * (aqq - app);
+                    const double v = d * d + apq * apq;
+                    double rs = __builtin_amdgcn_rsq(v);
+                    rs = rs * (1.5 - 0.5 * v * rs * rs);
+                    rs = rs * (1.5 - 0.5 * v * rs * rs);
+                    const double den = fabs(d) + v * rs;
+                    double ri = __builtin_amdgcn_rcp(den);
+                    ri = ri * (2.0 - den * ri);
+                    ri = ri * (2.0 - den * ri);
+                    const double t = (d >= 0 ? apq : -apq) * ri;
+                    const double u = 1.0 + t * t;
+                    double rc = __builtin_amdgcn_rsq(u);
+                    rc = rc * (1.5 - 0.5 * u * rc * rc);
+                    rc = rc * (1.5 - 0.5 * u * rc * rc);
+                    c = rc;
+                    sn = t * rc;
                 }
-                S.rc[tid] = c; S.rs[tid] = sn; S.pp[tid] = p; S.qq[tid] = q;
+                S.rcs[tid] = make_double2(c, sn);
+                S.pq[tid] = p | (q << 8);
             }
             __syncthreads();
+#ifdef MVMC_IK_PROFILE
+            const long long _ts1 = clock64();
+            if (tid == 0) S.prof[3] += _ts1 - _ts0;
+#endif
             // all loads first, then all stores (LDS stores would otherwise serialise the items)
-            double b00[IBK], b01[IBK], b10[IBK], b11[IBK], ci[IBK], si[IBK], cj[IBK], sj[IBK];
-            int pi_[IBK], qi_[IBK], pj_[IBK], qj_[IBK];
+            double b00[IBK], b01[IBK], b10[IBK], b11[IBK];
+            double2 ri[IBK], rj[IBK];
+            int a00[IBK], a01[IBK], a10[IBK], a11[IBK];
 #pragma unroll
             for (int t = 0; t < IBK; ++t) {
                 const int i = bi[t] < 0 ? 0 : bi[t], j = bj[t];
-                ci[t] = S.rc[i]; si[t] = S.rs[i]; cj[t] = S.rc[j]; sj[t] = S.rs[j];
-                pi_[t] = S.pp[i]; qi_[t] = S.qq[i]; pj_[t] = S.pp[j]; qj_[t] = S.qq[j];
-                b00[t] = A[pi_[t] * LD + pj_[t]]; b01[t] = A[pi_[t] * LD + qj_[t]];
-                b10[t] = A[qi_[t] * LD + pj_[t]]; b11[t] = A[qi_[t] * LD + qj_[t]];
+                ri[t] = S.rcs[i]; rj[t] = S.rcs[j];
+                const int pqi = S.pq[i], pqj = S.pq[j];
+                const int pi = pqi & 255, qi = pqi >> 8, pj = pqj & 255, qj = pqj >> 8;
+                // canonical (upper-triangle) address of element (r, c)
+                a00[t] = pi <= pj ? pi * LD + pj : pj * LD + pi;
+                a01[t] = pi <= qj ? pi * LD + qj : qj * LD + pi;
+                a10[t] = qi <= pj ? qi * LD + pj : pj * LD + qi;
+                a11[t] = qi <= qj ? qi * LD + qj : qj * LD + qi;
+                b00[t] = A[a00[t]]; b01[t] = A[a01[t]]; b10[t] = A[a10[t]]; b11[t] = A[a11[t]];
             }
-            double va[IV], vb[IV], vc[IV], vs[IV];
+            double2 va[IV], vb[IV], rv[IV];
             int ia[IV], ib[IV];
 #pragma unroll
             for (int t = 0; t < IV; ++t) {
                 const int i = vi[t] < 0 ? 0 : vi[t];
-                vc[t] = S.rc[i]; vs[t] = S.rs[i];
-                ia[t] = vr[t] * LD + S.pp[i]; ib[t] = vr[t] * LD + S.qq[i];
-                va[t] = V[ia[t]]; vb[t] = V[ib[t]];
+                rv[t] = S.rcs[i];
+                const int pqi = S.pq[i];
+                ia[t] = (pqi & 255) * LDV + vr[t]; ib[t] = (pqi >> 8) * LDV + vr[t];
+                va[t] = *reinterpret_cast<const double2*>(&Vt[ia[t]]);
+                vb[t] = *reinterpret_cast<const double2*>(&Vt[ib[t]]);
             }
 #pragma unroll
             for (int t = 0; t < IBK; ++t) {
                 if (bi[t] < 0) continue;
-                const double t00 = cj[t] * b00[t] - sj[t] * b01[t], t01 = sj[t] * b00[t] + cj[t] * b01[t];
-                const double t10 = cj[t] * b10[t] - sj[t] * b11[t], t11 = sj[t] * b10[t] + cj[t] * b11[t];
-                const double n00 = ci[t] * t00 - si[t] * t10, n01 = ci[t] * t01 - si[t] * t11;
-                const double n10 = si[t] * t00 + ci[t] * t10, n11 = si[t] * t01 + ci[t] * t11;
-                A[pi_[t] * LD + pj_[t]] = n00; A[pi_[t] * LD + qj_[t]] = n01;
-                A[qi_[t] * LD + pj_[t]] = n10; A[qi_[t] * LD + qj_[t]] = n11;
-                if (bi[t] != bj[t]) {  // mirror: block (j, i) = block (i, j)^T
-                    A[pj_[t] * LD + pi_[t]] = n00; A[qj_[t] * LD + pi_[t]] = n01;
-                    A[pj_[t] * LD + qi_[t]] = n10; A[qj_[t] * LD + qi_[t]] = n11;
-                }
+                const double ci = ri[t].x, si = ri[t].y, cj = rj[t].x, sj = rj[t].y;
+                const double t00 = cj * b00[t] - sj * b01[t], t01 = sj * b00[t] + cj * b01[t];
+                const double t10 = cj * b10[t] - sj * b11[t], t11 = sj * b10[t] + cj * b11[t];
+                A[a00[t]] = ci * t00 - si * t10;
+                A[a11[t]] = si * t01 + ci * t11;
+                A[a01[t]] = ci * t01 - si * t11;
+                if (bi[t] != bj[t]) A[a10[t]] = si * t00 + ci * t10;  // diagonal block: (q,p) is (p,q)
             }
 #pragma unroll
             for (int t = 0; t < IV; ++t) {
                 if (vi[t] < 0) continue;
-                V[ia[t]] = vc[t] * va[t] - vs[t] * vb[t];
-                V[ib[t]] = vs[t] * va[t] + vc[t] * vb[t];
+                const double c = rv[t].x, sn = rv[t].y;
+                *reinterpret_cast<double2*>(&Vt[ia[t]]) = make_double2(c * va[t].x - sn * vb[t].x, c * va[t].y - sn * vb[t].y);
+                *reinterpret_cast<double2*>(&Vt[ib[t]]) = make_double2(sn * va[t].x + c * vb[t].x, sn * va[t].y + c * vb[t].y);
             }
             __syncthreads();
         }
@@ -465,7 +499,7 @@ __device__ void ik_trf(IkShared& S, const SkelRef& sk, int stage, int max_nfev, 
             const double l = S.bufB[tid * LD + tid];
             S.lam[tid] = l > 0.0 ? l : 0.0;
             double a = 0.0;
-            for (int i = 0; i < nap; ++i) a += S.bufC[i * LD + tid] * S.g[i];
+            for (int i = 0; i < nap; ++i) a += S.bufC[tid * LDV + i] * S.g[i];
             S.suf[tid] = a;
         }
         __syncthreads();
@@ -482,7 +516,7 @@ __device__ void ik_trf(IkShared& S, const SkelRef& sk, int stage, int max_nfev, 
             const double pred = S.sc[2];
             if (tid < nap) {
                 double a = 0.0;
-                for (int j = 0; j < nap; ++j) a += S.bufC[tid * LD + j] * S.cv[j];
+                for (int j = 0; j < nap; ++j) a += S.bufC[j * LDV + tid] * S.cv[j];
                 S.step[tid] = a;
             }
             __syncthreads();
@@ -709,8 +743,8 @@ ik_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restr
         // stage 2 appends the bone-length columns to stage 1's active set: embed the stage-1
         // eigenvectors as [[V1, 0], [0, I]]
         const int n1 = (S.na[0] + 1) & ~1, n2 = (S.na[1] + 1) & ~1;
-        for (int idx = tid; idx < n2 * LD; idx += NT) {
-            const int i = idx / LD, j = idx - i * LD;
+        for (int idx = tid; idx < n2 * LDV; idx += NT) {
+            const int i = idx / LDV, j = idx - i * LDV;
             if (i >= n1 || j >= n1) S.bufC[idx] = (i == j) ? 1.0 : 0.0;
         }
         __syncthreads();
@@ -728,7 +762,7 @@ ik_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restr
 #ifdef MVMC_IK_PROFILE
         // diagnostic build only: cycle shares instead of the costs
         info[0] = (double)S.prof[0]; info[3] = (double)S.prof[1]; info[2] = (double)S.prof[2];
-        info[5] = (double)(clock64() - t_all);
+        info[5] = (double)(clock64() - t_all); info[4] = (double)S.prof[3];
 #endif
     }
 }

@@ -30,6 +30,7 @@ print("cycles per solve (mean): total %.0f  eval %.0f  normal-eq %.0f  eigh %.0f
 print("shares: eval %.3f normal-eq %.3f eigh %.3f other %.3f" %
       (inf[:, 0].sum() / tot, inf[:, 3].sum() / tot, inf[:, 2].sum() / tot,
        1 - (inf[:, 0].sum() + inf[:, 3].sum() + inf[:, 2].sum()) / tot))
+print("jacobi param phase (incl. its barrier): %.0f cycles/step = %.2f of eigh" % (inf[:, 4].sum() / inf[:, 7].sum() / 49, inf[:, 4].sum() / inf[:, 2].sum()))
 print("cycles per eval %.0f ; per normal-eq %.0f ; per sweep %.0f ; per jacobi step %.0f" %
       (inf[:, 0].sum() / (inf[:, 1] + inf[:, 4]).sum(), inf[:, 3].sum() / inf[:, 6].sum(),
        inf[:, 2].sum() / inf[:, 7].sum(), inf[:, 2].sum() / inf[:, 7].sum() / 49))
