@@ -134,11 +134,17 @@ int mvmc_fk(const mvmcSkeleton* skel_host, const double* params, int n_problems,
  *   cold         (B) u8: 1 = cold start (DLT root, zero angles, reference lengths, max_nfev_cold),
  *                0 = warm (max_nfev_warm); NULL = all cold
  *   params_out   (B,68); joints_out (B,18,3); info_out (B,8) f64 =
- *                {cost1, nfev1, status1, cost2, nfev2, status2, njev1+njev2, Jacobi sweeps} or NULL */
+ *                {cost1, nfev1, status1, cost2, nfev2, status2, njev1+njev2, Jacobi sweeps} or NULL
+ *   basis_in / basis_src / basis_out (all optional, NULL = off): eigensolver warm start across frames.
+ *                basis_out (B, MVMC_IK_BASIS_DOUBLES) receives each problem's stage-1 eigenbasis;
+ *                basis_src (B) i32 = row of basis_in (any, MVMC_IK_BASIS_DOUBLES) to start from, -1 = none.
+ *                Purely a speed device: results do not depend on it beyond rounding. */
+#define MVMC_IK_BASIS_DOUBLES 2600
 int mvmc_ik_solve(const mvmcSkeleton* skel_host, const double* kps17, const double* Pmats,
                   const int32_t* members, int n_problems, int v_max, int n_views, int p_max,
                   const double* init_params, const uint8_t* cold, int max_nfev_cold, int max_nfev_warm,
-                  double* params_out, double* joints_out, double* info_out, mvmcStream_t stream);
+                  double* params_out, double* joints_out, double* info_out, const double* basis_in,
+                  const int32_t* basis_src, double* basis_out, mvmcStream_t stream);
 
 /* ---- temporal layer: match_spatial_time + tracker, batched over independent chains (sub-sequences) ---- */
 
@@ -172,10 +178,12 @@ int mvmc_track_assign(const int32_t* labels_sp, const int32_t* ncl_sp, const int
 
 /* TK-1, second half (MvTracklet.update / mark_missed / __init__, motion_capture.py:352-391, :924-963):
  * applies the frame's IK results to the tracklet table (order kept, survivors first, new ones appended).
- *   meta (B,T,4) i32 = {id, state (1 tentative, 2 confirmed), hits, length}; n_inits = 3 in the reference */
+ *   meta (B,T,4) i32 = {id, state (1 tentative, 2 confirmed), hits, length}; n_inits = 3 in the reference;
+ *   slot_src (B,T) i32 out or NULL: IK problem slot each table entry was solved in this frame (-1 = not solved) */
 int mvmc_track_commit(const int32_t* status, const int32_t* n_new, const double* ik_params, const double* ik_joints,
                       int n_chains, int t_max, int k_max, int n_inits, double* track_params, double* track_joints,
-                      int32_t* meta, int32_t* n_tracks, int32_t* next_id, int32_t* n_dead, mvmcStream_t stream);
+                      int32_t* meta, int32_t* n_tracks, int32_t* next_id, int32_t* n_dead, int32_t* slot_src,
+                      mvmcStream_t stream);
 
 #ifdef __cplusplus
 }

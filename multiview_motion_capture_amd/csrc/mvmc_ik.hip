@@ -618,7 +618,8 @@ __global__ void __launch_bounds__(NT, 2)
 ik_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restrict__ Pmats,
           const int32_t* __restrict__ members, int B, int V, int C, int Pmax, const double* __restrict__ init,
           const uint8_t* __restrict__ cold, int nfev_cold, int nfev_warm, double* __restrict__ params_out,
-          double* __restrict__ joints_out, double* __restrict__ info_out) {
+          double* __restrict__ joints_out, double* __restrict__ info_out, const double* __restrict__ basis_in,
+          const int32_t* __restrict__ basis_src, double* __restrict__ basis_out) {
     __shared__ IkShared S;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n_side = skarg.n_side;
@@ -681,6 +682,7 @@ ik_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restr
         for (int i = tid; i < 68; i += NT) params_out[(size_t)b * 68 + i] = nan;
         for (int i = tid; i < 54; i += NT) joints_out[(size_t)b * 54 + i] = nan;
         if (info && tid < 8) info[tid] = nan;
+        if (basis_out && tid == 0) basis_out[(size_t)b * NA * LDV + NA * LDV - 1] = 0.0;
         return;
     }
 
@@ -737,7 +739,23 @@ ik_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restr
     double cost1, cost2;
     int nf1, nj1, st1, nf2, nj2, st2, sweeps = 0;
     bool basis = false;
-    ik_trf(S, sk, 0, max_nfev, &cost1, &nf1, &nj1, &st1, &sweeps, false, &basis);
+    constexpr int NBAS = NA * LDV;
+    if (!is_cold && basis_in && basis_src && basis_src[b] >= 0) {
+        // warm start of the eigensolver from the same tracklet's stage-1 basis of the previous frame
+        const double* src = basis_in + (size_t)basis_src[b] * NBAS;
+        if (src[NBAS - 1] == 1.0) {
+            for (int idx = tid; idx < NBAS - 1; idx += NT) S.bufC[idx] = src[idx];
+            basis = true;
+        }
+        __syncthreads();
+    }
+    ik_trf(S, sk, 0, max_nfev, &cost1, &nf1, &nj1, &st1, &sweeps, basis, &basis);
+    __syncthreads();
+    if (basis_out) {
+        double* dst = basis_out + (size_t)b * NBAS;
+        for (int idx = tid; idx < NBAS - 1; idx += NT) dst[idx] = S.bufC[idx];
+        if (tid == 0) dst[NBAS - 1] = basis ? 1.0 : 0.0;  // validity tag in the unused pad corner
+    }
     __syncthreads();
     if (basis) {
         // stage 2 appends the bone-length columns to stage 1's active set: embed the stage-1
@@ -772,7 +790,8 @@ ik_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restr
 extern "C" int mvmc_ik_solve(const mvmcSkeleton* skel_host, const double* kps17, const double* Pmats,
                              const int32_t* members, int n_problems, int v_max, int n_views, int p_max,
                              const double* init_params, const uint8_t* cold, int max_nfev_cold, int max_nfev_warm,
-                             double* params_out, double* joints_out, double* info_out, mvmcStream_t stream) {
+                             double* params_out, double* joints_out, double* info_out, const double* basis_in,
+                             const int32_t* basis_src, double* basis_out, mvmcStream_t stream) {
     if (!skel_host || !kps17 || !Pmats || !members || !params_out || !joints_out) return MVMC_ERR_ARG;
     if (v_max <= 0 || n_views <= 0 || p_max <= 0 || max_nfev_cold < 1 || max_nfev_warm < 1) return MVMC_ERR_ARG;
     if (cold && !init_params) return MVMC_ERR_ARG;
@@ -782,7 +801,7 @@ extern "C" int mvmc_ik_solve(const mvmcSkeleton* skel_host, const double* kps17,
     if (sk.n_side != MVMC_N_SIDE) return MVMC_ERR_UNSUPPORTED;  // the solver is sized for 57 + 11 parameters
     hipLaunchKernelGGL(ik_kernel, dim3(n_problems), dim3(NT), 0, (hipStream_t)stream, sk, kps17, Pmats, members,
                        n_problems, v_max, n_views, p_max, init_params, init_params ? cold : nullptr, max_nfev_cold,
-                       max_nfev_warm, params_out, joints_out, info_out);
+                       max_nfev_warm, params_out, joints_out, info_out, basis_in, basis_src, basis_out);
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;
 }

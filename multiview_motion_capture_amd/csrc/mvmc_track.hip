@@ -232,7 +232,7 @@ __global__ void commit_kernel(const int32_t* __restrict__ status, const int32_t*
                               const double* __restrict__ ik_params, const double* __restrict__ ik_joints, int B, int T,
                               int K, int n_inits, double* __restrict__ track_params, double* __restrict__ track_joints,
                               int32_t* __restrict__ meta, int32_t* __restrict__ n_tracks, int32_t* __restrict__ next_id,
-                              int32_t* __restrict__ n_dead) {
+                              int32_t* __restrict__ n_dead, int32_t* __restrict__ slot_src) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const int NP = T + K;
@@ -259,6 +259,7 @@ __global__ void commit_kernel(const int32_t* __restrict__ status, const int32_t*
         for (int e = 0; e < 68; ++e) tp[w * 68 + e] = sp[e];
         for (int e = 0; e < 54; ++e) tj[w * 54 + e] = sj[e];
         mt[w * 4] = id; mt[w * 4 + 1] = state; mt[w * 4 + 2] = hits; mt[w * 4 + 3] = len;
+        if (slot_src) slot_src[(size_t)b * T + w] = (st == 2) ? s : -1;  // IK problem slot solved this frame
         ++w;
     }
     int id = next_id[b];
@@ -270,8 +271,11 @@ __global__ void commit_kernel(const int32_t* __restrict__ status, const int32_t*
         for (int e = 0; e < 68; ++e) tp[w * 68 + e] = sp[e];
         for (int e = 0; e < 54; ++e) tj[w * 54 + e] = sj[e];
         mt[w * 4] = id++; mt[w * 4 + 1] = 1; mt[w * 4 + 2] = 1; mt[w * 4 + 3] = 1;
+        if (slot_src) slot_src[(size_t)b * T + w] = T + k;
         ++w;
     }
+    if (slot_src)
+        for (int s = w; s < T; ++s) slot_src[(size_t)b * T + s] = -1;
     next_id[b] = id;
     n_tracks[b] = w;
     n_dead[b] += dead;
@@ -325,7 +329,7 @@ extern "C" int mvmc_track_assign(const int32_t* labels_sp, const int32_t* ncl_sp
 extern "C" int mvmc_track_commit(const int32_t* status, const int32_t* n_new, const double* ik_params,
                                  const double* ik_joints, int n_chains, int t_max, int k_max, int n_inits,
                                  double* track_params, double* track_joints, int32_t* meta, int32_t* n_tracks,
-                                 int32_t* next_id, int32_t* n_dead, mvmcStream_t stream) {
+                                 int32_t* next_id, int32_t* n_dead, int32_t* slot_src, mvmcStream_t stream) {
     if (!status || !n_new || !ik_params || !ik_joints || !track_params || !track_joints || !meta || !n_tracks ||
         !next_id || !n_dead)
         return MVMC_ERR_ARG;
@@ -333,7 +337,7 @@ extern "C" int mvmc_track_commit(const int32_t* status, const int32_t* n_new, co
     if (n_chains <= 0) return n_chains == 0 ? MVMC_OK : MVMC_ERR_ARG;
     hipLaunchKernelGGL(commit_kernel, dim3((n_chains + 63) / 64), dim3(64), 0, (hipStream_t)stream, status, n_new,
                        ik_params, ik_joints, n_chains, t_max, k_max, n_inits, track_params, track_joints, meta,
-                       n_tracks, next_id, n_dead);
+                       n_tracks, next_id, n_dead, slot_src);
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;
 }
