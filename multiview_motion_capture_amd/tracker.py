@@ -18,7 +18,7 @@ from .pipeline import HotPath
 
 class ChainTracker:
     def __init__(self, hp: HotPath, n_chains: int, p_max: int, t_max: int = 8, k_max: Optional[int] = None,
-                 v_max: Optional[int] = None, nfev_cold=50, nfev_warm=5):
+                 v_max: Optional[int] = None, nfev_cold=50, nfev_warm=5, carry_basis=False):
         d = hp.device
         self.hp, self.B, self.P, self.T = hp, n_chains, p_max, t_max
         C = hp.K.shape[0]
@@ -36,7 +36,12 @@ class ChainTracker:
         self.n_dead = torch.zeros((B,), dtype=torch.int32, device=d)
         self.frame_idx = torch.arange(B, dtype=torch.int32, device=d)
         NP = T + self.K
-        self.basis = [torch.zeros((B * NP, dev._cabi.IK_BASIS_DOUBLES), dtype=torch.float64, device=d) for _ in range(2)]
+        # Optional: carry each tracklet's stage-1 eigenbasis to the next frame (warm-started Jacobi).  Measured
+        # on the synthetic workload it saves ~3 % of the IK time for ~80 MB of extra HBM traffic per launch,
+        # so it is off by default.
+        self.carry_basis = carry_basis
+        nb = B * NP if carry_basis else 1
+        self.basis = [torch.zeros((nb, dev._cabi.IK_BASIS_DOUBLES), dtype=torch.float64, device=d) for _ in range(2)]
         self.basis_src = torch.full((B * NP,), -1, dtype=torch.int32, device=d)
         self.slot_src = torch.full((B, T), -1, dtype=torch.int32, device=d)
         self._row0 = (torch.arange(B, dtype=torch.int32, device=d) * NP)[:, None]
@@ -65,8 +70,9 @@ class ChainTracker:
             e0.record()
         p, j, info = dev.ik_solve(kps17, hp.P, mem.reshape(B * NP, V), init.reshape(B * NP, 68),
                                   cold.reshape(B * NP), self.nfev_cold, self.nfev_warm, hp.skeleton,
-                                  basis_in=self.basis[self._flip], basis_src=self.basis_src,
-                                  basis_out=self.basis[1 - self._flip])
+                                  basis_in=self.basis[self._flip] if self.carry_basis else None,
+                                  basis_src=self.basis_src if self.carry_basis else None,
+                                  basis_out=self.basis[1 - self._flip] if self.carry_basis else None)
         if self.events is not None:
             e1.record()
             self.events.append((e0, e1))
