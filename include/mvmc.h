@@ -158,12 +158,13 @@ int mvmc_fmats_from_projections(const double* Pmats, int n_views, double* F2, mv
  * > 0.1); 2D-3D: reprojection_error (motion_capture.py:403-414); same view / 3D-3D: NaN -> nanmax + 1;
  * S = 1/(1+exp(5 (D-15)/30)) clamped (S < 1e-3 -> 0).  Chains with n_tracks == 0 get an empty graph (they
  * take the match_spatial path).
- *   track_joints (B,T,18,3) f64; W (B,NS,NS) f64 out, NS = T + C*P; D (B,NS,NS) out or NULL;
+ *   track_joints (B,T,18,3) f64; min_score = 0.1 in the reference (motion_capture.py:696,714,725);
+ *   W (B,NS,NS) f64 out, NS = T + C*P; D (B,NS,NS) raw distances (NaN kept) out or NULL;
  *   group_counts (B,C+1) i32 out = {n_tracks, people per view} */
 int mvmc_st_affinity(const double* kps17, const int32_t* counts, const int32_t* frame_idx,
                      const double* track_joints, const int32_t* n_tracks, const double* Pmats, const double* F2,
-                     int n_chains, int n_views, int p_max, int t_max, double* W, double* D, int32_t* group_counts,
-                     mvmcStream_t stream);
+                     int n_chains, int n_views, int p_max, int t_max, double min_score, double* W, double* D,
+                     int32_t* group_counts, mvmcStream_t stream);
 
 /* TK-1, first half (motion_capture.py:763-808 and :618-626): cluster labels -> IK problems of the frame.
  * Chains without tracklets read labels_sp (B,C*P) (match_spatial, every member kept); the others read

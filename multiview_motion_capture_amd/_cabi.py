@@ -67,7 +67,7 @@ def load():
     lib.mvmc_ik_solve.argtypes = [C.POINTER(MvmcSkeleton), vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, i32,
                                   vp, vp, vp, vp, vp, vp, vp]
     lib.mvmc_fmats_from_projections.argtypes = [vp, i32, vp, vp]
-    lib.mvmc_st_affinity.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
+    lib.mvmc_st_affinity.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f64, vp, vp, vp, vp]
     lib.mvmc_track_assign.argtypes = [vp] * 8 + [i32] * 6 + [vp] * 6
     lib.mvmc_track_commit.argtypes = [vp] * 4 + [i32] * 4 + [vp] * 8
     for name in SYMBOLS:

@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(64)
 st_affinity_kernel(const double* __restrict__ kps17, const int32_t* __restrict__ counts,
                    const int32_t* __restrict__ frame_idx, const double* __restrict__ track_joints,
                    const int32_t* __restrict__ n_tracks, const double* __restrict__ Pm, const double* __restrict__ F2,
-                   int C, int P, int T, double* __restrict__ W, double* __restrict__ Dout,
+                   int C, int P, int T, double min_score, double* __restrict__ W, double* __restrict__ Dout,
                    int32_t* __restrict__ group_counts) {
     extern __shared__ double sm[];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -119,9 +119,9 @@ st_affinity_kernel(const double* __restrict__ kps17, const int32_t* __restrict__
         else {
             const int vi = nview[i], vj = nview[j];
             if (vi >= 0 && vi == vj) d = nan;
-            else if (vi >= 0 && vj >= 0) d = epipolar_error(F2 + (vi * C + vj) * 9, kf + nidx[i] * 51, kf + nidx[j] * 51, 0.1);
-            else if (vi >= 0) d = reproj_error(tj + nidx[j] * 54, kf + nidx[i] * 51, Pm + vi * 12, 0.1);
-            else if (vj >= 0) d = reproj_error(tj + nidx[i] * 54, kf + nidx[j] * 51, Pm + vj * 12, 0.1);
+            else if (vi >= 0 && vj >= 0) d = epipolar_error(F2 + (vi * C + vj) * 9, kf + nidx[i] * 51, kf + nidx[j] * 51, min_score);
+            else if (vi >= 0) d = reproj_error(tj + nidx[j] * 54, kf + nidx[i] * 51, Pm + vi * 12, min_score);
+            else if (vj >= 0) d = reproj_error(tj + nidx[i] * 54, kf + nidx[j] * 51, Pm + vj * 12, min_score);
             else d = nan;
         }
         D[e] = d;
@@ -137,16 +137,16 @@ st_affinity_kernel(const double* __restrict__ kps17, const int32_t* __restrict__
     double* Db = Dout ? Dout + (size_t)b * NS * NS : nullptr;
     for (int e = tid; e < NS * NS; e += 64) {
         const int i = e / NS, j = e - i * NS;
-        double d = 0.0, s = 0.0;
+        double d = 0.0, s = 0.0, raw = 0.0;
         if (i < n && j < n) {
-            d = D[i * n + j];
+            d = raw = D[i * n + j];
             if (!(d == d)) d = s_max + 1.0;
             s = 1.0 / (1.0 + exp(5.0 * ((d - 15.0) / 30.0)));
             if (s < 1e-3) s = 0.0;
             if (s > 1.0) s = 1.0;
         }
         Wb[e] = s;
-        if (Db) Db[e] = d;
+        if (Db) Db[e] = raw;  // raw distances (NaN where the reference's matrix holds NaN before its nanmax fill)
     }
 }
 
@@ -293,8 +293,8 @@ extern "C" int mvmc_fmats_from_projections(const double* Pmats, int n_views, dou
 
 extern "C" int mvmc_st_affinity(const double* kps17, const int32_t* counts, const int32_t* frame_idx,
                                 const double* track_joints, const int32_t* n_tracks, const double* Pmats,
-                                const double* F2, int n_chains, int n_views, int p_max, int t_max, double* W,
-                                double* D, int32_t* group_counts, mvmcStream_t stream) {
+                                const double* F2, int n_chains, int n_views, int p_max, int t_max, double min_score,
+                                double* W, double* D, int32_t* group_counts, mvmcStream_t stream) {
     if (!kps17 || !counts || !frame_idx || !track_joints || !n_tracks || !Pmats || !F2 || !W || !group_counts)
         return MVMC_ERR_ARG;
     if (n_views <= 0 || p_max <= 0 || t_max <= 0) return MVMC_ERR_ARG;
@@ -303,7 +303,7 @@ extern "C" int mvmc_st_affinity(const double* kps17, const int32_t* counts, cons
     if (n_chains <= 0) return n_chains == 0 ? MVMC_OK : MVMC_ERR_ARG;
     const size_t shm = (size_t)NS * NS * sizeof(double) + (size_t)2 * NS * sizeof(int);
     hipLaunchKernelGGL(st_affinity_kernel, dim3(n_chains), dim3(64), shm, (hipStream_t)stream, kps17, counts, frame_idx,
-                       track_joints, n_tracks, Pmats, F2, n_views, p_max, t_max, W, D, group_counts);
+                       track_joints, n_tracks, Pmats, F2, n_views, p_max, t_max, min_score, W, D, group_counts);
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;
 }

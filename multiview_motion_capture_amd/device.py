@@ -255,7 +255,7 @@ def fmats_from_projections(Pmats: torch.Tensor) -> torch.Tensor:
     return F2
 
 
-def st_affinity(kps17, counts, frame_idx, track_joints, n_tracks, Pmats, F2, want_D=False):
+def st_affinity(kps17, counts, frame_idx, track_joints, n_tracks, Pmats, F2, want_D=False, min_score=0.1):
     """AS-7/8/9.  -> (W (B,NS,NS) f64, D | None, group_counts (B,C+1) i32)."""
     F, Cn, P = kps17.shape[:3]
     B, T = track_joints.shape[:2]
@@ -271,7 +271,8 @@ def st_affinity(kps17, counts, frame_idx, track_joints, n_tracks, Pmats, F2, wan
     D = torch.empty((B, NS, NS), dtype=torch.float64, device=kps17.device) if want_D else None
     gc = torch.empty((B, Cn + 1), dtype=torch.int32, device=kps17.device)
     check(_cabi.load().mvmc_st_affinity(_p(kps17), _p(counts), _p(frame_idx), _p(track_joints), _p(n_tracks), _p(Pmats),
-                                        _p(F2), B, Cn, P, T, _p(W), _p(D), _p(gc), _stream()), "mvmc_st_affinity")
+                                        _p(F2), B, Cn, P, T, float(min_score), _p(W), _p(D), _p(gc), _stream()),
+          "mvmc_st_affinity")
     return W, D, gc
 
 

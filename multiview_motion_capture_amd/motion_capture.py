@@ -118,3 +118,121 @@ def match_spatial(frames: List[FrameData]) -> SpatialTimeMatch:
         out.spatial_matches.append(m)
     out.dst_mat, out.sim_mat = dst_mat, s_mat
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# temporal layer: reprojection_error, match_spatial_time, MvTracklet / MvTracker
+# ------------------------------------------------------------------------------------------------
+from enum import Enum  # noqa: E402
+
+import torch  # noqa: E402
+
+from . import device as _dev  # noqa: E402
+from .inverse_kinematics import PoseShapeParam, Skeleton, load_skeleton  # noqa: E402,F401
+from .mv_math_util import _d, _pair_graph  # noqa: E402
+
+
+class TrackState(Enum):
+    Tentative = 1
+    Confirmed = 2
+    Dead = 3
+
+
+def reprojection_error(p_3d: Pose, p_2d: Pose, calib: Calib, min_valid_kps_score=0.05,
+                       invalid_default_error=np.nan):
+    """motion_capture.py:403-414 (BASIC_18 3-D pose against a COCO 2-D pose)."""
+    k2 = np.concatenate([p_2d.keypoints, np.asarray(p_2d.keypoints_score).reshape(-1, 1)], axis=1)
+    e = float(_pair_graph(p_3d.keypoints, [k2], [calib.P], min_valid_kps_score)[0, 1])
+    return invalid_default_error if np.isnan(e) else e
+
+
+class MvTracklet:
+    """Host-side record of one tracklet (motion_capture.py:312-400); the numbers come from the device."""
+
+    def __init__(self, tid, frm_idx, pparam, pose):
+        self.track_id = tid
+        self.frame_idxs = [frm_idx]
+        self.poses = [(frm_idx, pparam, pose)]
+        self.state = TrackState.Tentative
+        self.hits = 1
+        self.time_since_update = 0
+
+    @property
+    def last_pose_3d(self):
+        return self.poses[-1][-1]
+
+    def __len__(self):
+        return len(self.frame_idxs)
+
+    def is_tentative(self):
+        return self.state == TrackState.Tentative
+
+    def is_confirmed(self):
+        return self.state == TrackState.Confirmed
+
+    def is_dead(self):
+        return self.state == TrackState.Dead
+
+
+class MvTracker:
+    """MvTracker (motion_capture.py:840-963): update_4d runs association (match_spatial /
+    match_spatial_time), the IK solves and the track bookkeeping on the GPU for one sequence."""
+
+    def __init__(self, skel: Skeleton = None, p_max: int = 8, t_max: int = 8):
+        self.skeleton = skel or load_skeleton()
+        self.tracklets: List[MvTracklet] = []
+        self.dead_tracklets: List[MvTracklet] = []
+        self._p_max, self._t_max = p_max, t_max
+        self._chain = None
+        self._by_id = {}
+
+    def _ensure(self, d_frames):
+        if self._chain is None:
+            from .pipeline import HotPath
+            from .tracker import ChainTracker
+            hp = HotPath(np.array([f.calib.K for f in d_frames]), np.array([f.calib.Rt for f in d_frames]), device=_d())
+            self._chain = ChainTracker(hp, 1, self._p_max, self._t_max)
+
+    def update_4d(self, frm_idx: int, d_frames: List[FrameData], debug_view_imgs=None):
+        self._ensure(d_frames)
+        ch = self._chain
+        C, P = len(d_frames), self._p_max
+        kps = np.zeros((1, C, P, 17, 3))
+        cnt = np.zeros((1, C), dtype=np.int32)
+        for c, frm in enumerate(d_frames):
+            if len(frm.poses) > P:
+                raise ValueError(f"update_4d: more than p_max={P} people in view {c}")
+            for k, pose in enumerate(frm.poses.values()):
+                kps[0, c, k, :, :2] = pose.keypoints
+                kps[0, c, k, :, 2] = np.asarray(pose.keypoints_score).ravel()
+            cnt[0, c] = len(frm.poses)
+        d = ch.hp.device
+        for t in self.tracklets:
+            t.time_since_update += 1
+        ch.step(torch.as_tensor(kps, device=d), torch.as_tensor(cnt, device=d))
+        n = int(ch.n_tracks[0])
+        meta = ch.meta[0, :n].cpu().numpy()
+        params = ch.params[0, :n].cpu().numpy()
+        joints = ch.joints[0, :n].cpu().numpy()
+        alive = []
+        for k in range(n):
+            tid, state, hits, length = (int(v) for v in meta[k])
+            x = params[k]
+            pparam = PoseShapeParam(x[:3].copy(), x[3:57].reshape(18, 3).copy(), x[57:].copy())
+            pose = Pose(KpsFormat.BASIC_18, joints[k].copy(), np.ones((18, 1)), None)
+            t = self._by_id.get(tid)
+            if t is None:
+                t = MvTracklet(tid, frm_idx, pparam, pose)
+                self._by_id[tid] = t
+            elif hits > t.hits:
+                t.frame_idxs.append(frm_idx)
+                t.poses.append((frm_idx, pparam, pose))
+                t.time_since_update = 0
+            t.hits, t.state = hits, TrackState(state)
+            alive.append(t)
+        ids = {t.track_id for t in alive}
+        for t in self.tracklets:
+            if t.track_id not in ids:
+                t.state = TrackState.Dead
+                self.dead_tracklets.append(t)
+        self.tracklets = alive

@@ -74,3 +74,37 @@ def triangulate_point_from_multiple_views_linear(proj_matricies, points):
     pts = np.concatenate([np.asarray(points, np.float64), np.ones((len(points), 1))], axis=1)
     out = triangulate_point_groups_from_multiple_views_linear(proj_matricies, [p[None] for p in pts], 0.0)
     return out[0, :3]
+
+
+def get_fundamental_matrix(p1, p2) -> np.ndarray:
+    """mv_math_util.py:57-77: F with x2^T F x1 = 0 from two 3x4 projection matrices."""
+    d = _d()
+    P = torch.as_tensor(np.array([np.asarray(p1, np.float64), np.asarray(p2, np.float64)]), device=d).contiguous()
+    return dev.fmats_from_projections(P)[0, 1].cpu().numpy()
+
+
+def _pair_graph(joints3d, views, projs, min_score):
+    """One-frame match_spatial_time graph with optional tracklet 0 and one pose per view -> raw D (numpy)."""
+    d = _d()
+    C = len(views)
+    kps = torch.as_tensor(np.array([np.asarray(v, np.float64) for v in views])[None, :, None], device=d).contiguous()
+    cnt = torch.ones((1, C), dtype=torch.int32, device=d)
+    P = torch.as_tensor(np.array([np.asarray(p, np.float64) for p in projs]), device=d).contiguous()
+    tj = torch.zeros((1, 1, 18, 3), dtype=torch.float64, device=d)
+    if joints3d is not None:
+        tj[0, 0] = torch.as_tensor(np.asarray(joints3d, np.float64), device=d)
+    _, D, _ = dev.st_affinity(kps, cnt, torch.zeros(1, dtype=torch.int32, device=d), tj,
+                              torch.ones(1, dtype=torch.int32, device=d), P, dev.fmats_from_projections(P),
+                              want_D=True, min_score=min_score)
+    return D[0].cpu().numpy()
+
+
+def calc_epipolar_error(cam1: Calib, keypoints_1, scores_1, cam2: Calib, keypoints_2, scores_2,
+                        min_valid_kps_score=0.05, invalid_default_error=np.nan):
+    """mv_math_util.py:80-115 (17 COCO joints)."""
+    if len(keypoints_1) == 0:
+        return invalid_default_error
+    k1 = np.concatenate([np.asarray(keypoints_1, np.float64), np.asarray(scores_1, np.float64).reshape(-1, 1)], axis=1)
+    k2 = np.concatenate([np.asarray(keypoints_2, np.float64), np.asarray(scores_2, np.float64).reshape(-1, 1)], axis=1)
+    e = float(_pair_graph(None, [k1, k2], [cam1.P, cam2.P], min_valid_kps_score)[1, 2])
+    return invalid_default_error if np.isnan(e) else e

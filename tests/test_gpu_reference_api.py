@@ -97,3 +97,51 @@ def test_pose_solver_and_fk(api):
     assert np.isfinite(pose.keypoints).all() and param.bone_lens.shape == (11,)
     with pytest.raises(ValueError):
         ik.PoseSolver(skel, None, list(g["poses"][i, :1]), list(g["projs"][i, :1]), obs_kps_format=pd.KpsFormat.COCO)
+
+
+def test_pairwise_errors_and_fundamental(api):
+    """calc_epipolar_error / reprojection_error / get_fundamental_matrix against the oracle."""
+    mu, mc, pd = api["mu"], api["mc"], api["pose_def"]
+    g = load_golden("shelf_spatial.npz")
+    pts, sc = g["f150_points"], g["f150_scores"]
+    dim = g["f150_dim"]
+    calibs = api["calibs"]
+    F = mu.get_fundamental_matrix(calibs[0].P, calibs[1].P)
+    ref = o.fundamental_from_projections(calibs[0].P, calibs[1].P)
+    assert np.abs(F - ref).max() <= 1e-12 * np.abs(ref).max()
+    n_checked = 0
+    for a in range(dim[0], dim[1]):
+        for b in range(dim[1], dim[2]):
+            e = mu.calc_epipolar_error(calibs[0], pts[a], sc[a], calibs[1], pts[b], sc[b], 0.1, np.nan)
+            r = o.epipolar_error(calibs[0].P, pts[a], sc[a], calibs[1].P, pts[b], sc[b], 0.1, np.nan)
+            assert (np.isnan(e) and np.isnan(r)) or abs(e - r) <= 1e-9 * max(1.0, abs(r))
+            n_checked += 1
+    assert n_checked >= 4
+    ik = load_golden("ik_cases.npz")
+    i = int(np.nonzero(~ik["cold"])[0][0])
+    p3 = pd.Pose(pd.KpsFormat.BASIC_18, ik["joints"][i], np.ones((18, 1)), None)
+    for v in range(int(ik["n_views"][i])):
+        k = ik["poses"][i, v]
+        p2 = pd.Pose(pd.KpsFormat.COCO, k[:, :2], k[:, 2:], None)
+        cal = next(c for c in calibs if np.array_equal(c.P, ik["projs"][i, v]))
+        e = mc.reprojection_error(p3, p2, cal, 0.1, np.nan)
+        r = o.reprojection_error(ik["joints"][i], k[:, :2], k[:, 2], cal.P, 0.1, np.nan)
+        assert abs(e - r) <= 1e-9 * max(1.0, abs(r))
+    none = pd.Pose(pd.KpsFormat.COCO, np.zeros((17, 2)), np.zeros((17, 1)), None)
+    assert mc.reprojection_error(p3, none, calibs[0], 0.1, -1.0) == -1.0
+
+
+def test_mvtracker_update_4d_matches_reference_log(api):
+    """The reference's driver loop (motion_capture.py:1077-1111) through the mirrored MvTracker."""
+    mc = api["mc"]
+    g = load_golden("shelf_tracker.npz")
+    tracker = mc.MvTracker(api["ik"].load_skeleton())
+    for fi in range(1, 41):
+        tracker.update_4d(fi, _frames(api, fi), None)
+        exp = g["alive_after"][fi - 1]
+        exp = exp[exp[:, 0] >= 0]
+        got = [(t.track_id, t.state.value, t.hits, len(t)) for t in tracker.tracklets]
+        assert got == [tuple(int(v) for v in r) for r in exp], fi
+        assert len(tracker.dead_tracklets) == int(g["n_dead"][fi - 1])
+    t0 = tracker.tracklets[0]
+    assert t0.last_pose_3d.keypoints.shape == (18, 3) and t0.is_confirmed() and len(t0.poses) == 40
