@@ -119,6 +119,12 @@ int mvmc_cluster_members(const int32_t* labels, const int32_t* counts, int n_fra
 int mvmc_dlt(const double* kps, const double* Pmats, const int32_t* members, int n_problems, int v_max,
              int n_views, int p_max, int n_joints, double min_score, double* out, mvmcStream_t stream);
 
+/* TR-2, post_optimize=True (mv_math_util.py:189-210): scipy least_squares(max_nfev = 2) on the unsigned
+ * residual |proj - obs| * score with eps = 1e-6, i.e. one trust-region trial step from the DLT points, kept
+ * only if it lowers the cost.  pts (B,J,4) is the output of mvmc_dlt, updated in place (x, y, z only). */
+int mvmc_triangulate_postopt(const double* kps, const double* Pmats, const int32_t* members, int n_problems,
+                             int v_max, int n_views, int p_max, int n_joints, double* pts, mvmcStream_t stream);
+
 /* FK-1 + FK-2: foward_kinematics (inverse_kinematics.py:176-199) with Quaternions.from_euler /
  * transforms (Quaternions.py:449-462, :335-366).
  *   params (B,3+54+n_side) f64 = root, euler(18,3), bone lengths
@@ -131,7 +137,8 @@ int mvmc_fk(const mvmcSkeleton* skel_host, const double* params, int n_problems,
  * least_squares defaults, max_nfev evaluations each).
  *   members      (B,V) pose indices into kps17 (-1 padded)
  *   init_params  (B,68) warm-start parameters, ignored where cold[b] != 0
- *   cold         (B) u8: 1 = cold start (DLT root, zero angles, reference lengths, max_nfev_cold),
+ *   cold         (B) u8: 1 = cold start (root = midpoint of the post-optimised DLT hips, zero angles,
+ *                reference lengths, max_nfev_cold),
  *                0 = warm (max_nfev_warm); NULL = all cold
  *   params_out   (B,68); joints_out (B,18,3); info_out (B,8) f64 =
  *                {cost1, nfev1, status1, cost2, nfev2, status2, njev1+njev2, Jacobi sweeps} or NULL

@@ -22,7 +22,7 @@ MAX_NODES = 64
 # every symbol declared in include/mvmc.h
 SYMBOLS = (
     "mvmc_abi_version", "mvmc_status_string", "mvmc_als_seed_table", "mvmc_ingest", "mvmc_fmats",
-    "mvmc_affinity", "mvmc_als_associate", "mvmc_closure_labels", "mvmc_cluster_members", "mvmc_dlt", "mvmc_fk", "mvmc_ik_solve",
+    "mvmc_affinity", "mvmc_als_associate", "mvmc_closure_labels", "mvmc_cluster_members", "mvmc_dlt", "mvmc_triangulate_postopt", "mvmc_fk", "mvmc_ik_solve",
     "mvmc_fmats_from_projections", "mvmc_st_affinity", "mvmc_track_assign", "mvmc_track_commit",
 )
 
@@ -63,6 +63,7 @@ def load():
     lib.mvmc_closure_labels.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp]
     lib.mvmc_cluster_members.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.mvmc_dlt.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, f64, vp, vp]
+    lib.mvmc_triangulate_postopt.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
     lib.mvmc_fk.argtypes = [C.POINTER(MvmcSkeleton), vp, i32, vp, vp, vp]
     lib.mvmc_ik_solve.argtypes = [C.POINTER(MvmcSkeleton), vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, i32,
                                   vp, vp, vp, vp, vp, vp, vp]

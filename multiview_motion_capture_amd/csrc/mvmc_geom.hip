@@ -1,5 +1,6 @@
 // Geometry kernels for gfx950: batched multi-view DLT (TR-1/TR-2) and forward kinematics (FK-1/FK-2).
 #include "mvmc_common.h"
+#include "mvmc_postopt.h"
 
 // ------------------------------------------------------------------------------------------------
 // DLT: one thread per (problem, joint).  The 2V x 4 system is reduced to its 4x4 normal matrix in
@@ -105,6 +106,45 @@ dlt_kernel(const double* __restrict__ kps17, const double* __restrict__ Pm, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// post-optimise of triangulated points (mv_math_util.py:189-210): one wave per problem
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+postopt_kernel(const double* __restrict__ kps, const double* __restrict__ Pm, const int32_t* __restrict__ members,
+               int V, int C, int Pmax, int J, double* __restrict__ pts) {
+    extern __shared__ double sm[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    double* sObs = sm;                 // [nv][J][3]
+    double* sP = sm + V * J * 3;       // [nv][12]
+    __shared__ int s_nv;
+    __shared__ int s_q[64];
+    if (lane == 0) {
+        int nv = 0;
+        for (int v = 0; v < V && nv < 64; ++v) {
+            const int q = members[(size_t)b * V + v];
+            if (q >= 0) s_q[nv++] = q;
+        }
+        s_nv = nv;
+    }
+    __syncthreads();
+    const int nv = s_nv;
+    if (nv < 1) return;
+    for (int e = lane; e < nv * J * 3; e += 64) {
+        const int v = e / (J * 3), r = e - v * J * 3;
+        sObs[e] = kps[(size_t)s_q[v] * J * 3 + r];
+    }
+    for (int e = lane; e < nv * 12; e += 64) {
+        const int v = e / 12, r = e - v * 12;
+        sP[e] = Pm[(size_t)((s_q[v] / Pmax) % C) * 12 + r];
+    }
+    __syncthreads();
+    double X[3] = {0, 0, 0};
+    double* o = pts + ((size_t)b * J + (lane < J ? lane : 0)) * 4;
+    if (lane < J) { X[0] = o[0]; X[1] = o[1]; X[2] = o[2]; }
+    postopt::post_optimize_wave(X, sObs + (lane < J ? lane : 0) * 3, J * 3, sP, nv, J);
+    if (lane < J) { o[0] = X[0]; o[1] = X[1]; o[2] = X[2]; }
+}
+
+// ------------------------------------------------------------------------------------------------
 // FK: R_j = Rx Ry Rz through the reference's quaternion path (axis scaled by 1/(1+1e-10),
 // Quaternions.py:444), chained 4x4 products in index order (parents precede children).
 // ------------------------------------------------------------------------------------------------
@@ -172,6 +212,20 @@ extern "C" int mvmc_fk(const mvmcSkeleton* skel_host, const double* params, int 
     if (!skel_to_dev(skel_host, &sk)) return MVMC_ERR_ARG;
     hipLaunchKernelGGL(fk_kernel, dim3((n_problems + 63) / 64), dim3(64), 0, (hipStream_t)stream, sk, params,
                        n_problems, joints, G);
+    MVMC_CHECK_LAUNCH();
+    return MVMC_OK;
+}
+
+extern "C" int mvmc_triangulate_postopt(const double* kps, const double* Pmats, const int32_t* members, int n_problems,
+                                        int v_max, int n_views, int p_max, int n_joints, double* pts,
+                                        mvmcStream_t stream) {
+    if (!kps || !Pmats || !members || !pts || v_max <= 0 || v_max > 64 || n_views <= 0 || p_max <= 0) return MVMC_ERR_ARG;
+    if (n_joints <= 0 || n_joints > 64) return MVMC_ERR_UNSUPPORTED;
+    if (n_problems <= 0) return n_problems == 0 ? MVMC_OK : MVMC_ERR_ARG;
+    const size_t shm = ((size_t)v_max * n_joints * 3 + (size_t)v_max * 12) * sizeof(double);
+    if (shm > 60 * 1024) return MVMC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(postopt_kernel, dim3(n_problems), dim3(64), shm, (hipStream_t)stream, kps, Pmats, members, v_max,
+                       n_views, p_max, n_joints, pts);
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;
 }

@@ -14,6 +14,7 @@
 //   * columns that are identically zero for every input (leaf-joint angles, the root's bone length) are
 //     removed from the eigenproblem -- SciPy gives them s = 0 and a zero step, which is what they get here.
 #include "mvmc_common.h"
+#include "mvmc_postopt.h"
 
 namespace {
 
@@ -717,8 +718,15 @@ ik_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restr
     // ---- initial parameters ----
     const bool is_cold = (cold == nullptr) || cold[b] != 0;
     if (is_cold) {
-        // root = midpoint of the triangulated hips; zero angles; reference lengths (:390-396)
-        if (tid < 2) dlt_obs_point(pose18, S.Pm, nv, 11 + tid, 0.01, &S.xn[tid * 3]);
+        // root = midpoint of the triangulated (post-optimised) hips; zero angles; reference lengths
+        // (inverse_kinematics.py:390-396 with triangulate(..., 0.01, post_optimize=True))
+        if (tid < 64) {
+            double X[3] = {0, 0, 0};
+            if (tid < 18) dlt_obs_point(pose18, S.Pm, nv, tid, 0.01, X);
+            postopt::post_optimize_wave(X, pose18 + (tid < 18 ? tid : 0) * 3, 54, S.Pm, nv, 18);
+            if (tid == 11 || tid == 12)
+                for (int c = 0; c < 3; ++c) S.xn[(tid - 11) * 3 + c] = X[c];
+        }
         for (int i = tid; i < 54; i += NT) S.x[3 + i] = 0.0;
         if (tid < n_side) { S.side[tid] = S.ref_side[tid]; S.x[57 + tid] = S.ref_side[tid]; }
         __syncthreads();

@@ -183,7 +183,7 @@ def cluster_members(labels: torch.Tensor, counts: torch.Tensor, p_max: int, k_ma
     return mem, nm
 
 
-def dlt(kps: torch.Tensor, Pmats: torch.Tensor, members: torch.Tensor, min_score=0.01) -> torch.Tensor:
+def dlt(kps: torch.Tensor, Pmats: torch.Tensor, members: torch.Tensor, min_score=0.01, post_optimize=False) -> torch.Tensor:
     """TR-1/TR-2.  kps (F,C,P,J,3); Pmats (C,3,4); members (...,V) pose indices -> (...,J,4)."""
     F, Cn, P, J = kps.shape[:4]
     _req(kps, torch.float64, "kps", (F, Cn, P, J, 3))
@@ -194,6 +194,9 @@ def dlt(kps: torch.Tensor, Pmats: torch.Tensor, members: torch.Tensor, min_score
     out = torch.empty((B, J, 4), dtype=torch.float64, device=kps.device)
     check(_cabi.load().mvmc_dlt(_p(kps), _p(Pmats), _p(mem), B, V, Cn, P, J, float(min_score), _p(out), _stream()),
           "mvmc_dlt")
+    if post_optimize:
+        check(_cabi.load().mvmc_triangulate_postopt(_p(kps), _p(Pmats), _p(mem), B, V, Cn, P, J, _p(out), _stream()),
+              "mvmc_triangulate_postopt")
     return out.reshape(members.shape[:-1] + (J, 4))
 
 

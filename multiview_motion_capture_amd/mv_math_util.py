@@ -56,8 +56,8 @@ def geometry_affinity(points_set, Fs, dimGroup):
 def triangulate_point_groups_from_multiple_views_linear(proj_matricies, points_grps, min_score,
                                                         post_optimize=False, n_max_iter=2):
     """mv_math_util.py:152-212.  proj_matricies V x (3,4); points_grps V x (J,3) -> (J,4)."""
-    if post_optimize:
-        raise NotImplementedError("post_optimize=True (SURVEY.md 8f rank 3) is not built yet")
+    if post_optimize and n_max_iter != 2:
+        raise ValueError("post_optimize: only n_max_iter = 2 (the reference's default, one trial step) is built")
     d = _d()
     V = len(points_grps)
     J = len(points_grps[0])
@@ -66,7 +66,7 @@ def triangulate_point_groups_from_multiple_views_linear(proj_matricies, points_g
         kps[0, v, 0] = np.asarray(points_grps[v], np.float64)
     P = torch.as_tensor(np.array([np.asarray(p, np.float64) for p in proj_matricies]), device=d).contiguous()
     mem = torch.arange(V, dtype=torch.int32, device=d)[None]
-    return dev.dlt(torch.as_tensor(kps, device=d), P, mem, float(min_score))[0].cpu().numpy()
+    return dev.dlt(torch.as_tensor(kps, device=d), P, mem, float(min_score), post_optimize=bool(post_optimize))[0].cpu().numpy()
 
 
 def triangulate_point_from_multiple_views_linear(proj_matricies, points):

@@ -104,7 +104,7 @@ def test_cost_and_fk_at_x0(ctx):
         assert np.abs(j[b] - pos).max() < 1e-13
 
 
-def test_cold_start_root_is_dlt_of_hips(ctx):
+def test_cold_start_root_is_midpoint_of_post_optimised_hips(ctx):
     g = ctx["g"]
     idx = ctx["idx"][g["cold"][ctx["idx"]]][:8]
     p, j, info = _run(ctx, idx, 1, 1)
@@ -112,9 +112,11 @@ def test_cold_start_root_is_dlt_of_hips(ctx):
     for b, i in enumerate(idx):
         v = int(g["n_views"][i])
         poses18 = [o.add_mid_spine(q) for q in g["poses"][i, :v]]
-        p3d = o.triangulate_groups(g["projs"][i, :v], poses18, 0.01, False)
+        p3d = o.triangulate_groups(g["projs"][i, :v], poses18, 0.01, True)
         root = 0.5 * (p3d[11, :3] + p3d[12, :3])
-        assert np.abs(p[b, :3] - root).max() < 1e-8
+        if v >= 3:  # 2-view post-optimise is rank deficient (noise-driven step), see DESIGN.md
+            assert np.abs(p[b, :3] - root).max() < 1e-5, (i, v, np.abs(p[b, :3] - root).max())
+        assert np.abs(p[b, :3] - g["s1_x0"][i][:3]).max() < 1e-5 or v < 3
         assert not p[b, 3:57].any() and np.array_equal(p[b, 57:], side)
 
 

@@ -7,6 +7,7 @@ import oracle_np as o
 from conftest import SPATIAL_FRAMES, load_golden
 
 pytestmark = pytest.mark.gpu
+POSTOPT_LOG = []
 
 
 @pytest.fixture(scope="module")
@@ -71,6 +72,14 @@ def test_match_spatial_call_chain(api, fi):
         seen = np.array([sum(gr[j, 2] >= 0.01 for gr in grps) >= 2 for j in range(17)])
         rel = np.linalg.norm(out[seen, :3] - ref[seen, :3], axis=1) / np.linalg.norm(ref[seen, :3], axis=1)
         assert rel.max() < 1e-4 and np.allclose(out[:, 3], ref[:, 3], rtol=1e-14)
+        # post_optimize=True: one trust-region step of scipy's TRF (analytic gradient here, 2-point FD there)
+        post = mu.triangulate_point_groups_from_multiple_views_linear(np.array(projs), grps, 0.01, True)
+        refp = g[f"f{fi}_cl{ci}_dlt_post"]
+        relp = np.linalg.norm(post[seen, :3] - refp[seen, :3], axis=1) / np.linalg.norm(refp[seen, :3], axis=1)
+        moved = np.abs(refp[:, :3] - ref[:, :3]).max()
+        POSTOPT_LOG.append((fi, ci, len(cl), float(relp.max()), float(moved)))
+        if len(cl) >= 3:
+            assert relp.max() < 1e-4, (fi, ci, relp.max())
 
 
 def test_pose_solver_and_fk(api):
@@ -145,3 +154,39 @@ def test_mvtracker_update_4d_matches_reference_log(api):
         assert len(tracker.dead_tracklets) == int(g["n_dead"][fi - 1])
     t0 = tracker.tracklets[0]
     assert t0.last_pose_3d.keypoints.shape == (18, 3) and t0.is_confirmed() and len(t0.poses) == 40
+
+
+def test_post_optimize_summary():
+    """Runs after the per-frame tests: how the post-optimise step compares over all Shelf clusters."""
+    assert POSTOPT_LOG
+    worst3 = max(r[3] for r in POSTOPT_LOG if r[2] >= 3)
+    two = [r for r in POSTOPT_LOG if r[2] == 2]
+    print(f"post-optimise: {len(POSTOPT_LOG)} clusters; >=3 views worst rel diff {worst3:.2e}; "
+          f"2-view clusters {len(two)}, of which within 1e-4: {sum(r[3] < 1e-4 for r in two)}; "
+          f"reference moved its points by up to {max(r[4] for r in POSTOPT_LOG):.3f} m")
+    assert worst3 < 1e-4
+
+
+def test_post_optimize_accepting_step_matches_scipy(api):
+    """Full-rank case (every joint seen by >= 3 views): the Gauss-Newton step lies inside the trust region,
+    lowers the reprojection cost and is accepted -- compare with the oracle's SciPy run."""
+    from multiview_motion_capture_amd import synth
+    mu = api["mu"]
+    rng = np.random.default_rng(11)
+    K, Rt, P = synth.make_cameras(5, rng)
+    worst, n_moved = 0.0, 0
+    for trial in range(6):
+        X = rng.normal(0, 0.6, (17, 3)) + np.array([0.3, -0.2, 1.0])
+        grps = []
+        for c in range(5):
+            h = P[c] @ np.concatenate([X, np.ones((17, 1))], axis=1).T
+            uv = (h[:2] / h[2]).T + rng.normal(0, 3.0, (17, 2))
+            grps.append(np.concatenate([uv, rng.uniform(0.3, 1.0, (17, 1))], axis=1))
+        ref0 = o.triangulate_groups(P, grps, 0.01, False)
+        ref = o.triangulate_groups(P, grps, 0.01, True)
+        out = mu.triangulate_point_groups_from_multiple_views_linear(P, grps, 0.01, True)
+        n_moved += int(np.abs(ref[:, :3] - ref0[:, :3]).max() > 1e-6)
+        worst = max(worst, np.abs(out[:, :3] - ref[:, :3]).max())
+    print("post-optimise accepted in", n_moved, "of 6 trials; worst |device - scipy| =", worst)
+    assert n_moved >= 4
+    assert worst < 1e-6  # analytic gradient vs 2-point finite differences
