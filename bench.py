@@ -209,7 +209,7 @@ def main():
         if os.path.exists(tp):
             rec = json.load(open(tp))
             key = f"{dom}:{F}x{C}x{Pn}"
-            traffic = rec.get(key)
+            traffic = (rec.get(key) or {}).get("bytes")  # measured offline: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
         res = {
             "metric": "frames/s (assoc+triangulate+IK) at C=5,P=4,J=25" if with_ik else "frames/s (assoc+triangulate)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -541,7 +541,13 @@ __device__ __forceinline__ void gj_chain(double (&g)[R], double* __restrict__ mu
     for (int p = 0; p < R; ++p) {
         double piv[R];
 #pragma unroll
-        for (int b = p; b < R; ++b) piv[b] = __shfl(g[b], p, 64);
+        for (int b = p; b < R; ++b) {
+            // broadcast row p (lane p) through SGPRs: v_readlane, no LDS crossbar round trip
+            const unsigned long long bits = __double_as_longlong(g[b]);
+            const unsigned lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffu), p);
+            const unsigned hi = __builtin_amdgcn_readlane((int)(bits >> 32), p);
+            piv[b] = __longlong_as_double(((unsigned long long)hi << 32) | lo);
+        }
         const double m = (a == p) ? 0.0 : g[p] * fast_rcp(piv[p]);
 #pragma unroll
         for (int b = p + 1; b < R; ++b) g[b] -= m * piv[b];
@@ -555,14 +561,21 @@ __device__ __forceinline__ void gj_apply(double (&hv)[R], const double* __restri
 #pragma unroll
     for (int p = 0; p < R; ++p) {
         const double hp = hv[p];
+        const double2* mr = reinterpret_cast<const double2*>(&mul[p * R]);
 #pragma unroll
-        for (int a = 0; a < R; ++a) hv[a] -= mul[p * R + a] * hp;  // mul[p][p] == 0
+        for (int a = 0; a < R; a += 2) { const double2 v2 = mr[a >> 1]; hv[a] -= v2.x * hp; hv[a + 1] -= v2.y * hp; }  // mul[p][p] == 0
         hv[p] = hp;
     }
 #pragma unroll
     for (int a = 0; a < R; ++a) hv[a] *= dinv[a];
 }
 
+#ifdef MVMC_ALS_PROFILE
+__shared__ long long g_alsprof[8];
+#define APROF(k) { const long long _t = clock64(); if (threadIdx.x == 0) g_alsprof[k] += _t - _tp; _tp = _t; }
+#else
+#define APROF(k)
+#endif
 template <typename TW, int NMAX, int R>
 __device__ __forceinline__ int als2_iterate(const TW* __restrict__ Wf, int ldw, int n, int r, const int* sGid,
                                             const double* __restrict__ seed, double* sX, double* sA, double* sB,
@@ -598,43 +611,52 @@ __device__ __forceinline__ int als2_iterate(const TW* __restrict__ Wf, int ldw, 
     __syncthreads();
     double mu = 64.0;
     int iters = 1000;
+    const int n4 = (n + 3) & ~3;  // rows beyond n are exact zeros: loops stop at the next multiple of 4
+#ifdef MVMC_ALS_PROFILE
+    if (threadIdx.x < 8) g_alsprof[threadIdx.x] = 0;
+    long long _tp = clock64();
+#endif
     for (int it = 0; it < 1000; ++it) {
         // ---- X1 = Z - (Y - W + beta)/mu ; own row half in registers, whole matrix in LDS ----
+        const double inv_mu = 1.0 / mu;  // mu = 64 * 2^k: the reciprocal is exact, x * inv_mu == x / mu bit for bit
 #pragma unroll
         for (int c = 0; c < NH; ++c) {
             double v = 0.0;
             if ((valid >> c) & 1) {
                 if (sizeof(TW) == 4 && it == 0) v = (double)(w32[c] - faddr(-w32[c], 0.1f) / 64.f);
-                else v = z[c] - ((y[c] - w[c]) + 0.1) / mu;
+                else v = z[c] - ((y[c] - w[c]) + 0.1) * inv_mu;
             }
             x1[c] = v;
             if (i < NMAX) sX[i * LDX + h * NH + c] = v;
         }
         __syncthreads();
+        APROF(0)
         const double ridge = 50.0 / mu;
         double hv[R];
         // ---- B update: G = A^T A + ridge I ; H[:, j] = A^T X1[:, j] ----
         for (int e = lane; e < R * R; e += 64) {
             const int a = e / R, b = e - a * R;
-            double g = (a == b) ? ridge : 0.0;
-#pragma unroll 8
-            for (int k = 0; k < NMAX; ++k) g += sA[k * R + a] * sA[k * R + b];
-            sG[e] = g;
+            double g0 = (a == b) ? ridge : 0.0, g1 = 0.0;
+#pragma unroll 4
+            for (int k = 0; k < n4; k += 2) { g0 += sA[k * R + a] * sA[k * R + b]; g1 += sA[(k + 1) * R + a] * sA[(k + 1) * R + b]; }
+            sG[e] = g0 + g1;
         }
 #pragma unroll
         for (int a = 0; a < R; ++a) hv[a] = 0.0;
         if (i < NMAX) {
+            const int k_end = (h + 1) * NH < n4 ? (h + 1) * NH : n4;
 #pragma unroll 4
-            for (int kk = 0; kk < NH; ++kk) {
-                const int k = h * NH + kk;
+            for (int k = h * NH; k < k_end; ++k) {
                 const double xv = sX[k * LDX + i];
+                const double2* ar = reinterpret_cast<const double2*>(&sA[k * R]);
 #pragma unroll
-                for (int a = 0; a < R; ++a) hv[a] += sA[k * R + a] * xv;
+                for (int a = 0; a < R; a += 2) { const double2 v2 = ar[a >> 1]; hv[a] += v2.x * xv; hv[a + 1] += v2.y * xv; }
             }
         }
 #pragma unroll
         for (int a = 0; a < R; ++a) hv[a] += __shfl_xor(hv[a], 32, 64);
         __syncthreads();
+        APROF(1)
         {
             double g[R];
 #pragma unroll
@@ -642,18 +664,20 @@ __device__ __forceinline__ int als2_iterate(const TW* __restrict__ Wf, int ldw, 
             gj_chain<R>(g, sMul, sDinv);
         }
         __syncthreads();
+        APROF(2)
         gj_apply<R>(hv, sMul, sDinv);  // hv = B[i][:]
         if (h == 0 && i < NMAX)
 #pragma unroll
             for (int a = 0; a < R; ++a) sB[i * R + a] = hv[a];
         __syncthreads();
+        APROF(3)
         // ---- A update: G = B^T B + ridge I ; H[:, i] = B^T X1[i, :]^T (own row, registers) ----
         for (int e = lane; e < R * R; e += 64) {
             const int a = e / R, b = e - a * R;
-            double g = (a == b) ? ridge : 0.0;
-#pragma unroll 8
-            for (int k = 0; k < NMAX; ++k) g += sB[k * R + a] * sB[k * R + b];
-            sG[e] = g;
+            double g0 = (a == b) ? ridge : 0.0, g1 = 0.0;
+#pragma unroll 4
+            for (int k = 0; k < n4; k += 2) { g0 += sB[k * R + a] * sB[k * R + b]; g1 += sB[(k + 1) * R + a] * sB[(k + 1) * R + b]; }
+            sG[e] = g0 + g1;
         }
         double av[R];
 #pragma unroll
@@ -661,12 +685,14 @@ __device__ __forceinline__ int als2_iterate(const TW* __restrict__ Wf, int ldw, 
 #pragma unroll
         for (int c = 0; c < NH; ++c) {
             const double xv = x1[c];
+            const double2* br = reinterpret_cast<const double2*>(&sB[(h * NH + c) * R]);
 #pragma unroll
-            for (int a = 0; a < R; ++a) av[a] += sB[(h * NH + c) * R + a] * xv;
+            for (int a = 0; a < R; a += 2) { const double2 v2 = br[a >> 1]; av[a] += v2.x * xv; av[a + 1] += v2.y * xv; }
         }
 #pragma unroll
         for (int a = 0; a < R; ++a) av[a] += __shfl_xor(av[a], 32, 64);
         __syncthreads();
+        APROF(4)
         {
             double g[R];
 #pragma unroll
@@ -674,6 +700,7 @@ __device__ __forceinline__ int als2_iterate(const TW* __restrict__ Wf, int ldw, 
             gj_chain<R>(g, sMul, sDinv);
         }
         __syncthreads();
+        APROF(5)
         gj_apply<R>(av, sMul, sDinv);  // av = A[i][:]
         if (h == 0 && i < NMAX)
 #pragma unroll
@@ -683,11 +710,13 @@ __device__ __forceinline__ int als2_iterate(const TW* __restrict__ Wf, int ldw, 
 #pragma unroll
         for (int c = 0; c < NH; ++c) {
             const int j = h * NH + c;
-            double x = 0.0;
+            double xa = 0.0, xb = 0.0;
+            const double2* br = reinterpret_cast<const double2*>(&sB[j * R]);
 #pragma unroll
-            for (int a = 0; a < R; ++a) x += av[a] * sB[j * R + a];
+            for (int a = 0; a < R; a += 2) { const double2 v2 = br[a >> 1]; xa += av[a] * v2.x; xb += av[a + 1] * v2.y; }
+            const double x = xa + xb;
             if ((valid >> c) & 1) {
-                double zz = x + y[c] / mu;
+                double zz = x + y[c] * inv_mu;
                 if ((same >> c) & 1) zz = 0.0;
                 if (i == j) zz = 1.0;
                 zz = zz < 0.0 ? 0.0 : (zz > 1.0 ? 1.0 : zz);
@@ -702,6 +731,7 @@ __device__ __forceinline__ int als2_iterate(const TW* __restrict__ Wf, int ldw, 
         const double p_res = sqrt(wave_sum(acc_p)) / n;
         const double d_res = mu * sqrt(wave_sum(acc_d)) / n;
         __syncthreads();  // sA complete before the next iteration reads it
+        APROF(6)
         if (p_res < 1e-4 && d_res < 1e-4) { iters = it + 1; break; }
         if (p_res > 10 * d_res) mu = 2 * mu;
         else if (d_res > 10 * p_res) mu = mu / 2;
@@ -723,10 +753,10 @@ als2_kernel(const TW* __restrict__ W, const int32_t* __restrict__ gcounts, int G
             int32_t* __restrict__ iters_out) {
     constexpr int RMAX = 16;
     __shared__ double sX[NMAX * (NMAX + 1)];
-    __shared__ double sA[NMAX * RMAX];
-    __shared__ double sB[NMAX * RMAX];
+    __shared__ __attribute__((aligned(16))) double sA[NMAX * RMAX];
+    __shared__ __attribute__((aligned(16))) double sB[NMAX * RMAX];
     __shared__ double sG[RMAX * RMAX];
-    __shared__ double sMul[RMAX * RMAX];
+    __shared__ __attribute__((aligned(16))) double sMul[RMAX * RMAX];
     __shared__ double sDinv[RMAX];
     __shared__ int sGid[NMAX];
     __shared__ uint8_t sVis[NMAX];
@@ -805,6 +835,9 @@ als2_kernel(const TW* __restrict__ W, const int32_t* __restrict__ gcounts, int G
         for (int c = 0; c < n; ++c) k += sKeep[c];
         n_clusters[f] = k;
         iters_out[f] = iters;
+#ifdef MVMC_ALS_PROFILE
+        for (int q = 0; q < 7; ++q) lab[ldw - 7 + q] = (int)(g_alsprof[q] / iters);
+#endif
     }
     if (x_bin || match_mat) {
         for (int e = tid; e < ldw * ldw; e += 64) {
