@@ -45,7 +45,7 @@ enum { MVMC_F32 = 0, MVMC_F64 = 1 };
 #define MVMC_N_SKEL 18
 #define MVMC_N_SIDE 11
 #define MVMC_N_PARAM 68   /* root(3) + euler(18*3) + side bone lengths(11) */
-#define MVMC_MAX_NODES 64 /* max graph nodes (2-D poses + tracklets) per frame */
+#define MVMC_MAX_NODES 80 /* max graph nodes (2-D poses + tracklets) per frame: C8 P8 + 16 tracklets */
 
 typedef void* mvmcStream_t; /* hipStream_t */
 

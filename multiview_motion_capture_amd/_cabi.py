@@ -17,7 +17,7 @@ MVMC_OK = 0
 MVMC_F32, MVMC_F64 = 0, 1
 N_PARAM = 68
 IK_BASIS_DOUBLES = 2600
-MAX_NODES = 64
+MAX_NODES = 80
 
 # every symbol declared in include/mvmc.h
 SYMBOLS = (

@@ -988,11 +988,14 @@ static int launch_als(const TW* W, const int32_t* gc, int F, int G, int n_max, i
 #define MVMC_ALS2(NM)                                                                                     \
     hipLaunchKernelGGL((als2_kernel<TW, NM>), dim3(F), dim3(64), 0, s, W, gc, G, n_max, seed, seed_len, xb, mm, \
                        lab, nc, it)
+    // Variants are sized by (max nodes, max rank).  r_max is only the caller's bound (2 x largest group
+    // capacity); the kernels check the frame's actual rank and flag iters = -1 if it does not fit.
     if (n_max <= 24 && r_max <= 16) MVMC_ALS2(24);
     else if (n_max <= 32 && r_max <= 16) MVMC_ALS2(32);
     else if (n_max <= 24) MVMC_ALS(24, 24, 64);
     else if (n_max <= 32) MVMC_ALS(32, 32, 128);
-    else if (n_max <= 64 && r_max <= 16) MVMC_ALS(64, 16, 256);
+    else if (n_max <= 64) MVMC_ALS(64, 16, 256);
+    else if (n_max <= 80) MVMC_ALS(80, 16, 512);
     else return MVMC_ERR_UNSUPPORTED;
 #undef MVMC_ALS
 #undef MVMC_ALS2
