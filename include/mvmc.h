@@ -193,6 +193,16 @@ int mvmc_track_commit(const int32_t* status, const int32_t* n_new, const double*
                       int32_t* meta, int32_t* n_tracks, int32_t* next_id, int32_t* n_dead, int32_t* slot_src,
                       mvmcStream_t stream);
 
+/* ---- diagnostics (used by the tests; not part of the hot path's call surface) ---- */
+
+/* The IK kernel's symmetric eigensolver on caller-supplied matrices: A (B,n,n) symmetric PSD, g (B,n),
+ * 3 <= n <= 50.  lam (B,n) ascending with the numerically-null cluster (lam <= 1e-13 lam_max) set to 0;
+ * Vt (B,n,n) rows = eigenvectors (rows 0..k0-1 of the null cluster are zero); k0 (B) = size of the null
+ * cluster; phase_cycles (B,5) or NULL = shader cycles of {tridiagonalisation, multisection, twisted
+ * factorisation, re-orthogonalisation, back-transformation}.  g is unused (kept for ABI stability). */
+int mvmc_debug_eigh(const double* A, const double* g, int n_problems, int n, double* lam, double* Vt, int32_t* k0,
+                    double* phase_cycles, mvmcStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

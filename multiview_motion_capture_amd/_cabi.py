@@ -23,7 +23,7 @@ MAX_NODES = 80
 SYMBOLS = (
     "mvmc_abi_version", "mvmc_status_string", "mvmc_als_seed_table", "mvmc_ingest", "mvmc_fmats",
     "mvmc_affinity", "mvmc_als_associate", "mvmc_closure_labels", "mvmc_cluster_members", "mvmc_dlt", "mvmc_triangulate_postopt", "mvmc_fk", "mvmc_ik_solve",
-    "mvmc_fmats_from_projections", "mvmc_st_affinity", "mvmc_track_assign", "mvmc_track_commit",
+    "mvmc_fmats_from_projections", "mvmc_st_affinity", "mvmc_track_assign", "mvmc_track_commit", "mvmc_debug_eigh",
 )
 
 
@@ -71,6 +71,7 @@ def load():
     lib.mvmc_st_affinity.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f64, vp, vp, vp, vp]
     lib.mvmc_track_assign.argtypes = [vp] * 8 + [i32] * 6 + [vp] * 6
     lib.mvmc_track_commit.argtypes = [vp] * 4 + [i32] * 4 + [vp] * 8
+    lib.mvmc_debug_eigh.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp]
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError if the library does not export it
         if name not in ("mvmc_status_string",):

@@ -29,6 +29,41 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// DPP cross-lane helpers (no LDS crossbar round trip): quad exchanges and a full-wave sum.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 4 lanes of a quad (lanes 4q..4q+3); every lane gets the result
+__device__ __forceinline__ double quad_sum(double v) {
+    v += dpp_mov<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);  // quad_perm [2,3,0,1]
+    return v;
+}
+// sum over the wave: rotate-butterfly inside each row of 16 lanes (row_ror), then the four row totals
+// through SGPRs (v_readlane); every lane gets the result
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_mov<0x128>(v);  // row_ror:8
+    v += dpp_mov<0x124>(v);  // row_ror:4
+    v += dpp_mov<0x122>(v);  // row_ror:2
+    v += dpp_mov<0x121>(v);  // row_ror:1
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        t += __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * r), __builtin_amdgcn_readlane(lo, 16 * r));
+    return t;
+}
+__device__ __forceinline__ double fast_rcp64(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = r * (2.0 - x * r);
+    r = r * (2.0 - x * r);
+    return r;
+}
+
 // ---- skeleton + rotation helpers shared by the FK and IK kernels ----
 struct SkelDev {
     double dirs[18][3];

@@ -15,6 +15,13 @@
 //     removed from the eigenproblem -- SciPy gives them s = 0 and a zero step, which is what they get here.
 #include "mvmc_common.h"
 #include "mvmc_postopt.h"
+#include "mvmc_eigh_tri.h"
+
+// Eigensolver of the trust-region step: 1 = Householder tridiagonalisation + Sturm multisection + twisted
+// factorisation (mvmc_eigh_tri.h); 0 = the parallel cyclic Jacobi of the first version (kept for A/B runs).
+#ifndef MVMC_IK_TRIDIAG
+#define MVMC_IK_TRIDIAG 1
+#endif
 
 namespace {
 
@@ -29,7 +36,12 @@ namespace {
 constexpr int NT = 256;    // threads per problem
 constexpr int NA = 50;     // max active parameters (even)
 constexpr int LD = 51;     // odd leading dimension: conflict-free column walks on 8-byte elements
-constexpr int LDV = 52;    // leading dimension of the transposed eigenvector matrix (even: 16-byte aligned row pairs)
+constexpr int LDV = 52;    // leading dimension of the transposed eigenvector matrix in the Jacobi solver (even: 16-byte row pairs)
+#if MVMC_IK_TRIDIAG
+constexpr int LDZ = LD;    // eigenvector rows as the tridiagonal solver writes them (odd: lanes walk one column)
+#else
+constexpr int LDZ = LDV;
+#endif
 constexpr int VMAX = 8;    // max views per person
 constexpr int NOBS = 16;   // observed joints per view
 
@@ -433,10 +445,21 @@ __device__ int ik_eigh(IkShared& S, int nap, bool have_basis) {
 // exist, so SciPy's full-rank Gauss-Newton shortcut never fires).  Wave 0 only; writes cv[] and
 // returns alpha; *pred receives the predicted reduction, all lanes hold the same scalars.
 // ---------------------------------------------------------------------------------------------
-__device__ double ik_tr_solve(IkShared& S, int nap, double Delta, double alpha0, double* pred) {
+__device__ double ik_tr_solve(IkShared& S, int nap, double Delta, double alpha0, double gg, double* pred, double* pnorm) {
     const int lane = threadIdx.x;
-    const bool on = lane < nap;
-    const double lam = on ? S.lam[lane] : 1.0, suf = on ? S.suf[lane] : 0.0;
+    const bool on = lane <= nap;
+    double lam = lane < nap ? S.lam[lane] : 1.0, suf = lane < nap ? S.suf[lane] : 0.0;
+#if MVMC_IK_TRIDIAG
+    // Virtual absorber (lane nap): a direction with lambda = 0 and a small fixed weight.  In the reference
+    // the numerically-null directions of J carry finite-difference noise (s*u^T f ~ 1e-8 |g|), and because
+    // SciPy normalises every rank-deficient step to |p| = Delta, that noise soaks up whatever part of the
+    // trust-region length the Gauss-Newton step does not use -- in directions that do not move the skeleton.
+    // The absorber plays that role deterministically and its coefficient is dropped from the step.
+    if (lane == nap) {
+        lam = 0.0;
+        suf = 1e-8 * sqrt(gg);
+    }
+#endif
     double alpha_upper = sqrt(wave_sum(suf * suf)) / Delta;
     double alpha_lower = 0.0;
     double alpha = (alpha0 == 0.0) ? fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper)) : alpha0;
@@ -444,22 +467,22 @@ __device__ double ik_tr_solve(IkShared& S, int nap, double Delta, double alpha0,
         if (alpha < alpha_lower || alpha > alpha_upper)
             alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
         const double denom = lam + alpha;
-        const double t = suf / denom;
+        const double t = suf != 0.0 ? suf / denom : 0.0;
         const double p_norm = sqrt(wave_sum(t * t));
         const double phi = p_norm - Delta;
-        const double phi_prime = -wave_sum(suf * suf / (denom * denom * denom)) / p_norm;
+        const double phi_prime = -wave_sum(suf != 0.0 ? suf * suf / (denom * denom * denom) : 0.0) / p_norm;
         if (phi < 0) alpha_upper = alpha;
         const double ratio = phi / phi_prime;
         alpha_lower = fmax(alpha_lower, alpha - ratio);
         alpha -= (phi + Delta) * ratio / Delta;
         if (fabs(phi) < 0.01 * Delta) break;
     }
-    double c = -suf / (lam + alpha);
-    if (!on) c = 0.0;
+    double c = (on && suf != 0.0) ? -suf / (lam + alpha) : 0.0;
     const double pn = sqrt(wave_sum(c * c));
     c *= Delta / pn;
-    if (on) S.cv[lane] = c;
+    if (lane < nap) S.cv[lane] = c;
     *pred = -(0.5 * wave_sum(lam * c * c) + wave_sum(suf * c));
+    *pnorm = sqrt(wave_sum(c * c));  // |step_h| including the absorber (== Delta up to rounding, as in SciPy)
     return alpha;
 }
 
@@ -494,35 +517,52 @@ __device__ void ik_trf(IkShared& S, const SkelRef& sk, int stage, int max_nfev, 
         if (S.sc[0] < gtol) status = 1;
         if (status != -1 || nfev == max_nfev) break;
 
+#if MVMC_IK_TRIDIAG
+        {
+            PROF_T0
+            eightri::eigh(S.bufB, LD, S.bufC, LDZ, S.bufA, LD, nap, S.lam, S.step, S.cv, S.suf,
+                          reinterpret_cast<double*>(S.rcs), S.xn, S.red,
+                          reinterpret_cast<int*>(S.bufA + 128));  // Sturm counts: 4 KB of the scratch matrix
+            PROF_ADD(S, 2)
+        }
+        have_basis = false;
+        if (tid < nap) {
+#else
         { PROF_T0 *sweeps_out += ik_eigh(S, nap, have_basis); PROF_ADD(S, 2) }
         have_basis = true;
         if (tid < nap) {
             const double l = S.bufB[tid * LD + tid];
             S.lam[tid] = l > 0.0 ? l : 0.0;
+#endif
             double a = 0.0;
-            for (int i = 0; i < nap; ++i) a += S.bufC[tid * LDV + i] * S.g[i];
+            for (int i = 0; i < nap; ++i) a += S.bufC[tid * LDZ + i] * S.g[i];
             S.suf[tid] = a;
         }
         __syncthreads();
+        const double gg = block_sum256(tid < nap ? S.g[tid] * S.g[tid] : 0.0, S.red);
 
         double actual = -1.0, cost_new = cost;
         while (actual <= 0.0 && nfev < max_nfev) {
             if (tid < 64) {
-                double pred;
-                const double al = ik_tr_solve(S, nap, Delta, alpha, &pred);
-                if (tid == 0) { S.sc[1] = al; S.sc[2] = pred; }
+                double pred, pnorm;
+                const double al = ik_tr_solve(S, nap, Delta, alpha, gg, &pred, &pnorm);
+                if (tid == 0) { S.sc[1] = al; S.sc[2] = pred; S.sc[3] = pnorm; }
             }
             __syncthreads();
             alpha = S.sc[1];
             const double pred = S.sc[2];
             if (tid < nap) {
                 double a = 0.0;
-                for (int j = 0; j < nap; ++j) a += S.bufC[j * LDV + tid] * S.cv[j];
+                for (int j = 0; j < nap; ++j) a += S.bufC[j * LDZ + tid] * S.cv[j];
                 S.step[tid] = a;
             }
             __syncthreads();
+#if MVMC_IK_TRIDIAG
+            const double step_norm = S.sc[3];
+#else
             double sq = (tid < na) ? S.step[tid] * S.step[tid] : 0.0;
             const double step_norm = sqrt(block_sum256(sq, S.red));
+#endif
             xx = (tid < nfull) ? S.x[tid] * S.x[tid] : 0.0;
             const double x_norm = sqrt(block_sum256(xx, S.red));
             if (tid < nfull) {
