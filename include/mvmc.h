@@ -203,6 +203,14 @@ int mvmc_track_commit(const int32_t* status, const int32_t* n_new, const double*
 int mvmc_debug_eigh(const double* A, const double* g, int n_problems, int n, double* lam, double* Vt, int32_t* k0,
                     double* phase_cycles, mvmcStream_t stream);
 
+/* One trust-region step of the IK solver computed in the tridiagonal basis (no eigendecomposition), on a
+ * caller-supplied least-squares model: J = B (n_problems,m,n row-major), residual image r (n_problems,m), so
+ * g = B^T r.  dual = 0 works on B^T B (n x n), dual = 1 on B B^T (m x m, for m < n).  3 <= m,n <= 50.
+ * step (n_problems,n); out4 (n_problems,4) = {alpha, predicted reduction, |step| incl. absorber, number of
+ * numerically-null eigenvalues found (then the kernel would fall back to the eigensolver: alpha = -1, step = 0)}. */
+int mvmc_debug_trstep(const double* B, const double* r, int n_problems, int m, int n, int dual, double Delta,
+                      double alpha0, double* step, double* out4, mvmcStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,6 +6,7 @@
 //   5. the numerically-null cluster (lambda <= 1e-13 lambda_max) is not resolved into vectors (zero rows)
 // Replaces the cyclic Jacobi of the first version (~320 LDS-bound steps) with ~50 cheaper steps.
 #pragma once
+#include <type_traits>
 #include "mvmc_common.h"
 
 namespace eightri {
@@ -50,9 +51,268 @@ __device__ inline int sturm_count(const double* dpad, const double* e2pad, int n
     return cnt;
 }
 
+// Householder tridiagonalisation of a symmetric matrix held in registers, optionally carrying one right-hand side.
+// 16 x 16 thread grid, thread (ty, tx) = (tid >> 4, tid & 15) owns a[q][u] = M[ty + 16 q][tx + 16 u] (cyclic, so
+// the shrinking trailing block stays balanced; both triangles are kept; entries outside n x n must be zero).
+// Row k lives in one 16-lane DPP row of one wave: its owners form the Householder vector with row rotations and
+// publish it (sv, and column k of the LDS matrix V for later applications of Q); everyone then does the 4 x 4
+// piece of p = tau M v, the row sums by DPP, one exchange of p and of the per-wave parts of p.v through LDS, and
+// the rank-2 update in registers: two barriers per step and no LDS traffic for the matrix itself.  Rows <= k are
+// not zeroed: v vanishes there, so they only ever receive an orthogonal transformation of their stale tail and
+// are never read again.
+//   M = Q T Q^T,  Q = H_0 H_1 ... H_{n-3},  H_k = I - tau_k v_k v_k^T,  v_k stored in V[j * ldv + k], j > k.
+//   rq[q] = r[ty + 16 q] (replicated over tx) comes back as (Q^T r)[ty + 16 q] when WITH_RHS.
+// sv, pw: 64 doubles each; red: 8 doubles.  Ends with a barrier; d[0..n), e[0..n-1), tau[0..n-1) are then valid.
+template <bool WITH_RHS>
+__device__ inline void tridiag_regs(double (&a)[4][4], double (&rq)[4], double* V, int ldv, int n, double* d, double* e,
+                                    double* tau, double* sv, double* pw, double* red) {
+    const int tid = threadIdx.x, lane = tid & 63, wv_id = tid >> 6;
+    const int ty = tid >> 4, tx = tid & 15;
+    auto row_sum16 = [](double v) {
+        v += dpp_mov<0x128>(v); v += dpp_mov<0x124>(v); v += dpp_mov<0x122>(v); v += dpp_mov<0x121>(v);
+        return v;
+    };
+    // the owners of row k (register row QK of the 16 lanes with ty == k mod 16)
+    auto householder = [&](auto qk_tag, int k) {
+        constexpr int QK = decltype(qk_tag)::value;
+        const int j1 = k + 1;
+        double al = 0.0, sg = 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = tx + 16 * u;
+            const double xu = a[QK][u];
+            al = j == j1 ? xu : al;
+            sg += j > j1 ? xu * xu : 0.0;
+        }
+        const double alpha = row_sum16(al);
+        const double sig = row_sum16(sg);
+        double tk = 0.0, beta = alpha, sc = 0.0;
+        if (sig > 0.0) {
+            const double q2 = alpha * alpha + sig;
+            double rs = __builtin_amdgcn_rsq(q2);
+            rs = rs * (1.5 - 0.5 * q2 * rs * rs);
+            rs = rs * (1.5 - 0.5 * q2 * rs * rs);
+            const double nrm = q2 * rs;
+            beta = alpha >= 0.0 ? -nrm : nrm;
+            tk = 1.0 - alpha * fast_rcp64(beta);
+            sc = fast_rcp64(alpha - beta);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = tx + 16 * u;
+            const double vi = j == j1 ? 1.0 : (j > j1 ? a[QK][u] * sc : 0.0);
+            sv[j] = vi;
+            if (j > k && j < n) V[j * ldv + k] = vi;
+        }
+        if (tx == 0) { e[k] = beta; tau[k] = tk; }
+    };
+    for (int k = 0; k < n - 2; ++k) {
+        if (ty == (k & 15)) {
+            switch (k >> 4) {
+                case 0: householder(std::integral_constant<int, 0>{}, k); break;
+                case 1: householder(std::integral_constant<int, 1>{}, k); break;
+                case 2: householder(std::integral_constant<int, 2>{}, k); break;
+                default: householder(std::integral_constant<int, 3>{}, k); break;
+            }
+        }
+        __syncthreads();
+        const double tk = tau[k];
+        if (tk != 0.0) {
+            double vj[4], vi[4], s[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { vj[u] = sv[tx + 16 * u]; vi[u] = sv[ty + 16 * u]; }
+            double t = 0.0, t2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double acc = a[q][0] * vj[0];
+#pragma unroll
+                for (int u = 1; u < 4; ++u) acc += a[q][u] * vj[u];
+                s[q] = row_sum16(acc) * tk;   // p_i, i = ty + 16 q (all 16 lanes of the row hold it)
+                t += s[q] * vi[q];
+                if (WITH_RHS) t2 += rq[q] * vi[q];
+            }
+            {   // this wave's part of p.v (and of r.v): lane 16 r holds the part of the wave's r-th row
+                const int lo = __double2loint(t), hi = __double2hiint(t);
+                double tw = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    tw += __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * r), __builtin_amdgcn_readlane(lo, 16 * r));
+                if (lane == 0) red[wv_id] = tw;
+                if (WITH_RHS) {
+                    const int lo2 = __double2loint(t2), hi2 = __double2hiint(t2);
+                    double tw2 = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        tw2 += __hiloint2double(__builtin_amdgcn_readlane(hi2, 16 * r), __builtin_amdgcn_readlane(lo2, 16 * r));
+                    if (lane == 0) red[4 + wv_id] = tw2;
+                }
+            }
+            if (tx == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pw[ty + 16 * q] = s[q];
+            }
+            __syncthreads();
+            const double h = 0.5 * tk * ((red[0] + red[1]) + (red[2] + red[3]));
+            double wj[4], wi[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                wj[u] = pw[tx + 16 * u] - h * vj[u];
+                wi[u] = s[u] - h * vi[u];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[q][u] -= vi[q] * wj[u] + wi[q] * vj[u];
+            if (WITH_RHS) {
+                const double h2 = tk * ((red[4] + red[5]) + (red[6] + red[7]));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rq[q] -= h2 * vi[q];
+            }
+        }
+    }
+    // the diagonal and the last off-diagonal
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = ty + 16 * q, j = tx + 16 * u;
+            if (i == j && i < n) d[i] = a[q][u];   // M[k][k] is final once step k - 1 is done
+            if (i == n - 1 && j == n - 2) e[n - 2] = a[q][u];
+        }
+    if (tid == 0) tau[n - 2] = 0.0;
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Trust-region step without an eigendecomposition.  With M = Q T Q^T and rh = Q^T r, every quantity of SciPy's
+// solve_lsq_trust_region (common.py:57-168; rank-deficient branch, see ik_tr_solve for the absorber) is a solve
+// with the tridiagonal T + alpha I:
+//   primal (M = J^T J, r = g):      p(alpha) = -Q y,      y = (T + alpha)^-1 rh,   |p|^2 = y.y,    sum suf^2/(lam+alpha)^3 = y.z
+//   dual   (M = B B^T, g = B^T r):  p(alpha) = -B^T Q y,                           |p|^2 = y.Ty,   sum suf^2/(lam+alpha)^3 = Ty.z
+// with z = (T + alpha)^-1 y.  T + alpha I = L D L^T is factorised by the plain serial recurrence (all lanes of the
+// wave run it redundantly: few instructions, the co-resident workgroup keeps the SIMD busy), the sums are taken
+// one lane per component.  Valid when T has no numerically-null eigenvalue (the caller checks with a Sturm count).
+// One wave.  lmul, dinv, yb, zb: LDS scratch of n doubles; cout: LDS, the step's coefficients c = -y Delta/|p|.
+// Returns alpha; *pred = predicted reduction, *pnorm = |step| including the absorber's share.
+template <bool DUAL>
+__device__ inline double tr_solve_tri(const double* d, const double* e, const double* rh, int n, double Delta, double alpha0,
+                                      double gg, double pivmin, double* lmul, double* dinv, double* yb, double* zb,
+                                      double* cout, double* pred, double* pnorm) {
+    const int lane = threadIdx.x & 63;
+    const bool on = lane < n;
+    const double a2 = 1e-16 * gg;  // absorber weight squared: suf_abs = 1e-8 |g|
+    const double dj = on ? d[lane] : 0.0, el = (on && lane > 0) ? e[lane - 1] : 0.0, eu = (lane < n - 1) ? e[lane] : 0.0;
+    const double rj = on ? rh[lane] : 0.0;
+    double yy, yw, ww, rw, ry, yz, wz;
+    auto evaluate = [&](double alpha, bool want_z) {
+        // factorisation + forward substitution
+        double D = d[0] + alpha, f = rh[0];
+        for (int j = 0; j < n - 1; ++j) {
+            if (D < pivmin) D = pivmin;
+            const double inv = fast_rcp64(D);
+            const double l = e[j] * inv;
+            if (lane == 0) { dinv[j] = inv; lmul[j] = l; yb[j] = f; }
+            D = (d[j + 1] + alpha) - l * e[j];
+            f = rh[j + 1] - l * f;
+        }
+        if (D < pivmin) D = pivmin;
+        double y = f * fast_rcp64(D);
+        if (lane == 0) { dinv[n - 1] = fast_rcp64(D); yb[n - 1] = y; }
+        for (int j = n - 2; j >= 0; --j) {
+            y = yb[j] * dinv[j] - lmul[j] * y;
+            if (lane == 0) yb[j] = y;
+        }
+        const double yj = on ? yb[lane] : 0.0;
+        const double ym = (on && lane > 0) ? yb[lane - 1] : 0.0, yp = (lane < n - 1) ? yb[lane + 1] : 0.0;
+        const double wj = el * ym + dj * yj + eu * yp;  // (T y)_j
+        yy = wave_sum_dpp(yj * yj);
+        yw = wave_sum_dpp(yj * wj);
+        ry = wave_sum_dpp(rj * yj);
+        if (DUAL) { ww = wave_sum_dpp(wj * wj); rw = wave_sum_dpp(rj * wj); }
+        if (want_z) {
+            double fz = yb[0];
+            if (lane == 0) zb[0] = fz;
+            for (int j = 0; j < n - 1; ++j) {
+                fz = yb[j + 1] - lmul[j] * fz;
+                if (lane == 0) zb[j + 1] = fz;
+            }
+            double z = fz * dinv[n - 1];
+            if (lane == 0) zb[n - 1] = z;
+            for (int j = n - 2; j >= 0; --j) {
+                z = zb[j] * dinv[j] - lmul[j] * z;
+                if (lane == 0) zb[j] = z;
+            }
+            const double zj = on ? zb[lane] : 0.0;
+            if (DUAL) wz = wave_sum_dpp(wj * zj); else yz = wave_sum_dpp(yj * zj);
+        }
+    };
+    double alpha_upper = sqrt(gg + a2) / Delta;
+    double alpha_lower = 0.0;
+    double alpha = (alpha0 == 0.0) ? fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper)) : alpha0;
+    for (int it = 0; it < 10; ++it) {
+        if (alpha < alpha_lower || alpha > alpha_upper)
+            alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+        evaluate(alpha, true);
+        const double ia = 1.0 / alpha;
+        const double s1 = (DUAL ? yw : yy) + a2 * ia * ia;
+        const double s3 = (DUAL ? wz : yz) + a2 * ia * ia * ia;
+        const double p_norm = sqrt(s1);
+        const double phi = p_norm - Delta;
+        const double phi_prime = -s3 / p_norm;
+        if (phi < 0) alpha_upper = alpha;
+        const double ratio = phi / phi_prime;
+        alpha_lower = fmax(alpha_lower, alpha - ratio);
+        alpha -= (phi + Delta) * ratio / Delta;
+        if (fabs(phi) < 0.01 * Delta) break;
+    }
+    evaluate(alpha, false);
+    const double ia = 1.0 / alpha;
+    const double pn = sqrt((DUAL ? yw : yy) + a2 * ia * ia);
+    const double sc = Delta / pn;
+    if (on) cout[lane] = -yb[lane] * sc;
+    // pred = -(0.5 sum lam c^2 + sum suf c), absorber included (lam = 0, suf c = -(a^2/alpha) sc)
+    const double lcc = sc * sc * (DUAL ? ww : yw);
+    const double sfc = -sc * (DUAL ? rw : ry) - a2 * ia * sc;
+    *pred = -(0.5 * lcc + sfc);
+    *pnorm = sc * pn;
+    return alpha;
+}
+
+// Q c for the Householder vectors stored by tridiag_regs (one wave; lane j holds component j)
+__device__ inline double apply_q(const double* V, int ldv, const double* tau, int n, double cj) {
+    const int lane = threadIdx.x & 63;
+    for (int k = n - 3; k >= 0; --k) {
+        const double tk = tau[k];
+        if (tk == 0.0) continue;
+        const double v = (lane > k && lane < n) ? V[lane * ldv + k] : 0.0;
+        const double s = wave_sum_dpp(v * cj);
+        cj -= tk * s * v;
+    }
+    return cj;
+}
+
+// Number of eigenvalues of the tridiagonal (d, e) below tol_rel times the Gershgorin bound (one wave, uniform
+// result).  dsc / e2sc: 64 doubles of LDS scratch each.  *bound gets the Gershgorin bound.
+__device__ inline int tri_null_count(const double* d, const double* e, int n, double tol_rel, double* dsc, double* e2sc,
+                                     double* bound) {
+    const int lane = threadIdx.x & 63;
+    double gb = 0.0;
+    if (lane < n) {
+        const double r = (lane > 0 ? fabs(e[lane - 1]) : 0.0) + (lane < n - 1 ? fabs(e[lane]) : 0.0);
+        gb = fabs(d[lane]) + r;
+    }
+    for (int off = 32; off > 0; off >>= 1) gb = fmax(gb, __shfl_xor(gb, off, 64));
+    const double ts = gb > 0.0 ? gb : 1.0;
+    dsc[lane] = lane < n ? d[lane] / ts : 4.0;
+    const double es = lane < n - 1 ? e[lane] / ts : 0.0;
+    e2sc[lane] = es * es;
+    *bound = gb;
+    return sturm_count(dsc, e2sc, (n - 1 + 7) >> 3, tol_rel);
+}
+
 // A (n x n, ld lda, full symmetric, destroyed) -> lam (n, ascending, null cluster set to 0),
 // Zt (rows = eigenvectors, ld ldz; rows 0..k0-1 of the null cluster are zero).
-// W1: n x ldw scratch (>= 128 doubles).  d, e, tau, pv, wv: LDS vectors of >= n doubles.  icnt: 16*64 ints.
+// W1: n x ldw scratch (>= 256 doubles).  d, e, tau, pv, wv: LDS vectors of >= n doubles.  icnt: 4*64 ints.
 // Returns k0.
 __device__ int eigh(double* A, int lda, double* Zt, int ldz, double* W1, int ldw, int n,
                     double* lam, double* d, double* e, double* tau, double* pv, double* wv, double* red, int* icnt,
@@ -60,90 +320,22 @@ __device__ int eigh(double* A, int lda, double* Zt, int ldz, double* W1, int ldw
     const int tid = threadIdx.x, lane = tid & 63, wv_id = tid >> 6;
     long long t_prev = prof ? clock64() : 0;
     auto stamp = [&](int k) { if (prof) { const long long t = clock64(); if (tid == 0) prof[k] = t - t_prev; t_prev = t; } };
-    // ---------------- 1. tridiagonalisation (lower form: column k holds v_k below the sub-diagonal) ----------------
-    // sv = pv (Householder vector, contiguous copy), sw = wv
-    double* sv = pv;
-    for (int k = 0; k < n - 2; ++k) {
-        const int m = n - k - 1;
-        if (tid < 64) {
-            const double xi = (lane < m) ? A[(k + 1 + lane) * lda + k] : 0.0;
-            const double alpha = __shfl(xi, 0, 64);
-            const double sig = wave_sum_dpp((lane >= 1 && lane < m) ? xi * xi : 0.0);
-            double tk = 0.0, beta = alpha, vi = (lane == 0) ? 1.0 : 0.0;
-            if (sig > 0.0) {
-                const double q = alpha * alpha + sig;
-                double rs = __builtin_amdgcn_rsq(q);
-                rs = rs * (1.5 - 0.5 * q * rs * rs);
-                rs = rs * (1.5 - 0.5 * q * rs * rs);
-                const double nrm = q * rs;
-                beta = alpha >= 0.0 ? -nrm : nrm;
-                tk = 1.0 - alpha * fast_rcp64(beta);
-                const double sc = fast_rcp64(alpha - beta);
-                vi = (lane == 0) ? 1.0 : xi * sc;
+    // ---------------- 1. tridiagonalisation (matrix in registers, Householder vectors back into A) ----------------
+    {
+        const int ty = tid >> 4, tx = tid & 15;
+        double a[4][4], rq[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = ty + 16 * q, j = tx + 16 * u;
+                a[q][u] = (i < n && j < n) ? A[i * lda + j] : 0.0;
             }
-            if (lane < m) { A[(k + 1 + lane) * lda + k] = vi; sv[lane] = vi; }
-            if (lane == 0) { e[k] = beta; tau[k] = tk; }
-        }
-        __syncthreads();
-        const double tk = tau[k];
-        if (tk != 0.0) {
-            // p = tau * A22 v, four lanes per row, all loads of a lane issued before the sums
-            {
-                const int r = tid >> 2, qd = tid & 3;
-                double s = 0.0;
-                if (r < m) {
-                    const double* row = &A[(k + 1 + r) * lda + (k + 1)];
-                    double a[13], b[13];
-#pragma unroll
-                    for (int t = 0; t < 13; ++t) {
-                        const int j = qd + 4 * t;
-                        const int jj = j < m ? j : 0;
-                        a[t] = row[jj]; b[t] = j < m ? sv[jj] : 0.0;
-                    }
-#pragma unroll
-                    for (int t = 0; t < 13; ++t) s += a[t] * b[t];
-                }
-                s = quad_sum(s);
-                if (qd == 0 && r < m) wv[r] = tk * s;   // p
-            }
-            __syncthreads();
-            if (tid < 64) {
-                const double vi = (lane < m) ? sv[lane] : 0.0;
-                const double pi = (lane < m) ? wv[lane] : 0.0;
-                const double dot = wave_sum_dpp(pi * vi);
-                if (lane < m) wv[lane] = pi - 0.5 * tk * dot * vi;   // w (in place: only this wave touches wv here)
-            }
-            __syncthreads();
-            // A22 -= v w^T + w v^T on a 16 x 16 thread grid
-            {
-                const int ty = tid >> 4, tx = tid & 15;
-                double vj[4], wj[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = tx + 16 * u;
-                    vj[u] = j < m ? sv[j] : 0.0; wj[u] = j < m ? wv[j] : 0.0;
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int i = ty + 16 * q;
-                    if (i < m) {
-                        const double vi = sv[i], wi = wv[i];
-                        double* row = &A[(k + 1 + i) * lda + (k + 1)];
-                        double cur[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) { const int j = tx + 16 * u; cur[u] = j < m ? row[j] : 0.0; }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) { const int j = tx + 16 * u; if (j < m) row[j] = cur[u] - (vi * wj[u] + wi * vj[u]); }
-                    }
-                }
-            }
-            __syncthreads();
-        }
+        __syncthreads();  // the LDS copy is overwritten with the Householder vectors from here on
+        // exchange vectors in the scratch matrix (free until the twisted factorisation)
+        tridiag_regs<false>(a, rq, A, lda, n, d, e, tau, W1 + 128, W1 + 192, red);
     }
     stamp(0);
-    if (tid < n) d[tid] = A[tid * lda + tid];
-    if (tid == 0) { e[n - 2] = A[(n - 1) * lda + (n - 2)]; tau[n - 2] = 0.0; }
-    __syncthreads();
     // squared off-diagonals in pv
     if (tid < n - 1) pv[tid] = e[tid] * e[tid];
     __syncthreads();
@@ -202,9 +394,18 @@ __device__ int eigh(double* A, int lda, double* Zt, int ldz, double* W1, int ldw
     int k0 = 0;
     for (int i = 0; i < n; ++i) k0 += lam[i] <= tol0;  // ascending: the null cluster is lam[0..k0)
     const double pivmin = 1e-16 * lmax + 1e-300;
+    // shifts of the twisted factorisation: eigenvalues closer than a few ulps of lam_max are pushed apart (as
+    // LAPACK's dstein does), so that the vectors of a numerically repeated eigenvalue are independent before the
+    // Gram-Schmidt pass below
+    if (tid == 0) {
+        const double sep = 4.4e-16 * lmax;
+        double prev = -1e300;
+        for (int i = 0; i < n; ++i) { prev = fmax(lam[i], prev + sep); wv[i] = prev; }
+    }
+    __syncthreads();
     // ---------------- 3. eigenvectors of T: twisted factorisation ----------------
     if (wv_id == 0 && lane < n && lane >= k0) {        // forward pivots D+ -> W1 row
-        const double l = lam[lane];
+        const double l = wv[lane];
         double dp = d[0] - l;
         for (int j = 0; j < n - 1; ++j) {
             if (fabs(dp) < pivmin) dp = dp < 0.0 ? -pivmin : pivmin;
@@ -213,7 +414,7 @@ __device__ int eigh(double* A, int lda, double* Zt, int ldz, double* W1, int ldw
         }
         W1[lane * ldw + n - 1] = dp;
     } else if (wv_id == 1 && lane < n && lane >= k0) {  // backward pivots D- -> Zt row
-        const double l = lam[lane];
+        const double l = wv[lane];
         double dm = d[n - 1] - l;
         for (int j = n - 1; j > 0; --j) {
             if (fabs(dm) < pivmin) dm = dm < 0.0 ? -pivmin : pivmin;
@@ -224,7 +425,7 @@ __device__ int eigh(double* A, int lda, double* Zt, int ldz, double* W1, int ldw
     }
     __syncthreads();
     if (wv_id == 0 && lane < n && lane >= k0) {
-        const double l = lam[lane];
+        const double l = wv[lane];
         double* zr = &Zt[lane * ldz];
         const double* dpr = &W1[lane * ldw];
         int r = 0;

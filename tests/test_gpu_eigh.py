@@ -114,3 +114,85 @@ def test_eigh_on_real_ik_normal_matrices():
             assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-8
     print("k0 on IK matrices:", k0)
     print("eigensolver phase cycles [tridiag, multisection, twisted, reorth, backtransform]:", _run.last_cycles.mean(0).round(0))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# trust-region step in the tridiagonal basis vs the eigenbasis formulation it replaces
+# ---------------------------------------------------------------------------------------------------------------
+def _tr_step_eigen(J, r, Delta, alpha0):
+    """ik_tr_solve's semantics from a full eigendecomposition of J^T J (numpy): null cluster dropped, one
+    virtual absorber (lam = 0, suf = 1e-8 |g|), Newton on phi(alpha), step normalised to Delta."""
+    A, g = J.T @ J, J.T @ r
+    lam, V = np.linalg.eigh(A)
+    keep = lam > 1e-13 * lam[-1]
+    lam, V = lam[keep], V[:, keep]
+    suf = V.T @ g
+    lam = np.append(lam, 0.0)
+    suf = np.append(suf, 1e-8 * np.linalg.norm(g))
+    upper, lower = np.linalg.norm(suf) / Delta, 0.0
+    alpha = max(0.001 * upper, 0.0) if alpha0 == 0 else alpha0
+    for _ in range(10):
+        if alpha < lower or alpha > upper:
+            alpha = max(0.001 * upper, (lower * upper) ** 0.5)
+        den = lam + alpha
+        pn = np.linalg.norm(suf / den)
+        phi, dphi = pn - Delta, -np.sum(suf ** 2 / den ** 3) / pn
+        if phi < 0:
+            upper = alpha
+        ratio = phi / dphi
+        lower = max(lower, alpha - ratio)
+        alpha -= (phi + Delta) * ratio / Delta
+        if abs(phi) < 0.01 * Delta:
+            break
+    c = -suf / (lam + alpha)
+    c *= Delta / np.linalg.norm(c)
+    pred = -(0.5 * np.sum(lam * c * c) + np.sum(suf * c))
+    return V @ c[:-1], alpha, pred
+
+
+def _run_trstep(Bm, r, dual, Delta, alpha0):
+    from multiview_motion_capture_amd import _cabi
+    lib = _cabi.load()
+    d = torch.device("cuda:0")
+    nb, m, n = Bm.shape
+    Bt, rt = torch.from_numpy(Bm).to(d), torch.from_numpy(r).to(d)
+    step = torch.empty((nb, n), dtype=torch.float64, device=d)
+    out4 = torch.empty((nb, 4), dtype=torch.float64, device=d)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    assert lib.mvmc_debug_trstep(p(Bt), p(rt), nb, m, n, int(dual), float(Delta), float(alpha0), p(step), p(out4), None) == 0
+    torch.cuda.synchronize()
+    return step.cpu().numpy(), out4.cpu().numpy()
+
+
+@pytest.mark.parametrize("m,n,dual", [(48, 39, False), (48, 49, True), (48, 48, False), (30, 12, False), (20, 33, True)])
+@pytest.mark.parametrize("delta_scale,alpha0", [(0.05, 0.0), (1.0, 0.0), (30.0, 0.0), (0.3, 2.0)])
+def test_tr_step_in_tridiagonal_basis_matches_eigenbasis(m, n, dual, delta_scale, alpha0):
+    """Constrained (Delta << |Gauss-Newton step|), marginal and unconstrained (absorber takes the slack) regimes,
+    cold and warm-started alpha; the dual form has the structural null space of a wide Jacobian."""
+    rng = np.random.default_rng(1000 * m + n)
+    nb = 12
+    Bm = rng.normal(size=(nb, m, n)) * 10.0 ** rng.uniform(-1, 1, size=(nb, 1, n))   # badly scaled columns
+    r = rng.normal(size=(nb, m))
+    ref = []
+    gn = []
+    for b in range(nb):
+        gn.append(np.linalg.norm(np.linalg.lstsq(Bm[b], r[b], rcond=None)[0]))
+    Delta = delta_scale * float(np.median(gn))
+    step, out4 = _run_trstep(Bm, r, dual, Delta, alpha0 * 1.0)
+    for b in range(nb):
+        p_ref, a_ref, pred_ref = _tr_step_eigen(Bm[b], r[b], Delta, alpha0)
+        assert out4[b, 3] == 0
+        assert abs(out4[b, 0] - a_ref) <= 1e-7 * a_ref, (out4[b, 0], a_ref)
+        assert np.abs(step[b] - p_ref).max() <= 1e-8 * Delta
+        assert abs(out4[b, 1] - pred_ref) <= 1e-8 * abs(pred_ref)
+        assert abs(out4[b, 2] - Delta) <= 1e-12 * Delta
+
+
+def test_tr_step_reports_numerically_null_directions():
+    """A rank-deficient Gram matrix must be reported (the IK kernel then takes the eigensolver path)."""
+    rng = np.random.default_rng(3)
+    Bm = rng.normal(size=(4, 48, 39))
+    Bm[:, :, 5] = Bm[:, :, 7] * 2.0 - Bm[:, :, 9]          # one dependent column
+    r = rng.normal(size=(4, 48))
+    _, out4 = _run_trstep(Bm, r, False, 1.0, 0.0)
+    assert (out4[:, 3] >= 1).all() and (out4[:, 0] == -1).all()
