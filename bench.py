@@ -203,7 +203,7 @@ def main():
             inf = info.reshape(-1, 8)
             ok = ~torch.isnan(inf[:, 1])
             extra = dict(ik_solves_per_step=int(ok.sum()), mean_nfev=float((inf[ok, 1] + inf[ok, 4]).mean()),
-                         mean_njev=float(inf[ok, 6].mean()), mean_jacobi_sweeps=float(inf[ok, 7].mean()))
+                         mean_njev=float(inf[ok, 6].mean()), eigensolver_fallbacks_per_solve=float(inf[ok, 7].mean()))
         traffic = None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tp):

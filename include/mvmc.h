@@ -141,17 +141,12 @@ int mvmc_fk(const mvmcSkeleton* skel_host, const double* params, int n_problems,
  *                reference lengths, max_nfev_cold),
  *                0 = warm (max_nfev_warm); NULL = all cold
  *   params_out   (B,68); joints_out (B,18,3); info_out (B,8) f64 =
- *                {cost1, nfev1, status1, cost2, nfev2, status2, njev1+njev2, Jacobi sweeps} or NULL
- *   basis_in / basis_src / basis_out (all optional, NULL = off): eigensolver warm start across frames.
- *                basis_out (B, MVMC_IK_BASIS_DOUBLES) receives each problem's stage-1 eigenbasis;
- *                basis_src (B) i32 = row of basis_in (any, MVMC_IK_BASIS_DOUBLES) to start from, -1 = none.
- *                Purely a speed device: results do not depend on it beyond rounding. */
-#define MVMC_IK_BASIS_DOUBLES 2600
+ *                {cost1, nfev1, status1, cost2, nfev2, status2, njev1+njev2, number of trust-region models that
+ *                took the eigensolver fallback (numerically singular Gram matrix)} or NULL */
 int mvmc_ik_solve(const mvmcSkeleton* skel_host, const double* kps17, const double* Pmats,
                   const int32_t* members, int n_problems, int v_max, int n_views, int p_max,
                   const double* init_params, const uint8_t* cold, int max_nfev_cold, int max_nfev_warm,
-                  double* params_out, double* joints_out, double* info_out, const double* basis_in,
-                  const int32_t* basis_src, double* basis_out, mvmcStream_t stream);
+                  double* params_out, double* joints_out, double* info_out, mvmcStream_t stream);
 
 /* ---- temporal layer: match_spatial_time + tracker, batched over independent chains (sub-sequences) ---- */
 
@@ -203,13 +198,13 @@ int mvmc_track_commit(const int32_t* status, const int32_t* n_new, const double*
 int mvmc_debug_eigh(const double* A, const double* g, int n_problems, int n, double* lam, double* Vt, int32_t* k0,
                     double* phase_cycles, mvmcStream_t stream);
 
-/* One trust-region step of the IK solver computed in the tridiagonal basis (no eigendecomposition), on a
+/* One trust-region step of the IK solver computed in the Krylov tridiagonal basis (no eigendecomposition), on a
  * caller-supplied least-squares model: J = B (n_problems,m,n row-major), residual image r (n_problems,m), so
- * g = B^T r.  dual = 0 works on B^T B (n x n), dual = 1 on B B^T (m x m, for m < n).  3 <= m,n <= 50.
- * step (n_problems,n); out4 (n_problems,4) = {alpha, predicted reduction, |step| incl. absorber, number of
- * numerically-null eigenvalues found (then the kernel would fall back to the eigensolver: alpha = -1, step = 0)}. */
-int mvmc_debug_trstep(const double* B, const double* r, int n_problems, int m, int n, int dual, double Delta,
-                      double alpha0, double* step, double* out4, mvmcStream_t stream);
+ * g = B^T r and M = B^T B.  3 <= m,n <= 50.  step (n_problems,n); out4 (n_problems,4) = {alpha, predicted
+ * reduction, |step| incl. absorber, size of the leading (range) block, or -1 where the IK kernel would fall back
+ * to the eigensolver (then alpha = -1, step = 0)}. */
+int mvmc_debug_trstep(const double* B, const double* r, int n_problems, int m, int n, double Delta, double alpha0,
+                      double* step, double* out4, mvmcStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,6 @@ _lib = None
 MVMC_OK = 0
 MVMC_F32, MVMC_F64 = 0, 1
 N_PARAM = 68
-IK_BASIS_DOUBLES = 2600
 MAX_NODES = 80
 
 # every symbol declared in include/mvmc.h
@@ -67,13 +66,13 @@ def load():
     lib.mvmc_triangulate_postopt.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
     lib.mvmc_fk.argtypes = [C.POINTER(MvmcSkeleton), vp, i32, vp, vp, vp]
     lib.mvmc_ik_solve.argtypes = [C.POINTER(MvmcSkeleton), vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, i32,
-                                  vp, vp, vp, vp, vp, vp, vp]
+                                  vp, vp, vp, vp]
     lib.mvmc_fmats_from_projections.argtypes = [vp, i32, vp, vp]
     lib.mvmc_st_affinity.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f64, vp, vp, vp, vp]
     lib.mvmc_track_assign.argtypes = [vp] * 8 + [i32] * 6 + [vp] * 6
     lib.mvmc_track_commit.argtypes = [vp] * 4 + [i32] * 4 + [vp] * 8
     lib.mvmc_debug_eigh.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp]
-    lib.mvmc_debug_trstep.argtypes = [vp, vp, i32, i32, i32, i32, C.c_double, C.c_double, vp, vp, vp]
+    lib.mvmc_debug_trstep.argtypes = [vp, vp, i32, i32, i32, C.c_double, C.c_double, vp, vp, vp]
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError if the library does not export it
         if name not in ("mvmc_status_string",):

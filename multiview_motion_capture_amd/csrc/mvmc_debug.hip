@@ -25,14 +25,14 @@ debug_eigh_kernel(const double* __restrict__ Ain, const double* __restrict__ gin
     if (tid < 5 && cyc_out) cyc_out[(size_t)b * 5 + tid] = (double)prof[tid];
 }
 
-// One trust-region step in the tridiagonal basis (mvmc_eigh_tri.h: tridiag_regs + tr_solve_tri + apply_q), exactly
-// as the IK kernel strings them together: J = Bm (m x n), g = Bm^T r; primal works on Bm^T Bm, dual on Bm Bm^T.
+// One trust-region step in the Krylov tridiagonal basis (mvmc_eigh_tri.h: tridiag_krylov + krylov_block_ok +
+// tr_solve_tri + apply_q_krylov), strung together as in the IK kernel: J = Bm (m x n), g = Bm^T r, M = Bm^T Bm.
 __global__ void __launch_bounds__(256)
-debug_trstep_kernel(const double* __restrict__ Bin, const double* __restrict__ rin, int m, int n, int dual, double Delta,
+debug_trstep_kernel(const double* __restrict__ Bin, const double* __restrict__ rin, int m, int n, double Delta,
                     double alpha0, double* __restrict__ step_out, double* __restrict__ out4) {
     __shared__ double Bm[NMAXE * LDE], V[NMAXE * LDE];
-    __shared__ double r[64], g[64], d[64], e[64], tau[64], rh[64], sv[64], pw[64], red[8];
-    __shared__ double lmul[64], dinv[64], yb[64], zb[64], cv[64], dsc[64], e2sc[64], sc[8];
+    __shared__ double r[64], g[64], d[64], e[64], tau[64], rh[64], v0[64], sv[64], pw[64], red[8];
+    __shared__ double lmul[64], dinv[64], yb[64], zb[64], cv[64], wn[64], dsc[64], e2sc[64], sc[8], k4[4];
     const int b = blockIdx.x, tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     for (int idx = tid; idx < m * n; idx += 256) Bm[(idx / n) * LDE + idx % n] = Bin[(size_t)b * m * n + idx];
     if (tid < m) r[tid] = rin[(size_t)b * m + tid];
@@ -45,51 +45,39 @@ debug_trstep_kernel(const double* __restrict__ Bin, const double* __restrict__ r
     __syncthreads();
     double gg = 0.0;
     for (int i = 0; i < n; ++i) gg += g[i] * g[i];
-    const int nn = dual ? m : n;
-    double a[4][4], rq[4];
+    double a[4][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int i = ty + 16 * q;
-        rq[q] = i < nn ? (dual ? r[i] : g[i]) : 0.0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int j = tx + 16 * u;
             double acc = 0.0;
-            if (i < nn && j < nn) {
-                if (dual) for (int c = 0; c < n; ++c) acc += Bm[i * LDE + c] * Bm[j * LDE + c];
-                else for (int c = 0; c < m; ++c) acc += Bm[c * LDE + i] * Bm[c * LDE + j];
-            }
+            if (i < n && j < n)
+                for (int c = 0; c < m; ++c) acc += Bm[c * LDE + i] * Bm[c * LDE + j];
             a[q][u] = acc;
         }
     }
-    eightri::tridiag_regs<true>(a, rq, V, LDE, nn, d, e, tau, sv, pw, red);
-    if (tx == 0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rh[ty + 16 * q] = rq[q];
-    }
-    __syncthreads();
+    const int kk = eightri::tridiag_krylov(a, g, V, LDE, n, d, e, tau, v0, sv, pw, red, k4);
     if (tid < 64) {
-        double bound;
-        const int nnull = eightri::tri_null_count(d, e, nn, 1e-13, dsc, e2sc, &bound);
         double alpha = -1.0, pred = 0.0, pnorm = 0.0, cj = 0.0;
-        if (nnull == 0) {
-            const double pivmin = 1e-16 * bound + 1e-300;
-            alpha = dual ? eightri::tr_solve_tri<true>(d, e, rh, nn, Delta, alpha0, gg, pivmin, lmul, dinv, yb, zb, cv, &pred, &pnorm)
-                         : eightri::tr_solve_tri<false>(d, e, rh, nn, Delta, alpha0, gg, pivmin, lmul, dinv, yb, zb, cv, &pred, &pnorm);
-            cj = eightri::apply_q(V, LDE, tau, nn, tid < nn ? cv[tid] : 0.0);
+        const bool ok = kk > 0 && eightri::krylov_block_ok(d, e, kk, n, k4[2], k4[3], dsc, e2sc, lmul, dinv, wn);
+        if (ok) {
+            rh[tid] = tid == 0 ? k4[0] : 0.0;
+            const double pivmin = 1e-16 * k4[2] + 1e-300;
+            alpha = eightri::tr_solve_tri<false>(d, e, rh, kk, Delta, alpha0, gg, pivmin, lmul, dinv, yb, zb, cv, &pred, &pnorm);
+            double c = tid < kk ? cv[tid] : 0.0;
+            if (kk < n) {
+                const double eta = k4[3] * wave_sum_dpp(tid < kk ? wn[tid] * c : 0.0);
+                if (tid == kk) c = eta;
+            }
+            cj = eightri::apply_q_krylov(V, LDE, tau, v0, k4[1], kk, n, c);
         }
         cv[tid] = cj;
-        if (tid == 0) { sc[0] = alpha; sc[1] = pred; sc[2] = pnorm; sc[3] = (double)nnull; }
+        if (tid == 0) { sc[0] = alpha; sc[1] = pred; sc[2] = pnorm; sc[3] = ok ? (double)kk : -1.0; }
     }
     __syncthreads();
-    if (tid < n) {
-        double p = cv[tid];
-        if (dual) {
-            p = 0.0;
-            for (int i = 0; i < m; ++i) p += Bm[i * LDE + tid] * cv[i];
-        }
-        step_out[(size_t)b * n + tid] = p;
-    }
+    if (tid < n) step_out[(size_t)b * n + tid] = cv[tid];
     if (tid < 4) out4[(size_t)b * 4 + tid] = sc[tid];
 }
 }  // namespace
@@ -103,11 +91,11 @@ extern "C" int mvmc_debug_eigh(const double* A, const double* g, int n_problems,
     return MVMC_OK;
 }
 
-extern "C" int mvmc_debug_trstep(const double* B, const double* r, int n_problems, int m, int n, int dual, double Delta,
+extern "C" int mvmc_debug_trstep(const double* B, const double* r, int n_problems, int m, int n, double Delta,
                                  double alpha0, double* step, double* out4, mvmcStream_t stream) {
     if (!B || !r || !step || !out4 || m < 3 || n < 3 || m > NMAXE || n > NMAXE || !(Delta > 0.0)) return MVMC_ERR_ARG;
     if (n_problems <= 0) return n_problems == 0 ? MVMC_OK : MVMC_ERR_ARG;
-    hipLaunchKernelGGL(debug_trstep_kernel, dim3(n_problems), dim3(256), 0, (hipStream_t)stream, B, r, m, n, dual, Delta,
+    hipLaunchKernelGGL(debug_trstep_kernel, dim3(n_problems), dim3(256), 0, (hipStream_t)stream, B, r, m, n, Delta,
                        alpha0, step, out4);
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;

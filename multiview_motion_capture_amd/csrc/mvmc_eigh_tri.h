@@ -310,6 +310,241 @@ __device__ inline int tri_null_count(const double* d, const double* e, int n, do
     return sturm_count(dsc, e2sc, (n - 1 + 7) >> 3, tol_rel);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Krylov form of the tridiagonalisation: a first reflector H_g maps g onto e_1, then the usual steps.  With
+// Q = H_g H_0 H_1 ..., T = Q^T M Q is the Lanczos matrix of (M, g) computed with Householder stability, and
+// Q^T g = beta0 e_1.  p(alpha) = -(M + alpha)^-1 g lives in the Krylov space of (M, g), which never leaves
+// range(M): where that space is exhausted the sub-diagonal of T collapses (to rounding times the condition
+// number of the range part) and everything behind it is the null space of M -- the structural null directions of
+// the IK Jacobian (bone twists, ...) never enter the leading block, which is positive definite.  The routine
+//   * stops at the first sub-diagonal |e_k| <= 1e-8 |M|_inf and checks that the untouched trailing block is null
+//     (<= 1e-13 |M|_inf): leading block size kk = k + 1, coupling e_k returned; or
+//   * runs to the end (kk = n) if no sub-diagonal collapses; or
+//   * returns -1 when a sub-diagonal collapses in front of a block that is not null (the caller falls back to the
+//     eigensolver).
+// Same register layout and exchange scheme as tridiag_regs; v0: 64 doubles for the first reflector.
+// out4 = {beta0, tau0, |M|_inf, coupling}.  Ends with a barrier; d[0..kk), e[0..kk-1), tau[0..kk-1) valid.
+__device__ inline int tridiag_krylov(double (&a)[4][4], const double* g, double* V, int ldv, int n, double* d, double* e,
+                                     double* tau, double* v0, double* sv, double* pw, double* red, double* out4) {
+    const int tid = threadIdx.x, lane = tid & 63, wv_id = tid >> 6;
+    const int ty = tid >> 4, tx = tid & 15;
+    auto row_sum16 = [](double v) {
+        v += dpp_mov<0x128>(v); v += dpp_mov<0x124>(v); v += dpp_mov<0x122>(v); v += dpp_mov<0x121>(v);
+        return v;
+    };
+    auto block_max = [&](double v) {  // two barriers; uniform result
+        for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+        __syncthreads();
+        if (lane == 0) red[wv_id] = v;
+        __syncthreads();
+        return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    };
+    // Householder vector from x (alpha at index j1, tail beyond); returns (tau, beta, scale of the tail)
+    auto reflector = [&](double alpha, double sig, double& tk, double& beta, double& sc) {
+        tk = 0.0; beta = alpha; sc = 0.0;
+        if (sig > 0.0) {
+            const double q2 = alpha * alpha + sig;
+            double rs = __builtin_amdgcn_rsq(q2);
+            rs = rs * (1.5 - 0.5 * q2 * rs * rs);
+            rs = rs * (1.5 - 0.5 * q2 * rs * rs);
+            const double nrm = q2 * rs;
+            beta = alpha >= 0.0 ? -nrm : nrm;
+            tk = 1.0 - alpha * fast_rcp64(beta);
+            sc = fast_rcp64(alpha - beta);
+        }
+    };
+    // M <- H M H for the reflector in sv with coefficient tk (p = tk M v; w = p - (tk/2)(p.v) v; M -= v w^T + w v^T)
+    auto two_sided = [&](double tk) {
+        double vj[4], vi[4], s[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { vj[u] = sv[tx + 16 * u]; vi[u] = sv[ty + 16 * u]; }
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double acc = a[q][0] * vj[0];
+#pragma unroll
+            for (int u = 1; u < 4; ++u) acc += a[q][u] * vj[u];
+            s[q] = row_sum16(acc) * tk;
+            t += s[q] * vi[q];
+        }
+        {
+            const int lo = __double2loint(t), hi = __double2hiint(t);
+            double tw = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                tw += __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * r), __builtin_amdgcn_readlane(lo, 16 * r));
+            if (lane == 0) red[4 + wv_id] = tw;
+        }
+        if (tx == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pw[ty + 16 * q] = s[q];
+        }
+        __syncthreads();
+        const double h = 0.5 * tk * ((red[4] + red[5]) + (red[6] + red[7]));
+        double wj[4], wi[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            wj[u] = pw[tx + 16 * u] - h * vj[u];
+            wi[u] = s[u] - h * vi[u];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[q][u] -= vi[q] * wj[u] + wi[q] * vj[u];
+    };
+    auto householder = [&](auto qk_tag, int k) {
+        constexpr int QK = decltype(qk_tag)::value;
+        const int j1 = k + 1;
+        double al = 0.0, sg = 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = tx + 16 * u;
+            const double xu = a[QK][u];
+            al = j == j1 ? xu : al;
+            sg += j > j1 ? xu * xu : 0.0;
+        }
+        double tk, beta, sc;
+        reflector(row_sum16(al), row_sum16(sg), tk, beta, sc);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = tx + 16 * u;
+            const double vi = j == j1 ? 1.0 : (j > j1 ? a[QK][u] * sc : 0.0);
+            sv[j] = vi;
+            if (j > k && j < n) V[j * ldv + k] = vi;
+        }
+        if (tx == 0) { e[k] = beta; tau[k] = tk; }
+    };
+
+    // |M|_inf
+    double anorm;
+    {
+        double m = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double r = 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) r += fabs(a[q][u]);
+            m = fmax(m, row_sum16(r));
+        }
+        anorm = block_max(m);
+    }
+    const double tol_c = 1e-8 * anorm, tol_n = 1e-13 * anorm;
+    // first reflector: H_g g = beta0 e_1
+    if (ty == 0) {
+        double x[4], al = 0.0, sg = 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = tx + 16 * u;
+            x[u] = j < n ? g[j] : 0.0;
+            al = j == 0 ? x[u] : al;
+            sg += j > 0 ? x[u] * x[u] : 0.0;
+        }
+        double tk, beta, sc;
+        reflector(row_sum16(al), row_sum16(sg), tk, beta, sc);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = tx + 16 * u;
+            const double vi = j == 0 ? 1.0 : x[u] * sc;
+            sv[j] = vi; v0[j] = vi;
+        }
+        if (tx == 0) { out4[0] = beta; out4[1] = tk; out4[2] = anorm; out4[3] = 0.0; }
+    }
+    __syncthreads();
+    {
+        const double t0 = out4[1];
+        if (t0 != 0.0) two_sided(t0);
+    }
+    int kk = n;
+    for (int k = 0; k < n - 1; ++k) {
+        if (ty == (k & 15)) {
+            switch (k >> 4) {
+                case 0: householder(std::integral_constant<int, 0>{}, k); break;
+                case 1: householder(std::integral_constant<int, 1>{}, k); break;
+                case 2: householder(std::integral_constant<int, 2>{}, k); break;
+                default: householder(std::integral_constant<int, 3>{}, k); break;
+            }
+        }
+        __syncthreads();
+        const double tk = tau[k], ek = e[k];
+        if (fabs(ek) <= tol_c) {
+            // the Krylov space is exhausted: everything behind row k must be the null space
+            double m = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (ty + 16 * q > k && tx + 16 * u > k) m = fmax(m, fabs(a[q][u]));
+            m = block_max(m);
+            if (tid == 0) { tau[k] = 0.0; out4[3] = ek; }
+            kk = (m <= tol_n) ? k + 1 : -1;
+            break;
+        }
+        if (tk != 0.0) two_sided(tk);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = ty + 16 * q, j = tx + 16 * u;
+            if (i == j && i < n) d[i] = a[q][u];
+        }
+    __syncthreads();
+    return kk;
+}
+
+// Leading-block checks and the null-vector coupling of the Krylov tridiagonalisation (one wave).
+//   * the leading kk x kk block of T must have no eigenvalue <= 1e-13 |M|_inf (Sturm count);
+//   * if kk < n: w = T_kk^-1 e_last (LDS, kk doubles).  The null vector of the (kk+1)-block is z = [-ec w; 1], so the
+//     range-restricted solution has the extra component eta = ec (w . y) at index kk; the neglected second-order
+//     term is (ec |w|)^2, which must stay below 1e-8.
+// Returns true if the fast path may be used.  dsc, e2sc: 64 doubles scratch each; lmul, dinv: kk doubles scratch.
+__device__ inline bool krylov_block_ok(const double* d, const double* e, int kk, int n, double anorm, double ec,
+                                       double* dsc, double* e2sc, double* lmul, double* dinv, double* w) {
+    const int lane = threadIdx.x & 63;
+    const double ts = anorm > 0.0 ? anorm : 1.0;
+    dsc[lane] = lane < kk ? d[lane] / ts : 4.0;
+    const double es = lane < kk - 1 ? e[lane] / ts : 0.0;
+    e2sc[lane] = es * es;
+    if (sturm_count(dsc, e2sc, (kk - 1 + 7) >> 3, 1e-13) != 0) return false;
+    if (kk == n) return true;
+    // T_kk = L D L^T (positive definite by the count above); w = T_kk^-1 e_{kk-1}: forward substitution leaves
+    // only the last component, so w_{kk-1} = 1/D_{kk-1} and w_j = -l_j w_{j+1}
+    double D = d[0];
+    for (int j = 0; j < kk - 1; ++j) {
+        const double inv = fast_rcp64(D);
+        const double l = e[j] * inv;
+        if (lane == 0) lmul[j] = l;
+        D = d[j + 1] - l * e[j];
+    }
+    double wj = fast_rcp64(D), ww = wj * wj;
+    if (lane == 0) w[kk - 1] = wj;
+    for (int j = kk - 2; j >= 0; --j) {
+        wj = -lmul[j] * wj;
+        ww += wj * wj;
+        if (lane == 0) w[j] = wj;
+    }
+    return ec * ec * ww <= 1e-8;
+}
+
+// Q c for the Krylov tridiagonalisation: reflectors k = kk-2 .. 0 from V, then the first reflector v0 (one wave)
+__device__ inline double apply_q_krylov(const double* V, int ldv, const double* tau, const double* v0, double tau0, int kk,
+                                        int n, double cj) {
+    const int lane = threadIdx.x & 63;
+    for (int k = kk - 2; k >= 0; --k) {
+        const double tk = tau[k];
+        if (tk == 0.0) continue;
+        const double v = (lane > k && lane < n) ? V[lane * ldv + k] : 0.0;
+        const double s = wave_sum_dpp(v * cj);
+        cj -= tk * s * v;
+    }
+    if (tau0 != 0.0) {
+        const double v = lane < n ? v0[lane] : 0.0;
+        const double s = wave_sum_dpp(v * cj);
+        cj -= tau0 * s * v;
+    }
+    return cj;
+}
+
 // A (n x n, ld lda, full symmetric, destroyed) -> lam (n, ascending, null cluster set to 0),
 // Zt (rows = eigenvectors, ld ldz; rows 0..k0-1 of the null cluster are zero).
 // W1: n x ldw scratch (>= 256 doubles).  d, e, tau, pv, wv: LDS vectors of >= n doubles.  icnt: 4*64 ints.

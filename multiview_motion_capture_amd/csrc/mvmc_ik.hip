@@ -7,21 +7,19 @@
 //   stage 2  x = [root, euler, side bone lengths]   (68 parameters, 49 structurally non-null)
 // Differences from the reference that are deliberate (DESIGN.md "IK parity"):
 //   * analytic Jacobian of the FK chain instead of 2-point finite differences;
-//   * the trust-region sub-problem is solved from the normal equations: with J^T J = V L V^T,
-//     s^2 = L and s*(U^T f) = V^T g, so p(alpha) = -V (V^T g / (L + alpha)); J^T J is assembled from the
-//     per-joint 3x3 image-space blocks (J^T J = D^T W D, D = d pos / d x is 48 x n) and diagonalised by a
-//     parallel cyclic Jacobi in LDS;
+//   * the trust-region sub-problem is solved from the normal equations J^T J = D^T W D (D = d pos / d x is
+//     48 x n, W the per-joint 3x3 image-space blocks).  J^T J is assembled straight into registers and
+//     tridiagonalised from g = J^T f (Householder form of the Lanczos process, mvmc_eigh_tri.h): the Krylov space
+//     of (J^T J, g) contains every p(alpha) = -(J^T J + alpha)^-1 g and none of the Jacobian's null directions
+//     (bone twists etc., 9 of the 39 / 49 columns), so SciPy's Newton iteration on |p(alpha)| = Delta runs on a
+//     small positive-definite tridiagonal matrix -- no eigendecomposition.  When the split between range and
+//     null space is not clean (weakly observed directions, missing joints) the step falls back to the full
+//     eigensolver, where p(alpha) = -V (V^T g / (L + alpha)) with the null cluster removed;
 //   * columns that are identically zero for every input (leaf-joint angles, the root's bone length) are
-//     removed from the eigenproblem -- SciPy gives them s = 0 and a zero step, which is what they get here.
+//     removed from the problem -- SciPy gives them s = 0 and a zero step, which is what they get here.
 #include "mvmc_common.h"
 #include "mvmc_postopt.h"
 #include "mvmc_eigh_tri.h"
-
-// Eigensolver of the trust-region step: 1 = Householder tridiagonalisation + Sturm multisection + twisted
-// factorisation (mvmc_eigh_tri.h); 0 = the parallel cyclic Jacobi of the first version (kept for A/B runs).
-#ifndef MVMC_IK_TRIDIAG
-#define MVMC_IK_TRIDIAG 1
-#endif
 
 namespace {
 
@@ -36,12 +34,13 @@ namespace {
 constexpr int NT = 256;    // threads per problem
 constexpr int NA = 50;     // max active parameters (even)
 constexpr int LD = 51;     // odd leading dimension: conflict-free column walks on 8-byte elements
-constexpr int LDV = 52;    // leading dimension of the transposed eigenvector matrix in the Jacobi solver (even: 16-byte row pairs)
-#if MVMC_IK_TRIDIAG
-constexpr int LDZ = LD;    // eigenvector rows as the tridiagonal solver writes them (odd: lanes walk one column)
-#else
-constexpr int LDZ = LDV;
-#endif
+constexpr int LDZ = LD;    // eigenvector rows of the fallback eigensolver (odd: lanes walk one column)
+constexpr int NROW = 48;   // rows of D: 16 observed joints x 3
+// fast-path scratch vectors, 64 doubles each, behind ik_eval's per-(view,joint) scratch in bufB
+constexpr int SCR0 = 1290;
+enum { SC_SV = 0, SC_PW, SC_DSC, SC_E2, SC_LMUL, SC_DINV, SC_YB, SC_ZB, SC_RH, SC_TAU, SC_D, SC_E, SC_QC, SC_V0, SC_WN, SC_COUNT };
+static_assert(SCR0 >= 8 * 16 * 10, "scratch overlaps the Jacobian blocks");
+static_assert(SCR0 + SC_COUNT * 64 <= NA * LD, "scratch does not fit bufB");
 constexpr int VMAX = 8;    // max views per person
 constexpr int NOBS = 16;   // observed joints per view
 
@@ -50,13 +49,13 @@ __device__ __constant__ const int kIkSkel[NOBS] = {1, 2, 3, 4, 5, 6, 7, 9, 10, 1
 __device__ __constant__ const int kIkObs[NOBS] = {11, 13, 15, 12, 14, 16, 17, 5, 7, 9, 6, 8, 10, 0, 3, 4};
 
 struct IkShared {
-    double bufA[NA * LD];  // D (48 x LD)  | T = (J^T J) V for the basis change
-    double bufB[NA * LD];  // per-(view,joint) scratch | Y = W D (48 x LD) | J^T J -> diag(L) (NA x LD)
-    double bufC[NA * LDV]; // eigenvector basis, TRANSPOSED (row = eigenvector), kept across the iterations of a solve
+    double bufA[NA * LD];  // D (48 x LD) | scratch matrix of the fallback eigensolver
+    double bufB[NA * LD];  // per-(view,joint) Jacobian blocks [0, 1280) + fast-path vectors [SCR0, ...) | Y = W D | fallback: J^T J
+    double bufC[NA * LD];  // Householder vectors of the tridiagonalisation | fallback: eigenvectors (rows)
     double x[68], xn[68];
     double side[18];       // side bone lengths used by stage 1 (fixed)
     double g[NA], lam[NA], suf[NA], cv[NA], step[NA];
-    double2 rcs[NA / 2];   // (cos, sin) of the step's rotations
+    double rcs[NA];        // fallback eigensolver scratch
     double obs[VMAX * NOBS * 3], Pm[VMAX * 12];
     double Rl[18 * 9], Rg[18 * 9], pos[18 * 3], bvec[18 * 3], off[18 * 3], axes[18 * 9];
     double Wk[NOBS * 6], tk[NOBS * 3];
@@ -65,7 +64,6 @@ struct IkShared {
     int act[2][NA], inv_act[2][68], na[2];
     int colkind[2][NA], cola[2][NA], colc[2][NA];
     int anc[18], depth[18], maxdepth, nviews;
-    int pq[NA / 2];        // p | q << 8
     // skeleton tables (copied from the kernel argument once: dynamic indexing of by-value kernel
     // arguments costs SGPR spills and scratch)
     double dirs[18 * 3], ref_side[18];
@@ -162,9 +160,40 @@ __device__ double ik_eval(IkShared& S, const SkelRef& sk, const double* xs, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Jacobian blocks -> J^T J (into bufB), g = J^T f.  Needs ik_eval(want_jac) state.
+// Jacobian model at the accepted point.  Needs ik_eval(want_jac) state (blocks in bufB, FK arrays).
+//   ik_model:        W_k, t_k, rotation axes, D -> bufA (48 x nap, zero padded), g = D^T t
+//   ik_normal_matrix bufB <- D^T W D (fallback eigensolver path; bufA must hold D)
 // ---------------------------------------------------------------------------------------------
-__device__ void ik_normal_equations(IkShared& S, const SkelRef& sk, const double* xs, int stage) {
+__device__ void ik_build_D(IkShared& S, const SkelRef& sk, int stage) {
+    const int tid = threadIdx.x;
+    const int na = S.na[stage], nap = (na + 1) & ~1;
+    // D[row = 3k + c3][col] = d pos_K[c3] / d x_col
+    for (int idx = tid; idx < NROW * nap; idx += NT) {
+        const int row = idx / nap, col = idx - row * nap;
+        const int k = row / 3, c3 = row - k * 3, K = kIkSkel[k];
+        double d = 0.0;
+        if (col < na) {
+            const int kind = S.colkind[stage][col], a = S.cola[stage][col], c = S.colc[stage][col];
+            if (kind == 0) {
+                d = (c3 == c) ? 1.0 : 0.0;
+            } else if (kind == 1) {
+                if ((S.anc[K] >> a) & 1) {
+                    const double* ax = &S.axes[(a * 3 + c) * 3];
+                    const double r0 = S.pos[K * 3] - S.pos[a * 3], r1 = S.pos[K * 3 + 1] - S.pos[a * 3 + 1],
+                                 r2 = S.pos[K * 3 + 2] - S.pos[a * 3 + 2];
+                    d = (c3 == 0) ? ax[1] * r2 - ax[2] * r1 : (c3 == 1) ? ax[2] * r0 - ax[0] * r2 : ax[0] * r1 - ax[1] * r0;
+                }
+            } else {
+                for (int j = K; j > 0; j = sk.parents[j])
+                    if (sk.side_map[j] == a) d += S.bvec[j * 3 + c3];
+            }
+        }
+        S.bufA[row * LD + col] = d;
+    }
+    __syncthreads();
+}
+
+__device__ void ik_model(IkShared& S, const SkelRef& sk, const double* xs, int stage) {
     const int tid = threadIdx.x;
     const int na = S.na[stage], nap = (na + 1) & ~1;
     // per-joint blocks: W_k = sum_v s^2 (du du^T + dv dv^T), t_k = sum_v s (du fu + dv fv)
@@ -194,32 +223,20 @@ __device__ void ik_normal_equations(IkShared& S, const SkelRef& sk, const double
         }
     }
     __syncthreads();
-    // D[row = 3k + c3][col] = d pos_K[c3] / d x_col
-    for (int idx = tid; idx < 48 * nap; idx += NT) {
-        const int row = idx / nap, col = idx - row * nap;
-        const int k = row / 3, c3 = row - k * 3, K = kIkSkel[k];
-        double d = 0.0;
-        if (col < na) {
-            const int kind = S.colkind[stage][col], a = S.cola[stage][col], c = S.colc[stage][col];
-            if (kind == 0) {
-                d = (c3 == c) ? 1.0 : 0.0;
-            } else if (kind == 1) {
-                if ((S.anc[K] >> a) & 1) {
-                    const double* ax = &S.axes[(a * 3 + c) * 3];
-                    const double r0 = S.pos[K * 3] - S.pos[a * 3], r1 = S.pos[K * 3 + 1] - S.pos[a * 3 + 1],
-                                 r2 = S.pos[K * 3 + 2] - S.pos[a * 3 + 2];
-                    d = (c3 == 0) ? ax[1] * r2 - ax[2] * r1 : (c3 == 1) ? ax[2] * r0 - ax[0] * r2 : ax[0] * r1 - ax[1] * r0;
-                }
-            } else {
-                for (int j = K; j > 0; j = sk.parents[j])
-                    if (sk.side_map[j] == a) d += S.bvec[j * 3 + c3];
-            }
-        }
-        S.bufA[row * LD + col] = d;
+    ik_build_D(S, sk, stage);
+    if (tid < nap) {
+        double a = 0.0;
+        for (int row = 0; row < NROW; ++row) a += S.bufA[row * LD + tid] * S.tk[row];
+        S.g[tid] = a;
     }
     __syncthreads();
-    // Y = W D  (bufB; the per-(view,joint) scratch is dead now)
-    for (int idx = tid; idx < 48 * nap; idx += NT) {
+}
+
+// Y = W D into bufB (the per-(view,joint) scratch is dead once W_k, t_k are formed)
+__device__ void ik_weighted_D(IkShared& S, int stage) {
+    const int tid = threadIdx.x;
+    const int na = S.na[stage], nap = (na + 1) & ~1;
+    for (int idx = tid; idx < NROW * nap; idx += NT) {
         const int row = idx / nap, col = idx - row * nap;
         const int k = row / 3, c3 = row - k * 3;
         const double* W = &S.Wk[k * 6];
@@ -230,7 +247,13 @@ __device__ void ik_normal_equations(IkShared& S, const SkelRef& sk, const double
                                  w2 * S.bufA[(3 * k + 2) * LD + col];
     }
     __syncthreads();
-    // J^T J = D^T Y (registers first: the result overwrites Y), g = D^T t
+}
+
+__device__ void ik_normal_matrix(IkShared& S, int stage) {
+    const int tid = threadIdx.x;
+    const int na = S.na[stage], nap = (na + 1) & ~1;
+    ik_weighted_D(S, stage);
+    // J^T J = D^T Y (registers first: the result overwrites Y)
     constexpr int EPT = (NA * NA + NT - 1) / NT;
     double acc[EPT];
 #pragma unroll
@@ -239,14 +262,9 @@ __device__ void ik_normal_equations(IkShared& S, const SkelRef& sk, const double
         double a = 0.0;
         if (idx < nap * nap) {
             const int i = idx / nap, j = idx - i * nap;
-            for (int row = 0; row < 48; ++row) a += S.bufA[row * LD + i] * S.bufB[row * LD + j];
+            for (int row = 0; row < NROW; ++row) a += S.bufA[row * LD + i] * S.bufB[row * LD + j];
         }
         acc[t] = a;
-    }
-    if (tid < nap) {
-        double a = 0.0;
-        for (int row = 0; row < 48; ++row) a += S.bufA[row * LD + tid] * S.tk[row];
-        S.g[tid] = a;
     }
     __syncthreads();
 #pragma unroll
@@ -261,195 +279,63 @@ __device__ void ik_normal_equations(IkShared& S, const SkelRef& sk, const double
 }
 
 // ---------------------------------------------------------------------------------------------
-// Symmetric eigensolver of the trust-region step
+// Fast path: J^T J = D^T (W D) into registers, Krylov tridiagonalisation from g, leading-block checks.
+// Returns the size of the leading (range) block, or -1 (uniformly) when the eigensolver has to take over.
+// S.sc[4..7] = {beta0, tau0, |J^T J|_inf, coupling}.
 // ---------------------------------------------------------------------------------------------
-// out = M1 * M2 (TRANSB = false) or M1 * M2^T (TRANSB = true) on nap x nap LDS matrices with leading
-// dimensions l1, l2, lo; 1 x 5 register tiles
-template <bool TRANSB>
-__device__ inline void ik_matmul(const double* M1, int l1, const double* M2, int l2, double* out, int lo, int nap) {
-    const int jb = nap / 5;  // nap is 40 or 50
-    for (int tile = threadIdx.x; tile < nap * jb; tile += NT) {
-        const int i = tile / jb, j0 = (tile - i * jb) * 5;
-        double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
-        for (int k = 0; k < nap; ++k) {
-            const double m = M1[i * l1 + k];
-            if (TRANSB) {
-                a0 += m * M2[(j0 + 0) * l2 + k]; a1 += m * M2[(j0 + 1) * l2 + k]; a2 += m * M2[(j0 + 2) * l2 + k];
-                a3 += m * M2[(j0 + 3) * l2 + k]; a4 += m * M2[(j0 + 4) * l2 + k];
-            } else {
-                const double* r = &M2[k * l2 + j0];
-                a0 += m * r[0]; a1 += m * r[1]; a2 += m * r[2]; a3 += m * r[3]; a4 += m * r[4];
-            }
-        }
-        double* o = &out[i * lo + j0];
-        o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4;
-    }
-}
-
-// Parallel cyclic Jacobi (round-robin pairs).  On entry bufB = J^T J (full symmetric) and bufC = an
-// orthonormal basis, transposed (Vt: one eigenvector per row; identity or the previous iterate's).
-// The matrix is first moved into that basis (A' = Vt A Vt^T, nearly diagonal when J changed little), then
-// rotated to diag(lam); only the UPPER triangle of A is kept current during the sweeps.  Per step, the
-// two-sided update is one pass over the 2x2 blocks of the pair-of-pairs with i <= j (B' = L_i B R_j) and Vt
-// takes the same rotations on row pairs (two adjacent columns per 16-byte access).
-__device__ int ik_eigh(IkShared& S, int nap, bool have_basis) {
-    const int tid = threadIdx.x;
-    double* A = S.bufB;
-    double* Vt = S.bufC;
-    if (have_basis && (nap % 5) == 0) {
-        ik_matmul<false>(S.bufC, LDV, S.bufB, LD, S.bufA, LD, nap);  // T = Vt A
-        __syncthreads();
-        ik_matmul<true>(S.bufA, LD, S.bufC, LDV, S.bufB, LD, nap);   // A' = T Vt^T
-        __syncthreads();
-    } else {
-        for (int idx = tid; idx < nap * LDV; idx += NT) {
-            const int i = idx / LDV, j = idx - i * LDV;
-            Vt[idx] = (i == j) ? 1.0 : 0.0;
-        }
-        __syncthreads();
-    }
-    const int half = nap / 2;
-    constexpr int HM = NA / 2;
-    constexpr int IBK = (HM * (HM + 1) / 2 + NT - 1) / NT;   // 2x2 blocks per thread
-    constexpr int IV = (HM * (NA / 2) + NT - 1) / NT;        // (pair, two adjacent columns of Vt) per thread
-    short bi[IBK], bj[IBK], vi[IV], vr[IV];
+__device__ int ik_krylov_model(IkShared& S, int stage) {
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int na = S.na[stage];
+    double* scr = S.bufB + SCR0;
+    ik_weighted_D(S, stage);
+    double a[4][4];
+    int ic[4], jc[4];
 #pragma unroll
-    for (int t = 0; t < IBK; ++t) {
-        int idx = t * NT + tid;
-        bi[t] = -1; bj[t] = 0;
-        if (idx < half * (half + 1) / 2) {
-            int i = 0;
-            while (idx >= half - i) { idx -= half - i; ++i; }
-            bi[t] = (short)i; bj[t] = (short)(i + idx);
-        }
+    for (int q = 0; q < 4; ++q) {
+        const int i = ty + 16 * q, j = tx + 16 * q;
+        ic[q] = i < na ? i : na - 1;
+        jc[q] = j < na ? j : na - 1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[q][u] = 0.0;
+    }
+    for (int r = 0; r < NROW; ++r) {
+        double di[4], yj[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { di[q] = S.bufA[r * LD + ic[q]]; yj[q] = S.bufB[r * LD + jc[q]]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[q][u] += di[q] * yj[u];
     }
 #pragma unroll
-    for (int t = 0; t < IV; ++t) {
-        const int idx = t * NT + tid;
-        if (idx < half * half) { vi[t] = (short)(idx / half); vr[t] = (short)(2 * (idx % half)); }
-        else { vi[t] = -1; vr[t] = 0; }
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (ty + 16 * q >= na || tx + 16 * u >= na) a[q][u] = 0.0;
+    __syncthreads();  // Y (bufB) is dead from here: the scratch vectors live in its tail
+    const int kk = eightri::tridiag_krylov(a, S.g, S.bufC, LD, na, scr + 64 * SC_D, scr + 64 * SC_E, scr + 64 * SC_TAU,
+                                           scr + 64 * SC_V0, scr + 64 * SC_SV, scr + 64 * SC_PW, S.red, &S.sc[4]);
+    if (tid < 64) {
+        const bool ok = kk > 0 && eightri::krylov_block_ok(scr + 64 * SC_D, scr + 64 * SC_E, kk, na, S.sc[6], S.sc[7],
+                                                           scr + 64 * SC_DSC, scr + 64 * SC_E2, scr + 64 * SC_LMUL,
+                                                           scr + 64 * SC_DINV, scr + 64 * SC_WN);
+        scr[64 * SC_RH + tid] = tid == 0 ? S.sc[4] : 0.0;
+        if (tid == 0) S.sc[0] = ok ? (double)kk : -1.0;
     }
-    int sweeps = 0;
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        double off = 0.0, dg = 0.0;
-        for (int idx = tid; idx < nap * LD; idx += NT) {
-            const int i = idx / LD, j = idx - i * LD;
-            if (j < nap && j >= i) {
-                const double a = A[idx];
-                if (i == j) dg += a * a; else off += 2.0 * a * a;
-            }
-        }
-        off = block_sum256(off, S.red);
-        dg = block_sum256(dg, S.red);
-        // off-diagonal mass below (1e-14 |A|_F)^2: eigenvalues are converged to ~1e-14 lambda_max
-        if (off <= 1e-28 * (dg + off)) break;
-        ++sweeps;
-        const double tiny = 1e-17 * sqrt(dg + off);  // entries below this are rounding noise of the null space
-        for (int s = 0; s < nap - 1; ++s) {
-#ifdef MVMC_IK_PROFILE
-            const long long _ts0 = clock64();
-#endif
-            if (tid < half) {
-                int p, q;
-                if (tid == 0) { p = nap - 1; q = s; }
-                else {
-                    p = s + tid; if (p >= nap - 1) p -= nap - 1;
-                    q = s - tid; if (q < 0) q += nap - 1;
-                }
-                if (p > q) { const int t = p; p = q; q = t; }
-                const double apq = A[p * LD + q], app = A[p * LD + p], aqq = A[q * LD + q];
-                double c = 1.0, sn = 0.0;
-                if (fabs(apq) > tiny) {
-                    // t = sgn(d) apq / (|d| + sqrt(d^2 + apq^2)), c = 1/sqrt(1 + t^2), s = t c, with
-                    // Newton-refined v_rsq/v_rcp instead of IEEE sqrt/div sequences (this scalar chain is
-                    // on the critical path of every Jacobi step)
-                    const double d = 0.5 * (aqq - app);
-                    const double v = d * d + apq * apq;
-                    double rs = __builtin_amdgcn_rsq(v);
-                    rs = rs * (1.5 - 0.5 * v * rs * rs);
-                    rs = rs * (1.5 - 0.5 * v * rs * rs);
-                    const double den = fabs(d) + v * rs;
-                    double ri = __builtin_amdgcn_rcp(den);
-                    ri = ri * (2.0 - den * ri);
-                    ri = ri * (2.0 - den * ri);
-                    const double t = (d >= 0 ? apq : -apq) * ri;
-                    const double u = 1.0 + t * t;
-                    double rc = __builtin_amdgcn_rsq(u);
-                    rc = rc * (1.5 - 0.5 * u * rc * rc);
-                    rc = rc * (1.5 - 0.5 * u * rc * rc);
-                    c = rc;
-                    sn = t * rc;
-                }
-                S.rcs[tid] = make_double2(c, sn);
-                S.pq[tid] = p | (q << 8);
-            }
-            __syncthreads();
-#ifdef MVMC_IK_PROFILE
-            const long long _ts1 = clock64();
-            if (tid == 0) S.prof[3] += _ts1 - _ts0;
-#endif
-            // all loads first, then all stores (LDS stores would otherwise serialise the items)
-            double b00[IBK], b01[IBK], b10[IBK], b11[IBK];
-            double2 ri[IBK], rj[IBK];
-            int a00[IBK], a01[IBK], a10[IBK], a11[IBK];
-#pragma unroll
-            for (int t = 0; t < IBK; ++t) {
-                const int i = bi[t] < 0 ? 0 : bi[t], j = bj[t];
-                ri[t] = S.rcs[i]; rj[t] = S.rcs[j];
-                const int pqi = S.pq[i], pqj = S.pq[j];
-                const int pi = pqi & 255, qi = pqi >> 8, pj = pqj & 255, qj = pqj >> 8;
-                // canonical (upper-triangle) address of element (r, c)
-                a00[t] = pi <= pj ? pi * LD + pj : pj * LD + pi;
-                a01[t] = pi <= qj ? pi * LD + qj : qj * LD + pi;
-                a10[t] = qi <= pj ? qi * LD + pj : pj * LD + qi;
-                a11[t] = qi <= qj ? qi * LD + qj : qj * LD + qi;
-                b00[t] = A[a00[t]]; b01[t] = A[a01[t]]; b10[t] = A[a10[t]]; b11[t] = A[a11[t]];
-            }
-            double2 va[IV], vb[IV], rv[IV];
-            int ia[IV], ib[IV];
-#pragma unroll
-            for (int t = 0; t < IV; ++t) {
-                const int i = vi[t] < 0 ? 0 : vi[t];
-                rv[t] = S.rcs[i];
-                const int pqi = S.pq[i];
-                ia[t] = (pqi & 255) * LDV + vr[t]; ib[t] = (pqi >> 8) * LDV + vr[t];
-                va[t] = *reinterpret_cast<const double2*>(&Vt[ia[t]]);
-                vb[t] = *reinterpret_cast<const double2*>(&Vt[ib[t]]);
-            }
-#pragma unroll
-            for (int t = 0; t < IBK; ++t) {
-                if (bi[t] < 0) continue;
-                const double ci = ri[t].x, si = ri[t].y, cj = rj[t].x, sj = rj[t].y;
-                const double t00 = cj * b00[t] - sj * b01[t], t01 = sj * b00[t] + cj * b01[t];
-                const double t10 = cj * b10[t] - sj * b11[t], t11 = sj * b10[t] + cj * b11[t];
-                A[a00[t]] = ci * t00 - si * t10;
-                A[a11[t]] = si * t01 + ci * t11;
-                A[a01[t]] = ci * t01 - si * t11;
-                if (bi[t] != bj[t]) A[a10[t]] = si * t00 + ci * t10;  // diagonal block: (q,p) is (p,q)
-            }
-#pragma unroll
-            for (int t = 0; t < IV; ++t) {
-                if (vi[t] < 0) continue;
-                const double c = rv[t].x, sn = rv[t].y;
-                *reinterpret_cast<double2*>(&Vt[ia[t]]) = make_double2(c * va[t].x - sn * vb[t].x, c * va[t].y - sn * vb[t].y);
-                *reinterpret_cast<double2*>(&Vt[ib[t]]) = make_double2(sn * va[t].x + c * vb[t].x, sn * va[t].y + c * vb[t].y);
-            }
-            __syncthreads();
-        }
-    }
-    return sweeps;
+    __syncthreads();
+    return (int)S.sc[0];
 }
 
 // ---------------------------------------------------------------------------------------------
-// solve_lsq_trust_region (common.py:57-168), rank-deficient branch (structurally null columns
-// exist, so SciPy's full-rank Gauss-Newton shortcut never fires).  Wave 0 only; writes cv[] and
-// returns alpha; *pred receives the predicted reduction, all lanes hold the same scalars.
+// solve_lsq_trust_region (common.py:57-168) in the eigenbasis of J^T J (fallback path), one wave.
+// Every problem is rank deficient in the reference's terms (it keeps the structurally-zero columns, s = 0),
+// so only that branch exists: Newton on phi(alpha) = |p(alpha)| - Delta from alpha0, the step normalised to
+// |p| = Delta.  S.cv <- coefficients; returns alpha.
 // ---------------------------------------------------------------------------------------------
 __device__ double ik_tr_solve(IkShared& S, int nap, double Delta, double alpha0, double gg, double* pred, double* pnorm) {
     const int lane = threadIdx.x;
     const bool on = lane <= nap;
     double lam = lane < nap ? S.lam[lane] : 1.0, suf = lane < nap ? S.suf[lane] : 0.0;
-#if MVMC_IK_TRIDIAG
     // Virtual absorber (lane nap): a direction with lambda = 0 and a small fixed weight.  In the reference
     // the numerically-null directions of J carry finite-difference noise (s*u^T f ~ 1e-8 |g|), and because
     // SciPy normalises every rank-deficient step to |p| = Delta, that noise soaks up whatever part of the
@@ -459,7 +345,6 @@ __device__ double ik_tr_solve(IkShared& S, int nap, double Delta, double alpha0,
         lam = 0.0;
         suf = 1e-8 * sqrt(gg);
     }
-#endif
     double alpha_upper = sqrt(wave_sum(suf * suf)) / Delta;
     double alpha_lower = 0.0;
     double alpha = (alpha0 == 0.0) ? fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper)) : alpha0;
@@ -490,17 +375,17 @@ __device__ double ik_tr_solve(IkShared& S, int nap, double Delta, double alpha0,
 // trf_no_bounds (trf.py:401-560) with x_scale = 1, linear loss, ftol = xtol = gtol = 1e-8.
 // ---------------------------------------------------------------------------------------------
 __device__ void ik_trf(IkShared& S, const SkelRef& sk, int stage, int max_nfev, double* cost_out, int* nfev_out,
-                       int* njev_out, int* status_out, int* sweeps_out, bool basis_in, bool* basis_out) {
+                       int* njev_out, int* status_out, int* fallbacks_out) {
     const int tid = threadIdx.x;
     const int nfull = (stage == 0) ? 57 : 57 + sk.n_side;
     const int na = S.na[stage], nap = (na + 1) & ~1;
     const double ftol = 1e-8, xtol = 1e-8, gtol = 1e-8;
+    double* scr = S.bufB + SCR0;
 
     double cost;
     { PROF_T0 cost = ik_eval(S, sk, S.x, stage, true); PROF_ADD(S, 0) }
-    { PROF_T0 ik_normal_equations(S, sk, S.x, stage); PROF_ADD(S, 1) }
+    { PROF_T0 ik_model(S, sk, S.x, stage); PROF_ADD(S, 1) }
     int nfev = 1, njev = 1, status = -1;
-    bool have_basis = basis_in;
     double xx = (tid < nfull) ? S.x[tid] * S.x[tid] : 0.0;
     double Delta = sqrt(block_sum256(xx, S.red));
     if (Delta == 0.0) Delta = 1.0;
@@ -517,52 +402,68 @@ __device__ void ik_trf(IkShared& S, const SkelRef& sk, int stage, int max_nfev, 
         if (S.sc[0] < gtol) status = 1;
         if (status != -1 || nfev == max_nfev) break;
 
-#if MVMC_IK_TRIDIAG
+        const double gg = block_sum256(tid < nap ? S.g[tid] * S.g[tid] : 0.0, S.red);
+        int kk;
         {
             PROF_T0
-            eightri::eigh(S.bufB, LD, S.bufC, LDZ, S.bufA, LD, nap, S.lam, S.step, S.cv, S.suf,
-                          reinterpret_cast<double*>(S.rcs), S.xn, S.red,
-                          reinterpret_cast<int*>(S.bufA + 128));  // Sturm counts: 4 KB of the scratch matrix
+            kk = ik_krylov_model(S, stage);
+            if (kk < 0) {
+                // no clean split between range and null space: eigendecomposition of J^T J, null cluster removed
+                ik_normal_matrix(S, stage);
+                eightri::eigh(S.bufB, LD, S.bufC, LDZ, S.bufA, LD, nap, S.lam, S.step, S.cv, S.suf, S.rcs, S.xn, S.red,
+                              reinterpret_cast<int*>(S.bufA + 128));  // Sturm counts: 1 KB of the scratch matrix
+                if (tid < nap) {
+                    double a = 0.0;
+                    for (int i = 0; i < nap; ++i) a += S.bufC[tid * LDZ + i] * S.g[i];
+                    S.suf[tid] = a;
+                }
+                __syncthreads();
+                ++*fallbacks_out;
+            }
             PROF_ADD(S, 2)
         }
-        have_basis = false;
-        if (tid < nap) {
-#else
-        { PROF_T0 *sweeps_out += ik_eigh(S, nap, have_basis); PROF_ADD(S, 2) }
-        have_basis = true;
-        if (tid < nap) {
-            const double l = S.bufB[tid * LD + tid];
-            S.lam[tid] = l > 0.0 ? l : 0.0;
-#endif
-            double a = 0.0;
-            for (int i = 0; i < nap; ++i) a += S.bufC[tid * LDZ + i] * S.g[i];
-            S.suf[tid] = a;
-        }
-        __syncthreads();
-        const double gg = block_sum256(tid < nap ? S.g[tid] * S.g[tid] : 0.0, S.red);
+        const bool fast = kk > 0;
+        const double pivmin = 1e-16 * S.sc[6] + 1e-300, tau0 = S.sc[5], coupling = S.sc[7];
 
         double actual = -1.0, cost_new = cost;
         while (actual <= 0.0 && nfev < max_nfev) {
-            if (tid < 64) {
-                double pred, pnorm;
-                const double al = ik_tr_solve(S, nap, Delta, alpha, gg, &pred, &pnorm);
-                if (tid == 0) { S.sc[1] = al; S.sc[2] = pred; S.sc[3] = pnorm; }
+            {
+                PROF_T0
+                if (tid < 64) {
+                    double pred, pnorm, al;
+                    if (fast) {
+                        al = eightri::tr_solve_tri<false>(scr + 64 * SC_D, scr + 64 * SC_E, scr + 64 * SC_RH, kk, Delta, alpha, gg,
+                                                          pivmin, scr + 64 * SC_LMUL, scr + 64 * SC_DINV, scr + 64 * SC_YB,
+                                                          scr + 64 * SC_ZB, S.cv, &pred, &pnorm);
+                        double c = tid < kk ? S.cv[tid] : 0.0;
+                        if (kk < na) {
+                            // component along the first null coordinate: keeps the step orthogonal to the null vector
+                            const double eta = coupling * wave_sum_dpp(tid < kk ? scr[64 * SC_WN + tid] * c : 0.0);
+                            if (tid == kk) c = eta;
+                        }
+                        scr[64 * SC_QC + tid] = eightri::apply_q_krylov(S.bufC, LD, scr + 64 * SC_TAU, scr + 64 * SC_V0, tau0,
+                                                                        kk, na, c);
+                    } else {
+                        al = ik_tr_solve(S, nap, Delta, alpha, gg, &pred, &pnorm);
+                    }
+                    if (tid == 0) { S.sc[1] = al; S.sc[2] = pred; S.sc[3] = pnorm; }
+                }
+                __syncthreads();
+                if (tid < nap) {
+                    double a = 0.0;
+                    if (!fast) {
+                        for (int j = 0; j < nap; ++j) a += S.bufC[j * LDZ + tid] * S.cv[j];
+                    } else {
+                        a = scr[64 * SC_QC + tid];
+                    }
+                    S.step[tid] = a;
+                }
+                __syncthreads();
+                PROF_ADD(S, 3)
             }
-            __syncthreads();
             alpha = S.sc[1];
             const double pred = S.sc[2];
-            if (tid < nap) {
-                double a = 0.0;
-                for (int j = 0; j < nap; ++j) a += S.bufC[j * LDZ + tid] * S.cv[j];
-                S.step[tid] = a;
-            }
-            __syncthreads();
-#if MVMC_IK_TRIDIAG
             const double step_norm = S.sc[3];
-#else
-            double sq = (tid < na) ? S.step[tid] * S.step[tid] : 0.0;
-            const double step_norm = sqrt(block_sum256(sq, S.red));
-#endif
             xx = (tid < nfull) ? S.x[tid] * S.x[tid] : 0.0;
             const double x_norm = sqrt(block_sum256(xx, S.red));
             if (tid < nfull) {
@@ -597,16 +498,13 @@ __device__ void ik_trf(IkShared& S, const SkelRef& sk, int stage, int max_nfev, 
             cost = cost_new;
             if (status == -1 && nfev < max_nfev) {
                 // the accepted point's FK / residual blocks are still in LDS (last ik_eval was at xn)
-                { PROF_T0 ik_normal_equations(S, sk, S.x, stage); PROF_ADD(S, 1) }
+                { PROF_T0 ik_model(S, sk, S.x, stage); PROF_ADD(S, 1) }
                 ++njev;
             }
-        } else if (status == -1 && nfev < max_nfev) {
-            // not reachable: the inner loop only ends on acceptance, termination or the nfev cap
         }
     }
     if (status == -1) status = 0;
     *cost_out = cost; *nfev_out = nfev; *njev_out = njev; *status_out = status;
-    *basis_out = have_basis;
 }
 
 // 4x4 symmetric Jacobi for the cold-start DLT of one joint (same scheme as mvmc_geom.hip)
@@ -659,8 +557,7 @@ __global__ void __launch_bounds__(NT, 2)
 ik_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restrict__ Pmats,
           const int32_t* __restrict__ members, int B, int V, int C, int Pmax, const double* __restrict__ init,
           const uint8_t* __restrict__ cold, int nfev_cold, int nfev_warm, double* __restrict__ params_out,
-          double* __restrict__ joints_out, double* __restrict__ info_out, const double* __restrict__ basis_in,
-          const int32_t* __restrict__ basis_src, double* __restrict__ basis_out) {
+          double* __restrict__ joints_out, double* __restrict__ info_out) {
     __shared__ IkShared S;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n_side = skarg.n_side;
@@ -723,7 +620,6 @@ ik_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restr
         for (int i = tid; i < 68; i += NT) params_out[(size_t)b * 68 + i] = nan;
         for (int i = tid; i < 54; i += NT) joints_out[(size_t)b * 54 + i] = nan;
         if (info && tid < 8) info[tid] = nan;
-        if (basis_out && tid == 0) basis_out[(size_t)b * NA * LDV + NA * LDV - 1] = 0.0;
         return;
     }
 
@@ -785,37 +681,10 @@ ik_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restr
     __syncthreads();
 #endif
     double cost1, cost2;
-    int nf1, nj1, st1, nf2, nj2, st2, sweeps = 0;
-    bool basis = false;
-    constexpr int NBAS = NA * LDV;
-    if (!is_cold && basis_in && basis_src && basis_src[b] >= 0) {
-        // warm start of the eigensolver from the same tracklet's stage-1 basis of the previous frame
-        const double* src = basis_in + (size_t)basis_src[b] * NBAS;
-        if (src[NBAS - 1] == 1.0) {
-            for (int idx = tid; idx < NBAS - 1; idx += NT) S.bufC[idx] = src[idx];
-            basis = true;
-        }
-        __syncthreads();
-    }
-    ik_trf(S, sk, 0, max_nfev, &cost1, &nf1, &nj1, &st1, &sweeps, basis, &basis);
+    int nf1, nj1, st1, nf2, nj2, st2, fallbacks = 0;
+    ik_trf(S, sk, 0, max_nfev, &cost1, &nf1, &nj1, &st1, &fallbacks);
     __syncthreads();
-    if (basis_out) {
-        double* dst = basis_out + (size_t)b * NBAS;
-        for (int idx = tid; idx < NBAS - 1; idx += NT) dst[idx] = S.bufC[idx];
-        if (tid == 0) dst[NBAS - 1] = basis ? 1.0 : 0.0;  // validity tag in the unused pad corner
-    }
-    __syncthreads();
-    if (basis) {
-        // stage 2 appends the bone-length columns to stage 1's active set: embed the stage-1
-        // eigenvectors as [[V1, 0], [0, I]]
-        const int n1 = (S.na[0] + 1) & ~1, n2 = (S.na[1] + 1) & ~1;
-        for (int idx = tid; idx < n2 * LDV; idx += NT) {
-            const int i = idx / LDV, j = idx - i * LDV;
-            if (i >= n1 || j >= n1) S.bufC[idx] = (i == j) ? 1.0 : 0.0;
-        }
-        __syncthreads();
-    }
-    ik_trf(S, sk, 1, max_nfev, &cost2, &nf2, &nj2, &st2, &sweeps, basis, &basis);
+    ik_trf(S, sk, 1, max_nfev, &cost2, &nf2, &nj2, &st2, &fallbacks);
     __syncthreads();
     // final FK at the solution
     ik_eval(S, sk, S.x, 1, false);
@@ -824,7 +693,7 @@ ik_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restr
     for (int i = tid; i < 54; i += NT) joints_out[(size_t)b * 54 + i] = S.pos[i];
     if (info && tid == 0) {
         info[0] = cost1; info[1] = nf1; info[2] = st1; info[3] = cost2; info[4] = nf2; info[5] = st2;
-        info[6] = nj1 + nj2; info[7] = sweeps;
+        info[6] = nj1 + nj2; info[7] = fallbacks;
 #ifdef MVMC_IK_PROFILE
         // diagnostic build only: cycle shares instead of the costs
         info[0] = (double)S.prof[0]; info[3] = (double)S.prof[1]; info[2] = (double)S.prof[2];
@@ -838,8 +707,7 @@ ik_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restr
 extern "C" int mvmc_ik_solve(const mvmcSkeleton* skel_host, const double* kps17, const double* Pmats,
                              const int32_t* members, int n_problems, int v_max, int n_views, int p_max,
                              const double* init_params, const uint8_t* cold, int max_nfev_cold, int max_nfev_warm,
-                             double* params_out, double* joints_out, double* info_out, const double* basis_in,
-                             const int32_t* basis_src, double* basis_out, mvmcStream_t stream) {
+                             double* params_out, double* joints_out, double* info_out, mvmcStream_t stream) {
     if (!skel_host || !kps17 || !Pmats || !members || !params_out || !joints_out) return MVMC_ERR_ARG;
     if (v_max <= 0 || n_views <= 0 || p_max <= 0 || max_nfev_cold < 1 || max_nfev_warm < 1) return MVMC_ERR_ARG;
     if (cold && !init_params) return MVMC_ERR_ARG;
@@ -849,7 +717,7 @@ extern "C" int mvmc_ik_solve(const mvmcSkeleton* skel_host, const double* kps17,
     if (sk.n_side != MVMC_N_SIDE) return MVMC_ERR_UNSUPPORTED;  // the solver is sized for 57 + 11 parameters
     hipLaunchKernelGGL(ik_kernel, dim3(n_problems), dim3(NT), 0, (hipStream_t)stream, sk, kps17, Pmats, members,
                        n_problems, v_max, n_views, p_max, init_params, init_params ? cold : nullptr, max_nfev_cold,
-                       max_nfev_warm, params_out, joints_out, info_out, basis_in, basis_src, basis_out);
+                       max_nfev_warm, params_out, joints_out, info_out);
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;
 }

@@ -213,9 +213,7 @@ def fk(params: torch.Tensor, skeleton: Optional[MvmcSkeleton] = None, want_G=Fal
 
 def ik_solve(kps17: torch.Tensor, Pmats: torch.Tensor, members: torch.Tensor,
              init_params: Optional[torch.Tensor] = None, cold: Optional[torch.Tensor] = None,
-             max_nfev_cold=50, max_nfev_warm=5, skeleton: Optional[MvmcSkeleton] = None, want_info=True,
-             basis_in: Optional[torch.Tensor] = None, basis_src: Optional[torch.Tensor] = None,
-             basis_out: Optional[torch.Tensor] = None):
+             max_nfev_cold=50, max_nfev_warm=5, skeleton: Optional[MvmcSkeleton] = None, want_info=True):
     """IK-1..IK-4.  members (B,V) -> params (B,68), joints (B,18,3), info (B,8)."""
     sk = skeleton if skeleton is not None else make_skeleton()
     F, Cn, P = kps17.shape[:3]
@@ -230,18 +228,12 @@ def ik_solve(kps17: torch.Tensor, Pmats: torch.Tensor, members: torch.Tensor,
         _req(cold, torch.uint8, "cold", (B,))
     if init_params is None and cold is not None:
         raise ValueError("ik_solve: warm problems need init_params")
-    if basis_out is not None:
-        _req(basis_out, torch.float64, "basis_out", (B, _cabi.IK_BASIS_DOUBLES))
-    if basis_in is not None:
-        _req(basis_in, torch.float64, "basis_in", (None, _cabi.IK_BASIS_DOUBLES))
-        _req(basis_src, torch.int32, "basis_src", (B,))
     params = torch.empty((B, 68), dtype=torch.float64, device=dev)
     joints = torch.empty((B, 18, 3), dtype=torch.float64, device=dev)
     info = torch.empty((B, 8), dtype=torch.float64, device=dev) if want_info else None
     check(_cabi.load().mvmc_ik_solve(C.byref(sk), _p(kps17), _p(Pmats), _p(members), B, V, Cn, P, _p(init_params),
                                      _p(cold if init_params is not None else None), int(max_nfev_cold),
-                                     int(max_nfev_warm), _p(params), _p(joints), _p(info), _p(basis_in), _p(basis_src),
-                                     _p(basis_out), _stream()),
+                                     int(max_nfev_warm), _p(params), _p(joints), _p(info), _stream()),
           "mvmc_ik_solve")
     return params, joints, info
 

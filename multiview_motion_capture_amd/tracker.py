@@ -18,7 +18,7 @@ from .pipeline import HotPath
 
 class ChainTracker:
     def __init__(self, hp: HotPath, n_chains: int, p_max: int, t_max: int = 8, k_max: Optional[int] = None,
-                 v_max: Optional[int] = None, nfev_cold=50, nfev_warm=5, carry_basis=False):
+                 v_max: Optional[int] = None, nfev_cold=50, nfev_warm=5):
         d = hp.device
         self.hp, self.B, self.P, self.T = hp, n_chains, p_max, t_max
         C = hp.K.shape[0]
@@ -35,17 +35,7 @@ class ChainTracker:
         self.next_id = torch.zeros((B,), dtype=torch.int32, device=d)
         self.n_dead = torch.zeros((B,), dtype=torch.int32, device=d)
         self.frame_idx = torch.arange(B, dtype=torch.int32, device=d)
-        NP = T + self.K
-        # Optional: carry each tracklet's stage-1 eigenbasis to the next frame (warm-started Jacobi).  Measured
-        # on the synthetic workload it saves ~3 % of the IK time for ~80 MB of extra HBM traffic per launch,
-        # so it is off by default.
-        self.carry_basis = carry_basis
-        nb = B * NP if carry_basis else 1
-        self.basis = [torch.zeros((nb, dev._cabi.IK_BASIS_DOUBLES), dtype=torch.float64, device=d) for _ in range(2)]
-        self.basis_src = torch.full((B * NP,), -1, dtype=torch.int32, device=d)
         self.slot_src = torch.full((B, T), -1, dtype=torch.int32, device=d)
-        self._row0 = (torch.arange(B, dtype=torch.int32, device=d) * NP)[:, None]
-        self._flip = 0
         self.events = None  # set to a list to collect (start, end) CUDA events around every IK launch
 
     def step(self, kps17: torch.Tensor, counts: torch.Tensor, want_debug=False):
@@ -69,20 +59,13 @@ class ChainTracker:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         p, j, info = dev.ik_solve(kps17, hp.P, mem.reshape(B * NP, V), init.reshape(B * NP, 68),
-                                  cold.reshape(B * NP), self.nfev_cold, self.nfev_warm, hp.skeleton,
-                                  basis_in=self.basis[self._flip] if self.carry_basis else None,
-                                  basis_src=self.basis_src if self.carry_basis else None,
-                                  basis_out=self.basis[1 - self._flip] if self.carry_basis else None)
+                                  cold.reshape(B * NP), self.nfev_cold, self.nfev_warm, hp.skeleton)
         if self.events is not None:
             e1.record()
             self.events.append((e0, e1))
         p, j = p.reshape(B, NP, 68), j.reshape(B, NP, 18, 3)
         dev.track_commit(status, n_new, p, j, self.params, self.joints, self.meta, self.n_tracks, self.next_id,
                          self.n_dead, K, slot_src=self.slot_src)
-        # next frame: problem slot s (< T) is table slot s; its basis lives where it was solved this frame
-        self._flip = 1 - self._flip
-        src = torch.where(self.slot_src >= 0, self.slot_src + self._row0, torch.full_like(self.slot_src, -1))
-        self.basis_src.view(B, NP)[:, :T] = src
         out = dict(members=mem, status=status, n_new=n_new, ik_params=p, ik_joints=j, ik_info=info.reshape(B, NP, 8))
         if want_debug:
             out.update(D=D, W=W, st=st, sp=sp, group_counts=gc)
