@@ -192,7 +192,10 @@ __device__ inline void tridiag_regs(double (&a)[4][4], double (&rq)[4], double* 
 // with z = (T + alpha)^-1 y.  T + alpha I = L D L^T is factorised by the plain serial recurrence (all lanes of the
 // wave run it redundantly: few instructions, the co-resident workgroup keeps the SIMD busy), the sums are taken
 // one lane per component.  Valid when T has no numerically-null eigenvalue (the caller checks with a Sturm count).
-// One wave.  lmul, dinv, yb, zb: LDS scratch of n doubles; cout: LDS, the step's coefficients c = -y Delta/|p|.
+// One wave, lane j owns row j of T (n <= 64).  The solves use parallel cyclic reduction: six elimination rounds
+// at distances 1, 2, .., 32 decouple all rows (T + alpha I is positive definite, so no pivoting is needed); the
+// multipliers of the first solve are kept in registers and replayed on the second right-hand side.
+// lmul, dinv, yb, zb are unused (kept for the signature); cout: LDS, the step's coefficients c = -y Delta/|p|.
 // Returns alpha; *pred = predicted reduction, *pnorm = |step| including the absorber's share.
 template <bool DUAL>
 __device__ inline double tr_solve_tri(const double* d, const double* e, const double* rh, int n, double Delta, double alpha0,
@@ -201,48 +204,48 @@ __device__ inline double tr_solve_tri(const double* d, const double* e, const do
     const int lane = threadIdx.x & 63;
     const bool on = lane < n;
     const double a2 = 1e-16 * gg;  // absorber weight squared: suf_abs = 1e-8 |g|
-    const double dj = on ? d[lane] : 0.0, el = (on && lane > 0) ? e[lane - 1] : 0.0, eu = (lane < n - 1) ? e[lane] : 0.0;
+    const double dj = on ? d[lane] : 1.0, el = (on && lane > 0) ? e[lane - 1] : 0.0, eu = (lane < n - 1) ? e[lane] : 0.0;
     const double rj = on ? rh[lane] : 0.0;
-    double yy, yw, ww, rw, ry, yz, wz;
+    double yj, yy, yw, ww, rw, ry, yz, wz;
     auto evaluate = [&](double alpha, bool want_z) {
-        // factorisation + forward substitution
-        double D = d[0] + alpha, f = rh[0];
-        for (int j = 0; j < n - 1; ++j) {
-            if (D < pivmin) D = pivmin;
-            const double inv = fast_rcp64(D);
-            const double l = e[j] * inv;
-            if (lane == 0) { dinv[j] = inv; lmul[j] = l; yb[j] = f; }
-            D = (d[j + 1] + alpha) - l * e[j];
-            f = rh[j + 1] - l * f;
+        double a = el, bq = on ? dj + alpha : 1.0, c = eu, r = rj;
+        double k1[6], k2[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int sft = 1 << t;
+            // (shuffles first, selections after: every lane must take part in the exchange)
+            const bool lo_ok = lane >= sft, hi_ok = lane + sft < 64;
+            double am = __shfl_up(a, sft, 64), bm = __shfl_up(bq, sft, 64), cm = __shfl_up(c, sft, 64), rm = __shfl_up(r, sft, 64);
+            double ap = __shfl_down(a, sft, 64), bp = __shfl_down(bq, sft, 64), cp = __shfl_down(c, sft, 64), rp = __shfl_down(r, sft, 64);
+            am = lo_ok ? am : 0.0; bm = lo_ok ? bm : 1.0; cm = lo_ok ? cm : 0.0; rm = lo_ok ? rm : 0.0;
+            ap = hi_ok ? ap : 0.0; bp = hi_ok ? bp : 1.0; cp = hi_ok ? cp : 0.0; rp = hi_ok ? rp : 0.0;
+            k1[t] = a * fast_rcp64(bm);
+            k2[t] = c * fast_rcp64(bp);
+            bq = bq - cm * k1[t] - ap * k2[t];
+            r = r - rm * k1[t] - rp * k2[t];
+            a = -am * k1[t];
+            c = -cp * k2[t];
         }
-        if (D < pivmin) D = pivmin;
-        double y = f * fast_rcp64(D);
-        if (lane == 0) { dinv[n - 1] = fast_rcp64(D); yb[n - 1] = y; }
-        for (int j = n - 2; j >= 0; --j) {
-            y = yb[j] * dinv[j] - lmul[j] * y;
-            if (lane == 0) yb[j] = y;
-        }
-        const double yj = on ? yb[lane] : 0.0;
-        const double ym = (on && lane > 0) ? yb[lane - 1] : 0.0, yp = (lane < n - 1) ? yb[lane + 1] : 0.0;
-        const double wj = el * ym + dj * yj + eu * yp;  // (T y)_j
+        if (bq < pivmin) bq = pivmin;
+        const double binv = fast_rcp64(bq);
+        yj = on ? r * binv : 0.0;
+        double ym = __shfl_up(yj, 1, 64), yp = __shfl_down(yj, 1, 64);
+        ym = lane > 0 ? ym : 0.0; yp = lane < 63 ? yp : 0.0;
+        const double wj = on ? el * ym + dj * yj + eu * yp : 0.0;  // (T y)_j
         yy = wave_sum_dpp(yj * yj);
         yw = wave_sum_dpp(yj * wj);
         ry = wave_sum_dpp(rj * yj);
         if (DUAL) { ww = wave_sum_dpp(wj * wj); rw = wave_sum_dpp(rj * wj); }
         if (want_z) {
-            double fz = yb[0];
-            if (lane == 0) zb[0] = fz;
-            for (int j = 0; j < n - 1; ++j) {
-                fz = yb[j + 1] - lmul[j] * fz;
-                if (lane == 0) zb[j + 1] = fz;
+            double rz = yj;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const int sft = 1 << t;
+                double rm = __shfl_up(rz, sft, 64), rp = __shfl_down(rz, sft, 64);
+                rm = lane >= sft ? rm : 0.0; rp = lane + sft < 64 ? rp : 0.0;
+                rz = rz - rm * k1[t] - rp * k2[t];
             }
-            double z = fz * dinv[n - 1];
-            if (lane == 0) zb[n - 1] = z;
-            for (int j = n - 2; j >= 0; --j) {
-                z = zb[j] * dinv[j] - lmul[j] * z;
-                if (lane == 0) zb[j] = z;
-            }
-            const double zj = on ? zb[lane] : 0.0;
+            const double zj = on ? rz * binv : 0.0;
             if (DUAL) wz = wave_sum_dpp(wj * zj); else yz = wave_sum_dpp(yj * zj);
         }
     };
@@ -269,7 +272,7 @@ __device__ inline double tr_solve_tri(const double* d, const double* e, const do
     const double ia = 1.0 / alpha;
     const double pn = sqrt((DUAL ? yw : yy) + a2 * ia * ia);
     const double sc = Delta / pn;
-    if (on) cout[lane] = -yb[lane] * sc;
+    if (on) cout[lane] = -yj * sc;
     // pred = -(0.5 sum lam c^2 + sum suf c), absorber included (lam = 0, suf c = -(a^2/alpha) sc)
     const double lcc = sc * sc * (DUAL ? ww : yw);
     const double sfc = -sc * (DUAL ? rw : ry) - a2 * ia * sc;

@@ -697,7 +697,7 @@ ik_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restr
 #ifdef MVMC_IK_PROFILE
         // diagnostic build only: cycle shares instead of the costs
         info[0] = (double)S.prof[0]; info[3] = (double)S.prof[1]; info[2] = (double)S.prof[2];
-        info[5] = (double)(clock64() - t_all); info[4] = (double)S.prof[3];
+        info[5] = (double)(clock64() - t_all); info[7] = (double)S.prof[3];
 #endif
     }
 }

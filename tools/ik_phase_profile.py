@@ -24,13 +24,13 @@ inf = out["info"].reshape(-1, 8).cpu().numpy()
 ok = ~np.isnan(inf[:, 1])
 inf = inf[ok]
 tot = inf[:, 5].sum()
-print("solves", len(inf), "mean nfev", (inf[:, 1] + inf[:, 4]).mean(), "njev", inf[:, 6].mean(), "sweeps", inf[:, 7].mean())
-print("cycles per solve (mean): total %.0f  eval %.0f  normal-eq %.0f  eigh %.0f" %
-      (inf[:, 5].mean(), inf[:, 0].mean(), inf[:, 3].mean(), inf[:, 2].mean()))
-print("shares: eval %.3f normal-eq %.3f eigh %.3f other %.3f" %
-      (inf[:, 0].sum() / tot, inf[:, 3].sum() / tot, inf[:, 2].sum() / tot,
-       1 - (inf[:, 0].sum() + inf[:, 3].sum() + inf[:, 2].sum()) / tot))
-print("jacobi param phase (incl. its barrier): %.0f cycles/step = %.2f of eigh" % (inf[:, 4].sum() / inf[:, 7].sum() / 49, inf[:, 4].sum() / inf[:, 2].sum()))
-print("cycles per eval %.0f ; per normal-eq %.0f ; per sweep %.0f ; per jacobi step %.0f" %
-      (inf[:, 0].sum() / (inf[:, 1] + inf[:, 4]).sum(), inf[:, 3].sum() / inf[:, 6].sum(),
-       inf[:, 2].sum() / inf[:, 7].sum(), inf[:, 2].sum() / inf[:, 7].sum() / 49))
+print("solves", len(inf), "mean nfev", (inf[:, 1] + inf[:, 4]).mean(), "njev", inf[:, 6].mean(), "(fallback count not reported by the profile build)")
+nfev, njev = (inf[:, 1] + inf[:, 4]).sum(), inf[:, 6].sum()
+ev, ne, tri, trs = inf[:, 0].sum(), inf[:, 3].sum(), inf[:, 2].sum(), inf[:, 7].sum()
+# prof slots: 0 = ik_eval, 1 = ik_model (blocks, D, g), 2 = Gram + Krylov tridiagonalisation (+ eigensolver on fallback),
+# 3 = trust-region solve + Q c
+print("cycles per solve (mean): total %.0f" % inf[:, 5].mean())
+print("shares: eval %.3f model %.3f tridiag %.3f tr-solve %.3f other %.3f" %
+      (ev / tot, ne / tot, tri / tot, trs / tot, 1 - (ev + ne + tri + trs) / tot))
+print("cycles per eval %.0f ; per model %.0f ; per tridiag %.0f ; per tr-solve %.0f" %
+      (ev / nfev, ne / njev, tri / njev, trs / (nfev - 2 * len(inf))))
