@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--nfev-warm", type=int, default=5)
     ap.add_argument("--chain-len", type=int, default=16,
                     help="frames per temporal chain (cold start at the head, warm after); 1 = every frame cold")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="chain groups advanced on separate HIP streams (association of one group overlaps IK of another)")
     ap.add_argument("--cpu-frames", type=int, default=1, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--seed", type=int, default=20260103)
     args = ap.parse_args()
@@ -137,7 +139,7 @@ def main():
             e = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if timed else None
             if timed: e[0].record()
             out = run_chains(hp, kps, counts, L, nfev_cold=args.nfev_cold, nfev_warm=args.nfev_warm,
-                             events=ik_events if timed else None, want_info=timed)
+                             events=ik_events if timed else None, want_info=timed, n_groups=args.groups)
             if timed:
                 e[1].record()
                 ev["total"].append((e[0], e[1]))

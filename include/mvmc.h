@@ -202,9 +202,10 @@ int mvmc_debug_eigh(const double* A, const double* g, int n_problems, int n, dou
  * caller-supplied least-squares model: J = B (n_problems,m,n row-major), residual image r (n_problems,m), so
  * g = B^T r and M = B^T B.  3 <= m,n <= 50.  step (n_problems,n); out4 (n_problems,4) = {alpha, predicted
  * reduction, |step| incl. absorber, size of the leading (range) block, or -1 where the IK kernel would fall back
- * to the eigensolver (then alpha = -1, step = 0)}. */
+ * to the eigensolver (then alpha = -1, step = 0)}.  phase_cycles (n_problems,4) or NULL = shader cycles of the
+ * tridiagonalisation's {reflector + publish, matrix-vector + exchange, rank-2 update} phases and their total. */
 int mvmc_debug_trstep(const double* B, const double* r, int n_problems, int m, int n, double Delta, double alpha0,
-                      double* step, double* out4, mvmcStream_t stream);
+                      double* step, double* out4, double* phase_cycles, mvmcStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -72,7 +72,7 @@ def load():
     lib.mvmc_track_assign.argtypes = [vp] * 8 + [i32] * 6 + [vp] * 6
     lib.mvmc_track_commit.argtypes = [vp] * 4 + [i32] * 4 + [vp] * 8
     lib.mvmc_debug_eigh.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp]
-    lib.mvmc_debug_trstep.argtypes = [vp, vp, i32, i32, i32, C.c_double, C.c_double, vp, vp, vp]
+    lib.mvmc_debug_trstep.argtypes = [vp, vp, i32, i32, i32, C.c_double, C.c_double, vp, vp, vp, vp]
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError if the library does not export it
         if name not in ("mvmc_status_string",):

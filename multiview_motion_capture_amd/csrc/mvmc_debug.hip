@@ -29,7 +29,7 @@ debug_eigh_kernel(const double* __restrict__ Ain, const double* __restrict__ gin
 // tr_solve_tri + apply_q_krylov), strung together as in the IK kernel: J = Bm (m x n), g = Bm^T r, M = Bm^T Bm.
 __global__ void __launch_bounds__(256)
 debug_trstep_kernel(const double* __restrict__ Bin, const double* __restrict__ rin, int m, int n, double Delta,
-                    double alpha0, double* __restrict__ step_out, double* __restrict__ out4) {
+                    double alpha0, double* __restrict__ step_out, double* __restrict__ out4, double* __restrict__ cyc_out) {
     __shared__ double Bm[NMAXE * LDE], V[NMAXE * LDE];
     __shared__ double r[64], g[64], d[64], e[64], tau[64], rh[64], v0[64], sv[64], pw[64], red[8];
     __shared__ double lmul[64], dinv[64], yb[64], zb[64], cv[64], wn[64], dsc[64], e2sc[64], sc[8], k4[4];
@@ -58,7 +58,10 @@ debug_trstep_kernel(const double* __restrict__ Bin, const double* __restrict__ r
             a[q][u] = acc;
         }
     }
-    const int kk = eightri::tridiag_krylov(a, g, V, LDE, n, d, e, tau, v0, sv, pw, red, k4);
+    __shared__ long long prof[4];
+    const long long t_all = clock64();
+    const int kk = eightri::tridiag_krylov(a, g, V, LDE, n, d, e, tau, v0, sv, pw, red, k4, prof);
+    const long long t_tri = clock64() - t_all;
     if (tid < 64) {
         double alpha = -1.0, pred = 0.0, pnorm = 0.0, cj = 0.0;
         const bool ok = kk > 0 && eightri::krylov_block_ok(d, e, kk, n, k4[2], k4[3], dsc, e2sc, lmul, dinv, wn);
@@ -79,6 +82,8 @@ debug_trstep_kernel(const double* __restrict__ Bin, const double* __restrict__ r
     __syncthreads();
     if (tid < n) step_out[(size_t)b * n + tid] = cv[tid];
     if (tid < 4) out4[(size_t)b * 4 + tid] = sc[tid];
+    if (cyc_out && tid < 3) cyc_out[(size_t)b * 4 + tid] = (double)prof[tid];
+    if (cyc_out && tid == 3) cyc_out[(size_t)b * 4 + 3] = (double)t_tri;
 }
 }  // namespace
 
@@ -92,11 +97,11 @@ extern "C" int mvmc_debug_eigh(const double* A, const double* g, int n_problems,
 }
 
 extern "C" int mvmc_debug_trstep(const double* B, const double* r, int n_problems, int m, int n, double Delta,
-                                 double alpha0, double* step, double* out4, mvmcStream_t stream) {
+                                 double alpha0, double* step, double* out4, double* phase_cycles, mvmcStream_t stream) {
     if (!B || !r || !step || !out4 || m < 3 || n < 3 || m > NMAXE || n > NMAXE || !(Delta > 0.0)) return MVMC_ERR_ARG;
     if (n_problems <= 0) return n_problems == 0 ? MVMC_OK : MVMC_ERR_ARG;
     hipLaunchKernelGGL(debug_trstep_kernel, dim3(n_problems), dim3(256), 0, (hipStream_t)stream, B, r, m, n, Delta,
-                       alpha0, step, out4);
+                       alpha0, step, out4, phase_cycles);
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;
 }

@@ -328,8 +328,11 @@ __device__ inline int tri_null_count(const double* d, const double* e, int n, do
 // Same register layout and exchange scheme as tridiag_regs; v0: 64 doubles for the first reflector.
 // out4 = {beta0, tau0, |M|_inf, coupling}.  Ends with a barrier; d[0..kk), e[0..kk-1), tau[0..kk-1) valid.
 __device__ inline int tridiag_krylov(double (&a)[4][4], const double* g, double* V, int ldv, int n, double* d, double* e,
-                                     double* tau, double* v0, double* sv, double* pw, double* red, double* out4) {
+                                     double* tau, double* v0, double* sv, double* pw, double* red, double* out4,
+                                     long long* prof = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wv_id = tid >> 6;
+    long long t_prev = prof ? clock64() : 0, acc0 = 0, acc1 = 0, acc2 = 0;
+    auto lap = [&](long long& acc) { if (prof) { const long long t = clock64(); acc += t - t_prev; t_prev = t; } };
     const int ty = tid >> 4, tx = tid & 15;
     auto row_sum16 = [](double v) {
         v += dpp_mov<0x128>(v); v += dpp_mov<0x124>(v); v += dpp_mov<0x122>(v); v += dpp_mov<0x121>(v);
@@ -383,6 +386,7 @@ __device__ inline int tridiag_krylov(double (&a)[4][4], const double* g, double*
             for (int q = 0; q < 4; ++q) pw[ty + 16 * q] = s[q];
         }
         __syncthreads();
+        lap(acc1);
         const double h = 0.5 * tk * ((red[4] + red[5]) + (red[6] + red[7]));
         double wj[4], wi[4];
 #pragma unroll
@@ -394,6 +398,7 @@ __device__ inline int tridiag_krylov(double (&a)[4][4], const double* g, double*
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int u = 0; u < 4; ++u) a[q][u] -= vi[q] * wj[u] + wi[q] * vj[u];
+        lap(acc2);
     };
     auto householder = [&](auto qk_tag, int k) {
         constexpr int QK = decltype(qk_tag)::value;
@@ -468,6 +473,7 @@ __device__ inline int tridiag_krylov(double (&a)[4][4], const double* g, double*
             }
         }
         __syncthreads();
+        lap(acc0);
         const double tk = tau[k], ek = e[k];
         if (fabs(ek) <= tol_c) {
             // the Krylov space is exhausted: everything behind row k must be the null space
@@ -492,6 +498,7 @@ __device__ inline int tridiag_krylov(double (&a)[4][4], const double* g, double*
             if (i == j && i < n) d[i] = a[q][u];
         }
     __syncthreads();
+    if (prof && tid == 0) { prof[0] = acc0; prof[1] = acc1; prof[2] = acc2; }
     return kk;
 }
 

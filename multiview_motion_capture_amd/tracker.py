@@ -37,6 +37,7 @@ class ChainTracker:
         self.frame_idx = torch.arange(B, dtype=torch.int32, device=d)
         self.slot_src = torch.full((B, T), -1, dtype=torch.int32, device=d)
         self.events = None  # set to a list to collect (start, end) CUDA events around every IK launch
+        self.assoc_done = None
 
     def step(self, kps17: torch.Tensor, counts: torch.Tensor, want_debug=False):
         """kps17 (B,C,P,17,3) f64 + counts (B,C) i32 of the current frame of every chain."""
@@ -55,6 +56,9 @@ class ChainTracker:
                                                           st["n_clusters"], counts, self.frame_idx, self.n_tracks,
                                                           self.params, P, K, V)
         NP = T + K
+        if self.assoc_done is not None:   # one-shot marker for run_chains' stream stagger
+            self.assoc_done.record()
+            self.assoc_done = None
         if self.events is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -73,29 +77,64 @@ class ChainTracker:
 
 
 def run_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], chain_len: int, t_max=8,
-               nfev_cold=50, nfev_warm=5, events=None, want_info=False):
+               nfev_cold=50, nfev_warm=5, events=None, want_info=False, n_groups=1):
     """Whole shard: frames [c*L, (c+1)*L) form chain c (F must be a multiple of L).  Returns per-frame
-    tracklet tables: params (F,T,68), joints (F,T,18,3), meta (F,T,4), n_tracks (F)."""
+    tracklet tables: params (F,T,68), joints (F,T,18,3), meta (F,T,4), n_tracks (F).
+
+    n_groups > 1 splits the chains into that many groups, each advanced on its own HIP stream: inside a chain the
+    stages of a frame are strictly sequential (association -> assignment -> IK -> commit -> next frame), and the
+    association solver is a long dependent chain on few waves, so one group's association runs in the shadow of
+    another group's IK launch.  Results do not depend on n_groups (chains are independent)."""
     F, C, P = kps.shape[:3]
     L = chain_len
     if F % L:
         raise ValueError("run_chains: the frame count must be a multiple of the chain length")
     B = F // L
+    G = max(1, min(int(n_groups), B))
     kps17, cnt = dev.ingest(kps, counts)
     k4 = kps17.view(B, L, C, P, 17, 3)
     c4 = cnt.view(B, L, C)
-    tr = ChainTracker(hp, B, P, t_max, nfev_cold=nfev_cold, nfev_warm=nfev_warm)
-    tr.events = events
-    infos = []
     d = kps.device
     out_p = torch.empty((B, L, t_max, 68), dtype=torch.float64, device=d)
     out_j = torch.empty((B, L, t_max, 18, 3), dtype=torch.float64, device=d)
     out_m = torch.empty((B, L, t_max, 4), dtype=torch.int32, device=d)
     out_n = torch.empty((B, L), dtype=torch.int32, device=d)
+    n_dead = torch.empty((B,), dtype=torch.int32, device=d)
+    bounds = [B * g // G for g in range(G + 1)]
+    main = torch.cuda.current_stream(d)
+    streams = [main] if G == 1 else [torch.cuda.Stream(device=d) for _ in range(G)]
+    ready = torch.cuda.Event()
+    ready.record(main)
+    trackers, infos = [], [[] for _ in range(G)]
+    for g in range(G):
+        with torch.cuda.stream(streams[g]):
+            streams[g].wait_event(ready)
+            tr = ChainTracker(hp, bounds[g + 1] - bounds[g], P, t_max, nfev_cold=nfev_cold, nfev_warm=nfev_warm)
+            tr.events = events
+            trackers.append(tr)
+    # stagger: group g starts once group g-1 has finished the association of its first frame, so that from then on
+    # the association launches of one group and the IK launches of another alternate instead of colliding
+    stagger = [torch.cuda.Event() for _ in range(G - 1)]
+    for g in range(G - 1):
+        trackers[g].assoc_done = stagger[g]
     for t in range(L):
-        o = tr.step(k4[:, t].contiguous(), c4[:, t].contiguous())
-        if want_info:
-            infos.append(o["ik_info"])
-        out_p[:, t], out_j[:, t], out_m[:, t], out_n[:, t] = tr.params, tr.joints, tr.meta, tr.n_tracks
-    return dict(params=out_p.view(F, t_max, 68), joints=out_j.view(F, t_max, 18, 3), meta=out_m.view(F, t_max, 4),
-                n_tracks=out_n.view(F), n_dead=tr.n_dead, **({"ik_info": torch.stack(infos, 1)} if want_info else {}))
+        for g in range(G):
+            b0, b1 = bounds[g], bounds[g + 1]
+            with torch.cuda.stream(streams[g]):
+                tr = trackers[g]
+                if t == 0 and g > 0:
+                    streams[g].wait_event(stagger[g - 1])
+                o = tr.step(k4[b0:b1, t].contiguous(), c4[b0:b1, t].contiguous())
+                if want_info:
+                    infos[g].append(o["ik_info"])
+                out_p[b0:b1, t], out_j[b0:b1, t], out_m[b0:b1, t], out_n[b0:b1, t] = tr.params, tr.joints, tr.meta, tr.n_tracks
+    for g in range(G):
+        with torch.cuda.stream(streams[g]):
+            n_dead[bounds[g]:bounds[g + 1]] = trackers[g].n_dead
+        if streams[g] is not main:
+            main.wait_stream(streams[g])
+    res = dict(params=out_p.view(F, t_max, 68), joints=out_j.view(F, t_max, 18, 3), meta=out_m.view(F, t_max, 4),
+               n_tracks=out_n.view(F), n_dead=n_dead)
+    if want_info:
+        res["ik_info"] = torch.cat([torch.stack(i, 1) for i in infos], 0)
+    return res

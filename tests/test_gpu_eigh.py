@@ -159,8 +159,10 @@ def _run_trstep(Bm, r, Delta, alpha0):
     step = torch.empty((nb, n), dtype=torch.float64, device=d)
     out4 = torch.empty((nb, 4), dtype=torch.float64, device=d)
     p = lambda t: C.c_void_p(t.data_ptr())
-    assert lib.mvmc_debug_trstep(p(Bt), p(rt), nb, m, n, float(Delta), float(alpha0), p(step), p(out4), None) == 0
+    cyc = torch.zeros((nb, 4), dtype=torch.float64, device=d)
+    assert lib.mvmc_debug_trstep(p(Bt), p(rt), nb, m, n, float(Delta), float(alpha0), p(step), p(out4), p(cyc), None) == 0
     torch.cuda.synchronize()
+    _run_trstep.last_cycles = cyc.cpu().numpy()
     return step.cpu().numpy(), out4.cpu().numpy()
 
 
@@ -196,6 +198,8 @@ def test_tr_step_in_krylov_basis_matches_eigenbasis(m, n, nulls, delta_scale, al
         assert np.abs(step[b] - p_ref).max() <= 1e-8 * Delta
         assert abs(out4[b, 1] - pred_ref) <= 1e-8 * abs(pred_ref)
         assert abs(out4[b, 2] - Delta) <= 1e-12 * Delta
+    print("tridiagonalisation cycles [reflector, matvec, update, total] for n=%d rank=%d:" % (n, rank),
+          _run_trstep.last_cycles.mean(0).round(0))
 
 
 @pytest.mark.parametrize("weak", [1e-3, 1e-4, 1e-5, 3e-6, 1e-6, 3e-7, 1e-7])

@@ -88,3 +88,15 @@ def test_tracks_and_3d_accuracy_against_ground_truth(full):
           f"{np.quantile(errs, 0.95) * 100:.2f} cm")
     assert full_len > 0.9
     assert np.median(errs) < 0.05
+
+
+def test_stream_groups_do_not_change_results(full):
+    """run_chains(n_groups=G) advances G groups of chains on separate HIP streams; chains are independent, so
+    the tracklet tables must be identical to the single-stream run."""
+    run_chains, hp, kps, cnt = full["run_chains"], full["hp"], full["kps"], full["cnt"]
+    n = 64 * L
+    a = run_chains(hp, kps[:n].contiguous(), cnt[:n].contiguous(), L)
+    b = run_chains(hp, kps[:n].contiguous(), cnt[:n].contiguous(), L, n_groups=3)
+    torch.cuda.synchronize()
+    for k in ("params", "joints", "meta", "n_tracks", "n_dead"):
+        assert torch.equal(torch.nan_to_num(a[k].double()), torch.nan_to_num(b[k].double())), k
