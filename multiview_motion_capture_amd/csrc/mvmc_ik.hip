@@ -91,7 +91,7 @@ __device__ inline double block_sum256(double v, double* red) {
 // ---------------------------------------------------------------------------------------------
 // FK + residual (+ per-joint normal-equation blocks when want_jac).  Returns the cost 0.5*|f|^2.
 // ---------------------------------------------------------------------------------------------
-__device__ double ik_eval(IkShared& S, const SkelRef& sk, const double* xs, int stage, bool want_jac) {
+__device__ __noinline__ double ik_eval(IkShared& S, const SkelRef& sk, const double* xs, int stage, bool want_jac) {
     const int tid = threadIdx.x;
     if (tid < 18) {
         euler_to_rot(xs + 3 + 3 * tid, &S.Rl[tid * 9]);
@@ -193,17 +193,11 @@ __device__ void ik_build_D(IkShared& S, const SkelRef& sk, int stage) {
     __syncthreads();
 }
 
-__device__ void ik_model(IkShared& S, const SkelRef& sk, const double* xs, int stage) {
+// rotation axes in the world frame: R_a = Rx Ry Rz inside the parent's frame.  Out of line (like ik_eval): the
+// double-precision sincos expansions carry a dozen 64-bit constants that the compiler otherwise keeps live --
+// and spills -- across the whole kernel.
+__device__ __noinline__ void ik_rotation_axes(IkShared& S, const SkelRef& sk, const double* xs) {
     const int tid = threadIdx.x;
-    const int na = S.na[stage], nap = (na + 1) & ~1;
-    // per-joint blocks: W_k = sum_v s^2 (du du^T + dv dv^T), t_k = sum_v s (du fu + dv fv)
-    if (tid < NOBS * 9) {
-        const int k = tid / 9, e = tid - k * 9;
-        double a = 0.0;
-        for (int v = 0; v < S.nviews; ++v) a += S.bufB[(v * NOBS + k) * 10 + e];
-        if (e < 6) S.Wk[k * 6 + e] = a; else S.tk[k * 3 + (e - 6)] = a;
-    }
-    // rotation axes in the world frame: R_a = Rx Ry Rz inside the parent's frame
     if (tid >= 192 && tid < 192 + 54) {
         const int t = tid - 192, a = t / 3, c = t - a * 3;
         const double* e = xs + 3 + 3 * a;
@@ -222,6 +216,19 @@ __device__ void ik_model(IkShared& S, const SkelRef& sk, const double* xs, int s
             for (int r = 0; r < 3; ++r) S.axes[t * 3 + r] = Gp[r * 3] * l[0] + Gp[r * 3 + 1] * l[1] + Gp[r * 3 + 2] * l[2];
         }
     }
+}
+
+__device__ void ik_model(IkShared& S, const SkelRef& sk, const double* xs, int stage) {
+    const int tid = threadIdx.x;
+    const int na = S.na[stage], nap = (na + 1) & ~1;
+    // per-joint blocks: W_k = sum_v s^2 (du du^T + dv dv^T), t_k = sum_v s (du fu + dv fv)
+    if (tid < NOBS * 9) {
+        const int k = tid / 9, e = tid - k * 9;
+        double a = 0.0;
+        for (int v = 0; v < S.nviews; ++v) a += S.bufB[(v * NOBS + k) * 10 + e];
+        if (e < 6) S.Wk[k * 6 + e] = a; else S.tk[k * 3 + (e - 6)] = a;
+    }
+    ik_rotation_axes(S, sk, xs);
     __syncthreads();
     ik_build_D(S, sk, stage);
     if (tid < nap) {
@@ -327,6 +334,25 @@ __device__ int ik_krylov_model(IkShared& S, int stage) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fallback model: no clean split between range and null space -> eigendecomposition of J^T J with the null
+// cluster removed (lam, eigenvector rows in bufC, suf = V^T g).  Kept out of line: it runs for a fraction of a
+// percent of the models and would otherwise set the register budget of the whole kernel.
+// ---------------------------------------------------------------------------------------------
+__device__ __noinline__ void ik_eigen_model(IkShared& S, int stage) {
+    const int tid = threadIdx.x;
+    const int na = S.na[stage], nap = (na + 1) & ~1;
+    ik_normal_matrix(S, stage);
+    eightri::eigh(S.bufB, LD, S.bufC, LDZ, S.bufA, LD, nap, S.lam, S.step, S.cv, S.suf, S.rcs, S.xn, S.red,
+                  reinterpret_cast<int*>(S.bufA + 128));  // Sturm counts: 1 KB of the scratch matrix
+    if (tid < nap) {
+        double a = 0.0;
+        for (int i = 0; i < nap; ++i) a += S.bufC[tid * LDZ + i] * S.g[i];
+        S.suf[tid] = a;
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
 // solve_lsq_trust_region (common.py:57-168) in the eigenbasis of J^T J (fallback path), one wave.
 // Every problem is rank deficient in the reference's terms (it keeps the structurally-zero columns, s = 0),
 // so only that branch exists: Newton on phi(alpha) = |p(alpha)| - Delta from alpha0, the step normalised to
@@ -408,16 +434,7 @@ __device__ void ik_trf(IkShared& S, const SkelRef& sk, int stage, int max_nfev, 
             PROF_T0
             kk = ik_krylov_model(S, stage);
             if (kk < 0) {
-                // no clean split between range and null space: eigendecomposition of J^T J, null cluster removed
-                ik_normal_matrix(S, stage);
-                eightri::eigh(S.bufB, LD, S.bufC, LDZ, S.bufA, LD, nap, S.lam, S.step, S.cv, S.suf, S.rcs, S.xn, S.red,
-                              reinterpret_cast<int*>(S.bufA + 128));  // Sturm counts: 1 KB of the scratch matrix
-                if (tid < nap) {
-                    double a = 0.0;
-                    for (int i = 0; i < nap; ++i) a += S.bufC[tid * LDZ + i] * S.g[i];
-                    S.suf[tid] = a;
-                }
-                __syncthreads();
+                ik_eigen_model(S, stage);
                 ++*fallbacks_out;
             }
             PROF_ADD(S, 2)
@@ -680,12 +697,19 @@ ik_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restr
     const long long t_all = clock64();
     __syncthreads();
 #endif
-    double cost1, cost2;
-    int nf1, nj1, st1, nf2, nj2, st2, fallbacks = 0;
-    ik_trf(S, sk, 0, max_nfev, &cost1, &nf1, &nj1, &st1, &fallbacks);
-    __syncthreads();
-    ik_trf(S, sk, 1, max_nfev, &cost2, &nf2, &nj2, &st2, &fallbacks);
-    __syncthreads();
+    // the two stages share one call site (a loop, not two calls): one copy of the solver in the kernel, no
+    // call/return spills
+    double costs[2];
+    int nfs[2], njs[2], sts[2], fallbacks = 0;
+#pragma unroll 1
+    for (int stage = 0; stage < 2; ++stage) {
+        double c; int nf, nj, st;
+        ik_trf(S, sk, stage, max_nfev, &c, &nf, &nj, &st, &fallbacks);
+        costs[stage] = c; nfs[stage] = nf; njs[stage] = nj; sts[stage] = st;
+        __syncthreads();
+    }
+    const double cost1 = costs[0], cost2 = costs[1];
+    const int nf1 = nfs[0], nf2 = nfs[1], nj1 = njs[0], nj2 = njs[1], st1 = sts[0], st2 = sts[1];
     // final FK at the solution
     ik_eval(S, sk, S.x, 1, false);
     __syncthreads();
