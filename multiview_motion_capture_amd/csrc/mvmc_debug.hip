@@ -31,9 +31,9 @@ __global__ void __launch_bounds__(256)
 debug_trstep_kernel(const double* __restrict__ Bin, const double* __restrict__ rin, int m, int n, double Delta,
                     double alpha0, double* __restrict__ step_out, double* __restrict__ out4, double* __restrict__ cyc_out) {
     __shared__ double Bm[NMAXE * LDE], V[NMAXE * LDE];
-    __shared__ double r[64], g[64], d[64], e[64], tau[64], rh[64], v0[64], sv[64], pw[64], red[8];
+    __shared__ double r[64], g[64], d[64], e[64], tau[64], rh[64], v0[64], red[8];
     __shared__ double lmul[64], dinv[64], yb[64], zb[64], cv[64], wn[64], dsc[64], e2sc[64], sc[8], k4[4];
-    const int b = blockIdx.x, tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int b = blockIdx.x, tid = threadIdx.x;
     for (int idx = tid; idx < m * n; idx += 256) Bm[(idx / n) * LDE + idx % n] = Bin[(size_t)b * m * n + idx];
     if (tid < m) r[tid] = rin[(size_t)b * m + tid];
     __syncthreads();
@@ -45,22 +45,22 @@ debug_trstep_kernel(const double* __restrict__ Bin, const double* __restrict__ r
     __syncthreads();
     double gg = 0.0;
     for (int i = 0; i < n; ++i) gg += g[i] * g[i];
-    double a[4][4];
+    double a[eightri::KQ];
+    {
+        const int w = tid >> 6, l = tid & 63;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int i = ty + 16 * q;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = tx + 16 * u;
+        for (int q = 0; q < eightri::KQ; ++q) {
+            const int i = w + 4 * q;
             double acc = 0.0;
-            if (i < n && j < n)
-                for (int c = 0; c < m; ++c) acc += Bm[c * LDE + i] * Bm[c * LDE + j];
-            a[q][u] = acc;
+            if (i < n && l < n)
+                for (int c = 0; c < m; ++c) acc += Bm[c * LDE + i] * Bm[c * LDE + l];
+            a[q] = acc;
         }
     }
     __shared__ long long prof[4];
+    __shared__ double part[256], svx[66];
     const long long t_all = clock64();
-    const int kk = eightri::tridiag_krylov(a, g, V, LDE, n, d, e, tau, v0, sv, pw, red, k4, prof);
+    const int kk = eightri::tridiag_krylov(a, g, V, n, d, e, tau, v0, svx, part, red, k4, prof);
     const long long t_tri = clock64() - t_all;
     if (tid < 64) {
         double alpha = -1.0, pred = 0.0, pnorm = 0.0, cj = 0.0;
@@ -74,7 +74,7 @@ debug_trstep_kernel(const double* __restrict__ Bin, const double* __restrict__ r
                 const double eta = k4[3] * wave_sum_dpp(tid < kk ? wn[tid] * c : 0.0);
                 if (tid == kk) c = eta;
             }
-            cj = eightri::apply_q_krylov(V, LDE, tau, v0, k4[1], kk, n, c);
+            cj = eightri::apply_q_krylov(V, tau, v0, k4[1], kk, n, c);
         }
         cv[tid] = cj;
         if (tid == 0) { sc[0] = alpha; sc[1] = pred; sc[2] = pnorm; sc[3] = ok ? (double)kk : -1.0; }

@@ -320,32 +320,36 @@ __device__ inline int tri_null_count(const double* d, const double* e, int n, do
 // range(M): where that space is exhausted the sub-diagonal of T collapses (to rounding times the condition
 // number of the range part) and everything behind it is the null space of M -- the structural null directions of
 // the IK Jacobian (bone twists, ...) never enter the leading block, which is positive definite.  The routine
-//   * stops at the first sub-diagonal |e_k| <= 1e-8 |M|_inf and checks that the untouched trailing block is null
-//     (<= 1e-13 |M|_inf): leading block size kk = k + 1, coupling e_k returned; or
+//   * stops at the first sub-diagonal |e_k| <= 1e-8 |M|_1 and checks that the untouched trailing block is null
+//     (<= 1e-13 |M|_1): leading block size kk = k + 1, coupling e_k returned; or
 //   * runs to the end (kk = n) if no sub-diagonal collapses; or
 //   * returns -1 when a sub-diagonal collapses in front of a block that is not null (the caller falls back to the
 //     eigensolver).
-// Same register layout and exchange scheme as tridiag_regs; v0: 64 doubles for the first reflector.
-// out4 = {beta0, tau0, |M|_inf, coupling}.  Ends with a barrier; d[0..kk), e[0..kk-1), tau[0..kk-1) valid.
-__device__ inline int tridiag_krylov(double (&a)[4][4], const double* g, double* V, int ldv, int n, double* d, double* e,
-                                     double* tau, double* v0, double* sv, double* pw, double* red, double* out4,
+// Register layout: lane l of every wave owns column l (n <= 52), wave w owns the rows i = w + 4 q, q < KQ:
+// a[q] = M[w + 4 q][l].  Row k sits in one register of one wave, one element per lane, so its reflector needs a
+// single wave reduction and comes out one component per lane -- the layout v is consumed in.  p = tau M v is
+// formed from column sums (M is symmetric): KQ local FMAs per lane, the four waves' parts meet in LDS; p.v is one
+// more wave reduction, the row-side values w_i come from v_readlane.  Two barriers per step.
+//   Vt[k * KLD + l] = v_k[l] (for apply_q_krylov), v0: 64 doubles for the first reflector,
+//   sv: 66 doubles, part: 256 doubles, red: 8 doubles.  out4 = {beta0, tau0, |M|_1, coupling}.
+// Ends with a barrier; d[0..kk), e[0..kk-1), tau[0..kk-1) valid.
+constexpr int KQ = 13;
+constexpr int KLD = 52;
+__device__ inline int tridiag_krylov(double (&a)[KQ], const double* g, double* Vt, int n, double* d, double* e, double* tau,
+                                     double* v0, double* sv, double* part, double* red, double* out4,
                                      long long* prof = nullptr) {
-    const int tid = threadIdx.x, lane = tid & 63, wv_id = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     long long t_prev = prof ? clock64() : 0, acc0 = 0, acc1 = 0, acc2 = 0;
     auto lap = [&](long long& acc) { if (prof) { const long long t = clock64(); acc += t - t_prev; t_prev = t; } };
-    const int ty = tid >> 4, tx = tid & 15;
-    auto row_sum16 = [](double v) {
-        v += dpp_mov<0x128>(v); v += dpp_mov<0x124>(v); v += dpp_mov<0x122>(v); v += dpp_mov<0x121>(v);
+    auto wave_max = [](double v) {
+        for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
         return v;
     };
-    auto block_max = [&](double v) {  // two barriers; uniform result
-        for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-        __syncthreads();
-        if (lane == 0) red[wv_id] = v;
-        __syncthreads();
-        return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    auto lane_value = [](double v, int src) {  // v of lane src (uniform) as a scalar
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
     };
-    // Householder vector from x (alpha at index j1, tail beyond); returns (tau, beta, scale of the tail)
+    // Householder vector for (alpha, |tail|^2): tau, beta, scale of the tail
     auto reflector = [&](double alpha, double sig, double& tk, double& beta, double& sc) {
         tk = 0.0; beta = alpha; sc = 0.0;
         if (sig > 0.0) {
@@ -359,144 +363,118 @@ __device__ inline int tridiag_krylov(double (&a)[4][4], const double* g, double*
             sc = fast_rcp64(alpha - beta);
         }
     };
-    // M <- H M H for the reflector in sv with coefficient tk (p = tk M v; w = p - (tk/2)(p.v) v; M -= v w^T + w v^T)
-    auto two_sided = [&](double tk) {
-        double vj[4], vi[4], s[4];
+    // M <- H M H for the reflector published in sv (coefficient tk)
+    auto two_sided = [&](double tk, double vj, const double (&vi)[KQ]) {
+        double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { vj[u] = sv[tx + 16 * u]; vi[u] = sv[ty + 16 * u]; }
-        double t = 0.0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            double acc = a[q][0] * vj[0];
-#pragma unroll
-            for (int u = 1; u < 4; ++u) acc += a[q][u] * vj[u];
-            s[q] = row_sum16(acc) * tk;
-            t += s[q] * vi[q];
-        }
-        {
-            const int lo = __double2loint(t), hi = __double2hiint(t);
-            double tw = 0.0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                tw += __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * r), __builtin_amdgcn_readlane(lo, 16 * r));
-            if (lane == 0) red[4 + wv_id] = tw;
-        }
-        if (tx == 0) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) pw[ty + 16 * q] = s[q];
-        }
+        for (int q = 0; q + 1 < KQ; q += 2) { s0 += a[q] * vi[q]; s1 += a[q + 1] * vi[q + 1]; }
+        s0 += a[KQ - 1] * vi[KQ - 1];
+        part[w * 64 + lane] = s0 + s1;          // this wave's rows of column sum l
         __syncthreads();
         lap(acc1);
-        const double h = 0.5 * tk * ((red[4] + red[5]) + (red[6] + red[7]));
-        double wj[4], wi[4];
+        const double p = tk * ((part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]));
+        const double h = 0.5 * tk * wave_sum_dpp(p * vj);
+        const double wj = p - h * vj;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            wj[u] = pw[tx + 16 * u] - h * vj[u];
-            wi[u] = s[u] - h * vi[u];
+        for (int q = 0; q < KQ; ++q) {
+            const double wi = lane_value(p, w + 4 * q) - h * vi[q];
+            a[q] -= vi[q] * wj + wi * vj;
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) a[q][u] -= vi[q] * wj[u] + wi[q] * vj[u];
         lap(acc2);
     };
+    // the owners of row k: register QK of wave k mod 4
     auto householder = [&](auto qk_tag, int k) {
         constexpr int QK = decltype(qk_tag)::value;
         const int j1 = k + 1;
-        double al = 0.0, sg = 0.0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = tx + 16 * u;
-            const double xu = a[QK][u];
-            al = j == j1 ? xu : al;
-            sg += j > j1 ? xu * xu : 0.0;
-        }
+        const double x = a[QK];
+        const double alpha = lane_value(x, j1);
+        const double sig = wave_sum_dpp((lane > j1 && lane < n) ? x * x : 0.0);
         double tk, beta, sc;
-        reflector(row_sum16(al), row_sum16(sg), tk, beta, sc);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = tx + 16 * u;
-            const double vi = j == j1 ? 1.0 : (j > j1 ? a[QK][u] * sc : 0.0);
-            sv[j] = vi;
-            if (j > k && j < n) V[j * ldv + k] = vi;
-        }
-        if (tx == 0) { e[k] = beta; tau[k] = tk; }
+        reflector(alpha, sig, tk, beta, sc);
+        const double v = lane == j1 ? 1.0 : ((lane > j1 && lane < n) ? x * sc : 0.0);
+        sv[lane] = v;
+        if (lane < KLD) Vt[k * KLD + lane] = v;
+        if (lane == 0) { sv[64] = tk; sv[65] = beta; e[k] = beta; tau[k] = tk; }
     };
 
-    // |M|_inf
+    // |M|_1 (= |M|_inf): column sums over the four waves' rows
     double anorm;
     {
-        double m = 0.0;
+        double cs = 0.0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            double r = 0.0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) r += fabs(a[q][u]);
-            m = fmax(m, row_sum16(r));
-        }
-        anorm = block_max(m);
+        for (int q = 0; q < KQ; ++q) cs += fabs(a[q]);
+        part[w * 64 + lane] = cs;
+        __syncthreads();
+        anorm = wave_max((part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]));
+        __syncthreads();
     }
     const double tol_c = 1e-8 * anorm, tol_n = 1e-13 * anorm;
-    // first reflector: H_g g = beta0 e_1
-    if (ty == 0) {
-        double x[4], al = 0.0, sg = 0.0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = tx + 16 * u;
-            x[u] = j < n ? g[j] : 0.0;
-            al = j == 0 ? x[u] : al;
-            sg += j > 0 ? x[u] * x[u] : 0.0;
-        }
+    // first reflector: H_g g = beta0 e_1 (wave 0 publishes it)
+    if (w == 0) {
+        const double x = lane < n ? g[lane] : 0.0;
+        const double alpha = lane_value(x, 0);
+        const double sig = wave_sum_dpp(lane > 0 ? x * x : 0.0);
         double tk, beta, sc;
-        reflector(row_sum16(al), row_sum16(sg), tk, beta, sc);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = tx + 16 * u;
-            const double vi = j == 0 ? 1.0 : x[u] * sc;
-            sv[j] = vi; v0[j] = vi;
-        }
-        if (tx == 0) { out4[0] = beta; out4[1] = tk; out4[2] = anorm; out4[3] = 0.0; }
+        reflector(alpha, sig, tk, beta, sc);
+        const double v = lane == 0 ? 1.0 : x * sc;
+        sv[lane] = v; v0[lane] = v;
+        if (lane == 0) { sv[64] = tk; sv[65] = beta; out4[0] = beta; out4[1] = tk; out4[2] = anorm; out4[3] = 0.0; }
     }
     __syncthreads();
     {
-        const double t0 = out4[1];
-        if (t0 != 0.0) two_sided(t0);
+        const double t0 = sv[64], vj = sv[lane];
+        double vi[KQ];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) vi[q] = sv[w + 4 * q];
+        if (t0 != 0.0) two_sided(t0, vj, vi);
     }
     int kk = n;
     for (int k = 0; k < n - 1; ++k) {
-        if (ty == (k & 15)) {
-            switch (k >> 4) {
+        if (w == (k & 3)) {
+            switch (k >> 2) {
                 case 0: householder(std::integral_constant<int, 0>{}, k); break;
                 case 1: householder(std::integral_constant<int, 1>{}, k); break;
                 case 2: householder(std::integral_constant<int, 2>{}, k); break;
-                default: householder(std::integral_constant<int, 3>{}, k); break;
+                case 3: householder(std::integral_constant<int, 3>{}, k); break;
+                case 4: householder(std::integral_constant<int, 4>{}, k); break;
+                case 5: householder(std::integral_constant<int, 5>{}, k); break;
+                case 6: householder(std::integral_constant<int, 6>{}, k); break;
+                case 7: householder(std::integral_constant<int, 7>{}, k); break;
+                case 8: householder(std::integral_constant<int, 8>{}, k); break;
+                case 9: householder(std::integral_constant<int, 9>{}, k); break;
+                case 10: householder(std::integral_constant<int, 10>{}, k); break;
+                case 11: householder(std::integral_constant<int, 11>{}, k); break;
+                default: householder(std::integral_constant<int, 12>{}, k); break;
             }
         }
         __syncthreads();
         lap(acc0);
-        const double tk = tau[k], ek = e[k];
+        const double tk = sv[64], ek = sv[65], vj = sv[lane];
+        double vi[KQ];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) vi[q] = sv[w + 4 * q];
         if (fabs(ek) <= tol_c) {
             // the Krylov space is exhausted: everything behind row k must be the null space
             double m = 0.0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (ty + 16 * q > k && tx + 16 * u > k) m = fmax(m, fabs(a[q][u]));
-            m = block_max(m);
+            for (int q = 0; q < KQ; ++q)
+                if (w + 4 * q > k && lane > k) m = fmax(m, fabs(a[q]));
+            m = wave_max(m);
+            __syncthreads();
+            if (lane == 0) red[w] = m;
+            __syncthreads();
+            m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
             if (tid == 0) { tau[k] = 0.0; out4[3] = ek; }
             kk = (m <= tol_n) ? k + 1 : -1;
             break;
         }
-        if (tk != 0.0) two_sided(tk);
+        if (tk != 0.0) two_sided(tk, vj, vi);
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = ty + 16 * q, j = tx + 16 * u;
-            if (i == j && i < n) d[i] = a[q][u];
-        }
+    for (int q = 0; q < KQ; ++q) {
+        const int i = w + 4 * q;
+        if (lane == i && i < n) d[i] = a[q];   // M[i][i] is final once step i - 1 is done
+    }
     __syncthreads();
     if (prof && tid == 0) { prof[0] = acc0; prof[1] = acc1; prof[2] = acc2; }
     return kk;
@@ -536,14 +514,14 @@ __device__ inline bool krylov_block_ok(const double* d, const double* e, int kk,
     return ec * ec * ww <= 1e-8;
 }
 
-// Q c for the Krylov tridiagonalisation: reflectors k = kk-2 .. 0 from V, then the first reflector v0 (one wave)
-__device__ inline double apply_q_krylov(const double* V, int ldv, const double* tau, const double* v0, double tau0, int kk,
-                                        int n, double cj) {
+// Q c for the Krylov tridiagonalisation: reflectors k = kk-2 .. 0 from Vt, then the first reflector v0 (one wave)
+__device__ inline double apply_q_krylov(const double* Vt, const double* tau, const double* v0, double tau0, int kk, int n,
+                                        double cj) {
     const int lane = threadIdx.x & 63;
     for (int k = kk - 2; k >= 0; --k) {
         const double tk = tau[k];
         if (tk == 0.0) continue;
-        const double v = (lane > k && lane < n) ? V[lane * ldv + k] : 0.0;
+        const double v = lane < KLD ? Vt[k * KLD + lane] : 0.0;   // zero up to k and beyond n by construction
         const double s = wave_sum_dpp(v * cj);
         cj -= tk * s * v;
     }

@@ -36,11 +36,13 @@ constexpr int NA = 50;     // max active parameters (even)
 constexpr int LD = 51;     // odd leading dimension: conflict-free column walks on 8-byte elements
 constexpr int LDZ = LD;    // eigenvector rows of the fallback eigensolver (odd: lanes walk one column)
 constexpr int NROW = 48;   // rows of D: 16 observed joints x 3
-// fast-path scratch vectors, 64 doubles each, behind ik_eval's per-(view,joint) scratch in bufB
+// fast-path scratch vectors behind ik_eval's per-(view,joint) scratch in bufB (64 doubles each; SV and PART longer)
 constexpr int SCR0 = 1290;
-enum { SC_SV = 0, SC_PW, SC_DSC, SC_E2, SC_LMUL, SC_DINV, SC_YB, SC_ZB, SC_RH, SC_TAU, SC_D, SC_E, SC_QC, SC_V0, SC_WN, SC_COUNT };
+enum { SC_DSC = 0, SC_E2, SC_LMUL, SC_DINV, SC_RH, SC_TAU, SC_D, SC_E, SC_QC, SC_V0, SC_WN, SC_SV /* 2 slots */, SC_SV2,
+       SC_PART /* 4 slots */, SC_PART2, SC_PART3, SC_PART4, SC_COUNT };
 static_assert(SCR0 >= 8 * 16 * 10, "scratch overlaps the Jacobian blocks");
 static_assert(SCR0 + SC_COUNT * 64 <= NA * LD, "scratch does not fit bufB");
+static_assert(48 * eightri::KLD <= NA * LD, "Householder vectors do not fit bufC");
 constexpr int VMAX = 8;    // max views per person
 constexpr int NOBS = 16;   // observed joints per view
 
@@ -69,7 +71,7 @@ struct IkShared {
     double dirs[18 * 3], ref_side[18];
     int parents[18], side_map[18], n_side;
 #ifdef MVMC_IK_PROFILE
-    long long prof[4];
+    long long prof[8];
 #endif
 };
 
@@ -291,37 +293,40 @@ __device__ void ik_normal_matrix(IkShared& S, int stage) {
 // S.sc[4..7] = {beta0, tau0, |J^T J|_inf, coupling}.
 // ---------------------------------------------------------------------------------------------
 __device__ int ik_krylov_model(IkShared& S, int stage) {
-    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int na = S.na[stage];
     double* scr = S.bufB + SCR0;
+#ifdef MVMC_IK_PROFILE
+    long long _tp = clock64();
+#define KSTAMP(k) { const long long _t = clock64(); if (tid == 0) S.prof[k] += _t - _tp; _tp = _t; }
+#else
+#define KSTAMP(k)
+#endif
     ik_weighted_D(S, stage);
-    double a[4][4];
-    int ic[4], jc[4];
+    // a[q] = (J^T J)[w + 4 q][lane] = sum_r D[r][w + 4 q] Y[r][lane]
+    double a[eightri::KQ];
+    int ic[eightri::KQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int i = ty + 16 * q, j = tx + 16 * q;
+    for (int q = 0; q < eightri::KQ; ++q) {
+        const int i = w + 4 * q;
         ic[q] = i < na ? i : na - 1;
-        jc[q] = j < na ? j : na - 1;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) a[q][u] = 0.0;
+        a[q] = 0.0;
     }
+    const int jc = lane < na ? lane : na - 1;
     for (int r = 0; r < NROW; ++r) {
-        double di[4], yj[4];
+        const double yj = S.bufB[r * LD + jc];
+        const double* Dr = &S.bufA[r * LD];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { di[q] = S.bufA[r * LD + ic[q]]; yj[q] = S.bufB[r * LD + jc[q]]; }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) a[q][u] += di[q] * yj[u];
+        for (int q = 0; q < eightri::KQ; ++q) a[q] += Dr[ic[q]] * yj;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (ty + 16 * q >= na || tx + 16 * u >= na) a[q][u] = 0.0;
+    for (int q = 0; q < eightri::KQ; ++q)
+        if (w + 4 * q >= na || lane >= na) a[q] = 0.0;
     __syncthreads();  // Y (bufB) is dead from here: the scratch vectors live in its tail
-    const int kk = eightri::tridiag_krylov(a, S.g, S.bufC, LD, na, scr + 64 * SC_D, scr + 64 * SC_E, scr + 64 * SC_TAU,
-                                           scr + 64 * SC_V0, scr + 64 * SC_SV, scr + 64 * SC_PW, S.red, &S.sc[4]);
+    KSTAMP(4)
+    const int kk = eightri::tridiag_krylov(a, S.g, S.bufC, na, scr + 64 * SC_D, scr + 64 * SC_E, scr + 64 * SC_TAU,
+                                           scr + 64 * SC_V0, scr + 64 * SC_SV, scr + 64 * SC_PART, S.red, &S.sc[4]);
+    KSTAMP(5)
     if (tid < 64) {
         const bool ok = kk > 0 && eightri::krylov_block_ok(scr + 64 * SC_D, scr + 64 * SC_E, kk, na, S.sc[6], S.sc[7],
                                                            scr + 64 * SC_DSC, scr + 64 * SC_E2, scr + 64 * SC_LMUL,
@@ -330,6 +335,7 @@ __device__ int ik_krylov_model(IkShared& S, int stage) {
         if (tid == 0) S.sc[0] = ok ? (double)kk : -1.0;
     }
     __syncthreads();
+    KSTAMP(6)
     return (int)S.sc[0];
 }
 
@@ -450,16 +456,14 @@ __device__ void ik_trf(IkShared& S, const SkelRef& sk, int stage, int max_nfev, 
                     double pred, pnorm, al;
                     if (fast) {
                         al = eightri::tr_solve_tri<false>(scr + 64 * SC_D, scr + 64 * SC_E, scr + 64 * SC_RH, kk, Delta, alpha, gg,
-                                                          pivmin, scr + 64 * SC_LMUL, scr + 64 * SC_DINV, scr + 64 * SC_YB,
-                                                          scr + 64 * SC_ZB, S.cv, &pred, &pnorm);
+                                                          pivmin, nullptr, nullptr, nullptr, nullptr, S.cv, &pred, &pnorm);
                         double c = tid < kk ? S.cv[tid] : 0.0;
                         if (kk < na) {
                             // component along the first null coordinate: keeps the step orthogonal to the null vector
                             const double eta = coupling * wave_sum_dpp(tid < kk ? scr[64 * SC_WN + tid] * c : 0.0);
                             if (tid == kk) c = eta;
                         }
-                        scr[64 * SC_QC + tid] = eightri::apply_q_krylov(S.bufC, LD, scr + 64 * SC_TAU, scr + 64 * SC_V0, tau0,
-                                                                        kk, na, c);
+                        scr[64 * SC_QC + tid] = eightri::apply_q_krylov(S.bufC, scr + 64 * SC_TAU, scr + 64 * SC_V0, tau0, kk, na, c);
                     } else {
                         al = ik_tr_solve(S, nap, Delta, alpha, gg, &pred, &pnorm);
                     }
@@ -693,7 +697,7 @@ ik_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restr
 
     const int max_nfev = is_cold ? nfev_cold : nfev_warm;
 #ifdef MVMC_IK_PROFILE
-    if (tid < 4) S.prof[tid] = 0;
+    if (tid < 8) S.prof[tid] = 0;
     const long long t_all = clock64();
     __syncthreads();
 #endif
@@ -722,6 +726,7 @@ ik_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restr
         // diagnostic build only: cycle shares instead of the costs
         info[0] = (double)S.prof[0]; info[3] = (double)S.prof[1]; info[2] = (double)S.prof[2];
         info[5] = (double)(clock64() - t_all); info[7] = (double)S.prof[3];
+        info[1] = (double)S.prof[4]; info[4] = (double)S.prof[5]; info[6] = (double)S.prof[6];
 #endif
     }
 }

@@ -24,13 +24,9 @@ inf = out["info"].reshape(-1, 8).cpu().numpy()
 ok = ~np.isnan(inf[:, 1])
 inf = inf[ok]
 tot = inf[:, 5].sum()
-print("solves", len(inf), "mean nfev", (inf[:, 1] + inf[:, 4]).mean(), "njev", inf[:, 6].mean(), "(fallback count not reported by the profile build)")
-nfev, njev = (inf[:, 1] + inf[:, 4]).sum(), inf[:, 6].sum()
-ev, ne, tri, trs = inf[:, 0].sum(), inf[:, 3].sum(), inf[:, 2].sum(), inf[:, 7].sum()
-# prof slots: 0 = ik_eval, 1 = ik_model (blocks, D, g), 2 = Gram + Krylov tridiagonalisation (+ eigensolver on fallback),
-# 3 = trust-region solve + Q c
+# profile build: info = {eval, gram, tridiag-phase total, model, krylov tridiagonalisation, total, block checks, tr-solve} cycles
+print("solves", len(inf))
+ev, gram, tri_all, ne, kry, chk, trs = (inf[:, k].sum() for k in (0, 1, 2, 3, 4, 6, 7))
 print("cycles per solve (mean): total %.0f" % inf[:, 5].mean())
-print("shares: eval %.3f model %.3f tridiag %.3f tr-solve %.3f other %.3f" %
-      (ev / tot, ne / tot, tri / tot, trs / tot, 1 - (ev + ne + tri + trs) / tot))
-print("cycles per eval %.0f ; per model %.0f ; per tridiag %.0f ; per tr-solve %.0f" %
-      (ev / nfev, ne / njev, tri / njev, trs / (nfev - 2 * len(inf))))
+print("shares: eval %.3f model %.3f [gram %.3f krylov %.3f checks %.3f] tr-solve %.3f other %.3f" %
+      (ev / tot, ne / tot, gram / tot, kry / tot, chk / tot, trs / tot, 1 - (ev + ne + tri_all + trs) / tot))
