@@ -142,11 +142,14 @@ int mvmc_fk(const mvmcSkeleton* skel_host, const double* params, int n_problems,
  *                0 = warm (max_nfev_warm); NULL = all cold
  *   params_out   (B,68); joints_out (B,18,3); info_out (B,8) f64 =
  *                {cost1, nfev1, status1, cost2, nfev2, status2, njev1+njev2, number of trust-region models that
- *                took the eigensolver fallback (numerically singular Gram matrix)} or NULL */
+ *                took the eigensolver fallback (no clean split between range and null space)} or NULL
+ *   scratch      (B, MVMC_IK_SCRATCH_DOUBLES) f64 device workspace: the matrices of the eigensolver fallback, touched
+ *                only by the (rare) problems that take it; contents undefined before and after */
+#define MVMC_IK_SCRATCH_DOUBLES 7680
 int mvmc_ik_solve(const mvmcSkeleton* skel_host, const double* kps17, const double* Pmats,
                   const int32_t* members, int n_problems, int v_max, int n_views, int p_max,
                   const double* init_params, const uint8_t* cold, int max_nfev_cold, int max_nfev_warm,
-                  double* params_out, double* joints_out, double* info_out, mvmcStream_t stream);
+                  double* params_out, double* joints_out, double* info_out, double* scratch, mvmcStream_t stream);
 
 /* ---- temporal layer: match_spatial_time + tracker, batched over independent chains (sub-sequences) ---- */
 

@@ -17,6 +17,7 @@ MVMC_OK = 0
 MVMC_F32, MVMC_F64 = 0, 1
 N_PARAM = 68
 MAX_NODES = 80
+IK_SCRATCH_DOUBLES = 7680
 
 # every symbol declared in include/mvmc.h
 SYMBOLS = (
@@ -66,7 +67,7 @@ def load():
     lib.mvmc_triangulate_postopt.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
     lib.mvmc_fk.argtypes = [C.POINTER(MvmcSkeleton), vp, i32, vp, vp, vp]
     lib.mvmc_ik_solve.argtypes = [C.POINTER(MvmcSkeleton), vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, i32,
-                                  vp, vp, vp, vp]
+                                  vp, vp, vp, vp, vp]
     lib.mvmc_fmats_from_projections.argtypes = [vp, i32, vp, vp]
     lib.mvmc_st_affinity.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f64, vp, vp, vp, vp]
     lib.mvmc_track_assign.argtypes = [vp] * 8 + [i32] * 6 + [vp] * 6

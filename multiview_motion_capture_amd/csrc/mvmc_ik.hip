@@ -36,13 +36,17 @@ constexpr int NA = 50;     // max active parameters (even)
 constexpr int LD = 51;     // odd leading dimension: conflict-free column walks on 8-byte elements
 constexpr int LDZ = LD;    // eigenvector rows of the fallback eigensolver (odd: lanes walk one column)
 constexpr int NROW = 48;   // rows of D: 16 observed joints x 3
-// fast-path scratch vectors behind ik_eval's per-(view,joint) scratch in bufB (64 doubles each; SV and PART longer)
-constexpr int SCR0 = 1290;
+// bufB = ik_eval's per-(view,joint) Jacobian blocks [0, EVS) + solver vectors (64 doubles each; SV and PART longer)
+constexpr int EVS = 8 * 16 * 10;
+constexpr int SCR0 = EVS;
 enum { SC_DSC = 0, SC_E2, SC_LMUL, SC_DINV, SC_RH, SC_TAU, SC_D, SC_E, SC_QC, SC_V0, SC_WN, SC_SV /* 2 slots */, SC_SV2,
        SC_PART /* 4 slots */, SC_PART2, SC_PART3, SC_PART4, SC_COUNT };
-static_assert(SCR0 >= 8 * 16 * 10, "scratch overlaps the Jacobian blocks");
-static_assert(SCR0 + SC_COUNT * 64 <= NA * LD, "scratch does not fit bufB");
-static_assert(48 * eightri::KLD <= NA * LD, "Householder vectors do not fit bufC");
+constexpr int BUFA = 48 * eightri::KLD;          // D (48 x LD) during the model build, Householder vectors after
+constexpr int BUFB = EVS + SC_COUNT * 64;
+static_assert(BUFA >= 48 * LD, "D does not fit bufA");
+// fallback eigensolver: three n x n matrices per workgroup in global memory (include/mvmc.h: MVMC_IK_SCRATCH_DOUBLES)
+constexpr int FBM = 2560;
+static_assert(FBM >= NA * LD && 3 * FBM == MVMC_IK_SCRATCH_DOUBLES, "fallback scratch size");
 constexpr int VMAX = 8;    // max views per person
 constexpr int NOBS = 16;   // observed joints per view
 
@@ -51,25 +55,23 @@ __device__ __constant__ const int kIkSkel[NOBS] = {1, 2, 3, 4, 5, 6, 7, 9, 10, 1
 __device__ __constant__ const int kIkObs[NOBS] = {11, 13, 15, 12, 14, 16, 17, 5, 7, 9, 6, 8, 10, 0, 3, 4};
 
 struct IkShared {
-    double bufA[NA * LD];  // D (48 x LD) | scratch matrix of the fallback eigensolver
-    double bufB[NA * LD];  // per-(view,joint) Jacobian blocks [0, 1280) + fast-path vectors [SCR0, ...) | Y = W D | fallback: J^T J
-    double bufC[NA * LD];  // Householder vectors of the tridiagonalisation | fallback: eigenvectors (rows)
+    double bufA[BUFA];     // D (48 x LD) | Householder vectors of the tridiagonalisation (row k = v_k, KLD apart)
+    double bufB[BUFB];     // per-(view,joint) Jacobian blocks [0, EVS) | solver vectors [SCR0, ...)
     double x[68], xn[68];
     double side[18];       // side bone lengths used by stage 1 (fixed)
-    double g[NA], lam[NA], suf[NA], cv[NA], step[NA];
-    double rcs[NA];        // fallback eigensolver scratch
+    double g[NA], cv[NA], step[NA];
     double obs[VMAX * NOBS * 3], Pm[VMAX * 12];
     double Rl[18 * 9], Rg[18 * 9], pos[18 * 3], bvec[18 * 3], off[18 * 3], axes[18 * 9];
     double Wk[NOBS * 6], tk[NOBS * 3];
     double red[8];
     double sc[8];          // broadcast scalars
-    int act[2][NA], inv_act[2][68], na[2];
-    int colkind[2][NA], cola[2][NA], colc[2][NA];
-    int anc[18], depth[18], maxdepth, nviews;
     // skeleton tables (copied from the kernel argument once: dynamic indexing of by-value kernel
     // arguments costs SGPR spills and scratch)
     double dirs[18 * 3], ref_side[18];
-    int parents[18], side_map[18], n_side;
+    int anc[18], depth[18], maxdepth, nviews, na[2], n_side;
+    int parents[18], side_map[18];
+    unsigned char act[2][NA], colkind[2][NA], cola[2][NA], colc[2][NA];
+    signed char inv_act[2][68];
 #ifdef MVMC_IK_PROFILE
     long long prof[8];
 #endif
@@ -241,8 +243,8 @@ __device__ void ik_model(IkShared& S, const SkelRef& sk, const double* xs, int s
     __syncthreads();
 }
 
-// Y = W D into bufB (the per-(view,joint) scratch is dead once W_k, t_k are formed)
-__device__ void ik_weighted_D(IkShared& S, int stage) {
+// Fallback only: Y = W D, then J^T J = D^T Y, both in the workgroup's global scratch (bufA must hold D)
+__device__ void ik_normal_matrix(IkShared& S, int stage, double* Y, double* A) {
     const int tid = threadIdx.x;
     const int na = S.na[stage], nap = (na + 1) & ~1;
     for (int idx = tid; idx < NROW * nap; idx += NT) {
@@ -252,37 +254,15 @@ __device__ void ik_weighted_D(IkShared& S, int stage) {
         const double w0 = (c3 == 0) ? W[0] : (c3 == 1) ? W[1] : W[2];
         const double w1 = (c3 == 0) ? W[1] : (c3 == 1) ? W[3] : W[4];
         const double w2 = (c3 == 0) ? W[2] : (c3 == 1) ? W[4] : W[5];
-        S.bufB[row * LD + col] = w0 * S.bufA[(3 * k) * LD + col] + w1 * S.bufA[(3 * k + 1) * LD + col] +
-                                 w2 * S.bufA[(3 * k + 2) * LD + col];
+        Y[row * LD + col] = w0 * S.bufA[(3 * k) * LD + col] + w1 * S.bufA[(3 * k + 1) * LD + col] +
+                            w2 * S.bufA[(3 * k + 2) * LD + col];
     }
     __syncthreads();
-}
-
-__device__ void ik_normal_matrix(IkShared& S, int stage) {
-    const int tid = threadIdx.x;
-    const int na = S.na[stage], nap = (na + 1) & ~1;
-    ik_weighted_D(S, stage);
-    // J^T J = D^T Y (registers first: the result overwrites Y)
-    constexpr int EPT = (NA * NA + NT - 1) / NT;
-    double acc[EPT];
-#pragma unroll
-    for (int t = 0; t < EPT; ++t) {
-        const int idx = t * NT + tid;
+    for (int idx = tid; idx < nap * nap; idx += NT) {
+        const int i = idx / nap, j = idx - i * nap;
         double a = 0.0;
-        if (idx < nap * nap) {
-            const int i = idx / nap, j = idx - i * nap;
-            for (int row = 0; row < NROW; ++row) a += S.bufA[row * LD + i] * S.bufB[row * LD + j];
-        }
-        acc[t] = a;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < EPT; ++t) {
-        const int idx = t * NT + tid;
-        if (idx < nap * nap) {
-            const int i = idx / nap, j = idx - i * nap;
-            S.bufB[i * LD + j] = acc[t];
-        }
+        for (int row = 0; row < NROW; ++row) a += S.bufA[row * LD + i] * Y[row * LD + j];
+        A[i * LD + j] = a;
     }
     __syncthreads();
 }
@@ -302,8 +282,8 @@ __device__ int ik_krylov_model(IkShared& S, int stage) {
 #else
 #define KSTAMP(k)
 #endif
-    ik_weighted_D(S, stage);
-    // a[q] = (J^T J)[w + 4 q][lane] = sum_r D[r][w + 4 q] Y[r][lane]
+    // a[q] = (J^T J)[w + 4 q][lane] = sum over joints k of D_k[:, i]^T (W_k D_k[:, lane]), the weighted column
+    // formed on the fly
     double a[eightri::KQ];
     int ic[eightri::KQ];
 #pragma unroll
@@ -313,18 +293,23 @@ __device__ int ik_krylov_model(IkShared& S, int stage) {
         a[q] = 0.0;
     }
     const int jc = lane < na ? lane : na - 1;
-    for (int r = 0; r < NROW; ++r) {
-        const double yj = S.bufB[r * LD + jc];
-        const double* Dr = &S.bufA[r * LD];
+    for (int k = 0; k < NOBS; ++k) {
+        const double* W = &S.Wk[k * 6];
+        const double* D0 = &S.bufA[(3 * k) * LD];
+        const double d0 = D0[jc], d1 = D0[LD + jc], d2 = D0[2 * LD + jc];
+        const double y0 = W[0] * d0 + W[1] * d1 + W[2] * d2;
+        const double y1 = W[1] * d0 + W[3] * d1 + W[4] * d2;
+        const double y2 = W[2] * d0 + W[4] * d1 + W[5] * d2;
 #pragma unroll
-        for (int q = 0; q < eightri::KQ; ++q) a[q] += Dr[ic[q]] * yj;
+        for (int q = 0; q < eightri::KQ; ++q)
+            a[q] += D0[ic[q]] * y0 + D0[LD + ic[q]] * y1 + D0[2 * LD + ic[q]] * y2;
     }
 #pragma unroll
     for (int q = 0; q < eightri::KQ; ++q)
         if (w + 4 * q >= na || lane >= na) a[q] = 0.0;
-    __syncthreads();  // Y (bufB) is dead from here: the scratch vectors live in its tail
+    __syncthreads();  // D is dead from here: bufA takes the Householder vectors
     KSTAMP(4)
-    const int kk = eightri::tridiag_krylov(a, S.g, S.bufC, na, scr + 64 * SC_D, scr + 64 * SC_E, scr + 64 * SC_TAU,
+    const int kk = eightri::tridiag_krylov(a, S.g, S.bufA, na, scr + 64 * SC_D, scr + 64 * SC_E, scr + 64 * SC_TAU,
                                            scr + 64 * SC_V0, scr + 64 * SC_SV, scr + 64 * SC_PART, S.red, &S.sc[4]);
     KSTAMP(5)
     if (tid < 64) {
@@ -344,16 +329,20 @@ __device__ int ik_krylov_model(IkShared& S, int stage) {
 // cluster removed (lam, eigenvector rows in bufC, suf = V^T g).  Kept out of line: it runs for a fraction of a
 // percent of the models and would otherwise set the register budget of the whole kernel.
 // ---------------------------------------------------------------------------------------------
-__device__ __noinline__ void ik_eigen_model(IkShared& S, int stage) {
+__device__ __noinline__ void ik_eigen_model(IkShared& S, const SkelRef& sk, int stage, double* fb) {
     const int tid = threadIdx.x;
     const int na = S.na[stage], nap = (na + 1) & ~1;
-    ik_normal_matrix(S, stage);
-    eightri::eigh(S.bufB, LD, S.bufC, LDZ, S.bufA, LD, nap, S.lam, S.step, S.cv, S.suf, S.rcs, S.xn, S.red,
-                  reinterpret_cast<int*>(S.bufA + 128));  // Sturm counts: 1 KB of the scratch matrix
+    double* scr = S.bufB + SCR0;
+    double *gA = fb, *gZ = fb + FBM, *gW = fb + 2 * FBM;
+    ik_build_D(S, sk, stage);               // bufA held Householder vectors
+    ik_normal_matrix(S, stage, gW, gA);
+    // lam -> SC_D, suf -> SC_E (they live until the next model); the other slots are eigensolver temporaries
+    eightri::eigh(gA, LD, gZ, LDZ, gW, LD, nap, scr + 64 * SC_D, scr + 64 * SC_TAU, scr + 64 * SC_RH, scr + 64 * SC_V0,
+                  scr + 64 * SC_WN, scr + 64 * SC_SV, S.red, reinterpret_cast<int*>(scr + 64 * SC_PART));
     if (tid < nap) {
         double a = 0.0;
-        for (int i = 0; i < nap; ++i) a += S.bufC[tid * LDZ + i] * S.g[i];
-        S.suf[tid] = a;
+        for (int i = 0; i < nap; ++i) a += gZ[tid * LDZ + i] * S.g[i];
+        scr[64 * SC_E + tid] = a;
     }
     __syncthreads();
 }
@@ -367,7 +356,8 @@ __device__ __noinline__ void ik_eigen_model(IkShared& S, int stage) {
 __device__ double ik_tr_solve(IkShared& S, int nap, double Delta, double alpha0, double gg, double* pred, double* pnorm) {
     const int lane = threadIdx.x;
     const bool on = lane <= nap;
-    double lam = lane < nap ? S.lam[lane] : 1.0, suf = lane < nap ? S.suf[lane] : 0.0;
+    const double* scr = S.bufB + SCR0;
+    double lam = lane < nap ? scr[64 * SC_D + lane] : 1.0, suf = lane < nap ? scr[64 * SC_E + lane] : 0.0;
     // Virtual absorber (lane nap): a direction with lambda = 0 and a small fixed weight.  In the reference
     // the numerically-null directions of J carry finite-difference noise (s*u^T f ~ 1e-8 |g|), and because
     // SciPy normalises every rank-deficient step to |p| = Delta, that noise soaks up whatever part of the
@@ -406,7 +396,7 @@ __device__ double ik_tr_solve(IkShared& S, int nap, double Delta, double alpha0,
 // ---------------------------------------------------------------------------------------------
 // trf_no_bounds (trf.py:401-560) with x_scale = 1, linear loss, ftol = xtol = gtol = 1e-8.
 // ---------------------------------------------------------------------------------------------
-__device__ void ik_trf(IkShared& S, const SkelRef& sk, int stage, int max_nfev, double* cost_out, int* nfev_out,
+__device__ void ik_trf(IkShared& S, const SkelRef& sk, int stage, int max_nfev, double* fb, double* cost_out, int* nfev_out,
                        int* njev_out, int* status_out, int* fallbacks_out) {
     const int tid = threadIdx.x;
     const int nfull = (stage == 0) ? 57 : 57 + sk.n_side;
@@ -440,7 +430,7 @@ __device__ void ik_trf(IkShared& S, const SkelRef& sk, int stage, int max_nfev, 
             PROF_T0
             kk = ik_krylov_model(S, stage);
             if (kk < 0) {
-                ik_eigen_model(S, stage);
+                ik_eigen_model(S, sk, stage, fb);
                 ++*fallbacks_out;
             }
             PROF_ADD(S, 2)
@@ -463,7 +453,7 @@ __device__ void ik_trf(IkShared& S, const SkelRef& sk, int stage, int max_nfev, 
                             const double eta = coupling * wave_sum_dpp(tid < kk ? scr[64 * SC_WN + tid] * c : 0.0);
                             if (tid == kk) c = eta;
                         }
-                        scr[64 * SC_QC + tid] = eightri::apply_q_krylov(S.bufC, scr + 64 * SC_TAU, scr + 64 * SC_V0, tau0, kk, na, c);
+                        scr[64 * SC_QC + tid] = eightri::apply_q_krylov(S.bufA, scr + 64 * SC_TAU, scr + 64 * SC_V0, tau0, kk, na, c);
                     } else {
                         al = ik_tr_solve(S, nap, Delta, alpha, gg, &pred, &pnorm);
                     }
@@ -473,7 +463,7 @@ __device__ void ik_trf(IkShared& S, const SkelRef& sk, int stage, int max_nfev, 
                 if (tid < nap) {
                     double a = 0.0;
                     if (!fast) {
-                        for (int j = 0; j < nap; ++j) a += S.bufC[j * LDZ + tid] * S.cv[j];
+                        for (int j = 0; j < nap; ++j) a += fb[FBM + j * LDZ + tid] * S.cv[j];
                     } else {
                         a = scr[64 * SC_QC + tid];
                     }
@@ -574,11 +564,11 @@ __device__ void dlt_obs_point(const double* pose18 /*[V][18][3]*/, const double*
     X[0] = e[0] / e[3]; X[1] = e[1] / e[3]; X[2] = e[2] / e[3];
 }
 
-__global__ void __launch_bounds__(NT, 2)
+__global__ void __launch_bounds__(NT, 3)
 ik_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restrict__ Pmats,
           const int32_t* __restrict__ members, int B, int V, int C, int Pmax, const double* __restrict__ init,
           const uint8_t* __restrict__ cold, int nfev_cold, int nfev_warm, double* __restrict__ params_out,
-          double* __restrict__ joints_out, double* __restrict__ info_out) {
+          double* __restrict__ joints_out, double* __restrict__ info_out, double* __restrict__ scratch) {
     __shared__ IkShared S;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n_side = skarg.n_side;
@@ -696,6 +686,7 @@ ik_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restr
     __syncthreads();
 
     const int max_nfev = is_cold ? nfev_cold : nfev_warm;
+    double* fb = scratch + (size_t)b * MVMC_IK_SCRATCH_DOUBLES;
 #ifdef MVMC_IK_PROFILE
     if (tid < 8) S.prof[tid] = 0;
     const long long t_all = clock64();
@@ -708,7 +699,7 @@ ik_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restr
 #pragma unroll 1
     for (int stage = 0; stage < 2; ++stage) {
         double c; int nf, nj, st;
-        ik_trf(S, sk, stage, max_nfev, &c, &nf, &nj, &st, &fallbacks);
+        ik_trf(S, sk, stage, max_nfev, fb, &c, &nf, &nj, &st, &fallbacks);
         costs[stage] = c; nfs[stage] = nf; njs[stage] = nj; sts[stage] = st;
         __syncthreads();
     }
@@ -736,8 +727,9 @@ ik_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restr
 extern "C" int mvmc_ik_solve(const mvmcSkeleton* skel_host, const double* kps17, const double* Pmats,
                              const int32_t* members, int n_problems, int v_max, int n_views, int p_max,
                              const double* init_params, const uint8_t* cold, int max_nfev_cold, int max_nfev_warm,
-                             double* params_out, double* joints_out, double* info_out, mvmcStream_t stream) {
-    if (!skel_host || !kps17 || !Pmats || !members || !params_out || !joints_out) return MVMC_ERR_ARG;
+                             double* params_out, double* joints_out, double* info_out, double* scratch,
+                             mvmcStream_t stream) {
+    if (!skel_host || !kps17 || !Pmats || !members || !params_out || !joints_out || !scratch) return MVMC_ERR_ARG;
     if (v_max <= 0 || n_views <= 0 || p_max <= 0 || max_nfev_cold < 1 || max_nfev_warm < 1) return MVMC_ERR_ARG;
     if (cold && !init_params) return MVMC_ERR_ARG;
     if (n_problems <= 0) return n_problems == 0 ? MVMC_OK : MVMC_ERR_ARG;
@@ -746,7 +738,7 @@ extern "C" int mvmc_ik_solve(const mvmcSkeleton* skel_host, const double* kps17,
     if (sk.n_side != MVMC_N_SIDE) return MVMC_ERR_UNSUPPORTED;  // the solver is sized for 57 + 11 parameters
     hipLaunchKernelGGL(ik_kernel, dim3(n_problems), dim3(NT), 0, (hipStream_t)stream, sk, kps17, Pmats, members,
                        n_problems, v_max, n_views, p_max, init_params, init_params ? cold : nullptr, max_nfev_cold,
-                       max_nfev_warm, params_out, joints_out, info_out);
+                       max_nfev_warm, params_out, joints_out, info_out, scratch);
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;
 }

@@ -211,6 +211,20 @@ def fk(params: torch.Tensor, skeleton: Optional[MvmcSkeleton] = None, want_G=Fal
     return (joints, G) if want_G else joints
 
 
+_IK_SCRATCH = {}
+
+
+def _ik_scratch(n_problems: int, dev) -> torch.Tensor:
+    """Workspace of the IK kernel's eigensolver fallback (include/mvmc.h: MVMC_IK_SCRATCH_DOUBLES per problem).
+    One buffer per (device, stream), grown on demand and never read by the host."""
+    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+    buf = _IK_SCRATCH.get(key)
+    if buf is None or buf.shape[0] < n_problems:
+        buf = torch.empty((n_problems, _cabi.IK_SCRATCH_DOUBLES), dtype=torch.float64, device=dev)
+        _IK_SCRATCH[key] = buf
+    return buf
+
+
 def ik_solve(kps17: torch.Tensor, Pmats: torch.Tensor, members: torch.Tensor,
              init_params: Optional[torch.Tensor] = None, cold: Optional[torch.Tensor] = None,
              max_nfev_cold=50, max_nfev_warm=5, skeleton: Optional[MvmcSkeleton] = None, want_info=True):
@@ -233,7 +247,8 @@ def ik_solve(kps17: torch.Tensor, Pmats: torch.Tensor, members: torch.Tensor,
     info = torch.empty((B, 8), dtype=torch.float64, device=dev) if want_info else None
     check(_cabi.load().mvmc_ik_solve(C.byref(sk), _p(kps17), _p(Pmats), _p(members), B, V, Cn, P, _p(init_params),
                                      _p(cold if init_params is not None else None), int(max_nfev_cold),
-                                     int(max_nfev_warm), _p(params), _p(joints), _p(info), _stream()),
+                                     int(max_nfev_warm), _p(params), _p(joints), _p(info), _p(_ik_scratch(B, dev)),
+                                     _stream()),
           "mvmc_ik_solve")
     return params, joints, info
 
