@@ -1,0 +1,21 @@
+"""ALS on the spatio-temporal graphs of the bench workload: iterations and cycles by phase."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, "/root/repo" if os.path.exists("/root/repo/bench.py") else os.getcwd())
+from multiview_motion_capture_amd import synth, device as dev
+from multiview_motion_capture_amd.pipeline import HotPath
+from multiview_motion_capture_amd.tracker import ChainTracker
+L, B = 16, 128
+data = synth.generate(B * L, 5, 4, 20260103, chain_len=L)
+hp = HotPath(data["K"], data["Rt"])
+kps17, cnt = dev.ingest(torch.from_numpy(data["kps25"]).cuda(), torch.from_numpy(data["counts"]).cuda())
+k4 = kps17.view(B, L, 5, 4, 17, 3); c4 = cnt.view(B, L, 5)
+tr = ChainTracker(hp, B, 4)
+its = []
+for t in range(6):
+    o = tr.step(k4[:, t].contiguous(), c4[:, t].contiguous(), want_debug=True)
+    st = o["st"]
+    it = st["iters"].cpu().numpy(); lab = st["labels"].cpu().numpy(); gc = o["group_counts"].cpu().numpy()
+    ph = lab[:, -7:].astype(float)
+    print("frame", t, "n nodes", gc.sum(1).mean(), "gmax", gc.max(), "iters mean %.1f max %d" % (it.mean(), it.max()),
+          "cycles/iter by phase:", ph[it > 0].mean(0).round(0), "sum", ph[it > 0].sum(1).mean().round(0))
