@@ -850,6 +850,300 @@ als2_kernel(const TW* __restrict__ W, const int32_t* __restrict__ gcounts, int G
 }
 
 // ------------------------------------------------------------------------------------------------
+// ALS, latency-oriented variant for few frames per launch: one 256-thread workgroup per frame.
+// The temporal path advances all chains one frame per launch, so a launch holds only a few hundred graphs and
+// its duration is the iteration count of the slowest graph times the latency of one iteration; als2 (one wave
+// per graph) leaves three quarters of each CU idle there.  Here thread (i = tid & 31, h = tid >> 5) owns row i
+// and the column slice [h NS, (h+1) NS) of W/Z/Y/X (NS = NMAX / 8), so the element-wise work, the A^T X1 / B^T X1
+// accumulations and X = A B^T are spread over four waves; the slices' partial sums meet in LDS.  The R x R normal
+// matrices are formed and eliminated by wave 0 (gj_chain) while the other waves accumulate, and one lane per
+// row applies the multipliers.  Same arithmetic per element as als2 except for the summation order of the
+// partial sums.
+// ------------------------------------------------------------------------------------------------
+template <typename TW, int NMAX, int R>
+__device__ __forceinline__ int als4_iterate(const TW* __restrict__ Wf, int ldw, int n, int r, const int* sGid,
+                                            const double* __restrict__ seed, double* sX, double* sA, double* sB,
+                                            double* sG, double* sMul, double* sDinv, double* sHp, double* sRed) {
+    constexpr int NS = NMAX / 8, LDX = NMAX + 1;
+    const int tid = threadIdx.x, i = tid & 31, h = tid >> 5, wv = tid >> 6, lane = tid & 63;
+    const bool row_ok = i < n && i < NMAX;
+    double w[NS], z[NS], y[NS], xp[NS], x1[NS];
+    float w32[NS];
+    unsigned valid = 0, same = 0;
+#pragma unroll
+    for (int c = 0; c < NS; ++c) {
+        const int j = h * NS + c;
+        const bool ok = row_ok && j < n;
+        if (ok) valid |= 1u << c;
+        if (ok && sGid[i] == sGid[j]) same |= 1u << c;
+        if constexpr (sizeof(TW) == 4) {
+            const float a = ok ? (float)Wf[i * ldw + j] : 0.f, b = ok ? (float)Wf[j * ldw + i] : 0.f;
+            w32[c] = fmulr(0.5f, faddr(a, b));
+            w[c] = (double)w32[c];
+        } else {
+            const double a = ok ? (double)Wf[i * ldw + j] : 0., b = ok ? (double)Wf[j * ldw + i] : 0.;
+            w[c] = 0.5 * (a + b);
+            w32[c] = 0.f;
+        }
+        z[c] = w[c]; xp[c] = w[c]; y[c] = 0.0;
+    }
+    for (int e = tid; e < NMAX * R; e += 256) {
+        const int k = e / R, a = e - k * R;
+        sA[e] = (k < n && a < r) ? seed[k * r + a] : 0.0;
+    }
+    __syncthreads();
+    double mu = 64.0;
+    int iters = 1000;
+    const int n4 = (n + 3) & ~3;  // rows beyond n are exact zeros: loops stop at the next multiple of 4
+    // normal matrix of factor F (rows in LDS) into sG; R*R <= 256 entries, one per thread
+    auto normal_matrix = [&](const double* F, double ridge) {
+        if (tid < R * R) {
+            const int a = tid / R, b = tid - a * R;
+            double g0 = (a == b) ? ridge : 0.0, g1 = 0.0;
+#pragma unroll 4
+            for (int k = 0; k < n4; k += 2) { g0 += F[k * R + a] * F[k * R + b]; g1 += F[(k + 1) * R + a] * F[(k + 1) * R + b]; }
+            sG[tid] = g0 + g1;
+        }
+    };
+    // slices' partial right-hand sides -> sHp[wave][row][R]; the two slices of a wave are added by shuffle
+    auto publish_partial = [&](double (&hv)[R]) {
+#pragma unroll
+        for (int a = 0; a < R; ++a) hv[a] += __shfl_xor(hv[a], 32, 64);
+        if ((lane & 32) == 0 && i < NMAX) {
+            double2* dst = reinterpret_cast<double2*>(&sHp[(wv * NMAX + i) * R]);
+#pragma unroll
+            for (int a = 0; a < R; a += 2) dst[a >> 1] = make_double2(hv[a], hv[a + 1]);
+        }
+    };
+    // wave 0 eliminates sG; then one lane per row sums the four partial right-hand sides, applies the
+    // multipliers and writes the factor row
+    auto solve_rows = [&](double* Fout) {
+        __syncthreads();                       // sG and sHp complete
+        if (wv == 0) {
+            double g[R];
+#pragma unroll
+            for (int b = 0; b < R; ++b) g[b] = sG[(lane % R) * R + b];
+            gj_chain<R>(g, sMul, sDinv);
+        }
+        __syncthreads();
+        if (tid < NMAX) {
+            double hv[R];
+#pragma unroll
+            for (int a = 0; a < R; a += 2) {
+                const double2 p0 = *reinterpret_cast<const double2*>(&sHp[(0 * NMAX + tid) * R + a]);
+                const double2 p1 = *reinterpret_cast<const double2*>(&sHp[(1 * NMAX + tid) * R + a]);
+                const double2 p2 = *reinterpret_cast<const double2*>(&sHp[(2 * NMAX + tid) * R + a]);
+                const double2 p3 = *reinterpret_cast<const double2*>(&sHp[(3 * NMAX + tid) * R + a]);
+                hv[a] = (p0.x + p1.x) + (p2.x + p3.x);
+                hv[a + 1] = (p0.y + p1.y) + (p2.y + p3.y);
+            }
+            gj_apply<R>(hv, sMul, sDinv);
+            double2* dst = reinterpret_cast<double2*>(&Fout[tid * R]);
+#pragma unroll
+            for (int a = 0; a < R; a += 2) dst[a >> 1] = make_double2(hv[a], hv[a + 1]);
+        }
+        __syncthreads();
+    };
+    for (int it = 0; it < 1000; ++it) {
+        // ---- X1 = Z - (Y - W + beta)/mu ----
+        const double inv_mu = 1.0 / mu;  // mu = 64 * 2^k: the reciprocal is exact, x * inv_mu == x / mu bit for bit
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {
+            double v = 0.0;
+            if ((valid >> c) & 1) {
+                if (sizeof(TW) == 4 && it == 0) v = (double)(w32[c] - faddr(-w32[c], 0.1f) / 64.f);
+                else v = z[c] - ((y[c] - w[c]) + 0.1) * inv_mu;
+            }
+            x1[c] = v;
+            if (i < NMAX) sX[i * LDX + h * NS + c] = v;
+        }
+        __syncthreads();
+        const double ridge = 50.0 / mu;
+        // ---- B update: (A^T A + ridge I) B[i]^T = A^T X1[:, i]; slice h covers rows k of its column range ----
+        normal_matrix(sA, ridge);
+        {
+            double hv[R];
+#pragma unroll
+            for (int a = 0; a < R; ++a) hv[a] = 0.0;
+            if (i < NMAX) {
+#pragma unroll
+                for (int c = 0; c < NS; ++c) {
+                    const int k = h * NS + c;
+                    const double xv = sX[k * LDX + i];
+                    const double2* ar = reinterpret_cast<const double2*>(&sA[k * R]);
+#pragma unroll
+                    for (int a = 0; a < R; a += 2) { const double2 v2 = ar[a >> 1]; hv[a] += v2.x * xv; hv[a + 1] += v2.y * xv; }
+                }
+            }
+            publish_partial(hv);
+        }
+        solve_rows(sB);
+        // ---- A update: (B^T B + ridge I) A[i]^T = B^T X1[i, :]^T (own row, own columns) ----
+        normal_matrix(sB, ridge);
+        {
+            double av[R];
+#pragma unroll
+            for (int a = 0; a < R; ++a) av[a] = 0.0;
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                const double xv = x1[c];
+                const double2* br = reinterpret_cast<const double2*>(&sB[(h * NS + c) * R]);
+#pragma unroll
+                for (int a = 0; a < R; a += 2) { const double2 v2 = br[a >> 1]; av[a] += v2.x * xv; av[a + 1] += v2.y * xv; }
+            }
+            publish_partial(av);
+        }
+        solve_rows(sA);
+        // ---- X = A B^T, Z, Y, residuals ----
+        double av[R];
+        {
+            const double2* ar = reinterpret_cast<const double2*>(&sA[(i < NMAX ? i : 0) * R]);
+#pragma unroll
+            for (int a = 0; a < R; a += 2) { const double2 v2 = ar[a >> 1]; av[a] = v2.x; av[a + 1] = v2.y; }
+        }
+        double acc_p = 0.0, acc_d = 0.0;
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {
+            const int j = h * NS + c;
+            double xa = 0.0, xb = 0.0;
+            const double2* br = reinterpret_cast<const double2*>(&sB[j * R]);
+#pragma unroll
+            for (int a = 0; a < R; a += 2) { const double2 v2 = br[a >> 1]; xa += av[a] * v2.x; xb += av[a + 1] * v2.y; }
+            const double x = xa + xb;
+            if ((valid >> c) & 1) {
+                double zz = x + y[c] * inv_mu;
+                if ((same >> c) & 1) zz = 0.0;
+                if (i == j) zz = 1.0;
+                zz = zz < 0.0 ? 0.0 : (zz > 1.0 ? 1.0 : zz);
+                const double dz = x - zz, dx = x - xp[c];
+                y[c] = y[c] + mu * dz;
+                z[c] = zz;
+                xp[c] = x;
+                acc_p += dz * dz;
+                acc_d += dx * dx;
+            }
+        }
+        acc_p = wave_sum(acc_p); acc_d = wave_sum(acc_d);
+        if (lane == 0) { sRed[wv] = acc_p; sRed[4 + wv] = acc_d; }
+        __syncthreads();
+        const double p_res = sqrt((sRed[0] + sRed[1]) + (sRed[2] + sRed[3])) / n;
+        const double d_res = mu * sqrt((sRed[4] + sRed[5]) + (sRed[6] + sRed[7])) / n;
+        __syncthreads();  // sRed is rewritten by the next iteration
+        if (p_res < 1e-4 && d_res < 1e-4) { iters = it + 1; break; }
+        if (p_res > 10 * d_res) mu = 2 * mu;
+        else if (d_res > 10 * p_res) mu = mu / 2;
+    }
+    // final X (dense n x n, leading dimension n) for the symmetrise / binarise tail
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NS; ++c)
+        if ((valid >> c) & 1) sX[i * n + h * NS + c] = xp[c];
+    __syncthreads();
+    return iters;
+}
+
+template <typename TW, int NMAX>
+__global__ void __launch_bounds__(256)
+als4_kernel(const TW* __restrict__ W, const int32_t* __restrict__ gcounts, int G, int ldw,
+            const double* __restrict__ seed, int seed_len, uint8_t* __restrict__ x_bin,
+            uint8_t* __restrict__ match_mat, int32_t* __restrict__ labels, int32_t* __restrict__ n_clusters,
+            int32_t* __restrict__ iters_out) {
+    constexpr int RMAX = 16, NT4 = 256;
+    __shared__ double sX[NMAX * (NMAX + 1)];
+    __shared__ __attribute__((aligned(16))) double sA[NMAX * RMAX];
+    __shared__ __attribute__((aligned(16))) double sB[NMAX * RMAX];
+    __shared__ __attribute__((aligned(16))) double sHp[4 * NMAX * RMAX];
+    __shared__ double sG[RMAX * RMAX];
+    __shared__ __attribute__((aligned(16))) double sMul[RMAX * RMAX];
+    __shared__ double sDinv[RMAX], sRed[8];
+    __shared__ int sGid[NMAX];
+    __shared__ uint8_t sVis[NMAX];
+    __shared__ int sKeep[NMAX];
+    __shared__ int s_n, s_r;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        int n = 0, total = 0, gmax = 0;
+        for (int g = 0; g < G; ++g) {
+            int c = gcounts[f * G + g];
+            c = c < 0 ? 0 : c;
+            total += c;
+            for (int k = 0; k < c && n < NMAX; ++k) sGid[n++] = g;
+            if (c > gmax) gmax = c;
+        }
+        s_n = total;
+        const int r = 2 * gmax;
+        s_r = r < total ? r : total;
+    }
+    __syncthreads();
+    const int n = s_n, r = s_r;
+    int32_t* lab = labels + (size_t)f * ldw;
+    if (n == 0 || n > NMAX || n > ldw || r > RMAX || n * r > seed_len) {
+        for (int i = tid; i < ldw; i += NT4) lab[i] = -1;
+        if (tid == 0) { n_clusters[f] = 0; iters_out[f] = (n == 0) ? 0 : -1; }
+        return;
+    }
+    const TW* Wf = W + (size_t)f * ldw * ldw;
+    const int iters = (r <= 8) ? als4_iterate<TW, NMAX, 8>(Wf, ldw, n, r, sGid, seed, sX, sA, sB, sG, sMul, sDinv, sHp, sRed)
+                               : als4_iterate<TW, NMAX, 16>(Wf, ldw, n, r, sGid, seed, sX, sA, sB, sG, sMul, sDinv, sHp, sRed);
+    // ---- tail: X_bin, closure (k = n-1 only), labels -- same rules as als_kernel ----
+    uint8_t* sBin = reinterpret_cast<uint8_t*>(sA);
+    uint8_t* sOut = reinterpret_cast<uint8_t*>(sB);
+    uint8_t* sTmp = reinterpret_cast<uint8_t*>(sHp);
+    for (int e = tid; e < n * n; e += NT4) {
+        const int i = e / n, j = e - i * n;
+        sBin[e] = (0.5 * (sX[i * n + j] + sX[j * n + i])) > 0.5;
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += NT4) {
+        const int i = e / n, j = e - i * n;
+        sOut[e] = 0;
+        sTmp[e] = sBin[e] | (sBin[i * n + (n - 1)] & sBin[(n - 1) * n + j]);
+    }
+    for (int i = tid; i < n; i += NT4) sVis[i] = 0;
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+        const bool skip = sVis[i] != 0;
+        __syncthreads();
+        if (!skip)
+            for (int j = tid; j < n; j += NT4)
+                if (sTmp[i * n + j]) { sVis[j] = 1; sOut[j * n + i] = 1; }
+        __syncthreads();
+    }
+    for (int c = tid; c < n; c += NT4) {
+        int s = 0;
+        for (int j = 0; j < n; ++j) s += sOut[j * n + c];
+        sKeep[c] = s >= 2;
+    }
+    __syncthreads();
+    for (int row = tid; row < ldw; row += NT4) {
+        int label = -1;
+        if (row < n) {
+            int ord = 0;
+            for (int c = 0; c < n; ++c) {
+                if (!sKeep[c]) continue;
+                if (sOut[row * n + c]) { label = ord; break; }
+                ++ord;
+            }
+        }
+        lab[row] = label;
+    }
+    if (tid == 0) {
+        int k = 0;
+        for (int c = 0; c < n; ++c) k += sKeep[c];
+        n_clusters[f] = k;
+        iters_out[f] = iters;
+    }
+    if (x_bin || match_mat) {
+        for (int e = tid; e < ldw * ldw; e += NT4) {
+            const int i = e / ldw, j = e - i * ldw;
+            const bool in = i < n && j < n;
+            if (x_bin) x_bin[(size_t)f * ldw * ldw + e] = in ? sBin[i * n + j] : 0;
+            if (match_mat) match_mat[(size_t)f * ldw * ldw + e] = in ? sOut[i * n + j] : 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // standalone closure + labelling (transform_closure, mv_association.py:99-121; the cluster rule of
 // parse_match_result, motion_capture.py:419-425) for callers that bring their own binary matrix
 // ------------------------------------------------------------------------------------------------
@@ -988,10 +1282,16 @@ static int launch_als(const TW* W, const int32_t* gc, int F, int G, int n_max, i
 #define MVMC_ALS2(NM)                                                                                     \
     hipLaunchKernelGGL((als2_kernel<TW, NM>), dim3(F), dim3(64), 0, s, W, gc, G, n_max, seed, seed_len, xb, mm, \
                        lab, nc, it)
+#define MVMC_ALS4(NM)                                                                                     \
+    hipLaunchKernelGGL((als4_kernel<TW, NM>), dim3(F), dim3(256), 0, s, W, gc, G, n_max, seed, seed_len, xb, mm, \
+                       lab, nc, it)
     // Variants are sized by (max nodes, max rank).  r_max is only the caller's bound (2 x largest group
     // capacity); the kernels check the frame's actual rank and flag iters = -1 if it does not fit.
-    if (n_max <= 24 && r_max <= 16) MVMC_ALS2(24);
-    else if (n_max <= 32 && r_max <= 16) MVMC_ALS2(32);
+    // Few graphs per launch (the temporal path: one frame of every chain): the launch lasts as long as its
+    // slowest graph, so a whole workgroup works on each; many graphs: one wave per graph fills the machine.
+    const bool few = F <= 4096;
+    if (n_max <= 24 && r_max <= 16) { if (few) MVMC_ALS4(24); else MVMC_ALS2(24); }
+    else if (n_max <= 32 && r_max <= 16) { if (few) MVMC_ALS4(32); else MVMC_ALS2(32); }
     else if (n_max <= 24) MVMC_ALS(24, 24, 64);
     else if (n_max <= 32) MVMC_ALS(32, 32, 128);
     else if (n_max <= 64) MVMC_ALS(64, 16, 256);
@@ -999,6 +1299,7 @@ static int launch_als(const TW* W, const int32_t* gc, int F, int G, int n_max, i
     else return MVMC_ERR_UNSUPPORTED;
 #undef MVMC_ALS
 #undef MVMC_ALS2
+#undef MVMC_ALS4
     return MVMC_OK;
 }
 
