@@ -272,7 +272,7 @@ __device__ void ik_normal_matrix(IkShared& S, int stage, double* Y, double* A) {
 // Returns the size of the leading (range) block, or -1 (uniformly) when the eigensolver has to take over.
 // S.sc[4..7] = {beta0, tau0, |J^T J|_inf, coupling}.
 // ---------------------------------------------------------------------------------------------
-__device__ int ik_krylov_model(IkShared& S, int stage) {
+__device__ __noinline__ int ik_krylov_model(IkShared& S, int stage) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int na = S.na[stage];
     double* scr = S.bufB + SCR0;
@@ -394,6 +394,28 @@ __device__ double ik_tr_solve(IkShared& S, int nap, double Delta, double alpha0,
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same routine on the leading block of the Krylov tridiagonal matrix (fast path), one wave: Newton on
+// phi(alpha) with cyclic-reduction solves, then the step back in parameter space (scratch slot SC_QC).
+// Out of line: its register needs (PCR multipliers of six rounds) would otherwise set the budget of the loop
+// around it.
+// ---------------------------------------------------------------------------------------------
+__device__ __noinline__ double ik_tr_solve_krylov(IkShared& S, int kk, int na, double Delta, double alpha0, double gg,
+                                                  double pivmin, double tau0, double coupling, double* pred, double* pnorm) {
+    const int tid = threadIdx.x;
+    double* scr = S.bufB + SCR0;
+    const double al = eightri::tr_solve_tri<false>(scr + 64 * SC_D, scr + 64 * SC_E, scr + 64 * SC_RH, kk, Delta, alpha0, gg,
+                                                   pivmin, nullptr, nullptr, nullptr, nullptr, S.cv, pred, pnorm);
+    double c = tid < kk ? S.cv[tid] : 0.0;
+    if (kk < na) {
+        // component along the first null coordinate: keeps the step orthogonal to the null vector
+        const double eta = coupling * wave_sum_dpp(tid < kk ? scr[64 * SC_WN + tid] * c : 0.0);
+        if (tid == kk) c = eta;
+    }
+    scr[64 * SC_QC + tid] = eightri::apply_q_krylov(S.bufA, scr + 64 * SC_TAU, scr + 64 * SC_V0, tau0, kk, na, c);
+    return al;
+}
+
+// ---------------------------------------------------------------------------------------------
 // trf_no_bounds (trf.py:401-560) with x_scale = 1, linear loss, ftol = xtol = gtol = 1e-8.
 // ---------------------------------------------------------------------------------------------
 __device__ void ik_trf(IkShared& S, const SkelRef& sk, int stage, int max_nfev, double* fb, double* cost_out, int* nfev_out,
@@ -445,15 +467,7 @@ __device__ void ik_trf(IkShared& S, const SkelRef& sk, int stage, int max_nfev, 
                 if (tid < 64) {
                     double pred, pnorm, al;
                     if (fast) {
-                        al = eightri::tr_solve_tri<false>(scr + 64 * SC_D, scr + 64 * SC_E, scr + 64 * SC_RH, kk, Delta, alpha, gg,
-                                                          pivmin, nullptr, nullptr, nullptr, nullptr, S.cv, &pred, &pnorm);
-                        double c = tid < kk ? S.cv[tid] : 0.0;
-                        if (kk < na) {
-                            // component along the first null coordinate: keeps the step orthogonal to the null vector
-                            const double eta = coupling * wave_sum_dpp(tid < kk ? scr[64 * SC_WN + tid] * c : 0.0);
-                            if (tid == kk) c = eta;
-                        }
-                        scr[64 * SC_QC + tid] = eightri::apply_q_krylov(S.bufA, scr + 64 * SC_TAU, scr + 64 * SC_V0, tau0, kk, na, c);
+                        al = ik_tr_solve_krylov(S, kk, na, Delta, alpha, gg, pivmin, tau0, coupling, &pred, &pnorm);
                     } else {
                         al = ik_tr_solve(S, nap, Delta, alpha, gg, &pred, &pnorm);
                     }
@@ -564,6 +578,19 @@ __device__ void dlt_obs_point(const double* pose18 /*[V][18][3]*/, const double*
     X[0] = e[0] / e[3]; X[1] = e[1] / e[3]; X[2] = e[2] / e[3];
 }
 
+// Cold start: DLT of the 18 keypoints + the reference's one-step post-optimisation, hips -> S.xn[0..6).  Out of line
+// (chain heads only; its 4x4 Jacobi arrays should not weigh on the solver's register budget).
+__device__ __noinline__ void ik_cold_root(IkShared& S, const double* pose18, int nv) {
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        double X[3] = {0, 0, 0};
+        if (tid < 18) dlt_obs_point(pose18, S.Pm, nv, tid, 0.01, X);
+        postopt::post_optimize_wave(X, pose18 + (tid < 18 ? tid : 0) * 3, 54, S.Pm, nv, 18);
+        if (tid == 11 || tid == 12)
+            for (int c = 0; c < 3; ++c) S.xn[(tid - 11) * 3 + c] = X[c];
+    }
+}
+
 __global__ void __launch_bounds__(NT, 3)
 ik_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restrict__ Pmats,
           const int32_t* __restrict__ members, int B, int V, int C, int Pmax, const double* __restrict__ init,
@@ -667,13 +694,7 @@ ik_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restr
     if (is_cold) {
         // root = midpoint of the triangulated (post-optimised) hips; zero angles; reference lengths
         // (inverse_kinematics.py:390-396 with triangulate(..., 0.01, post_optimize=True))
-        if (tid < 64) {
-            double X[3] = {0, 0, 0};
-            if (tid < 18) dlt_obs_point(pose18, S.Pm, nv, tid, 0.01, X);
-            postopt::post_optimize_wave(X, pose18 + (tid < 18 ? tid : 0) * 3, 54, S.Pm, nv, 18);
-            if (tid == 11 || tid == 12)
-                for (int c = 0; c < 3; ++c) S.xn[(tid - 11) * 3 + c] = X[c];
-        }
+        ik_cold_root(S, pose18, nv);
         for (int i = tid; i < 54; i += NT) S.x[3 + i] = 0.0;
         if (tid < n_side) { S.side[tid] = S.ref_side[tid]; S.x[57 + tid] = S.ref_side[tid]; }
         __syncthreads();
