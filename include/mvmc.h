@@ -143,8 +143,8 @@ int mvmc_fk(const mvmcSkeleton* skel_host, const double* params, int n_problems,
  *   params_out   (B,68); joints_out (B,18,3); info_out (B,8) f64 =
  *                {cost1, nfev1, status1, cost2, nfev2, status2, njev1+njev2, number of trust-region models that
  *                took the eigensolver fallback (no clean split between range and null space)} or NULL
- *   scratch      (B, MVMC_IK_SCRATCH_DOUBLES) f64 device workspace: the matrices of the eigensolver fallback, touched
- *                only by the (rare) problems that take it; contents undefined before and after */
+ *   scratch      (B, MVMC_IK_SCRATCH_DOUBLES) f64 device workspace: the Householder vectors of each trust-region model
+ *                and the eigenvectors of the (rare) eigensolver fallback; contents undefined before and after */
 #define MVMC_IK_SCRATCH_DOUBLES 7680
 int mvmc_ik_solve(const mvmcSkeleton* skel_host, const double* kps17, const double* Pmats,
                   const int32_t* members, int n_problems, int v_max, int n_views, int p_max,
@@ -209,6 +209,11 @@ int mvmc_debug_eigh(const double* A, const double* g, int n_problems, int n, dou
  * tridiagonalisation's {reflector + publish, matrix-vector + exchange, rank-2 update} phases and their total. */
 int mvmc_debug_trstep(const double* B, const double* r, int n_problems, int m, int n, double Delta, double alpha0,
                       double* step, double* out4, double* phase_cycles, mvmcStream_t stream);
+
+/* Which kernel mvmc_ik_solve launches: 0 = one wave per solve (ik1_kernel, the default); 1 = one 256-thread workgroup
+ * per solve (ik_kernel, the first layout, kept as the A/B reference).  Any other value only queries.  Returns the previous mode (-1 =
+ * not yet chosen: the first mvmc_ik_solve call takes it from the environment variable MVMC_IK_MODE, default 0). */
+int mvmc_debug_ik_mode(int mode);
 
 #ifdef __cplusplus
 }

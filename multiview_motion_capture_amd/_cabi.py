@@ -24,7 +24,7 @@ SYMBOLS = (
     "mvmc_abi_version", "mvmc_status_string", "mvmc_als_seed_table", "mvmc_ingest", "mvmc_fmats",
     "mvmc_affinity", "mvmc_als_associate", "mvmc_closure_labels", "mvmc_cluster_members", "mvmc_dlt", "mvmc_triangulate_postopt", "mvmc_fk", "mvmc_ik_solve",
     "mvmc_fmats_from_projections", "mvmc_st_affinity", "mvmc_track_assign", "mvmc_track_commit", "mvmc_debug_eigh",
-    "mvmc_debug_trstep",
+    "mvmc_debug_trstep", "mvmc_debug_ik_mode",
 )
 
 
@@ -74,6 +74,7 @@ def load():
     lib.mvmc_track_commit.argtypes = [vp] * 4 + [i32] * 4 + [vp] * 8
     lib.mvmc_debug_eigh.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp]
     lib.mvmc_debug_trstep.argtypes = [vp, vp, i32, i32, i32, C.c_double, C.c_double, vp, vp, vp, vp]
+    lib.mvmc_debug_ik_mode.argtypes = [i32]
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError if the library does not export it
         if name not in ("mvmc_status_string",):

@@ -487,13 +487,14 @@ __device__ inline int tridiag_krylov(double (&a)[KQ], const double* g, double* V
 //     term is (ec |w|)^2, which must stay below 1e-8.
 // Returns true if the fast path may be used.  dsc, e2sc: 64 doubles scratch each; lmul, dinv: kk doubles scratch.
 __device__ inline bool krylov_block_ok(const double* d, const double* e, int kk, int n, double anorm, double ec,
-                                       double* dsc, double* e2sc, double* lmul, double* dinv, double* w) {
+                                       double* dsc, double* e2sc, double* lmul, double* dinv, double* w,
+                                       int* why = nullptr) {
     const int lane = threadIdx.x & 63;
     const double ts = anorm > 0.0 ? anorm : 1.0;
     dsc[lane] = lane < kk ? d[lane] / ts : 4.0;
     const double es = lane < kk - 1 ? e[lane] / ts : 0.0;
     e2sc[lane] = es * es;
-    if (sturm_count(dsc, e2sc, (kk - 1 + 7) >> 3, 1e-13) != 0) return false;
+    if (sturm_count(dsc, e2sc, (kk - 1 + 7) >> 3, 1e-13) != 0) { if (why) *why = 2; return false; }
     if (kk == n) return true;
     // T_kk = L D L^T (positive definite by the count above); w = T_kk^-1 e_{kk-1}: forward substitution leaves
     // only the last component, so w_{kk-1} = 1/D_{kk-1} and w_j = -l_j w_{j+1}
@@ -511,6 +512,7 @@ __device__ inline bool krylov_block_ok(const double* d, const double* e, int kk,
         ww += wj * wj;
         if (lane == 0) w[j] = wj;
     }
+    if (why && !(ec * ec * ww <= 1e-8)) *why = 3;
     return ec * ec * ww <= 1e-8;
 }
 

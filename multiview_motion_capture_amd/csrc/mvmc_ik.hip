@@ -17,9 +17,12 @@
 //     eigensolver, where p(alpha) = -V (V^T g / (L + alpha)) with the null cluster removed;
 //   * columns that are identically zero for every input (leaf-joint angles, the root's bone length) are
 //     removed from the problem -- SciPy gives them s = 0 and a zero step, which is what they get here.
+#include <stdlib.h>
+
 #include "mvmc_common.h"
 #include "mvmc_postopt.h"
 #include "mvmc_eigh_tri.h"
+#include "mvmc_ik_shared.h"
 
 namespace {
 
@@ -47,12 +50,6 @@ static_assert(BUFA >= 48 * LD, "D does not fit bufA");
 // fallback eigensolver: three n x n matrices per workgroup in global memory (include/mvmc.h: MVMC_IK_SCRATCH_DOUBLES)
 constexpr int FBM = 2560;
 static_assert(FBM >= NA * LD && 3 * FBM == MVMC_IK_SCRATCH_DOUBLES, "fallback scratch size");
-constexpr int VMAX = 8;    // max views per person
-constexpr int NOBS = 16;   // observed joints per view
-
-// skeleton joint <-> observed keypoint (COCO-17 + synthetic mid-spine at 17); inverse_kinematics.py:366-378
-__device__ __constant__ const int kIkSkel[NOBS] = {1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17};
-__device__ __constant__ const int kIkObs[NOBS] = {11, 13, 15, 12, 14, 16, 17, 5, 7, 9, 6, 8, 10, 0, 3, 4};
 
 struct IkShared {
     double bufA[BUFA];     // D (48 x LD) | Householder vectors of the tridiagonalisation (row k = v_k, KLD apart)
@@ -532,52 +529,6 @@ __device__ void ik_trf(IkShared& S, const SkelRef& sk, int stage, int max_nfev, 
     *cost_out = cost; *nfev_out = nfev; *njev_out = njev; *status_out = status;
 }
 
-// 4x4 symmetric Jacobi for the cold-start DLT of one joint (same scheme as mvmc_geom.hip)
-template <int P, int Q>
-__device__ __forceinline__ void rot4(double (&a)[4][4], double (&v)[4][4]) {
-    const double apq = a[P][Q];
-    if (fabs(apq) < 1e-300) return;
-    const double theta = (a[Q][Q] - a[P][P]) / (2.0 * apq);
-    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { const double x = a[k][P], y = a[k][Q]; a[k][P] = c * x - s * y; a[k][Q] = s * x + c * y; }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { const double x = a[P][k], y = a[Q][k]; a[P][k] = c * x - s * y; a[Q][k] = s * x + c * y; }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { const double x = v[k][P], y = v[k][Q]; v[k][P] = c * x - s * y; v[k][Q] = s * x + c * y; }
-}
-
-// DLT of one observed keypoint (index into the 18-row pose: 17 = mid-spine) over the problem's views
-__device__ void dlt_obs_point(const double* pose18 /*[V][18][3]*/, const double* Pm, int nv, int jo, double min_score,
-                              double* X) {
-    int n_ok = 0;
-    for (int v = 0; v < nv; ++v) n_ok += pose18[(v * 18 + jo) * 3 + 2] >= min_score;
-    const bool use_all = n_ok < 2;
-    double a[4][4], vv[4][4];
-    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { a[r][c] = 0.0; vv[r][c] = (r == c) ? 1.0 : 0.0; }
-    for (int v = 0; v < nv; ++v) {
-        const double* kp = &pose18[(v * 18 + jo) * 3];
-        if (!use_all && !(kp[2] >= min_score)) continue;
-        const double* P = &Pm[v * 12];
-        double r1[4], r2[4];
-        for (int k = 0; k < 4; ++k) { r1[k] = kp[0] * P[8 + k] - P[k]; r2[k] = kp[1] * P[8 + k] - P[4 + k]; }
-        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) a[r][c] += r1[r] * r1[c] + r2[r] * r2[c];
-    }
-    const double tr = a[0][0] + a[1][1] + a[2][2] + a[3][3];
-    for (int sweep = 0; sweep < 16; ++sweep) {
-        const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[0][3] * a[0][3] + a[1][2] * a[1][2] +
-                           a[1][3] * a[1][3] + a[2][3] * a[2][3];
-        if (off <= 1e-36 * tr * tr) break;
-        rot4<0, 1>(a, vv); rot4<0, 2>(a, vv); rot4<0, 3>(a, vv); rot4<1, 2>(a, vv); rot4<1, 3>(a, vv); rot4<2, 3>(a, vv);
-    }
-    int m = 0;
-    for (int k = 1; k < 4; ++k) if (a[k][k] < a[m][m]) m = k;
-    double e[4];
-    for (int r = 0; r < 4; ++r) e[r] = (m == 0) ? vv[r][0] : (m == 1) ? vv[r][1] : (m == 2) ? vv[r][2] : vv[r][3];
-    X[0] = e[0] / e[3]; X[1] = e[1] / e[3]; X[2] = e[2] / e[3];
-}
-
 // Cold start: DLT of the 18 keypoints + the reference's one-step post-optimisation, hips -> S.xn[0..6).  Out of line
 // (chain heads only; its 4x4 Jacobi arrays should not weigh on the solver's register budget).
 __device__ __noinline__ void ik_cold_root(IkShared& S, const double* pose18, int nv) {
@@ -745,6 +696,20 @@ ik_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restr
 
 }  // namespace
 
+// mvmc_ik1.hip
+int mvmc_ik1_launch(const SkelDev& sk, const double* kps17, const double* Pmats, const int32_t* members, int n_problems,
+                    int v_max, int n_views, int p_max, const double* init_params, const uint8_t* cold, int max_nfev_cold,
+                    int max_nfev_warm, double* params_out, double* joints_out, double* info_out, double* scratch,
+                    hipStream_t stream);
+
+// 0: wave-per-solve kernel (default); 1: workgroup-per-solve kernel.  MVMC_IK_MODE in the environment sets the initial value.
+static int g_ik_mode = -1;
+extern "C" int mvmc_debug_ik_mode(int mode) {
+    const int prev = g_ik_mode;
+    if (mode == 0 || mode == 1) g_ik_mode = mode;
+    return prev;
+}
+
 extern "C" int mvmc_ik_solve(const mvmcSkeleton* skel_host, const double* kps17, const double* Pmats,
                              const int32_t* members, int n_problems, int v_max, int n_views, int p_max,
                              const double* init_params, const uint8_t* cold, int max_nfev_cold, int max_nfev_warm,
@@ -757,8 +722,16 @@ extern "C" int mvmc_ik_solve(const mvmcSkeleton* skel_host, const double* kps17,
     SkelDev sk;
     if (!skel_to_dev(skel_host, &sk)) return MVMC_ERR_ARG;
     if (sk.n_side != MVMC_N_SIDE) return MVMC_ERR_UNSUPPORTED;  // the solver is sized for 57 + 11 parameters
+    if (g_ik_mode < 0) {
+        const char* e = getenv("MVMC_IK_MODE");
+        g_ik_mode = (e && e[0] == '1') ? 1 : 0;
+    }
+    const uint8_t* cold_arg = init_params ? cold : nullptr;
+    if (g_ik_mode == 0)
+        return mvmc_ik1_launch(sk, kps17, Pmats, members, n_problems, v_max, n_views, p_max, init_params, cold_arg, max_nfev_cold,
+                               max_nfev_warm, params_out, joints_out, info_out, scratch, (hipStream_t)stream);
     hipLaunchKernelGGL(ik_kernel, dim3(n_problems), dim3(NT), 0, (hipStream_t)stream, sk, kps17, Pmats, members,
-                       n_problems, v_max, n_views, p_max, init_params, init_params ? cold : nullptr, max_nfev_cold,
+                       n_problems, v_max, n_views, p_max, init_params, cold_arg, max_nfev_cold,
                        max_nfev_warm, params_out, joints_out, info_out, scratch);
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;

@@ -1,0 +1,587 @@
+// Temporal inverse kinematics, one WAVE per solve (PoseSolver.solve, inverse_kinematics.py:351-433).
+//
+// Same algorithm as mvmc_ik.hip (analytic-Jacobian TRF, trust-region step in the Krylov tridiagonal basis of
+// (J^T J, g)), re-laid out so that one 64-lane wave owns a person-frame:
+//   * no workgroup barriers: every reduction is a DPP wave reduction, every exchange an in-wave LDS broadcast;
+//   * 15 KB of LDS and <= 168 VGPRs per solve: ten solves per CU instead of three, so the ~2,500 solves that one time
+//     step of the chain protocol launches are all resident at once (the old layout needed 3.3 rounds), and the
+//     association kernels of another chain group can share the CU;
+//   * J^T J = sum_k D_k^T W_k D_k is accumulated with lane = column, all rows in registers; a lane forms its own
+//     column of D_k (cross product of its rotation axis with the lever arm) on the fly, the row-side values come back
+//     from LDS as broadcasts, and the tree sparsity of D_k (only ancestors of joint k move it) is a per-joint row mask;
+//   * the tridiagonalisation runs on that register image (mvmc_tri_w1.h), Householder vectors go to a per-solve
+//     global scratch;
+//   * trust-region solve, block checks and the cold start were single-wave code already (mvmc_eigh_tri.h,
+//     mvmc_postopt.h).
+// A model that does not split cleanly into range and null space (1-2 % of the solves) takes the eigensolver
+// fallback in the T basis (tri_eigh_w1): same semantics as the fallback of mvmc_ik.hip, no second launch.
+#include "mvmc_common.h"
+#include "mvmc_postopt.h"
+#include "mvmc_eigh_tri.h"
+#include "mvmc_tri_w1.h"
+#include "mvmc_ik_shared.h"
+
+namespace {
+
+constexpr int NA1 = 50;  // max active parameters
+
+#ifdef MVMC_IK_PROFILE
+#define P1_T0 const long long _t0 = clock64();
+#define P1_ADD(k) if (threadIdx.x == 0) S.prof[k] += clock64() - _t0;
+#else
+#define P1_T0
+#define P1_ADD(k)
+#endif
+
+// phase-local LDS (S.tmp, 256 doubles):
+//   FK:       Rl [0,162)  off [162,216)
+//   J^T J:    d columns [0,192)
+//   tridiag:  vb [0,64)  pb [64,128)
+//   checks:   dsc [0,64)  e2 [64,128)  lmul [128,192)  dinv [192,256)
+//   tr solve: rh [0,64)  cv [64,128)
+// persistent solver vectors (S.sv): D, E, TAU, V0, WN, 64 doubles each
+enum { SV_D = 0, SV_E = 64, SV_TAU = 128, SV_V0 = 192, SV_WN = 256, SV_COUNT = 320 };
+
+template <int VM>
+struct Ik1Shared {
+    __attribute__((aligned(16))) double tmp[256];
+    double sv[SV_COUNT];
+    double x[68], xn[68], side[18];
+    double pose18[VM * 54], Pm[VM * 12];
+    double Rg[18 * 9], pos[18 * 3], bvec[18 * 3];
+    double hs[18 * 4];      // sin, cos of half the x and y Euler angles of every joint (from the last FK)
+    double Wk[NOBS * 6], tk[NOBS * 3];
+    double dirs[18 * 3], ref_side[18];
+    double sc[8];           // {.., beta0, tau0, |J^T J|_1, coupling} at [4..8)
+    unsigned long long rowmask[2][NOBS];
+    int anc[18];
+    int maxdepth, nviews, na[2], n_side;
+    signed char depth[18], parents[18], side_map[18];
+    unsigned char act[2][NA1], colkind[2][NA1], cola[2][NA1], colc[2][NA1];
+#ifdef MVMC_IK_PROFILE
+    long long prof[8];
+#endif
+};
+
+__device__ __forceinline__ double wave_max64(double v) {
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// R = Rx Ry Rz through the reference's quaternion product (common.h: euler_to_rot), also returning the half-angle
+// sines / cosines of the first two angles
+__device__ inline void euler_to_rot_hs(const double* e, double* R, double* hs) {
+    const double inv = 1.0 / (1.0 + 1e-10);
+    double sx, cx, sy, cy, sz, cz;
+    sincos(e[0] / 2.0, &sx, &cx);
+    sincos(e[1] / 2.0, &sy, &cy);
+    sincos(e[2] / 2.0, &sz, &cz);
+    hs[0] = sx; hs[1] = cx; hs[2] = sy; hs[3] = cy;
+    const double q0[4] = {cx, inv * sx, 0.0, 0.0};
+    const double q1[4] = {cy, 0.0, inv * sy, 0.0};
+    const double q2[4] = {cz, 0.0, 0.0, inv * sz};
+    double q12[4], q[4];
+    quat_mul(q1, q2, q12);
+    quat_mul(q0, q12, q);
+    const double qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+    const double x2 = qx + qx, y2 = qy + qy, z2 = qz + qz;
+    const double xx = qx * x2, yy = qy * y2, wx = qw * x2;
+    const double xy = qx * y2, yz = qy * z2, wy = qw * y2;
+    const double xz = qx * z2, zz = qz * z2, wz = qw * z2;
+    R[0] = 1.0 - (yy + zz); R[1] = xy - wz; R[2] = xz + wy;
+    R[3] = xy + wz; R[4] = 1.0 - (xx + zz); R[5] = yz - wx;
+    R[6] = xz - wy; R[7] = yz + wx; R[8] = 1.0 - (xx + yy);
+}
+
+// ---------------------------------------------------------------------------------------------
+// FK + residual; with want_jac also the per-joint normal-equation blocks W_k (S.Wk) and t_k (S.tk).
+// Lane (k, r) = (lane & 15, lane >> 4) handles observed joint k in the views r, r + 4.  Returns 0.5 |f|^2.
+// ---------------------------------------------------------------------------------------------
+template <int VM>
+__device__ __noinline__ double ik1_eval(Ik1Shared<VM>& S, const double* xs, int stage, bool want_jac) {
+    const int lane = threadIdx.x;
+    double* Rl = S.tmp;
+    double* off = S.tmp + 162;
+    if (lane < 18) {
+        euler_to_rot_hs(xs + 3 + 3 * lane, &Rl[lane * 9], &S.hs[lane * 4]);
+        double len = 0.0;
+        if (lane > 0) len = (stage == 0) ? S.side[S.side_map[lane]] : xs[57 + S.side_map[lane]];
+        for (int k = 0; k < 3; ++k) off[lane * 3 + k] = S.dirs[lane * 3 + k] * len;
+    }
+    __syncthreads();
+    if (lane < 9) S.Rg[lane] = Rl[lane];
+    if (lane < 3) S.pos[lane] = xs[lane];
+    __syncthreads();
+    for (int lev = 1; lev <= S.maxdepth; ++lev) {
+        for (int t = lane; t < 162; t += 64) {
+            const int j = t / 9, e = t - j * 9;
+            if (S.depth[j] == lev) {
+                const int p = S.parents[j], r = e / 3, c = e - r * 3;
+                const double* Gp = &S.Rg[p * 9];
+                const double* Rj = &Rl[j * 9];
+                S.Rg[j * 9 + e] = Gp[r * 3] * Rj[c] + Gp[r * 3 + 1] * Rj[3 + c] + Gp[r * 3 + 2] * Rj[6 + c];
+                if (e < 3) {
+                    S.pos[j * 3 + e] = Gp[e * 3] * off[j * 3] + Gp[e * 3 + 1] * off[j * 3 + 1] +
+                                       Gp[e * 3 + 2] * off[j * 3 + 2] + S.pos[p * 3 + e];
+                    S.bvec[j * 3 + e] = Gp[e * 3] * S.dirs[j * 3] + Gp[e * 3 + 1] * S.dirs[j * 3 + 1] +
+                                        Gp[e * 3 + 2] * S.dirs[j * 3 + 2];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int k = lane & 15, r = lane >> 4;
+    const double* X = &S.pos[kIkSkel[k] * 3];
+    const double X0 = X[0], X1 = X[1], X2 = X[2];
+    double f2 = 0.0, o[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int v = r; v < S.nviews; v += 4) {
+        const double* P = &S.Pm[v * 12];
+        const double h0 = P[0] * X0 + P[1] * X1 + P[2] * X2 + P[3];
+        const double h1 = P[4] * X0 + P[5] * X1 + P[6] * X2 + P[7];
+        const double h2 = P[8] * X0 + P[9] * X1 + P[10] * X2 + P[11];
+        const double w = 1e-5 + h2, iw = 1.0 / w;
+        const double u = h0 / w, vv = h1 / w;
+        const double* ob = &S.pose18[(v * 18 + kIkObs[k]) * 3];
+        const double s = ob[2];
+        const double fu = (u - ob[0]) * s, fv = (vv - ob[1]) * s;
+        f2 += fu * fu + fv * fv;
+        if (want_jac) {
+            double du[3], dv[3];
+            for (int c = 0; c < 3; ++c) {
+                du[c] = (P[c] - u * P[8 + c]) * iw;
+                dv[c] = (P[4 + c] - vv * P[8 + c]) * iw;
+            }
+            const double s2 = s * s;
+            o[0] += s2 * (du[0] * du[0] + dv[0] * dv[0]);
+            o[1] += s2 * (du[0] * du[1] + dv[0] * dv[1]);
+            o[2] += s2 * (du[0] * du[2] + dv[0] * dv[2]);
+            o[3] += s2 * (du[1] * du[1] + dv[1] * dv[1]);
+            o[4] += s2 * (du[1] * du[2] + dv[1] * dv[2]);
+            o[5] += s2 * (du[2] * du[2] + dv[2] * dv[2]);
+            o[6] += s * (du[0] * fu + dv[0] * fv);
+            o[7] += s * (du[1] * fu + dv[1] * fv);
+            o[8] += s * (du[2] * fu + dv[2] * fv);
+        }
+    }
+    const double cost = 0.5 * wave_sum(f2);
+    if (want_jac) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+            o[e] += __shfl_xor(o[e], 16, 64);
+            o[e] += __shfl_xor(o[e], 32, 64);
+        }
+        if (lane < NOBS) {
+#pragma unroll
+            for (int e = 0; e < 6; ++e) S.Wk[lane * 6 + e] = o[e];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) S.tk[lane * 3 + e] = o[6 + e];
+        }
+    }
+    __syncthreads();
+    return cost;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Trust-region model at the last evaluated point (FK state, Wk, tk, hs in LDS):
+//   g = D^T t (one component per lane),  J^T J = sum_k D_k^T W_k D_k into registers,
+//   then -- unless the gradient test or the evaluation budget stops the iteration (the caller's next step is a
+//   break) -- the Krylov tridiagonalisation and the leading-block checks.
+// Returns kk > 0 (fast path: size of the leading block), -m < 0 (eigenbasis path on m rows of T: lam in the WN slot,
+// suf in the D slot, vectors in the global scratch), 0 (stopped after g).
+// *gg = |g|^2, *ginf = |g|_inf.  S.sc[4..8) = {beta0, tau0, |J^T J|_1, coupling}.
+// ---------------------------------------------------------------------------------------------
+template <int VM, int N>
+__device__ __noinline__ int ik1_model(Ik1Shared<VM>& S, int stage, bool budget_left, double gtol, double* __restrict__ hh,
+                                      double* gg_out, double* ginf_out) {
+    const int lane = threadIdx.x;
+    const int na = S.na[stage];
+    const bool on = lane < na;
+    const int cl = on ? lane : 0;
+    const int kind = S.colkind[stage][cl], ja = S.cola[stage][cl], jc = S.colc[stage][cl];
+    // own rotation axis in the world frame and own pivot (kind 1): R_a = Rx Ry Rz inside the parent's frame
+    double ax0 = 0.0, ax1 = 0.0, ax2 = 0.0, pa0 = 0.0, pa1 = 0.0, pa2 = 0.0;
+#ifdef MVMC_IK_PROFILE
+    long long _tp = clock64();
+#define M1STAMP(k) { const long long _t = clock64(); if (lane == 0) S.prof[k] += _t - _tp; _tp = _t; }
+#else
+#define M1STAMP(k)
+#endif
+    if (kind == 1) {
+        const double* h = &S.hs[ja * 4];
+        const double s0 = 2.0 * h[0] * h[1], c0 = h[1] * h[1] - h[0] * h[0];
+        const double s1 = 2.0 * h[2] * h[3], c1 = h[3] * h[3] - h[2] * h[2];
+        double l0, l1, l2;
+        if (jc == 0) { l0 = 1.0; l1 = 0.0; l2 = 0.0; }
+        else if (jc == 1) { l0 = 0.0; l1 = c0; l2 = s0; }
+        else { l0 = s1; l1 = -s0 * c1; l2 = c0 * c1; }
+        if (ja == 0) { ax0 = l0; ax1 = l1; ax2 = l2; }
+        else {
+            const double* Gp = &S.Rg[S.parents[ja] * 9];
+            ax0 = Gp[0] * l0 + Gp[1] * l1 + Gp[2] * l2;
+            ax1 = Gp[3] * l0 + Gp[4] * l1 + Gp[5] * l2;
+            ax2 = Gp[6] * l0 + Gp[7] * l1 + Gp[8] * l2;
+        }
+        pa0 = S.pos[ja * 3]; pa1 = S.pos[ja * 3 + 1]; pa2 = S.pos[ja * 3 + 2];
+    }
+    double a[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) a[i] = 0.0;
+    double gj = 0.0;
+    double* db = S.tmp;
+    for (int k = 0; k < NOBS; ++k) {
+        const int K = kIkSkel[k];
+        double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+        if (on) {
+            if (kind == 0) {
+                d0 = jc == 0 ? 1.0 : 0.0; d1 = jc == 1 ? 1.0 : 0.0; d2 = jc == 2 ? 1.0 : 0.0;
+            } else if (kind == 1) {
+                if ((S.anc[K] >> ja) & 1) {
+                    const double r0 = S.pos[K * 3] - pa0, r1 = S.pos[K * 3 + 1] - pa1, r2 = S.pos[K * 3 + 2] - pa2;
+                    d0 = ax1 * r2 - ax2 * r1; d1 = ax2 * r0 - ax0 * r2; d2 = ax0 * r1 - ax1 * r0;
+                }
+            } else {
+                for (int j = K; j > 0; j = S.parents[j])
+                    if (S.side_map[j] == ja) { d0 += S.bvec[j * 3]; d1 += S.bvec[j * 3 + 1]; d2 += S.bvec[j * 3 + 2]; }
+            }
+        }
+        const double* W = &S.Wk[k * 6];
+        const double y0 = W[0] * d0 + W[1] * d1 + W[2] * d2;
+        const double y1 = W[1] * d0 + W[3] * d1 + W[4] * d2;
+        const double y2 = W[2] * d0 + W[4] * d1 + W[5] * d2;
+        gj += d0 * S.tk[k * 3] + d1 * S.tk[k * 3 + 1] + d2 * S.tk[k * 3 + 2];
+        __syncthreads();  // the previous joint's broadcasts are done
+        db[lane * 3] = d0; db[lane * 3 + 1] = d1; db[lane * 3 + 2] = d2;
+        __syncthreads();
+        // rows in chunks of 8 behind one wave-uniform test each (d_i vanishes on the other rows of a live chunk):
+        // 12 broadcast ds_read_b128 in flight per chunk instead of one LDS round trip per row
+        const unsigned long long m = S.rowmask[stage][k];
+        const unsigned mlo = __builtin_amdgcn_readfirstlane((unsigned)m), mhi = __builtin_amdgcn_readfirstlane((unsigned)(m >> 32));
+#pragma unroll
+        for (int c = 0; c < N; c += 8) {
+            const unsigned byte = c < 32 ? ((mlo >> (c & 31)) & 0xffu) : ((mhi >> (c & 31)) & 0xffu);
+            if (byte) {
+                double2 t[12];
+#pragma unroll
+                for (int u = 0; u < 12; ++u) t[u] = *reinterpret_cast<const double2*>(&db[c * 3 + 2 * u]);
+                const double* tt = reinterpret_cast<const double*>(t);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (c + i < N) a[c + i] += tt[3 * i] * y0 + tt[3 * i + 1] * y1 + tt[3 * i + 2] * y2;
+            }
+        }
+    }
+    __syncthreads();
+    const double gg = wave_sum_dpp(gj * gj), ginf = wave_max64(fabs(gj));
+    *gg_out = gg; *ginf_out = ginf;
+    M1STAMP(4)
+    if (ginf < gtol || !budget_left) return 0;
+    const int kk = eightri::tridiag_krylov_w1<N>(a, gj, hh, na, S.sv + SV_D, S.sv + SV_E, S.sv + SV_TAU, S.sv + SV_V0,
+                                                 S.tmp, S.tmp + 64, &S.sc[4]);
+    M1STAMP(5)
+    bool ok = kk > 0;
+    if (ok) ok = eightri::krylov_block_ok(S.sv + SV_D, S.sv + SV_E, kk, na, S.sc[6], S.sc[7], S.tmp, S.tmp + 64, S.tmp + 128,
+                                          S.tmp + 192, S.sv + SV_WN);
+    __syncthreads();
+    M1STAMP(6)
+    if (ok) return kk;
+    // No clean split between range and null space (weakly observed directions, missing joints): the step is taken
+    // in the eigenbasis of the tridiagonal matrix instead, with the numerically-null cluster removed -- the
+    // eigensolver fallback of mvmc_ik.hip in the T basis, where suf = V^T g = beta0 * (first components).
+    //   unclean collapse:  T is complete (na rows);   clean collapse: the leading block plus its coupling row.
+    const int m = kk < 0 ? na : (kk < na ? kk + 1 : na);
+    double* Zg = hh + 64 * NA1;
+    eightri::tri_eigh_w1<N>(S.sv + SV_D, S.sv + SV_E, m, S.sv + SV_WN, Zg, S.tmp, S.tmp + 64, S.tmp + 128);
+    const double suf = lane < m ? S.sc[4] * Zg[lane] : 0.0;
+    __syncthreads();
+    S.sv[SV_D + lane] = suf;   // d, e are dead: lam lives in the WN slot, suf in the D slot
+    __syncthreads();
+    return -m;
+}
+
+// ---------------------------------------------------------------------------------------------
+// trf_no_bounds (trf.py:401-560) with x_scale = 1, linear loss, ftol = xtol = gtol = 1e-8 -- the loop of ik_trf
+// in mvmc_ik.hip on one wave.
+// ---------------------------------------------------------------------------------------------
+template <int VM>
+__device__ void ik1_trf(Ik1Shared<VM>& S, int stage, int max_nfev, double* __restrict__ hh, double* cost_out, int* nfev_out,
+                        int* njev_out, int* status_out, int* fallbacks_out) {
+    const int lane = threadIdx.x;
+    const int nfull = (stage == 0) ? 57 : 57 + S.n_side;
+    const int na = S.na[stage];
+    const double ftol = 1e-8, xtol = 1e-8, gtol = 1e-8;
+    auto x_norm2 = [&]() {
+        double xx = (lane < nfull) ? S.x[lane] * S.x[lane] : 0.0;
+        if (lane + 64 < nfull) xx += S.x[lane + 64] * S.x[lane + 64];
+        return wave_sum(xx);
+    };
+    double cost;
+    { P1_T0 cost = ik1_eval(S, S.x, stage, true); P1_ADD(0) }
+    int nfev = 1, njev = 0, status = -1;
+    double Delta = sqrt(x_norm2());
+    if (Delta == 0.0) Delta = 1.0;
+    double alpha = 0.0, gg = 0.0, ginf = 1.0;
+    bool need_model = true;
+    int kk = 0;
+    while (true) {
+        if (need_model) {
+            P1_T0
+            kk = (na <= 40) ? ik1_model<VM, 40>(S, stage, nfev < max_nfev, gtol, hh, &gg, &ginf)
+                            : ik1_model<VM, 50>(S, stage, nfev < max_nfev, gtol, hh, &gg, &ginf);
+            ++njev;
+            need_model = false;
+            P1_ADD(2)
+        }
+        if (ginf < gtol) status = 1;
+        if (status != -1 || nfev == max_nfev) break;
+        const bool fast = kk > 0;
+        const int mq = fast ? kk : -kk;   // rows of the T basis in use
+        if (!fast) ++*fallbacks_out;
+        const double beta0 = S.sc[4], tau0 = S.sc[5], pivmin = 1e-16 * S.sc[6] + 1e-300, coupling = S.sc[7];
+
+        double actual = -1.0, cost_new = cost;
+        while (actual <= 0.0 && nfev < max_nfev) {
+            double pred, step_norm, stepj;
+            {
+                P1_T0
+                double* rh = S.tmp;
+                double* cv = S.tmp + 64;
+                double c;
+                if (fast) {
+                    rh[lane] = lane == 0 ? beta0 : 0.0;
+                    __syncthreads();
+                    alpha = eightri::tr_solve_tri<false>(S.sv + SV_D, S.sv + SV_E, rh, kk, Delta, alpha, gg, pivmin, nullptr,
+                                                         nullptr, nullptr, nullptr, cv, &pred, &step_norm);
+                    __syncthreads();
+                    c = lane < kk ? cv[lane] : 0.0;
+                    if (kk < na) {
+                        // component along the first null coordinate: keeps the step orthogonal to the null vector
+                        const double eta = coupling * wave_sum_dpp(lane < kk ? S.sv[SV_WN + lane] * c : 0.0);
+                        if (lane == kk) c = eta;
+                    }
+                } else {
+                    alpha = eightri::tr_solve_eig_w1(S.sv + SV_WN, S.sv + SV_D, mq, Delta, alpha, gg, cv, &pred, &step_norm);
+                    __syncthreads();
+                    c = eightri::eig_combine_w1(hh + 64 * NA1, mq, lane < mq ? cv[lane] : 0.0);
+                }
+                stepj = eightri::apply_q_w1(hh, S.sv + SV_TAU, S.sv + SV_V0, tau0, mq, na, c);
+                P1_ADD(3)
+            }
+            const double x_norm = sqrt(x_norm2());
+            if (lane < nfull) S.xn[lane] = S.x[lane];
+            if (lane + 64 < nfull) S.xn[lane + 64] = S.x[lane + 64];
+            __syncthreads();
+            if (lane < na) { const int f = S.act[stage][lane]; S.xn[f] = S.x[f] + stepj; }
+            __syncthreads();
+            { P1_T0 cost_new = ik1_eval(S, S.xn, stage, true); P1_ADD(0) }
+            ++nfev;
+            if (!isfinite(cost_new)) { Delta = 0.25 * step_norm; continue; }
+            actual = cost - cost_new;
+            // update_tr_radius (common.py:222-245)
+            double ratio;
+            if (pred > 0.0) ratio = actual / pred;
+            else if (pred == 0.0 && actual == 0.0) ratio = 1.0;
+            else ratio = 0.0;
+            double Delta_new = Delta;
+            if (ratio < 0.25) Delta_new = 0.25 * step_norm;
+            else if (ratio > 0.75 && step_norm > 0.95 * Delta) Delta_new = Delta * 2.0;
+            // check_termination (common.py:705-717)
+            const bool f_ok = (actual < ftol * cost) && (ratio > 0.25);
+            const bool x_ok = step_norm < xtol * (xtol + x_norm);
+            if (f_ok && x_ok) status = 4; else if (f_ok) status = 2; else if (x_ok) status = 3;
+            if (status != -1) break;
+            alpha *= Delta / Delta_new;
+            Delta = Delta_new;
+        }
+        if (actual > 0.0) {
+            if (lane < nfull) S.x[lane] = S.xn[lane];
+            if (lane + 64 < nfull) S.x[lane + 64] = S.xn[lane + 64];
+            __syncthreads();
+            cost = cost_new;
+            // the accepted point's FK state and blocks are still in LDS (the last evaluation was at xn)
+            need_model = status == -1 && nfev < max_nfev;
+        }
+    }
+    if (status == -1) status = 0;
+    *cost_out = cost; *nfev_out = nfev; *njev_out = njev; *status_out = status;
+}
+
+// Cold start: DLT of the 18 keypoints + the reference's one-step post-optimisation; hips -> S.xn[0..6)
+template <int VM>
+__device__ __noinline__ void ik1_cold_root(Ik1Shared<VM>& S, int nv) {
+    const int lane = threadIdx.x;
+    double X[3] = {0, 0, 0};
+    if (lane < 18) dlt_obs_point(S.pose18, S.Pm, nv, lane, 0.01, X);
+    postopt::post_optimize_wave(X, S.pose18 + (lane < 18 ? lane : 0) * 3, 54, S.Pm, nv, 18);
+    if (lane == 11 || lane == 12)
+        for (int c = 0; c < 3; ++c) S.xn[(lane - 11) * 3 + c] = X[c];
+}
+
+template <int VM>
+__global__ void __launch_bounds__(64, 3)
+ik1_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restrict__ Pmats,
+           const int32_t* __restrict__ members, int B, int V, int C, int Pmax, const double* __restrict__ init,
+           const uint8_t* __restrict__ cold, int nfev_cold, int nfev_warm, double* __restrict__ params_out,
+           double* __restrict__ joints_out, double* __restrict__ info_out, double* __restrict__ scratch) {
+    __shared__ Ik1Shared<VM> S;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    double* hh = scratch + (size_t)b * MVMC_IK_SCRATCH_DOUBLES;   // Householder vectors [0, 3200), eigenvectors [3200, 6400)
+    double* info = info_out ? info_out + (size_t)b * 8 : nullptr;
+    // views of this problem (the reference only solves clusters with >= 2 views: motion_capture.py:927,940)
+    int q_own = -1;
+    {
+        int nv = 0;
+        for (int v = 0; v < V; ++v) {
+            const int m = members[(size_t)b * V + v];
+            if (m >= 0) { if (nv == lane) q_own = m; ++nv; }
+        }
+        if (nv > VM) nv = VM;
+        if (nv < 2) {
+            const double nan = __longlong_as_double(0x7ff8000000000000LL);
+            for (int i = lane; i < 68; i += 64) params_out[(size_t)b * 68 + i] = nan;
+            if (lane < 54) joints_out[(size_t)b * 54 + lane] = nan;
+            if (info && lane < 8) info[lane] = nan;
+            return;
+        }
+        if (lane == 0) S.nviews = nv;
+    }
+    const int n_side = skarg.n_side;
+    if (lane < 18) {
+        for (int k = 0; k < 3; ++k) S.dirs[lane * 3 + k] = skarg.dirs[lane][k];
+        S.parents[lane] = (signed char)skarg.parents[lane];
+        S.side_map[lane] = (signed char)skarg.side_map[lane];
+        S.ref_side[lane] = skarg.ref_side[lane];
+    }
+    __syncthreads();
+    // ---- static tables: depth, ancestor masks, active columns and row masks of both stages ----
+    if (lane < 18) {
+        int d = 0, m = 0;
+        for (int a = S.parents[lane]; a >= 0; a = S.parents[a]) { ++d; m |= 1 << a; }
+        S.depth[lane] = (signed char)d; S.anc[lane] = m;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        int md = 0, moved = 0, lens = 0;  // joints whose rotation moves an observed joint; used length slots
+        for (int j = 0; j < 18; ++j) md = S.depth[j] > md ? S.depth[j] : md;
+        S.maxdepth = md;
+        S.n_side = n_side;
+        for (int k = 0; k < NOBS; ++k) {
+            const int K = kIkSkel[k];
+            moved |= S.anc[K];
+            for (int j = K; j > 0; j = S.parents[j]) {
+                const double* d = &S.dirs[j * 3];
+                if (d[0] != 0.0 || d[1] != 0.0 || d[2] != 0.0) lens |= 1 << S.side_map[j];
+            }
+        }
+        for (int st = 0; st < 2; ++st) {
+            int n = 0;
+            for (int c = 0; c < 3; ++c) { S.act[st][n] = c; S.colkind[st][n] = 0; S.cola[st][n] = 0; S.colc[st][n] = c; ++n; }
+            for (int a = 0; a < 18; ++a)
+                if ((moved >> a) & 1)
+                    for (int c = 0; c < 3 && n < NA1; ++c) {
+                        S.act[st][n] = 3 + 3 * a + c; S.colkind[st][n] = 1; S.cola[st][n] = a; S.colc[st][n] = c; ++n;
+                    }
+            if (st == 1)
+                for (int s = 0; s < n_side && n < NA1; ++s)
+                    if ((lens >> s) & 1) { S.act[st][n] = 57 + s; S.colkind[st][n] = 2; S.cola[st][n] = s; S.colc[st][n] = 0; ++n; }
+            S.na[st] = n;
+        }
+    }
+    __syncthreads();
+    if (lane < 2 * NOBS) {
+        const int st = lane >> 4, k = lane & 15, K = kIkSkel[k];
+        unsigned long long m = 0;
+        for (int col = 0; col < S.na[st]; ++col) {
+            const int kind = S.colkind[st][col], a = S.cola[st][col];
+            bool nz = kind == 0;
+            if (kind == 1) nz = (S.anc[K] >> a) & 1;
+            if (kind == 2)
+                for (int j = K; j > 0; j = S.parents[j]) nz |= S.side_map[j] == a;
+            if (nz) m |= 1ull << col;
+        }
+        S.rowmask[st][k] = m;
+    }
+    // ---- observations: 17 COCO rows + synthetic mid-spine (inverse_kinematics.py:339-348), projection matrices ----
+    const int nv = S.nviews;
+    if (lane < nv) {
+        const double* kp = kps17 + (size_t)q_own * 51;
+        double* dst = S.pose18 + lane * 54;
+        for (int e = 0; e < 51; ++e) dst[e] = kp[e];
+        for (int c = 0; c < 2; ++c) {
+            const double mid_sh = 0.5 * (kp[5 * 3 + c] + kp[6 * 3 + c]);
+            const double mid_hip = 0.5 * (kp[11 * 3 + c] + kp[12 * 3 + c]);
+            dst[51 + c] = 0.5 * (mid_sh + mid_hip);
+        }
+        double sc = kp[5 * 3 + 2] * kp[6 * 3 + 2];
+        sc *= kp[11 * 3 + 2] * kp[12 * 3 + 2];
+        dst[53] = sc;
+        const double* Pc = Pmats + (size_t)((q_own / Pmax) % C) * 12;
+        for (int e = 0; e < 12; ++e) S.Pm[lane * 12 + e] = Pc[e];
+    }
+    __syncthreads();
+    // ---- initial parameters ----
+    const bool is_cold = (cold == nullptr) || cold[b] != 0;
+    if (is_cold) {
+        // root = midpoint of the triangulated (post-optimised) hips; zero angles; reference lengths
+        // (inverse_kinematics.py:390-396 with triangulate(..., 0.01, post_optimize=True))
+        ik1_cold_root(S, nv);
+        if (lane < 54) S.x[3 + lane] = 0.0;
+        if (lane < n_side) { S.side[lane] = S.ref_side[lane]; S.x[57 + lane] = S.ref_side[lane]; }
+        __syncthreads();
+        if (lane < 3) S.x[lane] = 0.5 * (S.xn[lane] + S.xn[3 + lane]);
+    } else {
+        const double* p0 = init + (size_t)b * 68;
+        for (int i = lane; i < 57 + n_side; i += 64) S.x[i] = p0[i];
+        if (lane < n_side) S.side[lane] = p0[57 + lane];
+    }
+    __syncthreads();
+#ifdef MVMC_IK_PROFILE
+    if (lane < 8) S.prof[lane] = 0;
+    const long long t_all = clock64();
+    __syncthreads();
+#endif
+    const int max_nfev = is_cold ? nfev_cold : nfev_warm;
+    double costs[2];
+    int nfs[2], njs[2], sts[2], fallbacks = 0;
+#pragma unroll 1
+    for (int stage = 0; stage < 2; ++stage) {
+        double c = 0.0; int nf = 0, nj = 0, st = 0;
+        ik1_trf(S, stage, max_nfev, hh, &c, &nf, &nj, &st, &fallbacks);
+        costs[stage] = c; nfs[stage] = nf; njs[stage] = nj; sts[stage] = st;
+        __syncthreads();
+    }
+    ik1_eval(S, S.x, 1, false);  // final FK at the solution
+    for (int i = lane; i < 57 + n_side; i += 64) params_out[(size_t)b * 68 + i] = S.x[i];
+    if (lane < 54) joints_out[(size_t)b * 54 + lane] = S.pos[lane];
+    if (lane == 0) {
+        if (info) {
+            info[0] = costs[0]; info[1] = nfs[0]; info[2] = sts[0]; info[3] = costs[1]; info[4] = nfs[1]; info[5] = sts[1];
+            info[6] = njs[0] + njs[1]; info[7] = fallbacks;
+#ifdef MVMC_IK_PROFILE
+            // diagnostic build only: cycle counts instead of the costs (same slots as ik_kernel's)
+            info[0] = (double)S.prof[0]; info[3] = 0.0; info[2] = (double)S.prof[2];
+            info[5] = (double)(clock64() - t_all); info[7] = (double)S.prof[3];
+            info[1] = (double)S.prof[4]; info[4] = (double)S.prof[5]; info[6] = (double)S.prof[6];
+#endif
+        }
+    }
+}
+
+}  // namespace
+
+// launcher used by mvmc_ik_solve (mvmc_ik.hip)
+int mvmc_ik1_launch(const SkelDev& sk, const double* kps17, const double* Pmats, const int32_t* members, int n_problems,
+                    int v_max, int n_views, int p_max, const double* init_params, const uint8_t* cold, int max_nfev_cold,
+                    int max_nfev_warm, double* params_out, double* joints_out, double* info_out, double* scratch,
+                    hipStream_t stream) {
+    if (v_max <= 6) {
+        hipLaunchKernelGGL(ik1_kernel<6>, dim3(n_problems), dim3(64), 0, stream, sk, kps17, Pmats, members, n_problems, v_max,
+                           n_views, p_max, init_params, cold, max_nfev_cold, max_nfev_warm, params_out, joints_out, info_out,
+                           scratch);
+    } else {
+        hipLaunchKernelGGL(ik1_kernel<VMAX>, dim3(n_problems), dim3(64), 0, stream, sk, kps17, Pmats, members, n_problems,
+                           v_max, n_views, p_max, init_params, cold, max_nfev_cold, max_nfev_warm, params_out, joints_out,
+                           info_out, scratch);
+    }
+    MVMC_CHECK_LAUNCH();
+    return MVMC_OK;
+}

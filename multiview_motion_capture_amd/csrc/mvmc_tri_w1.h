@@ -1,0 +1,428 @@
+// The Krylov tridiagonalisation of mvmc_eigh_tri.h on ONE wave (mvmc_ik1.hip: one wave per solve, no workgroup
+// barriers).  Lane l owns column l of the symmetric matrix and keeps all N rows in registers: a[i] = M[i][l].
+// Per step: the reflector of row k (one wave reduction), then p = tau M v and the rank-2 update with the row-side
+// values v_i, w_i read back from LDS as broadcasts (two values per ds_read_b128) -- three FMAs per live row and
+// lane and no cross-lane VALU traffic in the inner loops.  Rows <= k are dead (never read again; their diagonal
+// entry survives because v vanishes there) and are skipped in pairs.  The Householder vectors go to global memory,
+// hh[k * 64 + lane] (coalesced 512-byte rows, read back by apply_q_w1): the matrix registers are needed by the rest
+// of the solver.
+#pragma once
+#include "mvmc_common.h"
+#include "mvmc_eigh_tri.h"
+
+namespace eightri {
+
+#define MVMC_ROWS50(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) \
+    X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37)  \
+    X(38) X(39) X(40) X(41) X(42) X(43) X(44) X(45) X(46) X(47) X(48) X(49)
+
+// a[k] for a wave-uniform k (register arrays need static indices)
+template <int N>
+__device__ __forceinline__ double row_of(const double (&a)[N], int k) {
+    double x = 0.0;
+#define MVMC_ROWCASE(Z) case Z: if constexpr (Z < N) x = a[Z]; break;
+    switch (k) { MVMC_ROWS50(MVMC_ROWCASE) default: break; }
+#undef MVMC_ROWCASE
+    return x;
+}
+
+//   a[N]: the matrix (destroyed); gj: g[lane]; n <= N active size; d, e, tau, v0: LDS, 64 doubles each;
+//   vb, pb: LDS exchange vectors, 64 doubles each, 16-byte aligned; out4 = {beta0, tau0, |M|_1, coupling}.
+// Same stopping rules as tridiag_krylov: returns the size kk of the leading (range) block (d[0..kk], e[0..kk-1],
+// tau[0..kk-1) valid; d[kk] is the first diagonal entry of the null block), n if no sub-diagonal collapses, and -1 if
+// one collapses in front of a block that is not null -- the tridiagonalisation is then complete (all n rows) and
+// meant for tri_eigh_w1.
+template <int N>
+__device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, double* __restrict__ hh, int n, double* d,
+                                                 double* e, double* tau, double* v0, double* vb, double* pb, double* out4) {
+    static_assert(N % 2 == 0 && N <= 50, "row count");
+    const int lane = threadIdx.x & 63;
+    auto wave_max = [](double v) {
+        for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+        return v;
+    };
+    auto lane_value = [](double v, int src) {  // v of lane src (uniform) as a scalar
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+    };
+    auto reflector = [&](double alpha, double sig, double& tk, double& beta, double& sc) {
+        tk = 0.0; beta = alpha; sc = 0.0;
+        if (sig > 0.0) {
+            const double q2 = alpha * alpha + sig;
+            double rs = __builtin_amdgcn_rsq(q2);
+            rs = rs * (1.5 - 0.5 * q2 * rs * rs);
+            rs = rs * (1.5 - 0.5 * q2 * rs * rs);
+            const double nrm = q2 * rs;
+            beta = alpha >= 0.0 ? -nrm : nrm;
+            tk = 1.0 - alpha * fast_rcp64(beta);
+            sc = fast_rcp64(alpha - beta);
+        }
+    };
+    // M <- H M H with H = I - tk v v^T; rows > k only, in chunks of CH rows behind one wave-uniform test each (a
+    // test per row would put a full LDS round trip in front of every FMA; v vanishes on the dead rows of a live chunk)
+    constexpr int CH = 10;
+    static_assert(N % CH == 0, "rows per chunk");
+    auto two_sided = [&](int k, double tk, double vj) {
+        vb[lane] = vj;
+        __syncthreads();
+        double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < N; c += CH)
+            if (c + CH - 1 > k) {
+                double2 v2[CH / 2];
+#pragma unroll
+                for (int u = 0; u < CH / 2; ++u) v2[u] = *reinterpret_cast<const double2*>(&vb[c + 2 * u]);
+#pragma unroll
+                for (int u = 0; u < CH / 2; ++u) { p0 += a[c + 2 * u] * v2[u].x; p1 += a[c + 2 * u + 1] * v2[u].y; }
+            }
+        const double p = tk * (p0 + p1);
+        const double h = 0.5 * tk * wave_sum_dpp(p * vj);
+        const double wj = p - h * vj;
+        pb[lane] = wj;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < N; c += CH)
+            if (c + CH - 1 > k) {
+                // two batches of loads per chunk (6 + 4 rows): ten 16-byte broadcasts in flight at once would push the
+                // N = 50 instance over its register budget
+#pragma unroll
+                for (int h0 = 0; h0 < CH / 2; h0 += 3) {
+                    constexpr int HB = 3;
+                    double2 v2[HB], w2[HB];
+#pragma unroll
+                    for (int u = 0; u < HB; ++u)
+                        if (h0 + u < CH / 2) {
+                            v2[u] = *reinterpret_cast<const double2*>(&vb[c + 2 * (h0 + u)]);
+                            w2[u] = *reinterpret_cast<const double2*>(&pb[c + 2 * (h0 + u)]);
+                        }
+#pragma unroll
+                    for (int u = 0; u < HB; ++u)
+                        if (h0 + u < CH / 2) {
+                            const int i = c + 2 * (h0 + u);
+                            a[i] = fma(-w2[u].x, vj, fma(-v2[u].x, wj, a[i]));
+                            a[i + 1] = fma(-w2[u].y, vj, fma(-v2[u].y, wj, a[i + 1]));
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        __syncthreads();  // vb / pb are rewritten by the next step
+    };
+    double anorm;
+    {
+        double cs = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) cs += fabs(a[i]);
+        anorm = wave_max(cs);
+    }
+    const double tol_c = 1e-8 * anorm, tol_n = 1e-13 * anorm;
+    double coupling = 0.0;
+    {   // first reflector: H_g g = beta0 e_1
+        const double x = lane < n ? gj : 0.0;
+        const double alpha = lane_value(x, 0);
+        const double sig = wave_sum_dpp(lane > 0 ? x * x : 0.0);
+        double tk, beta, sc;
+        reflector(alpha, sig, tk, beta, sc);
+        const double v = lane == 0 ? 1.0 : x * sc;
+        v0[lane] = v;
+        if (lane == 0) { out4[0] = beta; out4[1] = tk; out4[2] = anorm; }
+        if (tk != 0.0) two_sided(-1, tk, v);
+    }
+    int kk = n;
+    bool unclean = false;
+    for (int k = 0; k < n - 1; ++k) {
+        const int j1 = k + 1;
+        const double x = row_of<N>(a, k);
+        if (lane == k) d[k] = x;
+        const double alpha = lane_value(x, j1);
+        const double sig = wave_sum_dpp((lane > j1 && lane < n) ? x * x : 0.0);
+        double tk, beta, sc;
+        reflector(alpha, sig, tk, beta, sc);
+        const double v = lane == j1 ? 1.0 : ((lane > j1 && lane < n) ? x * sc : 0.0);
+        hh[k * 64 + lane] = v;
+        if (lane == 0) { e[k] = beta; tau[k] = tk; }
+        if (!unclean && fabs(beta) <= tol_c) {
+            // the Krylov space is exhausted: everything behind row k must be the null space
+            double m = 0.0;
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                if (i > k && lane > k) m = fmax(m, fabs(a[i]));
+            m = wave_max(m);
+            if (m <= tol_n) {
+                if (lane == 0) tau[k] = 0.0;
+                coupling = beta;
+                kk = k + 1;
+                const double xt = row_of<N>(a, j1);   // first diagonal entry of the null block (eigensolver path)
+                if (lane == j1) d[j1] = xt;
+                break;
+            }
+            // not null: no clean split.  The tridiagonalisation is completed (plain Householder steps from here) for
+            // the in-wave eigensolver; the return value says so.
+            unclean = true;
+        }
+        if (tk != 0.0) two_sided(k, tk, v);
+    }
+    if (kk == n) {   // ran to the end: the last diagonal entry
+        const double x = row_of<N>(a, n - 1);
+        if (lane == n - 1) d[n - 1] = x;
+    }
+    if (lane == 0) out4[3] = coupling;
+    __syncthreads();
+    return unclean ? -1 : kk;
+}
+
+// Q c for tridiag_krylov_w1 (one wave; lane j holds component j): reflectors kk-2 .. 0 from hh, then the first one.
+__device__ inline double apply_q_w1(const double* __restrict__ hh, const double* tau, const double* v0, double tau0, int kk,
+                                    int n, double cj) {
+    const int lane = threadIdx.x & 63;
+    int k = kk - 2;
+    for (; k >= 3; k -= 4) {   // four rows in flight: the loads do not depend on the running vector
+        const double va = hh[k * 64 + lane], vb = hh[(k - 1) * 64 + lane], vc = hh[(k - 2) * 64 + lane],
+                     vd = hh[(k - 3) * 64 + lane];
+        const double ta = tau[k], tb = tau[k - 1], tc = tau[k - 2], td = tau[k - 3];
+        cj -= ta * wave_sum_dpp(va * cj) * va;
+        cj -= tb * wave_sum_dpp(vb * cj) * vb;
+        cj -= tc * wave_sum_dpp(vc * cj) * vc;
+        cj -= td * wave_sum_dpp(vd * cj) * vd;
+    }
+    for (; k >= 0; --k) {
+        const double v = hh[k * 64 + lane];
+        cj -= tau[k] * wave_sum_dpp(v * cj) * v;
+    }
+    if (tau0 != 0.0) {
+        const double v = lane < n ? v0[lane] : 0.0;
+        cj -= tau0 * wave_sum_dpp(v * cj) * v;
+    }
+    return cj;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Eigendecomposition of the m x m tridiagonal T (d, e) on one wave -- the single-wave form of steps 2-3b of eigh():
+// lane i owns eigenpair i.  Eigenvalues by bisection on Sturm counts (60 halvings of the Gershgorin interval),
+// eigenvectors by twisted factorisation with the forward pivots in registers and the backward pivots parked in
+// global memory (Zg, which then receives the vectors), runs of close eigenvalues (gap < 1e-7 lam_max)
+// re-orthogonalised by classical Gram-Schmidt through v_readlane.  The numerically-null cluster
+// (lam <= 1e-13 lam_max) is not resolved: zero vectors, zero eigenvalues, as in eigh().
+//   lam[0..64) (LDS, ascending; 0 beyond m), Zg[j * 64 + i] = component j of eigenvector i (global, m rows),
+//   dsc, e2sc, wsh: 64 doubles of LDS scratch each.  Returns the size k0 of the null cluster.
+// No back-transformation: the caller works in the T basis (Q^T g = beta0 e_1 there) and applies Q to the one vector
+// it needs (apply_q_w1).
+// ---------------------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __noinline__ int tri_eigh_w1(const double* d, const double* e, int m, double* lam, double* __restrict__ Zg,
+                                        double* dsc, double* e2sc, double* wsh) {
+    const int lane = threadIdx.x & 63;
+    auto lane_value = [](double v, int src) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+    };
+    // ---- eigenvalues ----
+    double lo, hi, tscale;
+    {
+        double gl = 1e300, gu = -1e300;
+        if (lane < m) {
+            const double r = (lane > 0 ? fabs(e[lane - 1]) : 0.0) + (lane < m - 1 ? fabs(e[lane]) : 0.0);
+            gl = d[lane] - r; gu = d[lane] + r;
+        }
+        for (int off = 32; off > 0; off >>= 1) { gl = fmin(gl, __shfl_xor(gl, off, 64)); gu = fmax(gu, __shfl_xor(gu, off, 64)); }
+        const double bn = fmax(fabs(gl), fabs(gu));
+        tscale = bn > 0.0 ? bn : 1.0;
+        lo = (gl - 2.2e-14 * bn) / tscale - 1e-290; hi = (gu + 2.2e-14 * bn) / tscale + 1e-290;
+    }
+    dsc[lane] = lane < m ? d[lane] / tscale : 4.0;
+    {
+        const double es = lane < m - 1 ? e[lane] / tscale : 0.0;
+        e2sc[lane] = es * es;
+    }
+    __syncthreads();
+    const int nblk = (m - 1 + 7) >> 3;
+    for (int round = 0; round < 60; ++round) {
+        const double mid = 0.5 * (lo + hi);
+        const int c = sturm_count(dsc, e2sc, nblk, mid);
+        if (c > lane) hi = mid; else lo = mid;
+    }
+    const double lam_i = lane < m ? 0.5 * (lo + hi) * tscale : 0.0;
+    __syncthreads();
+    lam[lane] = lam_i;
+    e2sc[lane] = lane < m - 1 ? e[lane] * e[lane] : 0.0;   // unscaled squares for the twisted factorisation
+    __syncthreads();
+    const double lmax = fmax(fabs(lam[m - 1]), fabs(lam[0]));
+    const double tol0 = 1e-13 * lmax;
+    int k0 = 0;
+    for (int i = 0; i < m; ++i) k0 += lam[i] <= tol0;  // ascending: the null cluster is lam[0..k0)
+    const double pivmin = 1e-16 * lmax + 1e-300;
+    // shifts: eigenvalues closer than a few ulps of lam_max are pushed apart (as LAPACK's dstein does)
+    if (lane == 0) {
+        const double sep = 4.4e-16 * lmax;
+        double prev = -1e300;
+        for (int i = 0; i < m; ++i) { prev = fmax(lam[i], prev + sep); wsh[i] = prev; }
+    }
+    __syncthreads();
+    const bool on = lane < m && lane >= k0;
+    const double l = on ? wsh[lane] : 0.0;
+    auto clamp = [&](double p) { return fabs(p) < pivmin ? (p < 0.0 ? -pivmin : pivmin) : p; };
+    // ---- eigenvectors: forward pivots D+ in z[], backward pivots D- through Zg ----
+    double z[N];
+    {
+        double dp = d[0] - l;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if (j < m - 1) {
+                dp = clamp(dp);
+                z[j] = dp;
+                dp = (d[j + 1] - l) - e2sc[j] * fast_rcp64(dp);
+            } else if (j == m - 1) {
+                z[j] = dp;
+            } else {
+                z[j] = 0.0;
+            }
+        }
+    }
+    int r = 0;
+    {
+        double dm = d[m - 1] - l, gmin = 1e300;
+#pragma unroll
+        for (int j = N - 1; j >= 0; --j) {
+            if (j < m) {
+                if (j > 0) dm = clamp(dm);
+                Zg[j * 64 + lane] = dm;
+                const double gam = fabs(z[j] + dm - (d[j] - l));
+                if (gam <= gmin) { gmin = gam; r = j; }
+                if (j > 0) dm = (d[j - 1] - l) - e2sc[j - 1] * fast_rcp64(dm);
+            }
+        }
+    }
+    // z_r = 1; downward with L_j = e_j / D+_j (in place: z[j] still holds D+_j when it is consumed)
+    {
+        double zz = 1.0;
+#pragma unroll
+        for (int j = N - 2; j >= 0; --j) {
+            if (j < m - 1) {
+                if (j + 1 == r) zz = 1.0;
+                if (j < r) { zz = -e[j] * zz * fast_rcp64(clamp(z[j])); z[j] = zz; }
+            }
+        }
+    }
+    // upward with U_j = e_j / D-_{j+1}; the pivots come back from global memory eight rows at a time
+    {
+        double zz = 1.0;
+#pragma unroll
+        for (int c = 0; c < N; c += 8) {
+            if (c < m - 1) {
+                double dmv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) dmv[u] = (c + u + 1 < m && c + u + 1 < N) ? Zg[(c + u + 1) * 64 + lane] : 1.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = c + u;
+                    if (j + 1 < N && j < m - 1) {
+                        if (j == r) zz = 1.0;
+                        if (j >= r) { zz = -e[j] * zz * fast_rcp64(clamp(dmv[u])); z[j + 1] = zz; }
+                    }
+                }
+            }
+        }
+    }
+    {
+        double nrm = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if (j == r) z[j] = 1.0;
+            if (j >= m) z[j] = 0.0;
+            nrm += z[j] * z[j];
+        }
+        const double inv = 1.0 / sqrt(nrm);
+#pragma unroll
+        for (int j = 0; j < N; ++j) z[j] = on ? z[j] * inv : 0.0;
+    }
+    // ---- runs of close eigenvalues: classical Gram-Schmidt of vector i against the earlier vectors of its run ----
+    {
+        const double gtol = 1e-7 * lmax;
+        int start = k0;
+        for (int i = k0 + 1; i < m; ++i) {   // uniform control flow: lam is shared
+            if (lam[i] - lam[i - 1] >= gtol) { start = i; continue; }
+            for (int q = start; q < i; ++q) {
+                double sd = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) sd += lane_value(z[j], q) * z[j];
+                if (lane == i) wsh[q - start] = sd;   // dots against the unmodified vector i
+            }
+            __syncthreads();
+            for (int q = start; q < i; ++q) {
+                const double sq = wsh[q - start];
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const double zq = lane_value(z[j], q);
+                    if (lane == i) z[j] -= sq * zq;
+                }
+            }
+            double nn = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) nn += z[j] * z[j];
+            if (lane == i) {
+                const double inv = 1.0 / sqrt(nn);
+#pragma unroll
+                for (int j = 0; j < N; ++j) z[j] *= inv;
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+        if (j < m) Zg[j * 64 + lane] = z[j];
+    __syncthreads();
+    if (lane < k0) lam[lane] = 0.0;
+    __syncthreads();
+    return k0;
+}
+
+// solve_lsq_trust_region (common.py:57-168) in the eigenbasis (lam, suf; one lane per eigenpair, m < 64), the
+// rank-deficient branch with the virtual absorber at lane m -- ik_tr_solve of mvmc_ik.hip.  cv <- coefficients.
+__device__ inline double tr_solve_eig_w1(const double* lamv, const double* sufv, int m, double Delta, double alpha0, double gg,
+                                         double* cv, double* pred, double* pnorm) {
+    const int lane = threadIdx.x & 63;
+    const bool on = lane <= m;
+    double lam = lane < m ? lamv[lane] : 1.0, suf = lane < m ? sufv[lane] : 0.0;
+    if (lane == m) { lam = 0.0; suf = 1e-8 * sqrt(gg); }
+    double alpha_upper = sqrt(wave_sum(suf * suf)) / Delta;
+    double alpha_lower = 0.0;
+    double alpha = (alpha0 == 0.0) ? fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper)) : alpha0;
+    for (int it = 0; it < 10; ++it) {
+        if (alpha < alpha_lower || alpha > alpha_upper)
+            alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+        const double denom = lam + alpha;
+        const double t = suf != 0.0 ? suf / denom : 0.0;
+        const double p_norm = sqrt(wave_sum(t * t));
+        const double phi = p_norm - Delta;
+        const double phi_prime = -wave_sum(suf != 0.0 ? suf * suf / (denom * denom * denom) : 0.0) / p_norm;
+        if (phi < 0) alpha_upper = alpha;
+        const double ratio = phi / phi_prime;
+        alpha_lower = fmax(alpha_lower, alpha - ratio);
+        alpha -= (phi + Delta) * ratio / Delta;
+        if (fabs(phi) < 0.01 * Delta) break;
+    }
+    double c = (on && suf != 0.0) ? -suf / (lam + alpha) : 0.0;
+    const double pn = sqrt(wave_sum(c * c));
+    c *= Delta / pn;
+    if (lane < m) cv[lane] = c;
+    *pred = -(0.5 * wave_sum(lam * c * c) + wave_sum(suf * c));
+    *pnorm = sqrt(wave_sum(c * c));  // |step_h| including the absorber (== Delta up to rounding, as in SciPy)
+    return alpha;
+}
+
+// y = Z c: component j to lane j (Zg as written by tri_eigh_w1, c one coefficient per lane, zero beyond m)
+__device__ inline double eig_combine_w1(const double* __restrict__ Zg, int m, double c) {
+    const int lane = threadIdx.x & 63;
+    double y = 0.0;
+    int j = 0;
+    for (; j + 3 < m; j += 4) {
+        const double z0 = Zg[j * 64 + lane], z1 = Zg[(j + 1) * 64 + lane], z2 = Zg[(j + 2) * 64 + lane], z3 = Zg[(j + 3) * 64 + lane];
+        const double t0 = wave_sum_dpp(z0 * c), t1 = wave_sum_dpp(z1 * c), t2 = wave_sum_dpp(z2 * c), t3 = wave_sum_dpp(z3 * c);
+        y = lane == j ? t0 : (lane == j + 1 ? t1 : (lane == j + 2 ? t2 : (lane == j + 3 ? t3 : y)));
+    }
+    for (; j < m; ++j) {
+        const double t = wave_sum_dpp(Zg[j * 64 + lane] * c);
+        if (lane == j) y = t;
+    }
+    return y;
+}
+
+}  // namespace eightri
