@@ -894,6 +894,10 @@ __device__ __forceinline__ int als4_iterate(const TW* __restrict__ Wf, int ldw, 
     __syncthreads();
     double mu = 64.0;
     int iters = 1000;
+#ifdef MVMC_ALS_PROFILE
+    if (threadIdx.x < 8) g_alsprof[threadIdx.x] = 0;
+    long long _tp = clock64();
+#endif
     const int n4 = (n + 3) & ~3;  // rows beyond n are exact zeros: loops stop at the next multiple of 4
     // normal matrix of factor F (rows in LDS) into sG; R*R <= 256 entries, one per thread
     auto normal_matrix = [&](const double* F, double ridge) {
@@ -919,6 +923,7 @@ __device__ __forceinline__ int als4_iterate(const TW* __restrict__ Wf, int ldw, 
     // multipliers and writes the factor row
     auto solve_rows = [&](double* Fout) {
         __syncthreads();                       // sG and sHp complete
+        APROF(1)
         if (wv == 0) {
             double g[R];
 #pragma unroll
@@ -926,6 +931,7 @@ __device__ __forceinline__ int als4_iterate(const TW* __restrict__ Wf, int ldw, 
             gj_chain<R>(g, sMul, sDinv);
         }
         __syncthreads();
+        APROF(2)
         if (tid < NMAX) {
             double hv[R];
 #pragma unroll
@@ -943,6 +949,7 @@ __device__ __forceinline__ int als4_iterate(const TW* __restrict__ Wf, int ldw, 
             for (int a = 0; a < R; a += 2) dst[a >> 1] = make_double2(hv[a], hv[a + 1]);
         }
         __syncthreads();
+        APROF(3)
     };
     for (int it = 0; it < 1000; ++it) {
         // ---- X1 = Z - (Y - W + beta)/mu ----
@@ -958,6 +965,7 @@ __device__ __forceinline__ int als4_iterate(const TW* __restrict__ Wf, int ldw, 
             if (i < NMAX) sX[i * LDX + h * NS + c] = v;
         }
         __syncthreads();
+        APROF(0)
         const double ridge = 50.0 / mu;
         // ---- B update: (A^T A + ridge I) B[i]^T = A^T X1[:, i]; slice h covers rows k of its column range ----
         normal_matrix(sA, ridge);
@@ -1023,12 +1031,15 @@ __device__ __forceinline__ int als4_iterate(const TW* __restrict__ Wf, int ldw, 
                 acc_d += dx * dx;
             }
         }
+        APROF(4)
         acc_p = wave_sum(acc_p); acc_d = wave_sum(acc_d);
         if (lane == 0) { sRed[wv] = acc_p; sRed[4 + wv] = acc_d; }
         __syncthreads();
+        APROF(5)
         const double p_res = sqrt((sRed[0] + sRed[1]) + (sRed[2] + sRed[3])) / n;
         const double d_res = mu * sqrt((sRed[4] + sRed[5]) + (sRed[6] + sRed[7])) / n;
         __syncthreads();  // sRed is rewritten by the next iteration
+        APROF(6)
         if (p_res < 1e-4 && d_res < 1e-4) { iters = it + 1; break; }
         if (p_res > 10 * d_res) mu = 2 * mu;
         else if (d_res > 10 * p_res) mu = mu / 2;
@@ -1132,6 +1143,10 @@ als4_kernel(const TW* __restrict__ W, const int32_t* __restrict__ gcounts, int G
         for (int c = 0; c < n; ++c) k += sKeep[c];
         n_clusters[f] = k;
         iters_out[f] = iters;
+#ifdef MVMC_ALS_PROFILE
+        // diagnostic build: cycles per iteration by phase {X1, accumulate G+H, eliminate, apply, X/Z/Y, reduce, residuals}
+        for (int q = 0; q < 7; ++q) lab[ldw - 7 + q] = (int)(g_alsprof[q] / iters);
+#endif
     }
     if (x_bin || match_mat) {
         for (int e = tid; e < ldw * ldw; e += NT4) {
