@@ -131,7 +131,7 @@ def main():
 
     ev = {k: [] for k in ("assoc", "tri", "ik", "total")}
 
-    ik_events = []
+    ik_events, als_events = [], []
 
     def step(timed):
         if with_ik and L > 1:
@@ -139,7 +139,8 @@ def main():
             e = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if timed else None
             if timed: e[0].record()
             out = run_chains(hp, kps, counts, L, nfev_cold=args.nfev_cold, nfev_warm=args.nfev_warm,
-                             events=ik_events if timed else None, want_info=timed, n_groups=args.groups)
+                             events=ik_events if timed else None, want_info=timed, n_groups=args.groups,
+                             als_events=als_events if timed else None)
             if timed:
                 e[1].record()
                 ev["total"].append((e[0], e[1]))
@@ -185,16 +186,24 @@ def main():
     chain = with_ik and L > 1
     if chain:
         ik_launch_ms = [a.elapsed_time(b) for a, b in ik_events]
+        als_launch_ms = [a.elapsed_time(b) for a, b in als_events]
         stage_ms["ik"] = float(np.sum(ik_launch_ms) / args.steps)     # all IK launches of one step
-        stage_ms["assoc_tracker_other"] = stage_ms["total"] - stage_ms["ik"]
+        stage_ms["als_temporal"] = float(np.sum(als_launch_ms) / args.steps)   # ALS on the match_spatial_time graphs
+        stage_ms["other"] = stage_ms["total"] - stage_ms["ik"] - stage_ms["als_temporal"]
     if rank == 0:
         frames_total = F * world * args.steps
         value = frames_total / dt
         bpf = BYTES_PER_FRAME(C, Pn)
         dom = "ik" if with_ik else "assoc"
+        dom_kernel = "ik1_kernel" if with_ik else "als_kernel"
         if chain:
-            # dominant kernel: ik_kernel, launched once per time step over all chains; one launch serves F/L frames
-            launch_ms = float(np.mean(ik_launch_ms))
+            # dominant kernel = the one with the larger share of the step; both are launched once per time step over all
+            # chains, so one launch serves F/L frames
+            if stage_ms["als_temporal"] > stage_ms["ik"]:
+                dom, dom_kernel = "als", "als4_kernel<double, 32>"
+                launch_ms = float(np.mean([x for i, x in enumerate(als_launch_ms) if i % L]))  # heads have no graph yet
+            else:
+                launch_ms = float(np.mean(ik_launch_ms))
             achieved = bpf * (F // L) / (launch_ms * 1e-3) / 1e9
         else:
             launch_ms = stage_ms[dom]
@@ -224,11 +233,12 @@ def main():
                        "frames_per_gpu": F, "views": C, "people": Pn, "chain_len": L, "seed": args.seed, "parallelism": f"frames x{world}",
                        **extra},
             "stages_ms": stage_ms,
-            "roofline": {"bound": "hbm", "kernel": "ik_kernel" if with_ik else "als_kernel",
+            "roofline": {"bound": "hbm", "kernel": dom_kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "launch_ms": launch_ms,
                          "traffic": traffic, "bytes_per_frame": bpf,
-                         "note": "path is fp64-ALU/latency bound, not HBM bound (SURVEY.md F6); see DESIGN.md"},
+                         "note": "latency-bound path (dependent fp64 chains), not HBM bound (SURVEY.md F6); achieved = algorithmic "
+                                 "bytes of the frames one launch serves / mean launch duration of the dominant kernel; see DESIGN.md"},
         }
         if args.cpu_frames > 0 and world == 1:
             res["cpu_baseline"] = (cpu_baseline_chain(data, L) if chain else

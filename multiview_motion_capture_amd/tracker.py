@@ -37,6 +37,7 @@ class ChainTracker:
         self.frame_idx = torch.arange(B, dtype=torch.int32, device=d)
         self.slot_src = torch.full((B, T), -1, dtype=torch.int32, device=d)
         self.events = None  # set to a list to collect (start, end) CUDA events around every IK launch
+        self.als_events = None  # same for the association (ALS) launches of the spatio-temporal graph
         self.assoc_done = None
 
     def step(self, kps17: torch.Tensor, counts: torch.Tensor, want_debug=False):
@@ -51,7 +52,13 @@ class ChainTracker:
         # chains with tracklets: match_spatial_time graph
         W, D, gc = dev.st_affinity(kps17, counts, self.frame_idx, self.joints, self.n_tracks, hp.P, self.F2,
                                    want_D=want_debug)
+        if self.als_events is not None:
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
         st = dev.als_associate(W, gc, g_max=max(P, T), want_mats=want_debug)
+        if self.als_events is not None:
+            a1.record()
+            self.als_events.append((a0, a1))
         mem, cold, init, status, n_new = dev.track_assign(sp["labels"], sp["n_clusters"], st["labels"],
                                                           st["n_clusters"], counts, self.frame_idx, self.n_tracks,
                                                           self.params, P, K, V)
@@ -77,7 +84,7 @@ class ChainTracker:
 
 
 def run_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], chain_len: int, t_max=8,
-               nfev_cold=50, nfev_warm=5, events=None, want_info=False, n_groups=1):
+               nfev_cold=50, nfev_warm=5, events=None, want_info=False, n_groups=1, als_events=None):
     """Whole shard: frames [c*L, (c+1)*L) form chain c (F must be a multiple of L).  Returns per-frame
     tracklet tables: params (F,T,68), joints (F,T,18,3), meta (F,T,4), n_tracks (F).
 
@@ -111,6 +118,7 @@ def run_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], c
             streams[g].wait_event(ready)
             tr = ChainTracker(hp, bounds[g + 1] - bounds[g], P, t_max, nfev_cold=nfev_cold, nfev_warm=nfev_warm)
             tr.events = events
+            tr.als_events = als_events
             trackers.append(tr)
     # stagger: group g starts once group g-1 has finished the association of its first frame, so that from then on
     # the association launches of one group and the IK launches of another alternate instead of colliding

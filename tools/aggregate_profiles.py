@@ -50,15 +50,18 @@ def main():
             if k.startswith("at::") or k.startswith("__amd"):
                 continue
             w.writerow([k, len(fe[k]), "%.3f" % (sum(fe[k]) / len(fe[k])), "%.3f" % (sum(wr[k]) / max(1, len(wr[k])))])
-    ik_f = sum(fe["ik_kernel"]) / len(fe["ik_kernel"]) * 1024
-    ik_w = sum(wr["ik_kernel"]) / len(wr["ik_kernel"]) * 1024
     tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     rec = json.load(open(tp)) if os.path.exists(tp) else {}
-    rec["ik:10000x5x4"] = {
-        "fetch_bytes": ik_f, "write_bytes": ik_w, "bytes": ik_f + ik_w, "source": os.path.basename(out2),
-        "unit": "bytes per ik_kernel launch (one launch = one time step of all 625 chains); rocprofv3 --pmc FETCH_SIZE and "
-                "WRITE_SIZE in separate passes, KB x 1024; accesses are 8/12-byte, so the gfx950 x2 correction for 16-B "
-                "streaming reads does not apply (ingest_kernel calibrates 1:1 against its known 30 MB input)"}
+    unit = ("bytes per launch (one launch = one time step of all 625 chains); rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in "
+            "separate passes, KB x 1024; accesses are 8/12-byte, so the gfx950 x2 correction for 16-B streaming reads does not "
+            "apply (ingest_kernel calibrates 1:1 against its known 30 MB input)")
+    for key, kern in (("ik", "ik1_kernel<6>"), ("als", "als4_kernel<double, 32>")):
+        if kern not in fe:
+            continue
+        kf = sum(fe[kern]) / len(fe[kern]) * 1024
+        kw = sum(wr[kern]) / len(wr[kern]) * 1024
+        rec[f"{key}:10000x5x4"] = {"kernel": kern, "fetch_bytes": kf, "write_bytes": kw, "bytes": kf + kw,
+                                   "source": os.path.basename(out2), "unit": unit}
     json.dump(rec, open(tp, "w"), indent=1)
     print(open(out).read())
     print(open(out2).read())
