@@ -892,16 +892,24 @@ __device__ __forceinline__ int als4_iterate(const TW* __restrict__ Wf, int ldw, 
         sA[e] = (k < n && a < r) ? seed[k * r + a] : 0.0;
     }
     __syncthreads();
-    double mu = 64.0;
+    double mu = 64.0, inv_mu = 1.0 / 64.0;  // mu = 64 * 2^k: the reciprocal is exact, x * inv_mu == x / mu bit for bit
     int iters = 1000;
 #ifdef MVMC_ALS_PROFILE
     if (threadIdx.x < 8) g_alsprof[threadIdx.x] = 0;
     long long _tp = clock64();
 #endif
     const int n4 = (n + 3) & ~3;  // rows beyond n are exact zeros: loops stop at the next multiple of 4
-    // normal matrix of factor F (rows in LDS) into sG; R*R <= 256 entries, one per thread
+    // normal matrix of factor F (rows in LDS): R = 16 has one entry per thread; R = 8 has 64 entries, so each wave sums a
+    // quarter of the rows for all of them (sG[wave][entry]) and the eliminating wave adds the four parts
+    constexpr bool SPLITG = (R == 8);
     auto normal_matrix = [&](const double* F, double ridge) {
-        if (tid < R * R) {
+        if constexpr (SPLITG) {
+            const int e = tid & 63, a = e / R, b = e - a * R;
+            const int q4 = n4 >> 2, k0 = wv * q4;
+            double g0 = (wv == 0 && a == b) ? ridge : 0.0;
+            for (int k = k0; k < k0 + q4; ++k) g0 += F[k * R + a] * F[k * R + b];
+            sG[wv * 64 + e] = g0;
+        } else if (tid < R * R) {
             const int a = tid / R, b = tid - a * R;
             double g0 = (a == b) ? ridge : 0.0, g1 = 0.0;
 #pragma unroll 4
@@ -927,7 +935,11 @@ __device__ __forceinline__ int als4_iterate(const TW* __restrict__ Wf, int ldw, 
         if (wv == 0) {
             double g[R];
 #pragma unroll
-            for (int b = 0; b < R; ++b) g[b] = sG[(lane % R) * R + b];
+            for (int b = 0; b < R; ++b) {
+                const int e = (lane % R) * R + b;
+                if constexpr (SPLITG) g[b] = (sG[e] + sG[64 + e]) + (sG[128 + e] + sG[192 + e]);
+                else g[b] = sG[e];
+            }
             gj_chain<R>(g, sMul, sDinv);
         }
         __syncthreads();
@@ -953,7 +965,6 @@ __device__ __forceinline__ int als4_iterate(const TW* __restrict__ Wf, int ldw, 
     };
     for (int it = 0; it < 1000; ++it) {
         // ---- X1 = Z - (Y - W + beta)/mu ----
-        const double inv_mu = 1.0 / mu;  // mu = 64 * 2^k: the reciprocal is exact, x * inv_mu == x / mu bit for bit
 #pragma unroll
         for (int c = 0; c < NS; ++c) {
             double v = 0.0;
@@ -966,7 +977,7 @@ __device__ __forceinline__ int als4_iterate(const TW* __restrict__ Wf, int ldw, 
         }
         __syncthreads();
         APROF(0)
-        const double ridge = 50.0 / mu;
+        const double ridge = 50.0 * inv_mu;  // == 50 / mu exactly
         // ---- B update: (A^T A + ridge I) B[i]^T = A^T X1[:, i]; slice h covers rows k of its column range ----
         normal_matrix(sA, ridge);
         {
@@ -1032,7 +1043,7 @@ __device__ __forceinline__ int als4_iterate(const TW* __restrict__ Wf, int ldw, 
             }
         }
         APROF(4)
-        acc_p = wave_sum(acc_p); acc_d = wave_sum(acc_d);
+        acc_p = wave_sum_dpp(acc_p); acc_d = wave_sum_dpp(acc_d);
         if (lane == 0) { sRed[wv] = acc_p; sRed[4 + wv] = acc_d; }
         __syncthreads();
         APROF(5)
@@ -1041,8 +1052,8 @@ __device__ __forceinline__ int als4_iterate(const TW* __restrict__ Wf, int ldw, 
         __syncthreads();  // sRed is rewritten by the next iteration
         APROF(6)
         if (p_res < 1e-4 && d_res < 1e-4) { iters = it + 1; break; }
-        if (p_res > 10 * d_res) mu = 2 * mu;
-        else if (d_res > 10 * p_res) mu = mu / 2;
+        if (p_res > 10 * d_res) { mu = 2 * mu; inv_mu = 0.5 * inv_mu; }
+        else if (d_res > 10 * p_res) { mu = mu / 2; inv_mu = 2 * inv_mu; }
     }
     // final X (dense n x n, leading dimension n) for the symmetrise / binarise tail
     __syncthreads();

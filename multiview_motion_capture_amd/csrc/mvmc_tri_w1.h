@@ -3,8 +3,8 @@
 // Per step: the reflector of row k (one wave reduction), then p = tau M v and the rank-2 update with the row-side
 // values v_i, w_i read back from LDS as broadcasts (two values per ds_read_b128) -- three FMAs per live row and
 // lane and no cross-lane VALU traffic in the inner loops.  Rows <= k are dead (never read again; their diagonal
-// entry survives because v vanishes there) and are skipped in pairs.  The Householder vectors go to global memory,
-// hh[k * 64 + lane] (coalesced 512-byte rows, read back by apply_q_w1): the matrix registers are needed by the rest
+// entry survives because v vanishes there) and are skipped in chunks.  The Householder vectors go to global memory,
+// hh[k * 64 + lane] for lane > k (coalesced rows, read back by apply_q_w1): the matrix registers are needed by the rest
 // of the solver.
 #pragma once
 #include "mvmc_common.h"
@@ -137,7 +137,7 @@ __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, doub
         double tk, beta, sc;
         reflector(alpha, sig, tk, beta, sc);
         const double v = lane == j1 ? 1.0 : ((lane > j1 && lane < n) ? x * sc : 0.0);
-        hh[k * 64 + lane] = v;
+        if (lane > k && lane < n) hh[k * 64 + lane] = v;   // v vanishes elsewhere: only the live part travels
         if (lane == 0) { e[k] = beta; tau[k] = tk; }
         if (!unclean && fabs(beta) <= tol_c) {
             // the Krylov space is exhausted: everything behind row k must be the null space
@@ -174,9 +174,9 @@ __device__ inline double apply_q_w1(const double* __restrict__ hh, const double*
                                     int n, double cj) {
     const int lane = threadIdx.x & 63;
     int k = kk - 2;
+    auto row = [&](int r) { return (lane > r && lane < n) ? hh[r * 64 + lane] : 0.0; };
     for (; k >= 3; k -= 4) {   // four rows in flight: the loads do not depend on the running vector
-        const double va = hh[k * 64 + lane], vb = hh[(k - 1) * 64 + lane], vc = hh[(k - 2) * 64 + lane],
-                     vd = hh[(k - 3) * 64 + lane];
+        const double va = row(k), vb = row(k - 1), vc = row(k - 2), vd = row(k - 3);
         const double ta = tau[k], tb = tau[k - 1], tc = tau[k - 2], td = tau[k - 3];
         cj -= ta * wave_sum_dpp(va * cj) * va;
         cj -= tb * wave_sum_dpp(vb * cj) * vb;
@@ -184,7 +184,7 @@ __device__ inline double apply_q_w1(const double* __restrict__ hh, const double*
         cj -= td * wave_sum_dpp(vd * cj) * vd;
     }
     for (; k >= 0; --k) {
-        const double v = hh[k * 64 + lane];
+        const double v = row(k);
         cj -= tau[k] * wave_sum_dpp(v * cj) * v;
     }
     if (tau0 != 0.0) {
