@@ -210,6 +210,20 @@ int mvmc_debug_eigh(const double* A, const double* g, int n_problems, int n, dou
 int mvmc_debug_trstep(const double* B, const double* r, int n_problems, int m, int n, double Delta, double alpha0,
                       double* step, double* out4, double* phase_cycles, mvmcStream_t stream);
 
+/* The stages of PoseSolver.solve one at a time, and their 3-D-target variants:
+ *   stage_mask 1 = solve_pose_reproj (x = root, euler; inverse_kinematics.py:202-238),
+ *              2 = solve_pose_bone_lens_reproj (x = root, euler, side lengths; :241-277), 3 = both in sequence;
+ *   targets3d  NULL: reprojection residual on kps17 / members as in mvmc_ik_solve;
+ *              (B,18,4) f64 = x, y, z, weight per observation row (COCO-17 + mid-spine): solve_pose (:280-307) and
+ *              solve_pose_bone_lens (:310-336), residual (joint - target) * weight; kps17, Pmats, members are unused.
+ * Every problem starts from init_params (B,68) with max_nfev evaluations per stage (least_squares(max_nfev=n_max_iter)).
+ * Outputs and scratch as in mvmc_ik_solve; info of a stage that was not run is 0. */
+int mvmc_ik_solve_stages(const mvmcSkeleton* skel_host, const double* kps17, const double* Pmats,
+                         const int32_t* members, const double* targets3d, int n_problems, int v_max, int n_views,
+                         int p_max, const double* init_params, int stage_mask, int max_nfev,
+                         double* params_out, double* joints_out, double* info_out, double* scratch,
+                         mvmcStream_t stream);
+
 /* Which kernel mvmc_ik_solve launches: 0 = one wave per solve (ik1_kernel, the default); 1 = one 256-thread workgroup
  * per solve (ik_kernel, the first layout, kept as the A/B reference).  Any other value only queries.  Returns the previous mode (-1 =
  * not yet chosen: the first mvmc_ik_solve call takes it from the environment variable MVMC_IK_MODE, default 0). */

@@ -24,7 +24,7 @@ SYMBOLS = (
     "mvmc_abi_version", "mvmc_status_string", "mvmc_als_seed_table", "mvmc_ingest", "mvmc_fmats",
     "mvmc_affinity", "mvmc_als_associate", "mvmc_closure_labels", "mvmc_cluster_members", "mvmc_dlt", "mvmc_triangulate_postopt", "mvmc_fk", "mvmc_ik_solve",
     "mvmc_fmats_from_projections", "mvmc_st_affinity", "mvmc_track_assign", "mvmc_track_commit", "mvmc_debug_eigh",
-    "mvmc_debug_trstep", "mvmc_debug_ik_mode",
+    "mvmc_debug_trstep", "mvmc_debug_ik_mode", "mvmc_ik_solve_stages",
 )
 
 
@@ -75,6 +75,7 @@ def load():
     lib.mvmc_debug_eigh.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp]
     lib.mvmc_debug_trstep.argtypes = [vp, vp, i32, i32, i32, C.c_double, C.c_double, vp, vp, vp, vp]
     lib.mvmc_debug_ik_mode.argtypes = [i32]
+    lib.mvmc_ik_solve_stages.argtypes = [C.POINTER(MvmcSkeleton), vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp]
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError if the library does not export it
         if name not in ("mvmc_status_string",):

@@ -700,7 +700,7 @@ ik_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restr
 int mvmc_ik1_launch(const SkelDev& sk, const double* kps17, const double* Pmats, const int32_t* members, int n_problems,
                     int v_max, int n_views, int p_max, const double* init_params, const uint8_t* cold, int max_nfev_cold,
                     int max_nfev_warm, double* params_out, double* joints_out, double* info_out, double* scratch,
-                    hipStream_t stream);
+                    int stage_mask, const double* targets3d, hipStream_t stream);
 
 // 0: wave-per-solve kernel (default); 1: workgroup-per-solve kernel.  MVMC_IK_MODE in the environment sets the initial value.
 static int g_ik_mode = -1;
@@ -729,10 +729,29 @@ extern "C" int mvmc_ik_solve(const mvmcSkeleton* skel_host, const double* kps17,
     const uint8_t* cold_arg = init_params ? cold : nullptr;
     if (g_ik_mode == 0)
         return mvmc_ik1_launch(sk, kps17, Pmats, members, n_problems, v_max, n_views, p_max, init_params, cold_arg, max_nfev_cold,
-                               max_nfev_warm, params_out, joints_out, info_out, scratch, (hipStream_t)stream);
+                               max_nfev_warm, params_out, joints_out, info_out, scratch, 3, nullptr, (hipStream_t)stream);
     hipLaunchKernelGGL(ik_kernel, dim3(n_problems), dim3(NT), 0, (hipStream_t)stream, sk, kps17, Pmats, members,
                        n_problems, v_max, n_views, p_max, init_params, cold_arg, max_nfev_cold,
                        max_nfev_warm, params_out, joints_out, info_out, scratch);
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;
+}
+
+// Single stages of PoseSolver.solve and the 3-D-target variants (wave-per-solve kernel only); see include/mvmc.h
+extern "C" int mvmc_ik_solve_stages(const mvmcSkeleton* skel_host, const double* kps17, const double* Pmats,
+                                    const int32_t* members, const double* targets3d, int n_problems, int v_max, int n_views,
+                                    int p_max, const double* init_params, int stage_mask, int max_nfev,
+                                    double* params_out, double* joints_out, double* info_out, double* scratch,
+                                    mvmcStream_t stream) {
+    if (!skel_host || !init_params || !params_out || !joints_out || !scratch) return MVMC_ERR_ARG;
+    if (stage_mask < 1 || stage_mask > 3 || max_nfev < 1) return MVMC_ERR_ARG;
+    if (!targets3d && (!kps17 || !Pmats || !members || v_max <= 0 || n_views <= 0 || p_max <= 0)) return MVMC_ERR_ARG;
+    if (n_problems <= 0) return n_problems == 0 ? MVMC_OK : MVMC_ERR_ARG;
+    SkelDev sk;
+    if (!skel_to_dev(skel_host, &sk)) return MVMC_ERR_ARG;
+    if (sk.n_side != MVMC_N_SIDE) return MVMC_ERR_UNSUPPORTED;
+    // every problem is "warm": it starts from init_params with the one evaluation budget
+    return mvmc_ik1_launch(sk, kps17, Pmats, members, n_problems, targets3d ? 1 : v_max, targets3d ? 1 : n_views,
+                           targets3d ? 1 : p_max, init_params, /*cold=*/nullptr, max_nfev, max_nfev, params_out, joints_out,
+                           info_out, scratch, stage_mask | 4, targets3d, (hipStream_t)stream);
 }

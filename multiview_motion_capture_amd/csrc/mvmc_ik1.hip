@@ -53,6 +53,8 @@ struct Ik1Shared {
     double Wk[NOBS * 6], tk[NOBS * 3];
     double dirs[18 * 3], ref_side[18];
     double sc[8];           // {.., beta0, tau0, |J^T J|_1, coupling} at [4..8)
+    double tgt[NOBS * 4];   // 3-D-target mode (solve_pose / solve_pose_bone_lens): x, y, z, weight per observed joint
+    int mode3d;
     unsigned long long rowmask[2][NOBS];
     int anc[18];
     int maxdepth, nviews, na[2], n_side;
@@ -134,6 +136,17 @@ __device__ __noinline__ double ik1_eval(Ik1Shared<VM>& S, const double* xs, int 
     const double* X = &S.pos[kIkSkel[k] * 3];
     const double X0 = X[0], X1 = X[1], X2 = X[2];
     double f2 = 0.0, o[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (S.mode3d) {
+        // residual (pos_k - target_k) * w_k (inverse_kinematics.py:280-336): J_k = w_k D_k, so W_k = w_k^2 I, t_k = w_k f_k
+        if (r == 0) {
+            const double* tg = &S.tgt[k * 4];
+            const double w = tg[3], w2 = w * w;
+            const double f0 = (X0 - tg[0]) * w, f1 = (X1 - tg[1]) * w, f2c = (X2 - tg[2]) * w;
+            f2 = f0 * f0 + f1 * f1 + f2c * f2c;
+            o[0] = w2; o[3] = w2; o[5] = w2;
+            o[6] = w * f0; o[7] = w * f1; o[8] = w * f2c;
+        }
+    } else
     for (int v = r; v < S.nviews; v += 4) {
         const double* P = &S.Pm[v * 12];
         const double h0 = P[0] * X0 + P[1] * X1 + P[2] * X2 + P[3];
@@ -421,14 +434,15 @@ __global__ void __launch_bounds__(64, 3)
 ik1_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restrict__ Pmats,
            const int32_t* __restrict__ members, int B, int V, int C, int Pmax, const double* __restrict__ init,
            const uint8_t* __restrict__ cold, int nfev_cold, int nfev_warm, double* __restrict__ params_out,
-           double* __restrict__ joints_out, double* __restrict__ info_out, double* __restrict__ scratch) {
+           double* __restrict__ joints_out, double* __restrict__ info_out, double* __restrict__ scratch, int stage_mask,
+           const double* __restrict__ targets3d) {
     __shared__ Ik1Shared<VM> S;
     const int b = blockIdx.x, lane = threadIdx.x;
     double* hh = scratch + (size_t)b * MVMC_IK_SCRATCH_DOUBLES;   // Householder vectors [0, 3200), eigenvectors [3200, 6400)
     double* info = info_out ? info_out + (size_t)b * 8 : nullptr;
     // views of this problem (the reference only solves clusters with >= 2 views: motion_capture.py:927,940)
     int q_own = -1;
-    {
+    if (targets3d == nullptr) {
         int nv = 0;
         for (int v = 0; v < V; ++v) {
             const int m = members[(size_t)b * V + v];
@@ -442,7 +456,12 @@ ik1_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __rest
             if (info && lane < 8) info[lane] = nan;
             return;
         }
-        if (lane == 0) S.nviews = nv;
+        if (lane == 0) { S.nviews = nv; S.mode3d = 0; }
+    } else {
+        // 3-D-target mode: targets (B,18,4) in the observation row order (COCO-17 + mid-spine)
+        if (lane < NOBS)
+            for (int c = 0; c < 4; ++c) S.tgt[lane * 4 + c] = targets3d[(size_t)b * 72 + kIkObs[lane] * 4 + c];
+        if (lane == 0) { S.nviews = 0; S.mode3d = 1; }
     }
     const int n_side = skarg.n_side;
     if (lane < 18) {
@@ -519,7 +538,8 @@ ik1_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __rest
     }
     __syncthreads();
     // ---- initial parameters ----
-    const bool is_cold = (cold == nullptr) || cold[b] != 0;
+    // stage_mask bit 2: every problem starts from init (mvmc_ik_solve_stages); otherwise cold == NULL means all cold
+    const bool is_cold = (stage_mask & 4) ? false : ((cold == nullptr) || cold[b] != 0);
     if (is_cold) {
         // root = midpoint of the triangulated (post-optimised) hips; zero angles; reference lengths
         // (inverse_kinematics.py:390-396 with triangulate(..., 0.01, post_optimize=True))
@@ -545,7 +565,7 @@ ik1_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __rest
 #pragma unroll 1
     for (int stage = 0; stage < 2; ++stage) {
         double c = 0.0; int nf = 0, nj = 0, st = 0;
-        ik1_trf(S, stage, max_nfev, hh, &c, &nf, &nj, &st, &fallbacks);
+        if ((stage_mask >> stage) & 1) ik1_trf(S, stage, max_nfev, hh, &c, &nf, &nj, &st, &fallbacks);
         costs[stage] = c; nfs[stage] = nf; njs[stage] = nj; sts[stage] = st;
         __syncthreads();
     }
@@ -572,15 +592,15 @@ ik1_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __rest
 int mvmc_ik1_launch(const SkelDev& sk, const double* kps17, const double* Pmats, const int32_t* members, int n_problems,
                     int v_max, int n_views, int p_max, const double* init_params, const uint8_t* cold, int max_nfev_cold,
                     int max_nfev_warm, double* params_out, double* joints_out, double* info_out, double* scratch,
-                    hipStream_t stream) {
+                    int stage_mask, const double* targets3d, hipStream_t stream) {
     if (v_max <= 6) {
         hipLaunchKernelGGL(ik1_kernel<6>, dim3(n_problems), dim3(64), 0, stream, sk, kps17, Pmats, members, n_problems, v_max,
                            n_views, p_max, init_params, cold, max_nfev_cold, max_nfev_warm, params_out, joints_out, info_out,
-                           scratch);
+                           scratch, stage_mask, targets3d);
     } else {
         hipLaunchKernelGGL(ik1_kernel<VMAX>, dim3(n_problems), dim3(64), 0, stream, sk, kps17, Pmats, members, n_problems,
                            v_max, n_views, p_max, init_params, cold, max_nfev_cold, max_nfev_warm, params_out, joints_out,
-                           info_out, scratch);
+                           info_out, scratch, stage_mask, targets3d);
     }
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;

@@ -253,6 +253,35 @@ def ik_solve(kps17: torch.Tensor, Pmats: torch.Tensor, members: torch.Tensor,
     return params, joints, info
 
 
+def ik_solve_stages(init_params: torch.Tensor, stage_mask: int, max_nfev: int, kps17: Optional[torch.Tensor] = None,
+                    Pmats: Optional[torch.Tensor] = None, members: Optional[torch.Tensor] = None,
+                    targets3d: Optional[torch.Tensor] = None, skeleton: Optional[MvmcSkeleton] = None):
+    """Single stages of PoseSolver.solve (stage_mask 1 / 2 / 3) from init_params (B,68), either on the reprojection
+    residual (kps17, Pmats, members as in ik_solve) or on 3-D targets (B,18,4) = x, y, z, weight per observation row."""
+    sk = skeleton if skeleton is not None else make_skeleton()
+    B = init_params.shape[0]
+    _req(init_params, torch.float64, "init_params", (B, 68))
+    dev = init_params.device
+    if targets3d is not None:
+        _req(targets3d, torch.float64, "targets3d", (B, 18, 4))
+        V = Cn = P = 1
+    else:
+        if kps17 is None or Pmats is None or members is None:
+            raise ValueError("ik_solve_stages: reprojection mode needs kps17, Pmats and members")
+        F, Cn, P = kps17.shape[:3]
+        _req(kps17, torch.float64, "kps17", (F, Cn, P, 17, 3))
+        _req(Pmats, torch.float64, "Pmats", (Cn, 3, 4))
+        _req(members, torch.int32, "members", (B, None))
+        V = members.shape[1]
+    params = torch.empty((B, 68), dtype=torch.float64, device=dev)
+    joints = torch.empty((B, 18, 3), dtype=torch.float64, device=dev)
+    info = torch.empty((B, 8), dtype=torch.float64, device=dev)
+    check(_cabi.load().mvmc_ik_solve_stages(C.byref(sk), _p(kps17), _p(Pmats), _p(members), _p(targets3d), B, V, Cn, P,
+                                            _p(init_params), int(stage_mask), int(max_nfev), _p(params), _p(joints),
+                                            _p(info), _p(_ik_scratch(B, dev)), _stream()), "mvmc_ik_solve_stages")
+    return params, joints, info
+
+
 # ----------------------------------------------------------------------------
 # temporal layer (match_spatial_time + tracker), batched over chains
 # ----------------------------------------------------------------------------

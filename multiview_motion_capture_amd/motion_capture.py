@@ -5,6 +5,8 @@ mv_association); only list/dict bookkeeping happens on the host, as in the refer
 from __future__ import annotations
 
 import json
+import os
+import pickle
 from dataclasses import dataclass, field
 from pathlib import Path
 from typing import Dict, List, Optional
@@ -39,13 +41,18 @@ class SpatialTimeMatch:
 
 
 def load_calib(cpath: Path) -> Calib:
-    """motion_capture.py:250-272 (json branch)."""
+    """motion_capture.py:250-272: a calibration file, JSON ("K", "RT", "imgSize") or pickle ("K", "R", "t")."""
     cpath = Path(cpath)
-    if 'js' not in cpath.suffix:
-        raise ValueError(f'unsupported calibration format. {cpath.name}')
-    with open(str(cpath), 'r') as fh:
-        js = json.load(fh)
-    return Calib.from_k_rt(js["K"], js["RT"], js["imgSize"])
+    if 'pkl' in cpath.suffix:
+        with open(str(cpath), 'rb') as fh:
+            data = pickle.load(fh)
+        rt = np.concatenate([np.array(data["R"]).reshape((3, 3)), np.array(data["t"]).reshape((3, 1))], axis=1)
+        return Calib.from_k_rt(data["K"], rt, (1920, 1080))
+    if 'js' in cpath.suffix:
+        with open(str(cpath), 'r') as fh:
+            js = json.load(fh)
+        return Calib.from_k_rt(js["K"], js["RT"], js["imgSize"])
+    raise ValueError(f'unsupported calibration format. {cpath.name}')
 
 
 def parse_openpose_kps(js_path: Path) -> Dict[int, Pose]:
@@ -236,3 +243,105 @@ class MvTracker:
                 t.state = TrackState.Dead
                 self.dead_tracklets.append(t)
         self.tracklets = alive
+
+
+# ----------------------------------------------------------------------------------------------------
+# file formats of the reference's driver: OpenPose JSON directories, per-frame FrameData
+# pickles, the final {"tracklets": [...]} pickle
+# ----------------------------------------------------------------------------------------------------
+def _openpose_layout(in_dir: Path, calib_dir: Path):
+    """Camera directories sorted by name, their calibrations, and per camera the frame files sorted by the frame
+    number in '<cam>_<frame>_keypoints.json' (extract_frame_data_from_openpose, motion_capture.py:987-996)."""
+    in_dir, calib_dir = Path(in_dir), Path(calib_dir)
+    cam_dirs = sorted([d for d in in_dir.glob('*') if d.is_dir()], key=lambda path: path.stem)
+    calib_paths = {c.stem: c for c in calib_dir.glob('*.*')}
+    calibs = [load_calib(calib_paths[v.stem]) for v in cam_dirs]
+    cam_kps_paths = [sorted(d.glob('*.json'), key=lambda path: int(path.stem.split('_')[1])) for d in cam_dirs]
+    n_frms = min(len(k) for k in cam_kps_paths)
+    return calibs, cam_kps_paths, n_frms
+
+
+def extract_frame_data_from_openpose(in_dir: Path, calib_dir: Path, out_data_dir: Path):
+    """motion_capture.py:987-1005: one pickle per frame holding List[FrameData] (view_id = camera ordinal + 1)."""
+    calibs, cam_kps_paths, n_frms = _openpose_layout(in_dir, calib_dir)
+    out_data_dir = Path(out_data_dir)
+    os.makedirs(out_data_dir, exist_ok=True)
+    for frm_idx in range(n_frms):
+        cam_poses = [parse_openpose_kps(kps_paths[frm_idx]) for kps_paths in cam_kps_paths]
+        d_frames = [FrameData(frm_idx, poses, calib, view_id=v_idx + 1)
+                    for v_idx, (poses, calib) in enumerate(zip(cam_poses, calibs))]
+        with open(out_data_dir / f'{str(frm_idx).zfill(6)}.pkl', 'wb') as fh:
+            pickle.dump(obj=d_frames, file=fh)
+
+
+def load_pickle(fpath: Path, mode):
+    """motion_capture.py:1008-1010."""
+    with open(fpath, mode) as fh:
+        return pickle.load(fh)
+
+
+def load_openpose_sequence(in_dir: Path, calib_dir: Path, p_max: Optional[int] = None, frames: Optional[range] = None):
+    """The same directory as one batch for the device path: (kps25 (F,C,P,25,3) f64 zero padded, counts (F,C) i32,
+    calibs).  Rows are OpenPose's own (x, y, score) triples in file order; mvmc_ingest does the 25 -> 17 gather
+    and filter_bad_pose."""
+    calibs, cam_kps_paths, n_frms = _openpose_layout(in_dir, calib_dir)
+    frames = range(n_frms) if frames is None else frames
+    people = []
+    for f in frames:
+        row = []
+        for kps_paths in cam_kps_paths:
+            with open(kps_paths[f], 'rt') as fh:
+                row.append([np.array(p["pose_keypoints_2d"], np.float64).reshape((-1, 3)) for p in json.load(fh)["people"]])
+        people.append(row)
+    most = max((len(v) for row in people for v in row), default=0)
+    if p_max is None:
+        p_max = max(most, 1)
+    if most > p_max:
+        raise ValueError(f"load_openpose_sequence: {most} people in one view, p_max = {p_max}")
+    kps = np.zeros((len(people), len(cam_kps_paths), p_max, 25, 3))
+    counts = np.zeros((len(people), len(cam_kps_paths)), dtype=np.int32)
+    for f, row in enumerate(people):
+        for c, view in enumerate(row):
+            counts[f, c] = len(view)
+            for k, arr in enumerate(view):
+                if arr.shape != (25, 3):
+                    raise ValueError(f"load_openpose_sequence: expected 25 keypoints per person, got {arr.shape[0]}")
+                kps[f, c, k] = arr
+    return kps, counts, calibs
+
+
+def frame_data_from_batch(frm_idx: int, kps25_f: np.ndarray, counts_f: np.ndarray, calibs: List[Calib]) -> List[FrameData]:
+    """One frame of a batch as the reference's List[FrameData] (what extract_frame_data_from_openpose pickles)."""
+    out = []
+    for v_idx, calib in enumerate(calibs):
+        poses = {}
+        for p_id in range(int(counts_f[v_idx])):
+            coco = conversion_openpose_25_to_coco(kps25_f[v_idx, p_id])
+            poses[p_id] = Pose(KpsFormat.COCO, keypoints=coco[:, :2], keypoints_score=coco[:, -1][:, np.newaxis], box=None)
+        out.append(FrameData(frm_idx, poses, calib, view_id=v_idx + 1))
+    return out
+
+
+def run_main(video_dir: Optional[Path], pose_dir: Path, out_dir: Path, n_test: int = 300):
+    """run_main (motion_capture.py:1047-1129) without the video readers (they only feed the debug drawings): per-frame
+    pickles of pose_dir in frame order, filter_bad_pose(0.01, 4, 5), MvTracker.update_4d, and the tracklets -- longest
+    first -- as {"tracklets": [...]} in out_dir/tracklets.pkl.  Like the reference the loop starts at the second
+    file (frm_idx is incremented before the first read) and stops after n_test frames."""
+    frm_pose_paths = sorted(Path(pose_dir).glob('*.pkl'), key=lambda path: int(path.stem))
+    tracker = MvTracker(load_skeleton())
+    n_test = min(len(frm_pose_paths), n_test)
+    frm_idx = 0
+    while True:
+        frm_idx += 1
+        if frm_idx >= len(frm_pose_paths):
+            break
+        d_frames = load_pickle(frm_pose_paths[frm_idx], 'rb')
+        d_frames = [filter_bad_pose(frm, min_valid_kps_score=0.01, n_min_valid_kps=4, min_valib_bb_size=5) for frm in d_frames]
+        tracker.update_4d(frm_idx, d_frames, debug_view_imgs=None)
+        if frm_idx >= n_test:
+            break
+    all_tlets = sorted(tracker.tracklets + tracker.dead_tracklets, key=lambda tlet: -len(tlet))
+    os.makedirs(out_dir, exist_ok=True)
+    with open(f'{out_dir}/tracklets.pkl', 'wb') as fh:
+        pickle.dump(file=fh, obj={"tracklets": all_tlets})
+    return all_tlets

@@ -596,3 +596,32 @@ def pose_solver_solve(cam_poses_2d, cam_projs, init=None, return_info=False):
     if return_info:
         return (r2, e2, b2), joints, dict(init=(root, euler, blens), stage1=(r1, e1), res1=res1, res2=res2)
     return (r2, e2, b2), joints
+
+
+def ik_residual_3d(root, euler, side_blens, target, bone_dirs=None):
+    """_residual_step_joints_3d / _residual_root_angles_bone_lens of the 3-D-target variants
+    (inverse_kinematics.py:295-299, :325-330): (joint - target[:, :3]) * target[:, 3:], target = obs_pose_3d[obs idx]."""
+    joints, _ = forward_kinematics(root, euler, side_blens, bone_dirs)
+    d = (joints[IK_SKEL_IDX, :] - target[:, :3]) * target[:, -1:]
+    return d.flatten()
+
+
+def ik_stage1_3d(obs_pose_3d, root, euler, side_blens, max_nfev, bone_dirs=None):
+    """solve_pose, inverse_kinematics.py:280-307."""
+    target = np.asarray(obs_pose_3d, np.float64)[IK_OBS_IDX, :]
+
+    def fun(x):
+        return ik_residual_3d(x[:3], x[3:].reshape(-1, 3), side_blens, target, bone_dirs)
+    r = least_squares(fun, np.concatenate([np.ravel(root), np.ravel(euler)]), max_nfev=max_nfev)
+    return r.x[:3], r.x[3:].reshape(-1, 3), r
+
+
+def ik_stage2_3d(obs_pose_3d, root, euler, side_blens, max_nfev, bone_dirs=None):
+    """solve_pose_bone_lens, inverse_kinematics.py:310-336."""
+    target = np.asarray(obs_pose_3d, np.float64)[IK_OBS_IDX, :]
+    n3 = 3 + 3 * N_SKEL
+
+    def fun(x):
+        return ik_residual_3d(x[:3], x[3:n3].reshape(-1, 3), x[n3:], target, bone_dirs)
+    r = least_squares(fun, np.concatenate([np.ravel(root), np.ravel(euler), np.ravel(side_blens)]), max_nfev=max_nfev)
+    return r.x[:3], r.x[3:n3].reshape(-1, 3), r.x[n3:], r

@@ -198,3 +198,34 @@ def test_post_optimize_matches_scipy_on_random_clusters(api):
             n += 1
     print(f"post-optimise vs scipy: {n} clusters compared, reference accepted its step in {n_moved}; worst diff {worst:.2e}")
     assert n >= 20 and worst < 1e-6
+
+
+def test_run_main_writes_the_reference_tracklet_pickle(api, tmp_path):
+    """run_main (motion_capture.py:1047-1129) over per-frame FrameData pickles: same tracker states as the reference's log,
+    tracklets.pkl = {"tracklets": [...]} sorted longest first, each with (frame, PoseShapeParam, Pose) triples."""
+    import pickle
+    mc = api["mc"]
+    gin, g = load_golden("shelf_inputs.npz"), load_golden("shelf_tracker.npz")
+    calibs = [mc.Calib.from_k_rt(gin["K"][c], gin["Rt"][c], (1032, 776)) for c in range(5)]
+    pose_dir, out_dir = tmp_path / "frames", tmp_path / "out"
+    pose_dir.mkdir()
+    n = 25
+    for f in range(n + 1):   # file f holds frame f; the driver starts at file 1
+        with open(pose_dir / f"{f:06d}.pkl", "wb") as fh:
+            pickle.dump(mc.frame_data_from_batch(f, gin["kps25"][f], gin["counts"][f], calibs), fh)
+    tlets = mc.run_main(None, pose_dir, out_dir, n_test=n)
+    with open(out_dir / "tracklets.pkl", "rb") as fh:
+        data = pickle.load(fh)
+    assert list(data.keys()) == ["tracklets"] and len(data["tracklets"]) == len(tlets)
+    lens = [len(t) for t in data["tracklets"]]
+    assert lens == sorted(lens, reverse=True)
+    exp = g["alive_after"][n - 1]
+    exp = exp[exp[:, 0] >= 0]
+    alive = sorted([t for t in data["tracklets"] if not t.is_dead()], key=lambda t: t.track_id)
+    assert [(t.track_id, t.state.value, t.hits, len(t)) for t in alive] == [tuple(int(v) for v in r) for r in exp]
+    assert sum(t.is_dead() for t in data["tracklets"]) == int(g["n_dead"][n - 1])
+    t0 = data["tracklets"][0]
+    assert t0.frame_idxs == list(range(1, n + 1)) and [p[0] for p in t0.poses] == t0.frame_idxs
+    frm, pparam, pose = t0.poses[-1]
+    assert pparam.root.shape == (3,) and pparam.euler_angles.shape == (18, 3) and pose.keypoints.shape == (18, 3)
+    assert np.isfinite(pose.keypoints).all()
