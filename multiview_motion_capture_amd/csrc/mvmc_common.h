@@ -7,6 +7,16 @@
 
 #define MVMC_WAVE 64
 
+// Ordering point for LDS traffic INSIDE one wave (single-wave routines that may run in a multi-wave workgroup, where
+// __syncthreads() would be a real barrier across waves doing unrelated work).  LDS operations of a wave execute in
+// order, so only the compiler has to be kept from moving accesses across the point.
+#define MVMC_WAVE_SYNC()                                        \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+        __builtin_amdgcn_wave_barrier();                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+    } while (0)
+
 #define MVMC_CHECK_LAUNCH()                                  \
     do {                                                     \
         if (hipGetLastError() != hipSuccess) return MVMC_ERR_LAUNCH; \

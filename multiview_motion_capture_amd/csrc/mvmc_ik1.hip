@@ -27,7 +27,7 @@ constexpr int NA1 = 50;  // max active parameters
 
 #ifdef MVMC_IK_PROFILE
 #define P1_T0 const long long _t0 = clock64();
-#define P1_ADD(k) if (threadIdx.x == 0) S.prof[k] += clock64() - _t0;
+#define P1_ADD(k) if ((threadIdx.x & 63) == 0) S.prof[k] += clock64() - _t0;
 #else
 #define P1_T0
 #define P1_ADD(k)
@@ -42,24 +42,28 @@ constexpr int NA1 = 50;  // max active parameters
 // persistent solver vectors (S.sv): D, E, TAU, V0, WN, 64 doubles each
 enum { SV_D = 0, SV_E = 64, SV_TAU = 128, SV_V0 = 192, SV_WN = 256, SV_COUNT = 320 };
 
+// skeleton-derived tables: the same for every solve, one copy per workgroup
+struct Ik1Tables {
+    double dirs[18 * 3], ref_side[18];
+    unsigned long long rowmask[2][NOBS];
+    int anc[18];
+    int maxdepth, na[2], n_side;
+    signed char depth[18], parents[18], side_map[18];
+    unsigned char act[2][NA1], colkind[2][NA1], cola[2][NA1], colc[2][NA1];
+};
+
+// per-solve state (one wave)
 template <int VM>
 struct Ik1Shared {
     __attribute__((aligned(16))) double tmp[256];
     double sv[SV_COUNT];
     double x[68], xn[68], side[18];
-    double pose18[VM * 54], Pm[VM * 12];
+    double pose18[VM * 54], Pm[VM * 12];   // 3-D-target mode keeps its targets (16 x {x, y, z, weight}) in pose18
     double Rg[18 * 9], pos[18 * 3], bvec[18 * 3];
     double hs[18 * 4];      // sin, cos of half the x and y Euler angles of every joint (from the last FK)
     double Wk[NOBS * 6], tk[NOBS * 3];
-    double dirs[18 * 3], ref_side[18];
     double sc[8];           // {.., beta0, tau0, |J^T J|_1, coupling} at [4..8)
-    double tgt[NOBS * 4];   // 3-D-target mode (solve_pose / solve_pose_bone_lens): x, y, z, weight per observed joint
-    int mode3d;
-    unsigned long long rowmask[2][NOBS];
-    int anc[18];
-    int maxdepth, nviews, na[2], n_side;
-    signed char depth[18], parents[18], side_map[18];
-    unsigned char act[2][NA1], colkind[2][NA1], cola[2][NA1], colc[2][NA1];
+    int nviews, mode3d;
 #ifdef MVMC_IK_PROFILE
     long long prof[8];
 #endif
@@ -100,37 +104,37 @@ __device__ inline void euler_to_rot_hs(const double* e, double* R, double* hs) {
 // Lane (k, r) = (lane & 15, lane >> 4) handles observed joint k in the views r, r + 4.  Returns 0.5 |f|^2.
 // ---------------------------------------------------------------------------------------------
 template <int VM>
-__device__ __noinline__ double ik1_eval(Ik1Shared<VM>& S, const double* xs, int stage, bool want_jac) {
-    const int lane = threadIdx.x;
+__device__ __noinline__ double ik1_eval(Ik1Shared<VM>& S, const Ik1Tables& T, const double* xs, int stage, bool want_jac) {
+    const int lane = threadIdx.x & 63;
     double* Rl = S.tmp;
     double* off = S.tmp + 162;
     if (lane < 18) {
         euler_to_rot_hs(xs + 3 + 3 * lane, &Rl[lane * 9], &S.hs[lane * 4]);
         double len = 0.0;
-        if (lane > 0) len = (stage == 0) ? S.side[S.side_map[lane]] : xs[57 + S.side_map[lane]];
-        for (int k = 0; k < 3; ++k) off[lane * 3 + k] = S.dirs[lane * 3 + k] * len;
+        if (lane > 0) len = (stage == 0) ? S.side[T.side_map[lane]] : xs[57 + T.side_map[lane]];
+        for (int k = 0; k < 3; ++k) off[lane * 3 + k] = T.dirs[lane * 3 + k] * len;
     }
-    __syncthreads();
+    MVMC_WAVE_SYNC();
     if (lane < 9) S.Rg[lane] = Rl[lane];
     if (lane < 3) S.pos[lane] = xs[lane];
-    __syncthreads();
-    for (int lev = 1; lev <= S.maxdepth; ++lev) {
+    MVMC_WAVE_SYNC();
+    for (int lev = 1; lev <= T.maxdepth; ++lev) {
         for (int t = lane; t < 162; t += 64) {
             const int j = t / 9, e = t - j * 9;
-            if (S.depth[j] == lev) {
-                const int p = S.parents[j], r = e / 3, c = e - r * 3;
+            if (T.depth[j] == lev) {
+                const int p = T.parents[j], r = e / 3, c = e - r * 3;
                 const double* Gp = &S.Rg[p * 9];
                 const double* Rj = &Rl[j * 9];
                 S.Rg[j * 9 + e] = Gp[r * 3] * Rj[c] + Gp[r * 3 + 1] * Rj[3 + c] + Gp[r * 3 + 2] * Rj[6 + c];
                 if (e < 3) {
                     S.pos[j * 3 + e] = Gp[e * 3] * off[j * 3] + Gp[e * 3 + 1] * off[j * 3 + 1] +
                                        Gp[e * 3 + 2] * off[j * 3 + 2] + S.pos[p * 3 + e];
-                    S.bvec[j * 3 + e] = Gp[e * 3] * S.dirs[j * 3] + Gp[e * 3 + 1] * S.dirs[j * 3 + 1] +
-                                        Gp[e * 3 + 2] * S.dirs[j * 3 + 2];
+                    S.bvec[j * 3 + e] = Gp[e * 3] * T.dirs[j * 3] + Gp[e * 3 + 1] * T.dirs[j * 3 + 1] +
+                                        Gp[e * 3 + 2] * T.dirs[j * 3 + 2];
                 }
             }
         }
-        __syncthreads();
+        MVMC_WAVE_SYNC();
     }
     const int k = lane & 15, r = lane >> 4;
     const double* X = &S.pos[kIkSkel[k] * 3];
@@ -139,7 +143,7 @@ __device__ __noinline__ double ik1_eval(Ik1Shared<VM>& S, const double* xs, int 
     if (S.mode3d) {
         // residual (pos_k - target_k) * w_k (inverse_kinematics.py:280-336): J_k = w_k D_k, so W_k = w_k^2 I, t_k = w_k f_k
         if (r == 0) {
-            const double* tg = &S.tgt[k * 4];
+            const double* tg = &S.pose18[k * 4];
             const double w = tg[3], w2 = w * w;
             const double f0 = (X0 - tg[0]) * w, f1 = (X1 - tg[1]) * w, f2c = (X2 - tg[2]) * w;
             f2 = f0 * f0 + f1 * f1 + f2c * f2c;
@@ -190,7 +194,7 @@ __device__ __noinline__ double ik1_eval(Ik1Shared<VM>& S, const double* xs, int 
             for (int e = 0; e < 3; ++e) S.tk[lane * 3 + e] = o[6 + e];
         }
     }
-    __syncthreads();
+    MVMC_WAVE_SYNC();
     return cost;
 }
 
@@ -204,13 +208,13 @@ __device__ __noinline__ double ik1_eval(Ik1Shared<VM>& S, const double* xs, int 
 // *gg = |g|^2, *ginf = |g|_inf.  S.sc[4..8) = {beta0, tau0, |J^T J|_1, coupling}.
 // ---------------------------------------------------------------------------------------------
 template <int VM, int N>
-__device__ __noinline__ int ik1_model(Ik1Shared<VM>& S, int stage, bool budget_left, double gtol, double* __restrict__ hh,
+__device__ __noinline__ int ik1_model(Ik1Shared<VM>& S, const Ik1Tables& T, int stage, bool budget_left, double gtol, double* __restrict__ hh,
                                       double* gg_out, double* ginf_out) {
-    const int lane = threadIdx.x;
-    const int na = S.na[stage];
+    const int lane = threadIdx.x & 63;
+    const int na = T.na[stage];
     const bool on = lane < na;
     const int cl = on ? lane : 0;
-    const int kind = S.colkind[stage][cl], ja = S.cola[stage][cl], jc = S.colc[stage][cl];
+    const int kind = T.colkind[stage][cl], ja = T.cola[stage][cl], jc = T.colc[stage][cl];
     // own rotation axis in the world frame and own pivot (kind 1): R_a = Rx Ry Rz inside the parent's frame
     double ax0 = 0.0, ax1 = 0.0, ax2 = 0.0, pa0 = 0.0, pa1 = 0.0, pa2 = 0.0;
 #ifdef MVMC_IK_PROFILE
@@ -229,7 +233,7 @@ __device__ __noinline__ int ik1_model(Ik1Shared<VM>& S, int stage, bool budget_l
         else { l0 = s1; l1 = -s0 * c1; l2 = c0 * c1; }
         if (ja == 0) { ax0 = l0; ax1 = l1; ax2 = l2; }
         else {
-            const double* Gp = &S.Rg[S.parents[ja] * 9];
+            const double* Gp = &S.Rg[T.parents[ja] * 9];
             ax0 = Gp[0] * l0 + Gp[1] * l1 + Gp[2] * l2;
             ax1 = Gp[3] * l0 + Gp[4] * l1 + Gp[5] * l2;
             ax2 = Gp[6] * l0 + Gp[7] * l1 + Gp[8] * l2;
@@ -248,13 +252,13 @@ __device__ __noinline__ int ik1_model(Ik1Shared<VM>& S, int stage, bool budget_l
             if (kind == 0) {
                 d0 = jc == 0 ? 1.0 : 0.0; d1 = jc == 1 ? 1.0 : 0.0; d2 = jc == 2 ? 1.0 : 0.0;
             } else if (kind == 1) {
-                if ((S.anc[K] >> ja) & 1) {
+                if ((T.anc[K] >> ja) & 1) {
                     const double r0 = S.pos[K * 3] - pa0, r1 = S.pos[K * 3 + 1] - pa1, r2 = S.pos[K * 3 + 2] - pa2;
                     d0 = ax1 * r2 - ax2 * r1; d1 = ax2 * r0 - ax0 * r2; d2 = ax0 * r1 - ax1 * r0;
                 }
             } else {
-                for (int j = K; j > 0; j = S.parents[j])
-                    if (S.side_map[j] == ja) { d0 += S.bvec[j * 3]; d1 += S.bvec[j * 3 + 1]; d2 += S.bvec[j * 3 + 2]; }
+                for (int j = K; j > 0; j = T.parents[j])
+                    if (T.side_map[j] == ja) { d0 += S.bvec[j * 3]; d1 += S.bvec[j * 3 + 1]; d2 += S.bvec[j * 3 + 2]; }
             }
         }
         const double* W = &S.Wk[k * 6];
@@ -262,12 +266,12 @@ __device__ __noinline__ int ik1_model(Ik1Shared<VM>& S, int stage, bool budget_l
         const double y1 = W[1] * d0 + W[3] * d1 + W[4] * d2;
         const double y2 = W[2] * d0 + W[4] * d1 + W[5] * d2;
         gj += d0 * S.tk[k * 3] + d1 * S.tk[k * 3 + 1] + d2 * S.tk[k * 3 + 2];
-        __syncthreads();  // the previous joint's broadcasts are done
+        MVMC_WAVE_SYNC();  // the previous joint's broadcasts are done
         db[lane * 3] = d0; db[lane * 3 + 1] = d1; db[lane * 3 + 2] = d2;
-        __syncthreads();
+        MVMC_WAVE_SYNC();
         // rows in chunks of 8 behind one wave-uniform test each (d_i vanishes on the other rows of a live chunk):
         // 12 broadcast ds_read_b128 in flight per chunk instead of one LDS round trip per row
-        const unsigned long long m = S.rowmask[stage][k];
+        const unsigned long long m = T.rowmask[stage][k];
         const unsigned mlo = __builtin_amdgcn_readfirstlane((unsigned)m), mhi = __builtin_amdgcn_readfirstlane((unsigned)(m >> 32));
 #pragma unroll
         for (int c = 0; c < N; c += 8) {
@@ -283,7 +287,7 @@ __device__ __noinline__ int ik1_model(Ik1Shared<VM>& S, int stage, bool budget_l
             }
         }
     }
-    __syncthreads();
+    MVMC_WAVE_SYNC();
     const double gg = wave_sum_dpp(gj * gj), ginf = wave_max64(fabs(gj));
     *gg_out = gg; *ginf_out = ginf;
     M1STAMP(4)
@@ -294,7 +298,7 @@ __device__ __noinline__ int ik1_model(Ik1Shared<VM>& S, int stage, bool budget_l
     bool ok = kk > 0;
     if (ok) ok = eightri::krylov_block_ok(S.sv + SV_D, S.sv + SV_E, kk, na, S.sc[6], S.sc[7], S.tmp, S.tmp + 64, S.tmp + 128,
                                           S.tmp + 192, S.sv + SV_WN);
-    __syncthreads();
+    MVMC_WAVE_SYNC();
     M1STAMP(6)
     if (ok) return kk;
     // No clean split between range and null space (weakly observed directions, missing joints): the step is taken
@@ -305,9 +309,9 @@ __device__ __noinline__ int ik1_model(Ik1Shared<VM>& S, int stage, bool budget_l
     double* Zg = hh + 64 * NA1;
     eightri::tri_eigh_w1<N>(S.sv + SV_D, S.sv + SV_E, m, S.sv + SV_WN, Zg, S.tmp, S.tmp + 64, S.tmp + 128);
     const double suf = lane < m ? S.sc[4] * Zg[lane] : 0.0;
-    __syncthreads();
+    MVMC_WAVE_SYNC();
     S.sv[SV_D + lane] = suf;   // d, e are dead: lam lives in the WN slot, suf in the D slot
-    __syncthreads();
+    MVMC_WAVE_SYNC();
     return -m;
 }
 
@@ -316,11 +320,11 @@ __device__ __noinline__ int ik1_model(Ik1Shared<VM>& S, int stage, bool budget_l
 // in mvmc_ik.hip on one wave.
 // ---------------------------------------------------------------------------------------------
 template <int VM>
-__device__ void ik1_trf(Ik1Shared<VM>& S, int stage, int max_nfev, double* __restrict__ hh, double* cost_out, int* nfev_out,
+__device__ void ik1_trf(Ik1Shared<VM>& S, const Ik1Tables& T, int stage, int max_nfev, double* __restrict__ hh, double* cost_out, int* nfev_out,
                         int* njev_out, int* status_out, int* fallbacks_out) {
-    const int lane = threadIdx.x;
-    const int nfull = (stage == 0) ? 57 : 57 + S.n_side;
-    const int na = S.na[stage];
+    const int lane = threadIdx.x & 63;
+    const int nfull = (stage == 0) ? 57 : 57 + T.n_side;
+    const int na = T.na[stage];
     const double ftol = 1e-8, xtol = 1e-8, gtol = 1e-8;
     auto x_norm2 = [&]() {
         double xx = (lane < nfull) ? S.x[lane] * S.x[lane] : 0.0;
@@ -328,7 +332,7 @@ __device__ void ik1_trf(Ik1Shared<VM>& S, int stage, int max_nfev, double* __res
         return wave_sum(xx);
     };
     double cost;
-    { P1_T0 cost = ik1_eval(S, S.x, stage, true); P1_ADD(0) }
+    { P1_T0 cost = ik1_eval(S, T, S.x, stage, true); P1_ADD(0) }
     int nfev = 1, njev = 0, status = -1;
     double Delta = sqrt(x_norm2());
     if (Delta == 0.0) Delta = 1.0;
@@ -338,8 +342,8 @@ __device__ void ik1_trf(Ik1Shared<VM>& S, int stage, int max_nfev, double* __res
     while (true) {
         if (need_model) {
             P1_T0
-            kk = (na <= 40) ? ik1_model<VM, 40>(S, stage, nfev < max_nfev, gtol, hh, &gg, &ginf)
-                            : ik1_model<VM, 50>(S, stage, nfev < max_nfev, gtol, hh, &gg, &ginf);
+            kk = (na <= 40) ? ik1_model<VM, 40>(S, T, stage, nfev < max_nfev, gtol, hh, &gg, &ginf)
+                            : ik1_model<VM, 50>(S, T, stage, nfev < max_nfev, gtol, hh, &gg, &ginf);
             ++njev;
             need_model = false;
             P1_ADD(2)
@@ -361,10 +365,10 @@ __device__ void ik1_trf(Ik1Shared<VM>& S, int stage, int max_nfev, double* __res
                 double c;
                 if (fast) {
                     rh[lane] = lane == 0 ? beta0 : 0.0;
-                    __syncthreads();
+                    MVMC_WAVE_SYNC();
                     alpha = eightri::tr_solve_tri<false>(S.sv + SV_D, S.sv + SV_E, rh, kk, Delta, alpha, gg, pivmin, nullptr,
                                                          nullptr, nullptr, nullptr, cv, &pred, &step_norm);
-                    __syncthreads();
+                    MVMC_WAVE_SYNC();
                     c = lane < kk ? cv[lane] : 0.0;
                     if (kk < na) {
                         // component along the first null coordinate: keeps the step orthogonal to the null vector
@@ -373,7 +377,7 @@ __device__ void ik1_trf(Ik1Shared<VM>& S, int stage, int max_nfev, double* __res
                     }
                 } else {
                     alpha = eightri::tr_solve_eig_w1(S.sv + SV_WN, S.sv + SV_D, mq, Delta, alpha, gg, cv, &pred, &step_norm);
-                    __syncthreads();
+                    MVMC_WAVE_SYNC();
                     c = eightri::eig_combine_w1(hh + 64 * NA1, mq, lane < mq ? cv[lane] : 0.0);
                 }
                 stepj = eightri::apply_q_w1(hh, S.sv + SV_TAU, S.sv + SV_V0, tau0, mq, na, c);
@@ -382,10 +386,10 @@ __device__ void ik1_trf(Ik1Shared<VM>& S, int stage, int max_nfev, double* __res
             const double x_norm = sqrt(x_norm2());
             if (lane < nfull) S.xn[lane] = S.x[lane];
             if (lane + 64 < nfull) S.xn[lane + 64] = S.x[lane + 64];
-            __syncthreads();
-            if (lane < na) { const int f = S.act[stage][lane]; S.xn[f] = S.x[f] + stepj; }
-            __syncthreads();
-            { P1_T0 cost_new = ik1_eval(S, S.xn, stage, true); P1_ADD(0) }
+            MVMC_WAVE_SYNC();
+            if (lane < na) { const int f = T.act[stage][lane]; S.xn[f] = S.x[f] + stepj; }
+            MVMC_WAVE_SYNC();
+            { P1_T0 cost_new = ik1_eval(S, T, S.xn, stage, true); P1_ADD(0) }
             ++nfev;
             if (!isfinite(cost_new)) { Delta = 0.25 * step_norm; continue; }
             actual = cost - cost_new;
@@ -408,7 +412,7 @@ __device__ void ik1_trf(Ik1Shared<VM>& S, int stage, int max_nfev, double* __res
         if (actual > 0.0) {
             if (lane < nfull) S.x[lane] = S.xn[lane];
             if (lane + 64 < nfull) S.x[lane + 64] = S.xn[lane + 64];
-            __syncthreads();
+            MVMC_WAVE_SYNC();
             cost = cost_new;
             // the accepted point's FK state and blocks are still in LDS (the last evaluation was at xn)
             need_model = status == -1 && nfev < max_nfev;
@@ -421,7 +425,7 @@ __device__ void ik1_trf(Ik1Shared<VM>& S, int stage, int max_nfev, double* __res
 // Cold start: DLT of the 18 keypoints + the reference's one-step post-optimisation; hips -> S.xn[0..6)
 template <int VM>
 __device__ __noinline__ void ik1_cold_root(Ik1Shared<VM>& S, int nv) {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     double X[3] = {0, 0, 0};
     if (lane < 18) dlt_obs_point(S.pose18, S.Pm, nv, lane, 0.01, X);
     postopt::post_optimize_wave(X, S.pose18 + (lane < 18 ? lane : 0) * 3, 54, S.Pm, nv, 18);
@@ -429,15 +433,78 @@ __device__ __noinline__ void ik1_cold_root(Ik1Shared<VM>& S, int nv) {
         for (int c = 0; c < 3; ++c) S.xn[(lane - 11) * 3 + c] = X[c];
 }
 
+// Skeleton-derived tables (depth, ancestor masks, active columns and row masks of both stages); one wave builds them
+template <typename TB>
+__device__ __forceinline__ void ik1_build_tables(TB& T, const SkelDev& skarg) {
+    const int lane = threadIdx.x & 63;
+    const int n_side = skarg.n_side;
+    if (lane < 18) {
+        for (int k = 0; k < 3; ++k) T.dirs[lane * 3 + k] = skarg.dirs[lane][k];
+        T.parents[lane] = (signed char)skarg.parents[lane];
+        T.side_map[lane] = (signed char)skarg.side_map[lane];
+        T.ref_side[lane] = skarg.ref_side[lane];
+    }
+    MVMC_WAVE_SYNC();
+    if (lane < 18) {
+        int d = 0, m = 0;
+        for (int a = T.parents[lane]; a >= 0; a = T.parents[a]) { ++d; m |= 1 << a; }
+        T.depth[lane] = (signed char)d; T.anc[lane] = m;
+    }
+    MVMC_WAVE_SYNC();
+    if (lane == 0) {
+        int md = 0, moved = 0, lens = 0;  // joints whose rotation moves an observed joint; used length slots
+        for (int j = 0; j < 18; ++j) md = T.depth[j] > md ? T.depth[j] : md;
+        T.maxdepth = md;
+        T.n_side = n_side;
+        for (int k = 0; k < NOBS; ++k) {
+            const int K = kIkSkel[k];
+            moved |= T.anc[K];
+            for (int j = K; j > 0; j = T.parents[j]) {
+                const double* d = &T.dirs[j * 3];
+                if (d[0] != 0.0 || d[1] != 0.0 || d[2] != 0.0) lens |= 1 << T.side_map[j];
+            }
+        }
+        for (int st = 0; st < 2; ++st) {
+            int n = 0;
+            for (int c = 0; c < 3; ++c) { T.act[st][n] = c; T.colkind[st][n] = 0; T.cola[st][n] = 0; T.colc[st][n] = c; ++n; }
+            for (int a = 0; a < 18; ++a)
+                if ((moved >> a) & 1)
+                    for (int c = 0; c < 3 && n < NA1; ++c) {
+                        T.act[st][n] = 3 + 3 * a + c; T.colkind[st][n] = 1; T.cola[st][n] = a; T.colc[st][n] = c; ++n;
+                    }
+            if (st == 1)
+                for (int s = 0; s < n_side && n < NA1; ++s)
+                    if ((lens >> s) & 1) { T.act[st][n] = 57 + s; T.colkind[st][n] = 2; T.cola[st][n] = s; T.colc[st][n] = 0; ++n; }
+            T.na[st] = n;
+        }
+    }
+    MVMC_WAVE_SYNC();
+    if (lane < 2 * NOBS) {
+        const int st = lane >> 4, k = lane & 15, K = kIkSkel[k];
+        unsigned long long m = 0;
+        for (int col = 0; col < T.na[st]; ++col) {
+            const int kind = T.colkind[st][col], a = T.cola[st][col];
+            bool nz = kind == 0;
+            if (kind == 1) nz = (T.anc[K] >> a) & 1;
+            if (kind == 2)
+                for (int j = K; j > 0; j = T.parents[j]) nz |= T.side_map[j] == a;
+            if (nz) m |= 1ull << col;
+        }
+        T.rowmask[st][k] = m;
+    }
+    MVMC_WAVE_SYNC();
+}
+
+// One solve on the calling wave (problem b); S is this wave's LDS block.  Used by ik1_kernel (one wave per workgroup)
+// and by the chain kernel (four waves per workgroup, one solve each).
 template <int VM>
-__global__ void __launch_bounds__(64, 3)
-ik1_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restrict__ Pmats,
-           const int32_t* __restrict__ members, int B, int V, int C, int Pmax, const double* __restrict__ init,
-           const uint8_t* __restrict__ cold, int nfev_cold, int nfev_warm, double* __restrict__ params_out,
-           double* __restrict__ joints_out, double* __restrict__ info_out, double* __restrict__ scratch, int stage_mask,
-           const double* __restrict__ targets3d) {
-    __shared__ Ik1Shared<VM> S;
-    const int b = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void ik1_solve(Ik1Shared<VM>& S, const Ik1Tables& T, const double* __restrict__ kps17,
+                                          const double* __restrict__ Pmats, const int32_t* __restrict__ members, int b, int V,
+                                          int C, int Pmax, const double* __restrict__ init, const uint8_t* __restrict__ cold,
+                                          int nfev_cold, int nfev_warm, double* __restrict__ params_out,
+                                          double* __restrict__ joints_out, double* __restrict__ info_out,
+                                          double* __restrict__ scratch, int stage_mask, const double* __restrict__ targets3d) {
+    const int lane = threadIdx.x & 63;
     double* hh = scratch + (size_t)b * MVMC_IK_SCRATCH_DOUBLES;   // Householder vectors [0, 3200), eigenvectors [3200, 6400)
     double* info = info_out ? info_out + (size_t)b * 8 : nullptr;
     // views of this problem (the reference only solves clusters with >= 2 views: motion_capture.py:927,940)
@@ -460,65 +527,11 @@ ik1_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __rest
     } else {
         // 3-D-target mode: targets (B,18,4) in the observation row order (COCO-17 + mid-spine)
         if (lane < NOBS)
-            for (int c = 0; c < 4; ++c) S.tgt[lane * 4 + c] = targets3d[(size_t)b * 72 + kIkObs[lane] * 4 + c];
+            for (int c = 0; c < 4; ++c) S.pose18[lane * 4 + c] = targets3d[(size_t)b * 72 + kIkObs[lane] * 4 + c];
         if (lane == 0) { S.nviews = 0; S.mode3d = 1; }
     }
-    const int n_side = skarg.n_side;
-    if (lane < 18) {
-        for (int k = 0; k < 3; ++k) S.dirs[lane * 3 + k] = skarg.dirs[lane][k];
-        S.parents[lane] = (signed char)skarg.parents[lane];
-        S.side_map[lane] = (signed char)skarg.side_map[lane];
-        S.ref_side[lane] = skarg.ref_side[lane];
-    }
-    __syncthreads();
-    // ---- static tables: depth, ancestor masks, active columns and row masks of both stages ----
-    if (lane < 18) {
-        int d = 0, m = 0;
-        for (int a = S.parents[lane]; a >= 0; a = S.parents[a]) { ++d; m |= 1 << a; }
-        S.depth[lane] = (signed char)d; S.anc[lane] = m;
-    }
-    __syncthreads();
-    if (lane == 0) {
-        int md = 0, moved = 0, lens = 0;  // joints whose rotation moves an observed joint; used length slots
-        for (int j = 0; j < 18; ++j) md = S.depth[j] > md ? S.depth[j] : md;
-        S.maxdepth = md;
-        S.n_side = n_side;
-        for (int k = 0; k < NOBS; ++k) {
-            const int K = kIkSkel[k];
-            moved |= S.anc[K];
-            for (int j = K; j > 0; j = S.parents[j]) {
-                const double* d = &S.dirs[j * 3];
-                if (d[0] != 0.0 || d[1] != 0.0 || d[2] != 0.0) lens |= 1 << S.side_map[j];
-            }
-        }
-        for (int st = 0; st < 2; ++st) {
-            int n = 0;
-            for (int c = 0; c < 3; ++c) { S.act[st][n] = c; S.colkind[st][n] = 0; S.cola[st][n] = 0; S.colc[st][n] = c; ++n; }
-            for (int a = 0; a < 18; ++a)
-                if ((moved >> a) & 1)
-                    for (int c = 0; c < 3 && n < NA1; ++c) {
-                        S.act[st][n] = 3 + 3 * a + c; S.colkind[st][n] = 1; S.cola[st][n] = a; S.colc[st][n] = c; ++n;
-                    }
-            if (st == 1)
-                for (int s = 0; s < n_side && n < NA1; ++s)
-                    if ((lens >> s) & 1) { S.act[st][n] = 57 + s; S.colkind[st][n] = 2; S.cola[st][n] = s; S.colc[st][n] = 0; ++n; }
-            S.na[st] = n;
-        }
-    }
-    __syncthreads();
-    if (lane < 2 * NOBS) {
-        const int st = lane >> 4, k = lane & 15, K = kIkSkel[k];
-        unsigned long long m = 0;
-        for (int col = 0; col < S.na[st]; ++col) {
-            const int kind = S.colkind[st][col], a = S.cola[st][col];
-            bool nz = kind == 0;
-            if (kind == 1) nz = (S.anc[K] >> a) & 1;
-            if (kind == 2)
-                for (int j = K; j > 0; j = S.parents[j]) nz |= S.side_map[j] == a;
-            if (nz) m |= 1ull << col;
-        }
-        S.rowmask[st][k] = m;
-    }
+    const int n_side = T.n_side;
+    MVMC_WAVE_SYNC();
     // ---- observations: 17 COCO rows + synthetic mid-spine (inverse_kinematics.py:339-348), projection matrices ----
     const int nv = S.nviews;
     if (lane < nv) {
@@ -536,7 +549,7 @@ ik1_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __rest
         const double* Pc = Pmats + (size_t)((q_own / Pmax) % C) * 12;
         for (int e = 0; e < 12; ++e) S.Pm[lane * 12 + e] = Pc[e];
     }
-    __syncthreads();
+    MVMC_WAVE_SYNC();
     // ---- initial parameters ----
     // stage_mask bit 2: every problem starts from init (mvmc_ik_solve_stages); otherwise cold == NULL means all cold
     const bool is_cold = (stage_mask & 4) ? false : ((cold == nullptr) || cold[b] != 0);
@@ -545,19 +558,19 @@ ik1_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __rest
         // (inverse_kinematics.py:390-396 with triangulate(..., 0.01, post_optimize=True))
         ik1_cold_root(S, nv);
         if (lane < 54) S.x[3 + lane] = 0.0;
-        if (lane < n_side) { S.side[lane] = S.ref_side[lane]; S.x[57 + lane] = S.ref_side[lane]; }
-        __syncthreads();
+        if (lane < n_side) { S.side[lane] = T.ref_side[lane]; S.x[57 + lane] = T.ref_side[lane]; }
+        MVMC_WAVE_SYNC();
         if (lane < 3) S.x[lane] = 0.5 * (S.xn[lane] + S.xn[3 + lane]);
     } else {
         const double* p0 = init + (size_t)b * 68;
         for (int i = lane; i < 57 + n_side; i += 64) S.x[i] = p0[i];
         if (lane < n_side) S.side[lane] = p0[57 + lane];
     }
-    __syncthreads();
+    MVMC_WAVE_SYNC();
 #ifdef MVMC_IK_PROFILE
     if (lane < 8) S.prof[lane] = 0;
     const long long t_all = clock64();
-    __syncthreads();
+    MVMC_WAVE_SYNC();
 #endif
     const int max_nfev = is_cold ? nfev_cold : nfev_warm;
     double costs[2];
@@ -565,11 +578,11 @@ ik1_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __rest
 #pragma unroll 1
     for (int stage = 0; stage < 2; ++stage) {
         double c = 0.0; int nf = 0, nj = 0, st = 0;
-        if ((stage_mask >> stage) & 1) ik1_trf(S, stage, max_nfev, hh, &c, &nf, &nj, &st, &fallbacks);
+        if ((stage_mask >> stage) & 1) ik1_trf(S, T, stage, max_nfev, hh, &c, &nf, &nj, &st, &fallbacks);
         costs[stage] = c; nfs[stage] = nf; njs[stage] = nj; sts[stage] = st;
-        __syncthreads();
+        MVMC_WAVE_SYNC();
     }
-    ik1_eval(S, S.x, 1, false);  // final FK at the solution
+    ik1_eval(S, T, S.x, 1, false);  // final FK at the solution
     for (int i = lane; i < 57 + n_side; i += 64) params_out[(size_t)b * 68 + i] = S.x[i];
     if (lane < 54) joints_out[(size_t)b * 54 + lane] = S.pos[lane];
     if (lane == 0) {
@@ -584,6 +597,20 @@ ik1_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __rest
 #endif
         }
     }
+}
+
+template <int VM>
+__global__ void __launch_bounds__(64, 3)
+ik1_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restrict__ Pmats,
+           const int32_t* __restrict__ members, int B, int V, int C, int Pmax, const double* __restrict__ init,
+           const uint8_t* __restrict__ cold, int nfev_cold, int nfev_warm, double* __restrict__ params_out,
+           double* __restrict__ joints_out, double* __restrict__ info_out, double* __restrict__ scratch, int stage_mask,
+           const double* __restrict__ targets3d) {
+    __shared__ Ik1Shared<VM> S;
+    __shared__ Ik1Tables T;
+    ik1_build_tables(T, skarg);
+    ik1_solve<VM>(S, T, kps17, Pmats, members, blockIdx.x, V, C, Pmax, init, cold, nfev_cold, nfev_warm, params_out,
+                  joints_out, info_out, scratch, stage_mask, targets3d);
 }
 
 }  // namespace

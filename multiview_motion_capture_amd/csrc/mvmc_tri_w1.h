@@ -63,7 +63,7 @@ __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, doub
     static_assert(N % CH == 0, "rows per chunk");
     auto two_sided = [&](int k, double tk, double vj) {
         vb[lane] = vj;
-        __syncthreads();
+        MVMC_WAVE_SYNC();
         double p0 = 0.0, p1 = 0.0;
 #pragma unroll
         for (int c = 0; c < N; c += CH)
@@ -78,7 +78,7 @@ __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, doub
         const double h = 0.5 * tk * wave_sum_dpp(p * vj);
         const double wj = p - h * vj;
         pb[lane] = wj;
-        __syncthreads();
+        MVMC_WAVE_SYNC();
 #pragma unroll
         for (int c = 0; c < N; c += CH)
             if (c + CH - 1 > k) {
@@ -104,7 +104,7 @@ __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, doub
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-        __syncthreads();  // vb / pb are rewritten by the next step
+        MVMC_WAVE_SYNC();  // vb / pb are rewritten by the next step
     };
     double anorm;
     {
@@ -165,7 +165,7 @@ __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, doub
         if (lane == n - 1) d[n - 1] = x;
     }
     if (lane == 0) out4[3] = coupling;
-    __syncthreads();
+    MVMC_WAVE_SYNC();
     return unclean ? -1 : kk;
 }
 
@@ -232,7 +232,7 @@ __device__ __noinline__ int tri_eigh_w1(const double* d, const double* e, int m,
         const double es = lane < m - 1 ? e[lane] / tscale : 0.0;
         e2sc[lane] = es * es;
     }
-    __syncthreads();
+    MVMC_WAVE_SYNC();
     const int nblk = (m - 1 + 7) >> 3;
     for (int round = 0; round < 60; ++round) {
         const double mid = 0.5 * (lo + hi);
@@ -240,10 +240,10 @@ __device__ __noinline__ int tri_eigh_w1(const double* d, const double* e, int m,
         if (c > lane) hi = mid; else lo = mid;
     }
     const double lam_i = lane < m ? 0.5 * (lo + hi) * tscale : 0.0;
-    __syncthreads();
+    MVMC_WAVE_SYNC();
     lam[lane] = lam_i;
     e2sc[lane] = lane < m - 1 ? e[lane] * e[lane] : 0.0;   // unscaled squares for the twisted factorisation
-    __syncthreads();
+    MVMC_WAVE_SYNC();
     const double lmax = fmax(fabs(lam[m - 1]), fabs(lam[0]));
     const double tol0 = 1e-13 * lmax;
     int k0 = 0;
@@ -255,7 +255,7 @@ __device__ __noinline__ int tri_eigh_w1(const double* d, const double* e, int m,
         double prev = -1e300;
         for (int i = 0; i < m; ++i) { prev = fmax(lam[i], prev + sep); wsh[i] = prev; }
     }
-    __syncthreads();
+    MVMC_WAVE_SYNC();
     const bool on = lane < m && lane >= k0;
     const double l = on ? wsh[lane] : 0.0;
     auto clamp = [&](double p) { return fabs(p) < pivmin ? (p < 0.0 ? -pivmin : pivmin) : p; };
@@ -345,7 +345,7 @@ __device__ __noinline__ int tri_eigh_w1(const double* d, const double* e, int m,
                 for (int j = 0; j < N; ++j) sd += lane_value(z[j], q) * z[j];
                 if (lane == i) wsh[q - start] = sd;   // dots against the unmodified vector i
             }
-            __syncthreads();
+            MVMC_WAVE_SYNC();
             for (int q = start; q < i; ++q) {
                 const double sq = wsh[q - start];
 #pragma unroll
@@ -362,15 +362,15 @@ __device__ __noinline__ int tri_eigh_w1(const double* d, const double* e, int m,
 #pragma unroll
                 for (int j = 0; j < N; ++j) z[j] *= inv;
             }
-            __syncthreads();
+            MVMC_WAVE_SYNC();
         }
     }
 #pragma unroll
     for (int j = 0; j < N; ++j)
         if (j < m) Zg[j * 64 + lane] = z[j];
-    __syncthreads();
+    MVMC_WAVE_SYNC();
     if (lane < k0) lam[lane] = 0.0;
-    __syncthreads();
+    MVMC_WAVE_SYNC();
     return k0;
 }
 
