@@ -194,19 +194,20 @@ __device__ __noinline__ double proj_dist(const double* pa, const double* pb, con
     return mean17(d);
 }
 
-__global__ void __launch_bounds__(64)
-affinity_kernel(const double* __restrict__ kps17, const int32_t* __restrict__ counts, const float* __restrict__ Fm,
-                int C, int P, float* __restrict__ Dg, float* __restrict__ Sg) {
-    extern __shared__ double sm[];
-    const int f = blockIdx.x, tid = threadIdx.x;
+// One frame on the calling wave.  sm: N*51 doubles + 2*N*N floats + 2*N ints + 4 words of LDS.
+__device__ __forceinline__ void affinity_wave(double* sm, const double* __restrict__ kps17, const int32_t* __restrict__ counts,
+                                              const float* __restrict__ Fm, int C, int P, int f, float* __restrict__ Do,
+                                              float* __restrict__ So) {
+    const int tid = threadIdx.x & 63;
     const int N = C * P;
     double* pts = sm;                                   // [N][17][3] compact node order
     float* D = reinterpret_cast<float*>(pts + N * 51);  // [n*n] contiguous (ld = n)
     float* tmp = D + N * N;                             // [n*n]
     int* node_q = reinterpret_cast<int*>(tmp + N * N);  // [N] node -> local pose index c*P+p
     int* node_v = node_q + N;                           // [N] node -> view
-    __shared__ int s_n;
-    __shared__ float s_mean, s_std;
+    int& s_n = node_v[N];
+    float& s_mean = reinterpret_cast<float*>(node_v + N)[1];
+    float& s_std = reinterpret_cast<float*>(node_v + N)[2];
     if (tid == 0) {
         int n = 0;
         for (int c = 0; c < C; ++c) {
@@ -216,7 +217,7 @@ affinity_kernel(const double* __restrict__ kps17, const int32_t* __restrict__ co
         }
         s_n = n;
     }
-    __syncthreads();
+    MVMC_WAVE_SYNC();
     const int n = s_n;
     const double* src = kps17 + (size_t)f * N * 51;
     for (int e = tid; e < n * 51; e += 64) {
@@ -227,7 +228,7 @@ affinity_kernel(const double* __restrict__ kps17, const int32_t* __restrict__ co
         int i = e / n, j = e - i * n;
         D[e] = (i == j) ? 0.f : 50.f;
     }
-    __syncthreads();
+    MVMC_WAVE_SYNC();
     // every unordered node pair of different views
     for (int e = tid; e < n * n; e += 64) {
         int i = e / n, j = e - i * n;
@@ -240,20 +241,18 @@ affinity_kernel(const double* __restrict__ kps17, const int32_t* __restrict__ co
         D[i * n + j] = v;
         D[j * n + i] = v;
     }
-    __syncthreads();
+    MVMC_WAVE_SYNC();
     // float32 statistics in NumPy's order (mv_math_util.py:348): mean, population std
     const int nn = n * n;
     if (tid == 0 && nn > 0) s_mean = np_pairwise_sum_f32(D, nn) / (float)nn;
-    __syncthreads();
+    MVMC_WAVE_SYNC();
     for (int e = tid; e < nn; e += 64) {
         float x = D[e] - s_mean;
         tmp[e] = fmulr(x, x);
     }
-    __syncthreads();
+    MVMC_WAVE_SYNC();
     if (tid == 0 && nn > 0) s_std = sqrtf(np_pairwise_sum_f32(tmp, nn) / (float)nn);
-    __syncthreads();
-    float* Do = Dg ? Dg + (size_t)f * N * N : nullptr;
-    float* So = Sg ? Sg + (size_t)f * N * N : nullptr;
+    MVMC_WAVE_SYNC();
     for (int e = tid; e < N * N; e += 64) {
         int i = e / N, j = e - i * N;
         float d = 0.f, s = 0.f;
@@ -267,6 +266,14 @@ affinity_kernel(const double* __restrict__ kps17, const int32_t* __restrict__ co
         if (Do) Do[e] = d;
         if (So) So[e] = s;
     }
+}
+
+__global__ void __launch_bounds__(64)
+affinity_kernel(const double* __restrict__ kps17, const int32_t* __restrict__ counts, const float* __restrict__ Fm,
+                int C, int P, float* __restrict__ Dg, float* __restrict__ Sg) {
+    extern __shared__ double sm[];
+    const int f = blockIdx.x, N = C * P;
+    affinity_wave(sm, kps17, counts, Fm, C, P, f, Dg ? Dg + (size_t)f * N * N : nullptr, Sg ? Sg + (size_t)f * N * N : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1064,25 +1071,36 @@ __device__ __forceinline__ int als4_iterate(const TW* __restrict__ Wf, int ldw, 
     return iters;
 }
 
+template <int NMAX>
+struct Als4Lds {
+    static constexpr int RMAX = 16;
+    double sX[NMAX * (NMAX + 1)];
+    __attribute__((aligned(16))) double sA[NMAX * RMAX];
+    __attribute__((aligned(16))) double sB[NMAX * RMAX];
+    __attribute__((aligned(16))) double sHp[4 * NMAX * RMAX];
+    double sG[RMAX * RMAX];
+    __attribute__((aligned(16))) double sMul[RMAX * RMAX];
+    double sDinv[RMAX], sRed[8];
+    int sGid[NMAX];
+    uint8_t sVis[NMAX];
+    int sKeep[NMAX];
+    int s_n, s_r;
+};
+
+// One graph (index f of the batch) on a 256-thread workgroup; every thread of the workgroup must call it.
 template <typename TW, int NMAX>
-__global__ void __launch_bounds__(256)
-als4_kernel(const TW* __restrict__ W, const int32_t* __restrict__ gcounts, int G, int ldw,
-            const double* __restrict__ seed, int seed_len, uint8_t* __restrict__ x_bin,
-            uint8_t* __restrict__ match_mat, int32_t* __restrict__ labels, int32_t* __restrict__ n_clusters,
-            int32_t* __restrict__ iters_out) {
+__device__ __forceinline__ void als4_graph(Als4Lds<NMAX>& L, int f, const TW* __restrict__ W,
+                                           const int32_t* __restrict__ gcounts, int G, int ldw,
+                                           const double* __restrict__ seed, int seed_len, uint8_t* __restrict__ x_bin,
+                                           uint8_t* __restrict__ match_mat, int32_t* __restrict__ labels,
+                                           int32_t* __restrict__ n_clusters, int32_t* __restrict__ iters_out) {
     constexpr int RMAX = 16, NT4 = 256;
-    __shared__ double sX[NMAX * (NMAX + 1)];
-    __shared__ __attribute__((aligned(16))) double sA[NMAX * RMAX];
-    __shared__ __attribute__((aligned(16))) double sB[NMAX * RMAX];
-    __shared__ __attribute__((aligned(16))) double sHp[4 * NMAX * RMAX];
-    __shared__ double sG[RMAX * RMAX];
-    __shared__ __attribute__((aligned(16))) double sMul[RMAX * RMAX];
-    __shared__ double sDinv[RMAX], sRed[8];
-    __shared__ int sGid[NMAX];
-    __shared__ uint8_t sVis[NMAX];
-    __shared__ int sKeep[NMAX];
-    __shared__ int s_n, s_r;
-    const int f = blockIdx.x, tid = threadIdx.x;
+    double *sX = L.sX, *sA = L.sA, *sB = L.sB, *sHp = L.sHp, *sG = L.sG, *sMul = L.sMul, *sDinv = L.sDinv, *sRed = L.sRed;
+    int *sGid = L.sGid, *sKeep = L.sKeep;
+    uint8_t* sVis = L.sVis;
+    int &s_n = L.s_n, &s_r = L.s_r;
+    const int tid = threadIdx.x;
+    __syncthreads();   // the arena may still be in use by the caller's previous phase
     if (tid == 0) {
         int n = 0, total = 0, gmax = 0;
         for (int g = 0; g < G; ++g) {
@@ -1167,6 +1185,16 @@ als4_kernel(const TW* __restrict__ W, const int32_t* __restrict__ gcounts, int G
             if (match_mat) match_mat[(size_t)f * ldw * ldw + e] = in ? sOut[i * n + j] : 0;
         }
     }
+}
+
+template <typename TW, int NMAX>
+__global__ void __launch_bounds__(256)
+als4_kernel(const TW* __restrict__ W, const int32_t* __restrict__ gcounts, int G, int ldw,
+            const double* __restrict__ seed, int seed_len, uint8_t* __restrict__ x_bin,
+            uint8_t* __restrict__ match_mat, int32_t* __restrict__ labels, int32_t* __restrict__ n_clusters,
+            int32_t* __restrict__ iters_out) {
+    __shared__ Als4Lds<NMAX> L;
+    als4_graph<TW, NMAX>(L, blockIdx.x, W, gcounts, G, ldw, seed, seed_len, x_bin, match_mat, labels, n_clusters, iters_out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1292,7 +1320,7 @@ extern "C" int mvmc_affinity(const double* kps17, const int32_t* counts, const f
     const int N = n_views * p_max;
     if (N > MVMC_MAX_NODES) return MVMC_ERR_UNSUPPORTED;
     if (n_frames == 0) return MVMC_OK;
-    size_t shm = (size_t)N * 51 * sizeof(double) + (size_t)2 * N * N * sizeof(float) + (size_t)2 * N * sizeof(int);
+    size_t shm = (size_t)N * 51 * sizeof(double) + (size_t)2 * N * N * sizeof(float) + (size_t)2 * N * sizeof(int) + 16;
     hipLaunchKernelGGL(affinity_kernel, dim3(n_frames), dim3(64), shm, (hipStream_t)stream, kps17, counts, Fmats,
                        n_views, p_max, D, S);
     MVMC_CHECK_LAUNCH();

@@ -77,21 +77,20 @@ __device__ __noinline__ double reproj_error(const double* joints, const double* 
     return cnt ? total / cnt : __longlong_as_double(0x7ff8000000000000LL);
 }
 
-__global__ void __launch_bounds__(64)
-st_affinity_kernel(const double* __restrict__ kps17, const int32_t* __restrict__ counts,
-                   const int32_t* __restrict__ frame_idx, const double* __restrict__ track_joints,
-                   const int32_t* __restrict__ n_tracks, const double* __restrict__ Pm, const double* __restrict__ F2,
-                   int C, int P, int T, double min_score, double* __restrict__ W, double* __restrict__ Dout,
-                   int32_t* __restrict__ group_counts) {
-    extern __shared__ double sm[];
-    const int b = blockIdx.x, tid = threadIdx.x;
+// One chain-frame (chain b, frame f) on the calling wave.  sm: NS*NS doubles + 2*NS ints + 2 doubles of LDS, NS = T + C*P.
+__device__ __forceinline__ void st_affinity_wave(double* sm, const double* __restrict__ kps17, const int32_t* __restrict__ counts,
+                                                 int b, int f, const double* __restrict__ track_joints,
+                                                 const int32_t* __restrict__ n_tracks, const double* __restrict__ Pm,
+                                                 const double* __restrict__ F2, int C, int P, int T, double min_score,
+                                                 double* __restrict__ W, double* __restrict__ Dout,
+                                                 int32_t* __restrict__ group_counts) {
+    const int tid = threadIdx.x & 63;
     const int NS = T + C * P;
     double* D = sm;                       // [NS*NS]
-    int* nview = reinterpret_cast<int*>(D + NS * NS);  // node -> view (-1 = tracklet)
+    double& s_max = D[NS * NS];
+    int* nview = reinterpret_cast<int*>(D + NS * NS + 2);  // node -> view (-1 = tracklet)
     int* nidx = nview + NS;               // node -> tracklet slot or local pose index c*P+p
-    __shared__ int s_n;
-    __shared__ double s_max;
-    const int f = frame_idx[b];
+    int& s_n = reinterpret_cast<int*>(D + NS * NS + 1)[0];
     int nt = n_tracks[b];
     nt = nt < 0 ? 0 : (nt > T ? T : nt);
     if (tid == 0) {
@@ -107,7 +106,7 @@ st_affinity_kernel(const double* __restrict__ kps17, const int32_t* __restrict__
         }
         s_n = n;
     }
-    __syncthreads();
+    MVMC_WAVE_SYNC();
     const int n = s_n;
     const double* kf = kps17 + (size_t)f * C * P * 51;
     const double* tj = track_joints + (size_t)b * T * 54;
@@ -126,13 +125,13 @@ st_affinity_kernel(const double* __restrict__ kps17, const int32_t* __restrict__
         }
         D[e] = d;
     }
-    __syncthreads();
+    MVMC_WAVE_SYNC();
     // nanmax, NaN -> max + 1 (motion_capture.py:744-745)
     double m = -1e300;
     for (int e = tid; e < n * n; e += 64) { const double d = D[e]; if (d == d && d > m) m = d; }
     for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
     if (tid == 0) s_max = m;
-    __syncthreads();
+    MVMC_WAVE_SYNC();
     double* Wb = W + (size_t)b * NS * NS;
     double* Db = Dout ? Dout + (size_t)b * NS * NS : nullptr;
     for (int e = tid; e < NS * NS; e += 64) {
@@ -150,19 +149,28 @@ st_affinity_kernel(const double* __restrict__ kps17, const int32_t* __restrict__
     }
 }
 
+__global__ void __launch_bounds__(64)
+st_affinity_kernel(const double* __restrict__ kps17, const int32_t* __restrict__ counts,
+                   const int32_t* __restrict__ frame_idx, const double* __restrict__ track_joints,
+                   const int32_t* __restrict__ n_tracks, const double* __restrict__ Pm, const double* __restrict__ F2,
+                   int C, int P, int T, double min_score, double* __restrict__ W, double* __restrict__ Dout,
+                   int32_t* __restrict__ group_counts) {
+    extern __shared__ double sm[];
+    const int b = blockIdx.x;
+    st_affinity_wave(sm, kps17, counts, b, frame_idx[b], track_joints, n_tracks, Pm, F2, C, P, T, min_score, W, Dout,
+                     group_counts);
+}
+
 // One thread per chain: cluster labels -> IK problem descriptors.
 //   slots [0,T): live tracklets (warm, init = their parameters) -- status 0 unmatched, 1 one view, 2 update
 //   slots [T,T+K): new tracklets from 2-D-only clusters with >= 2 views (cold)
-__global__ void assign_kernel(const int32_t* __restrict__ labels_sp, const int32_t* __restrict__ ncl_sp,
-                              const int32_t* __restrict__ labels_st, const int32_t* __restrict__ ncl_st,
-                              const int32_t* __restrict__ counts, const int32_t* __restrict__ frame_idx,
-                              const int32_t* __restrict__ n_tracks, const double* __restrict__ track_params, int B,
-                              int C, int P, int T, int K, int V, int32_t* __restrict__ members,
-                              uint8_t* __restrict__ cold, double* __restrict__ init, int32_t* __restrict__ status,
-                              int32_t* __restrict__ n_new) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const int f = frame_idx[b];
+__device__ __forceinline__ void assign_chain(int b, int f, const int32_t* __restrict__ labels_sp,
+                                             const int32_t* __restrict__ ncl_sp, const int32_t* __restrict__ labels_st,
+                                             const int32_t* __restrict__ ncl_st, const int32_t* __restrict__ counts,
+                                             const int32_t* __restrict__ n_tracks, const double* __restrict__ track_params,
+                                             int C, int P, int T, int K, int V, int32_t* __restrict__ members,
+                                             uint8_t* __restrict__ cold, double* __restrict__ init,
+                                             int32_t* __restrict__ status, int32_t* __restrict__ n_new) {
     int nt = n_tracks[b];
     nt = nt < 0 ? 0 : (nt > T ? T : nt);
     const int NP = T + K;
@@ -226,15 +234,27 @@ __global__ void assign_kernel(const int32_t* __restrict__ labels_sp, const int32
     n_new[b] = created;
 }
 
-// One thread per chain: tracklet table after the frame's IK solves.
-// meta[b][slot] = {id, state (1 tentative, 2 confirmed), hits, length}
-__global__ void commit_kernel(const int32_t* __restrict__ status, const int32_t* __restrict__ n_new,
-                              const double* __restrict__ ik_params, const double* __restrict__ ik_joints, int B, int T,
-                              int K, int n_inits, double* __restrict__ track_params, double* __restrict__ track_joints,
-                              int32_t* __restrict__ meta, int32_t* __restrict__ n_tracks, int32_t* __restrict__ next_id,
-                              int32_t* __restrict__ n_dead, int32_t* __restrict__ slot_src) {
+__global__ void assign_kernel(const int32_t* __restrict__ labels_sp, const int32_t* __restrict__ ncl_sp,
+                              const int32_t* __restrict__ labels_st, const int32_t* __restrict__ ncl_st,
+                              const int32_t* __restrict__ counts, const int32_t* __restrict__ frame_idx,
+                              const int32_t* __restrict__ n_tracks, const double* __restrict__ track_params, int B,
+                              int C, int P, int T, int K, int V, int32_t* __restrict__ members,
+                              uint8_t* __restrict__ cold, double* __restrict__ init, int32_t* __restrict__ status,
+                              int32_t* __restrict__ n_new) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    assign_chain(b, frame_idx[b], labels_sp, ncl_sp, labels_st, ncl_st, counts, n_tracks, track_params, C, P, T, K, V, members,
+                 cold, init, status, n_new);
+}
+
+// One thread per chain: tracklet table after the frame's IK solves.
+// meta[b][slot] = {id, state (1 tentative, 2 confirmed), hits, length}
+__device__ __forceinline__ void commit_chain(int b, const int32_t* __restrict__ status, const int32_t* __restrict__ n_new,
+                                             const double* __restrict__ ik_params, const double* __restrict__ ik_joints, int T,
+                                             int K, int n_inits, double* __restrict__ track_params,
+                                             double* __restrict__ track_joints, int32_t* __restrict__ meta,
+                                             int32_t* __restrict__ n_tracks, int32_t* __restrict__ next_id,
+                                             int32_t* __restrict__ n_dead, int32_t* __restrict__ slot_src) {
     const int NP = T + K;
     int nt = n_tracks[b];
     nt = nt < 0 ? 0 : (nt > T ? T : nt);
@@ -281,6 +301,17 @@ __global__ void commit_kernel(const int32_t* __restrict__ status, const int32_t*
     n_dead[b] += dead;
 }
 
+__global__ void commit_kernel(const int32_t* __restrict__ status, const int32_t* __restrict__ n_new,
+                              const double* __restrict__ ik_params, const double* __restrict__ ik_joints, int B, int T,
+                              int K, int n_inits, double* __restrict__ track_params, double* __restrict__ track_joints,
+                              int32_t* __restrict__ meta, int32_t* __restrict__ n_tracks, int32_t* __restrict__ next_id,
+                              int32_t* __restrict__ n_dead, int32_t* __restrict__ slot_src) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    commit_chain(b, status, n_new, ik_params, ik_joints, T, K, n_inits, track_params, track_joints, meta, n_tracks, next_id,
+                 n_dead, slot_src);
+}
+
 }  // namespace
 
 extern "C" int mvmc_fmats_from_projections(const double* Pmats, int n_views, double* F2, mvmcStream_t stream) {
@@ -301,7 +332,7 @@ extern "C" int mvmc_st_affinity(const double* kps17, const int32_t* counts, cons
     const int NS = t_max + n_views * p_max;
     if (NS > MVMC_MAX_NODES) return MVMC_ERR_UNSUPPORTED;
     if (n_chains <= 0) return n_chains == 0 ? MVMC_OK : MVMC_ERR_ARG;
-    const size_t shm = (size_t)NS * NS * sizeof(double) + (size_t)2 * NS * sizeof(int);
+    const size_t shm = (size_t)(NS * NS + 2) * sizeof(double) + (size_t)2 * NS * sizeof(int);
     hipLaunchKernelGGL(st_affinity_kernel, dim3(n_chains), dim3(64), shm, (hipStream_t)stream, kps17, counts, frame_idx,
                        track_joints, n_tracks, Pmats, F2, n_views, p_max, t_max, min_score, W, D, group_counts);
     MVMC_CHECK_LAUNCH();
