@@ -224,6 +224,62 @@ int mvmc_ik_solve_stages(const mvmcSkeleton* skel_host, const double* kps17, con
                          double* params_out, double* joints_out, double* info_out, double* scratch,
                          mvmcStream_t stream);
 
+/* The whole temporal hot path of a shard in ONE launch: a persistent 256-thread workgroup per chain runs
+ * graph (match_spatial where the chain has no tracklet, match_spatial_time otherwise) -> ALS -> assignment -> IK ->
+ * commit for the chain_len frames of its chain -- MvTracker.update_4d (motion_capture.py:873-963) per chain, the
+ * same device code as mvmc_affinity / mvmc_st_affinity / mvmc_als_associate / mvmc_track_assign / mvmc_ik_solve /
+ * mvmc_track_commit issued frame by frame, and the same results.  Chain b owns frames [b chain_len, (b+1) chain_len).
+ * All pointers are device memory owned by the caller (N = n_views p_max, NS = t_max + N, NP = t_max + k_max,
+ * B = n_chains, F = B chain_len).  Supported sizes: N <= 20, NS <= 32, v_max <= 6, p_max <= 8, t_max <= 8;
+ * MVMC_ERR_UNSUPPORTED otherwise (use the per-stage entry points). */
+typedef struct mvmcChainBuffers {
+    int32_t n_chains, chain_len, n_views, p_max, t_max, k_max, v_max, max_nfev_cold, max_nfev_warm, n_inits, seed_len;
+    /* inputs */
+    const double* kps17;        /* (F,C,P,17,3) after mvmc_ingest */
+    const int32_t* counts;      /* (F,C) */
+    const double* Pmats;        /* (C,3,4) */
+    const float* Fmats;         /* (C,C,3,3) from mvmc_fmats */
+    const double* F2;           /* (C,C,3,3) from mvmc_fmats_from_projections */
+    const double* seed_table;   /* mvmc_als_seed_table, on the device */
+    /* tracker state, in/out (zero-initialised for fresh chains) */
+    double* params;             /* (B,T,68) */
+    double* joints;             /* (B,T,18,3) */
+    int32_t* meta;              /* (B,T,4) id, state, hits, length */
+    int32_t* n_tracks;          /* (B) */
+    int32_t* next_id;           /* (B) */
+    int32_t* n_dead;            /* (B) */
+    int32_t* slot_src;          /* (B,T) */
+    /* workspaces, contents undefined before and after */
+    float* S_sp;                /* (B,N,N) */
+    double* W_st;               /* (B,NS,NS) */
+    int32_t* group_counts;      /* (B,C+1) */
+    int32_t* labels_sp;         /* (B,N) */
+    int32_t* labels_st;         /* (B,NS) */
+    int32_t* n_clusters_sp;     /* (B) */
+    int32_t* n_clusters_st;     /* (B) */
+    int32_t* iters_sp;          /* (B) */
+    int32_t* iters_st;          /* (B) */
+    int32_t* members;           /* (B,NP,V) */
+    uint8_t* cold;              /* (B,NP) */
+    double* init;               /* (B,NP,68) */
+    int32_t* status;            /* (B,T) */
+    int32_t* n_new;             /* (B) */
+    double* ik_params;          /* (B,NP,68) */
+    double* ik_joints;          /* (B,NP,18,3) */
+    double* ik_info;            /* (B,NP,8) */
+    double* ik_scratch;         /* (B,4,MVMC_IK_SCRATCH_DOUBLES) */
+    /* per-frame outputs: the tracklet table after every frame */
+    double* out_params;         /* (F,T,68) */
+    double* out_joints;         /* (F,T,18,3) */
+    int32_t* out_meta;          /* (F,T,4) */
+    int32_t* out_n_tracks;      /* (F) */
+    double* out_info;           /* (F,NP,8) IK info rows of the frame's problems, or NULL */
+    int32_t* out_als_iters;     /* (F) ALS iterations of the frame's graph, or NULL */
+    double* out_phase_cycles;   /* (B,8) diagnostic: shader cycles of each chain by phase {graph, ALS, assignment, IK, commit,
+                                   outputs, whole chain, 0}, or NULL */
+} mvmcChainBuffers;
+int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuffers* buffers, mvmcStream_t stream);
+
 /* Which kernel mvmc_ik_solve launches: 0 = one wave per solve (ik1_kernel, the default); 1 = one 256-thread workgroup
  * per solve (ik_kernel, the first layout, kept as the A/B reference).  Any other value only queries.  Returns the previous mode (-1 =
  * not yet chosen: the first mvmc_ik_solve call takes it from the environment variable MVMC_IK_MODE, default 0). */

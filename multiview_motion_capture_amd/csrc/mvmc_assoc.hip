@@ -8,6 +8,8 @@
 // once on the way in and once on the way out (the path is ALU/latency bound).
 #include "mvmc_common.h"
 
+namespace {
+
 // ------------------------------------------------------------------------------------------------
 // ingest
 // ------------------------------------------------------------------------------------------------
@@ -268,7 +270,7 @@ __device__ __forceinline__ void affinity_wave(double* sm, const double* __restri
     }
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 3)   // (proj_dist is shared with the chain kernel, which runs three workgroups per CU)
 affinity_kernel(const double* __restrict__ kps17, const int32_t* __restrict__ counts, const float* __restrict__ Fm,
                 int C, int P, float* __restrict__ Dg, float* __restrict__ Sg) {
     extern __shared__ double sm[];
@@ -1282,6 +1284,9 @@ __global__ void members_kernel(const int32_t* __restrict__ labels, const int32_t
     }
 }
 
+}  // namespace
+
+#ifndef MVMC_DEVICE_ONLY   // (mvmc_chain.hip includes the device code above)
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
@@ -1399,3 +1404,4 @@ extern "C" int mvmc_closure_labels(const uint8_t* x_bin, const int32_t* n_nodes,
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;
 }
+#endif  // MVMC_DEVICE_ONLY

@@ -1,0 +1,221 @@
+// The temporal hot path with the chains decoupled: ONE persistent 256-thread workgroup per chain runs
+//   graph (match_spatial / match_spatial_time) -> ALS -> assignment -> IK (one wave per person) -> commit
+// for all frames of its chain, with no launch boundaries in between (MvTracker.update_4d, motion_capture.py:873-963,
+// per chain; tracker.ChainTracker.step is the launch-per-stage form of the same sequence).
+//
+// Why: in the launch-per-stage form every launch lasts as long as its slowest member -- the ALS launch as long as the
+// graph with the most iterations (~290 against a mean of 140), the IK launch as long as the slowest solve -- and the
+// chip idles meanwhile.  Chains are independent, so here each advances at its own pace: a chain's time is the sum of
+// its OWN graph and solve times, and all chains are resident at once (3 workgroups per CU: 768 slots).
+//
+// The device code is the code of the separate kernels (affinity_wave, st_affinity_wave, als4_graph, assign_chain,
+// ik1_solve, commit_chain), so the results are the same bit for bit; LDS is one arena reused by the phases:
+//   [ graph scratch | Als4Lds | 4 x Ik1Shared ]  (union)  +  Ik1Tables (persistent)
+#define MVMC_DEVICE_ONLY
+#include "mvmc_common.h"
+#include "mvmc_assoc.hip"
+#include "mvmc_track.hip"
+#include "mvmc_ik1.hip"
+
+namespace {
+
+constexpr int CH_VM = 6;   // views per IK problem (v_max <= 6)
+
+struct ChainArgs {
+    // inputs
+    const double* kps17;      // (F,C,P,17,3), F = n_chains * L, chain b owns frames [b L, (b+1) L)
+    const int32_t* counts;    // (F,C)
+    const double* Pm;         // (C,3,4)
+    const float* Fm;          // (C,C,3,3) f32 (match_spatial)
+    const double* F2;         // (C,C,3,3) f64 (match_spatial_time)
+    const double* seed;       // RandomState(0).rand() table
+    int seed_len;
+    int n_chains, L, C, P, T, K, V, nfev_cold, nfev_warm, n_inits;
+    // tracker state per chain
+    double* params;           // (B,T,68)
+    double* joints;           // (B,T,18,3)
+    int32_t* meta;            // (B,T,4)
+    int32_t* n_tracks;        // (B)
+    int32_t* next_id;         // (B)
+    int32_t* n_dead;          // (B)
+    int32_t* slot_src;        // (B,T)
+    // per-chain workspaces
+    float* S_sp;              // (B,N,N)          N = C P
+    double* W_st;             // (B,NS,NS)        NS = T + C P
+    int32_t* gc;              // (B,C+1)
+    int32_t* labels_sp;       // (B,N)
+    int32_t* labels_st;       // (B,NS)
+    int32_t* ncl_sp;          // (B)
+    int32_t* ncl_st;          // (B)
+    int32_t* iters_sp;        // (B)
+    int32_t* iters_st;        // (B)
+    int32_t* members;         // (B,NP,V)         NP = T + K
+    uint8_t* cold;            // (B,NP)
+    double* init;             // (B,NP,68)
+    int32_t* status;          // (B,T)
+    int32_t* n_new;           // (B)
+    double* ik_params;        // (B,NP,68)
+    double* ik_joints;        // (B,NP,54)
+    double* ik_info;          // (B,NP,8)
+    double* ik_scratch;       // (B,4,MVMC_IK_SCRATCH_DOUBLES)
+    // per-frame outputs
+    double* out_params;       // (F,T,68)
+    double* out_joints;       // (F,T,54)
+    int32_t* out_meta;        // (F,T,4)
+    int32_t* out_n;           // (F)
+    double* out_info;         // (F,NP,8) or NULL
+    int32_t* out_iters;       // (F) ALS iterations of the frame's graph, or NULL
+    double* out_cycles;       // (B,8) shader cycles by phase {graph, ALS, assign, IK, commit, outputs, total}, or NULL
+};
+
+union ChainArena {
+    Als4Lds<32> als64;
+    Als4Lds<24> als32;
+    Ik1Shared<CH_VM> ik[4];
+    double graph[32 * 32 + 2 + 32];   // st_affinity_wave (NS <= 32) / affinity_wave (N <= 20: 20*51 + 400 + 24 doubles)
+};
+static_assert(sizeof(double) * (20 * 51 + 20 * 20 + 24) <= sizeof(Als4Lds<24>), "affinity scratch fits the arena");
+
+// The phases as separate (non-inlined) functions: each gets its own register allocation inside the workgroup's budget
+// of 168 VGPRs (three workgroups per CU) instead of one allocation over the union of all phases.
+__device__ __noinline__ void chain_graph_spatial(ChainArena& arena, const ChainArgs& A, int b, int f) {
+    const int C = A.C, P = A.P, N = C * P;
+    float* S = A.S_sp + (size_t)b * N * N;
+    if ((threadIdx.x >> 6) == 0) affinity_wave(arena.graph, A.kps17, A.counts, A.Fm, C, P, f, nullptr, S);
+}
+__device__ __noinline__ void chain_graph_temporal(ChainArena& arena, const ChainArgs& A, int b, int f) {
+    const int C = A.C, P = A.P, T = A.T, NS = T + C * P;
+    double* W = A.W_st + (size_t)b * NS * NS;
+    if ((threadIdx.x >> 6) == 0)
+        st_affinity_wave(arena.graph, A.kps17, A.counts, 0, f, A.joints + (size_t)b * T * 54, A.n_tracks + b, A.Pm, A.F2, C, P, T,
+                         0.1, W, nullptr, A.gc + (size_t)b * (C + 1));
+}
+__device__ __noinline__ void chain_als_spatial(ChainArena& arena, const ChainArgs& A, int b, int f) {
+    const int C = A.C, N = C * A.P;
+    // batch index 0 with pre-offset pointers: the graph, its group counts (the frame's people per view) and outputs
+    als4_graph<float, 24>(arena.als32, 0, A.S_sp + (size_t)b * N * N, A.counts + (size_t)f * C, C, N, A.seed, A.seed_len, nullptr,
+                          nullptr, A.labels_sp + (size_t)b * N, A.ncl_sp + b, A.iters_sp + b);
+}
+__device__ __noinline__ void chain_als_temporal(ChainArena& arena, const ChainArgs& A, int b) {
+    const int C = A.C, NS = A.T + C * A.P;
+    als4_graph<double, 32>(arena.als64, 0, A.W_st + (size_t)b * NS * NS, A.gc + (size_t)b * (C + 1), C + 1, NS, A.seed, A.seed_len,
+                           nullptr, nullptr, A.labels_st + (size_t)b * NS, A.ncl_st + b, A.iters_st + b);
+}
+__device__ __noinline__ void chain_assign(const ChainArgs& A, int b, int f) {
+    assign_chain(b, f, A.labels_sp, A.ncl_sp, A.labels_st, A.ncl_st, A.counts, A.n_tracks, A.params, A.C, A.P, A.T, A.K, A.V,
+                 A.members, A.cold, A.init, A.status, A.n_new);
+}
+__device__ __noinline__ void chain_commit(const ChainArgs& A, int b) {
+    commit_chain(b, A.status, A.n_new, A.ik_params, A.ik_joints, A.T, A.K, A.n_inits, A.params, A.joints, A.meta, A.n_tracks,
+                 A.next_id, A.n_dead, A.slot_src);
+}
+__device__ __noinline__ void chain_ik(ChainArena& arena, const Ik1Tables& tables, const ChainArgs& A, int b) {
+    const int wave = threadIdx.x >> 6, NP = A.T + A.K;
+    // wave w takes the problem slots w, w + 4, ... of this chain
+    for (int s = wave; s < NP; s += 4) {
+        const int p = b * NP + s;
+        ik1_solve<CH_VM>(arena.ik[wave], tables, A.kps17, A.Pm, A.members, p, A.V, A.C, A.P, A.init, A.cold, A.nfev_cold,
+                         A.nfev_warm, A.ik_params, A.ik_joints, A.ik_info,
+                         A.ik_scratch + (ptrdiff_t)(b * 4 + wave - p) * MVMC_IK_SCRATCH_DOUBLES, 3, nullptr);
+    }
+}
+
+__global__ void __launch_bounds__(256, 3)
+chain_kernel(SkelDev skarg, ChainArgs A) {
+    __shared__ ChainArena arena;
+    __shared__ Ik1Tables tables;
+    __shared__ int s_nt;
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+    const int T = A.T, NP = T + A.K;
+    if (wave == 0) ik1_build_tables(tables, skarg);
+    __syncthreads();
+    long long cyc[6] = {0, 0, 0, 0, 0, 0}, t_prev = clock64();
+    const long long t_start = t_prev;
+    auto lap = [&](int k) { const long long now = clock64(); cyc[k] += now - t_prev; t_prev = now; };
+    for (int t = 0; t < A.L; ++t) {
+        const int f = b * A.L + t;
+        if (tid == 0) s_nt = A.n_tracks[b];
+        __syncthreads();
+        const int nt = s_nt;
+        // ---- graph + association ----
+        if (nt <= 0) {   // no live tracklets: match_spatial (motion_capture.py:597-631), f32 affinity
+            chain_graph_spatial(arena, A, b, f);
+            __syncthreads();
+            lap(0);
+            chain_als_spatial(arena, A, b, f);
+        } else {
+            chain_graph_temporal(arena, A, b, f);
+            __syncthreads();
+            lap(0);
+            chain_als_temporal(arena, A, b);
+        }
+        __syncthreads();
+        lap(1);
+        if (tid == 0) chain_assign(A, b, f);    // clusters -> IK problems
+        __syncthreads();
+        lap(2);
+        chain_ik(arena, tables, A, b);
+        __syncthreads();
+        lap(3);
+        if (tid == 0) chain_commit(A, b);       // tracklet table after the frame
+        __syncthreads();
+        lap(4);
+        // ---- per-frame outputs ----
+        for (int e = tid; e < T * 68; e += 256) A.out_params[(size_t)f * T * 68 + e] = A.params[(size_t)b * T * 68 + e];
+        for (int e = tid; e < T * 54; e += 256) A.out_joints[(size_t)f * T * 54 + e] = A.joints[(size_t)b * T * 54 + e];
+        for (int e = tid; e < T * 4; e += 256) A.out_meta[(size_t)f * T * 4 + e] = A.meta[(size_t)b * T * 4 + e];
+        if (A.out_info)
+            for (int e = tid; e < NP * 8; e += 256) A.out_info[(size_t)f * NP * 8 + e] = A.ik_info[(size_t)b * NP * 8 + e];
+        if (tid == 0) {
+            A.out_n[f] = A.n_tracks[b];
+            if (A.out_iters) A.out_iters[f] = nt <= 0 ? A.iters_sp[b] : A.iters_st[b];
+        }
+        __syncthreads();
+        lap(5);
+    }
+    if (A.out_cycles && tid == 0) {
+        for (int k = 0; k < 6; ++k) A.out_cycles[(size_t)b * 8 + k] = (double)cyc[k];
+        A.out_cycles[(size_t)b * 8 + 6] = (double)(clock64() - t_start);
+        A.out_cycles[(size_t)b * 8 + 7] = 0.0;
+    }
+}
+
+}  // namespace
+
+extern "C" int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuffers* buf, mvmcStream_t stream) {
+    if (!skel_host || !buf) return MVMC_ERR_ARG;
+    const mvmcChainBuffers& B = *buf;
+    if (B.n_chains < 0 || B.chain_len <= 0 || B.n_views <= 0 || B.p_max <= 0 || B.t_max <= 0 || B.k_max <= 0 || B.v_max <= 0)
+        return MVMC_ERR_ARG;
+    if (B.max_nfev_cold < 1 || B.max_nfev_warm < 1) return MVMC_ERR_ARG;
+    // sizes the workgroup's LDS arena is built for (the launch-per-stage path covers everything else)
+    if (B.n_views * B.p_max > 20 || B.t_max + B.n_views * B.p_max > 32 || B.v_max > CH_VM || B.n_views > 16 ||
+        2 * B.p_max > 16 || 2 * (B.t_max > B.p_max ? B.t_max : B.p_max) > 16)
+        return MVMC_ERR_UNSUPPORTED;
+    const void* need[] = {B.kps17, B.counts, B.Pmats, B.Fmats, B.F2, B.seed_table, B.params, B.joints, B.meta, B.n_tracks,
+                          B.next_id, B.n_dead, B.slot_src, B.S_sp, B.W_st, B.group_counts, B.labels_sp, B.labels_st, B.n_clusters_sp,
+                          B.n_clusters_st, B.iters_sp, B.iters_st, B.members, B.cold, B.init, B.status, B.n_new, B.ik_params, B.ik_joints, B.ik_info, B.ik_scratch,
+                          B.out_params, B.out_joints, B.out_meta, B.out_n_tracks};
+    for (const void* q : need)
+        if (!q) return MVMC_ERR_ARG;
+    if (B.n_chains == 0) return MVMC_OK;
+    SkelDev sk;
+    if (!skel_to_dev(skel_host, &sk)) return MVMC_ERR_ARG;
+    if (sk.n_side != MVMC_N_SIDE) return MVMC_ERR_UNSUPPORTED;
+    ChainArgs A;
+    A.kps17 = B.kps17; A.counts = B.counts; A.Pm = B.Pmats; A.Fm = B.Fmats; A.F2 = B.F2; A.seed = B.seed_table;
+    A.seed_len = B.seed_len;
+    A.n_chains = B.n_chains; A.L = B.chain_len; A.C = B.n_views; A.P = B.p_max; A.T = B.t_max; A.K = B.k_max; A.V = B.v_max;
+    A.nfev_cold = B.max_nfev_cold; A.nfev_warm = B.max_nfev_warm; A.n_inits = B.n_inits;
+    A.params = B.params; A.joints = B.joints; A.meta = B.meta; A.n_tracks = B.n_tracks; A.next_id = B.next_id;
+    A.n_dead = B.n_dead; A.slot_src = B.slot_src;
+    A.S_sp = B.S_sp; A.W_st = B.W_st; A.gc = B.group_counts; A.labels_sp = B.labels_sp; A.labels_st = B.labels_st;
+    A.ncl_sp = B.n_clusters_sp; A.ncl_st = B.n_clusters_st; A.iters_sp = B.iters_sp; A.iters_st = B.iters_st;
+    A.members = B.members; A.cold = B.cold; A.init = B.init; A.status = B.status;
+    A.n_new = B.n_new; A.ik_params = B.ik_params; A.ik_joints = B.ik_joints; A.ik_info = B.ik_info; A.ik_scratch = B.ik_scratch;
+    A.out_params = B.out_params; A.out_joints = B.out_joints; A.out_meta = B.out_meta; A.out_n = B.out_n_tracks;
+    A.out_info = B.out_info; A.out_iters = B.out_als_iters; A.out_cycles = B.out_phase_cycles;
+    hipLaunchKernelGGL(chain_kernel, dim3(B.n_chains), dim3(256), 0, (hipStream_t)stream, sk, A);
+    MVMC_CHECK_LAUNCH();
+    return MVMC_OK;
+}

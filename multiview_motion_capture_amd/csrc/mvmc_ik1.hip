@@ -615,6 +615,7 @@ ik1_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __rest
 
 }  // namespace
 
+#ifndef MVMC_DEVICE_ONLY   // (mvmc_chain.hip includes the device code above)
 // launcher used by mvmc_ik_solve (mvmc_ik.hip)
 int mvmc_ik1_launch(const SkelDev& sk, const double* kps17, const double* Pmats, const int32_t* members, int n_problems,
                     int v_max, int n_views, int p_max, const double* init_params, const uint8_t* cold, int max_nfev_cold,
@@ -632,3 +633,4 @@ int mvmc_ik1_launch(const SkelDev& sk, const double* kps17, const double* Pmats,
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;
 }
+#endif  // MVMC_DEVICE_ONLY

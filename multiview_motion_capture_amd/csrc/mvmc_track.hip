@@ -314,6 +314,7 @@ __global__ void commit_kernel(const int32_t* __restrict__ status, const int32_t*
 
 }  // namespace
 
+#ifndef MVMC_DEVICE_ONLY   // (mvmc_chain.hip includes the device code above)
 extern "C" int mvmc_fmats_from_projections(const double* Pmats, int n_views, double* F2, mvmcStream_t stream) {
     if (!Pmats || !F2 || n_views <= 0) return MVMC_ERR_ARG;
     const int n = n_views * n_views;
@@ -372,3 +373,4 @@ extern "C" int mvmc_track_commit(const int32_t* status, const int32_t* n_new, co
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;
 }
+#endif  // MVMC_DEVICE_ONLY

@@ -146,3 +146,68 @@ def run_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], c
     if want_info:
         res["ik_info"] = torch.cat([torch.stack(i, 1) for i in infos], 0)
     return res
+
+
+def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], chain_len: int, t_max=8,
+                     nfev_cold=50, nfev_warm=5, want_info=False, k_max: Optional[int] = None, v_max: Optional[int] = None):
+    """run_chains in ONE launch (mvmc_chain_run): a persistent workgroup per chain runs graph -> ALS -> assignment ->
+    IK -> commit for the chain's frames, so every chain advances at its own pace instead of waiting, stage by stage,
+    for the slowest member of every launch.  Same device code and the same results as run_chains."""
+    import ctypes as C
+    from . import _cabi
+    F, Cn, P = kps.shape[:3]
+    L = chain_len
+    if F % L:
+        raise ValueError("run_chains_fused: the frame count must be a multiple of the chain length")
+    B = F // L
+    T = t_max
+    K = k_max or P + 2
+    V = v_max or min(Cn + 1, 8)
+    N, NS, NP = Cn * P, T + Cn * P, T + K
+    kps17, cnt = dev.ingest(kps, counts)
+    d = kps.device
+    F2 = dev.fmats_from_projections(hp.P)
+    seed = dev.als_seed_table(_cabi.MAX_NODES * _cabi.MAX_NODES, d)
+    f64, i32 = torch.float64, torch.int32
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=d)
+    e = lambda shape, dt: torch.empty(shape, dtype=dt, device=d)
+    t = dict(
+        kps17=kps17, counts=cnt, Pmats=hp.P, Fmats=hp.F, F2=F2, seed_table=seed,
+        params=z((B, T, 68), f64), joints=z((B, T, 18, 3), f64), meta=z((B, T, 4), i32), n_tracks=z((B,), i32),
+        next_id=z((B,), i32), n_dead=z((B,), i32), slot_src=torch.full((B, T), -1, dtype=i32, device=d),
+        S_sp=e((B, N, N), torch.float32), W_st=e((B, NS, NS), f64), group_counts=e((B, Cn + 1), i32),
+        labels_sp=e((B, N), i32), labels_st=e((B, NS), i32), n_clusters_sp=z((B,), i32), n_clusters_st=z((B,), i32),
+        iters_sp=z((B,), i32), iters_st=z((B,), i32), members=e((B, NP, V), i32), cold=e((B, NP), torch.uint8),
+        init=e((B, NP, 68), f64), status=e((B, T), i32), n_new=e((B,), i32), ik_params=e((B, NP, 68), f64),
+        ik_joints=e((B, NP, 18, 3), f64), ik_info=e((B, NP, 8), f64), ik_scratch=_chain_scratch(B, d),
+        out_params=e((F, T, 68), f64), out_joints=e((F, T, 18, 3), f64), out_meta=e((F, T, 4), i32), out_n_tracks=e((F,), i32),
+        out_info=e((F, NP, 8), f64) if want_info else None, out_als_iters=e((F,), i32) if want_info else None,
+        out_phase_cycles=e((B, 8), f64) if want_info else None)
+    buf = _cabi.MvmcChainBuffers()
+    for name, val in dict(n_chains=B, chain_len=L, n_views=Cn, p_max=P, t_max=T, k_max=K, v_max=V, max_nfev_cold=nfev_cold,
+                          max_nfev_warm=nfev_warm, n_inits=3, seed_len=seed.numel()).items():
+        setattr(buf, name, int(val))
+    for name, ten in t.items():
+        setattr(buf, name, None if ten is None else ten.data_ptr())
+    _cabi.check(_cabi.load().mvmc_chain_run(C.byref(hp.skeleton), C.byref(buf),
+                                            C.c_void_p(torch.cuda.current_stream(d).cuda_stream)), "mvmc_chain_run")
+    res = dict(params=t["out_params"], joints=t["out_joints"], meta=t["out_meta"], n_tracks=t["out_n_tracks"],
+               n_dead=t["n_dead"], _keepalive=t)
+    if want_info:
+        res["ik_info"] = t["out_info"].view(B, L, NP, 8)
+        res["als_iters"] = t["out_als_iters"].view(B, L)
+        res["phase_cycles"] = t["out_phase_cycles"]
+    return res
+
+
+_CHAIN_SCRATCH = {}
+
+
+def _chain_scratch(n_chains: int, d) -> torch.Tensor:
+    key = (str(d), torch.cuda.current_stream(d).cuda_stream)
+    buf = _CHAIN_SCRATCH.get(key)
+    if buf is None or buf.shape[0] < n_chains:
+        from . import _cabi
+        buf = torch.empty((n_chains, 4, _cabi.IK_SCRATCH_DOUBLES), dtype=torch.float64, device=d)
+        _CHAIN_SCRATCH[key] = buf
+    return buf
