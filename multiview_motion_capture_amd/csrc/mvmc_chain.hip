@@ -72,7 +72,7 @@ union ChainArena {
     Als4Lds<32> als64;
     Als4Lds<24> als32;
     Ik1Shared<CH_VM> ik[4];
-    double graph[32 * 32 + 2 + 32];   // st_affinity_wave (NS <= 32) / affinity_wave (N <= 20: 20*51 + 400 + 24 doubles)
+    double graph[32 * 32 + 8 + 32];   // st_affinity_wave (NS <= 32) / affinity_wave (N <= 20: 20*51 + 400 + 24 doubles)
 };
 static_assert(sizeof(double) * (20 * 51 + 20 * 20 + 24) <= sizeof(Als4Lds<24>), "affinity scratch fits the arena");
 
@@ -86,9 +86,8 @@ __device__ __noinline__ void chain_graph_spatial(ChainArena& arena, const ChainA
 __device__ __noinline__ void chain_graph_temporal(ChainArena& arena, const ChainArgs& A, int b, int f) {
     const int C = A.C, P = A.P, T = A.T, NS = T + C * P;
     double* W = A.W_st + (size_t)b * NS * NS;
-    if ((threadIdx.x >> 6) == 0)
-        st_affinity_wave(arena.graph, A.kps17, A.counts, 0, f, A.joints + (size_t)b * T * 54, A.n_tracks + b, A.Pm, A.F2, C, P, T,
-                         0.1, W, nullptr, A.gc + (size_t)b * (C + 1));
+    st_affinity_wave<true>(arena.graph, A.kps17, A.counts, 0, f, A.joints + (size_t)b * T * 54, A.n_tracks + b, A.Pm, A.F2, C, P,
+                           T, 0.1, W, nullptr, A.gc + (size_t)b * (C + 1));
 }
 __device__ __noinline__ void chain_als_spatial(ChainArena& arena, const ChainArgs& A, int b, int f) {
     const int C = A.C, N = C * A.P;
@@ -102,11 +101,11 @@ __device__ __noinline__ void chain_als_temporal(ChainArena& arena, const ChainAr
                            nullptr, nullptr, A.labels_st + (size_t)b * NS, A.ncl_st + b, A.iters_st + b);
 }
 __device__ __noinline__ void chain_assign(const ChainArgs& A, int b, int f) {
-    assign_chain(b, f, A.labels_sp, A.ncl_sp, A.labels_st, A.ncl_st, A.counts, A.n_tracks, A.params, A.C, A.P, A.T, A.K, A.V,
+    assign_chain(threadIdx.x & 63, 64, b, f, A.labels_sp, A.ncl_sp, A.labels_st, A.ncl_st, A.counts, A.n_tracks, A.params, A.C, A.P, A.T, A.K, A.V,
                  A.members, A.cold, A.init, A.status, A.n_new);
 }
 __device__ __noinline__ void chain_commit(const ChainArgs& A, int b) {
-    commit_chain(b, A.status, A.n_new, A.ik_params, A.ik_joints, A.T, A.K, A.n_inits, A.params, A.joints, A.meta, A.n_tracks,
+    commit_chain(threadIdx.x & 63, 64, b, A.status, A.n_new, A.ik_params, A.ik_joints, A.T, A.K, A.n_inits, A.params, A.joints, A.meta, A.n_tracks,
                  A.next_id, A.n_dead, A.slot_src);
 }
 __device__ __noinline__ void chain_ik(ChainArena& arena, const Ik1Tables& tables, const ChainArgs& A, int b) {
@@ -151,13 +150,13 @@ chain_kernel(SkelDev skarg, ChainArgs A) {
         }
         __syncthreads();
         lap(1);
-        if (tid == 0) chain_assign(A, b, f);    // clusters -> IK problems
+        if (wave == 0) chain_assign(A, b, f);   // clusters -> IK problems (bulk copies on the wave, the logic on lane 0)
         __syncthreads();
         lap(2);
         chain_ik(arena, tables, A, b);
         __syncthreads();
         lap(3);
-        if (tid == 0) chain_commit(A, b);       // tracklet table after the frame
+        if (wave == 0) chain_commit(A, b);      // tracklet table after the frame
         __syncthreads();
         lap(4);
         // ---- per-frame outputs ----

@@ -77,18 +77,23 @@ __device__ __noinline__ double reproj_error(const double* joints, const double* 
     return cnt ? total / cnt : __longlong_as_double(0x7ff8000000000000LL);
 }
 
-// One chain-frame (chain b, frame f) on the calling wave.  sm: NS*NS doubles + 2*NS ints + 2 doubles of LDS, NS = T + C*P.
+// One chain-frame (chain b, frame f) on the calling wave (WG = false) or on the whole 256-thread workgroup (WG = true:
+// every thread must call).  sm: (NS*NS + 6) doubles + 2*NS ints of LDS, NS = T + C*P.
+template <bool WG>
 __device__ __forceinline__ void st_affinity_wave(double* sm, const double* __restrict__ kps17, const int32_t* __restrict__ counts,
                                                  int b, int f, const double* __restrict__ track_joints,
                                                  const int32_t* __restrict__ n_tracks, const double* __restrict__ Pm,
                                                  const double* __restrict__ F2, int C, int P, int T, double min_score,
                                                  double* __restrict__ W, double* __restrict__ Dout,
                                                  int32_t* __restrict__ group_counts) {
-    const int tid = threadIdx.x & 63;
+    const int tid = WG ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+    constexpr int NT = WG ? 256 : 64;
+    auto sync = [] { if constexpr (WG) __syncthreads(); else MVMC_WAVE_SYNC(); };
     const int NS = T + C * P;
     double* D = sm;                       // [NS*NS]
     double& s_max = D[NS * NS];
-    int* nview = reinterpret_cast<int*>(D + NS * NS + 2);  // node -> view (-1 = tracklet)
+    double* s_part = D + NS * NS + 2;     // per-wave maxima
+    int* nview = reinterpret_cast<int*>(D + NS * NS + 6);  // node -> view (-1 = tracklet)
     int* nidx = nview + NS;               // node -> tracklet slot or local pose index c*P+p
     int& s_n = reinterpret_cast<int*>(D + NS * NS + 1)[0];
     int nt = n_tracks[b];
@@ -106,12 +111,12 @@ __device__ __forceinline__ void st_affinity_wave(double* sm, const double* __res
         }
         s_n = n;
     }
-    MVMC_WAVE_SYNC();
+    sync();
     const int n = s_n;
     const double* kf = kps17 + (size_t)f * C * P * 51;
     const double* tj = track_joints + (size_t)b * T * 54;
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
-    for (int e = tid; e < n * n; e += 64) {
+    for (int e = tid; e < n * n; e += NT) {
         const int i = e / n, j = e - i * n;
         double d;
         if (i == j) d = 0.0;
@@ -125,16 +130,22 @@ __device__ __forceinline__ void st_affinity_wave(double* sm, const double* __res
         }
         D[e] = d;
     }
-    MVMC_WAVE_SYNC();
+    sync();
     // nanmax, NaN -> max + 1 (motion_capture.py:744-745)
     double m = -1e300;
-    for (int e = tid; e < n * n; e += 64) { const double d = D[e]; if (d == d && d > m) m = d; }
+    for (int e = tid; e < n * n; e += NT) { const double d = D[e]; if (d == d && d > m) m = d; }
     for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
-    if (tid == 0) s_max = m;
-    MVMC_WAVE_SYNC();
+    if ((tid & 63) == 0) s_part[tid >> 6] = m;
+    sync();
+    if (tid == 0) {
+        double mm = s_part[0];
+        if constexpr (WG) { for (int w = 1; w < 4; ++w) mm = s_part[w] > mm ? s_part[w] : mm; }
+        s_max = mm;
+    }
+    sync();
     double* Wb = W + (size_t)b * NS * NS;
     double* Db = Dout ? Dout + (size_t)b * NS * NS : nullptr;
-    for (int e = tid; e < NS * NS; e += 64) {
+    for (int e = tid; e < NS * NS; e += NT) {
         const int i = e / NS, j = e - i * NS;
         double d = 0.0, s = 0.0, raw = 0.0;
         if (i < n && j < n) {
@@ -157,14 +168,14 @@ st_affinity_kernel(const double* __restrict__ kps17, const int32_t* __restrict__
                    int32_t* __restrict__ group_counts) {
     extern __shared__ double sm[];
     const int b = blockIdx.x;
-    st_affinity_wave(sm, kps17, counts, b, frame_idx[b], track_joints, n_tracks, Pm, F2, C, P, T, min_score, W, Dout,
+    st_affinity_wave<false>(sm, kps17, counts, b, frame_idx[b], track_joints, n_tracks, Pm, F2, C, P, T, min_score, W, Dout,
                      group_counts);
 }
 
 // One thread per chain: cluster labels -> IK problem descriptors.
 //   slots [0,T): live tracklets (warm, init = their parameters) -- status 0 unmatched, 1 one view, 2 update
 //   slots [T,T+K): new tracklets from 2-D-only clusters with >= 2 views (cold)
-__device__ __forceinline__ void assign_chain(int b, int f, const int32_t* __restrict__ labels_sp,
+__device__ __forceinline__ void assign_chain(int lane, int nl, int b, int f, const int32_t* __restrict__ labels_sp,
                                              const int32_t* __restrict__ ncl_sp, const int32_t* __restrict__ labels_st,
                                              const int32_t* __restrict__ ncl_st, const int32_t* __restrict__ counts,
                                              const int32_t* __restrict__ n_tracks, const double* __restrict__ track_params,
@@ -175,14 +186,16 @@ __device__ __forceinline__ void assign_chain(int b, int f, const int32_t* __rest
     nt = nt < 0 ? 0 : (nt > T ? T : nt);
     const int NP = T + K;
     int32_t* mem = members + (size_t)b * NP * V;
-    for (int e = 0; e < NP * V; ++e) mem[e] = -1;
-    for (int s = 0; s < NP; ++s) cold[(size_t)b * NP + s] = s >= T;
-    for (int s = 0; s < T; ++s) {
-        status[(size_t)b * T + s] = 0;
-        const double* src = track_params + ((size_t)b * T + s) * 68;
-        double* dst = init + ((size_t)b * NP + s) * 68;
-        for (int e = 0; e < 68; ++e) dst[e] = s < nt ? src[e] : 0.0;
+    // bulk initialisation, spread over the nl lanes that call (lane = 0 .. nl-1; the cluster logic below is lane 0's)
+    for (int e = lane; e < NP * V; e += nl) mem[e] = -1;
+    for (int s = lane; s < NP; s += nl) cold[(size_t)b * NP + s] = s >= T;
+    for (int s = lane; s < T; s += nl) status[(size_t)b * T + s] = 0;
+    for (int e = lane; e < T * 68; e += nl) {
+        const int s = e / 68;
+        init[(size_t)b * NP * 68 + e] = s < nt ? track_params[(size_t)b * T * 68 + e] : 0.0;
     }
+    if (nl > 1) MVMC_WAVE_SYNC();   // (callers with several lanes pass lanes of ONE wave)
+    if (lane != 0) return;
     int cnt[16];
     for (int c = 0; c < C && c < 16; ++c) {
         int k = counts[f * C + c];
@@ -243,13 +256,13 @@ __global__ void assign_kernel(const int32_t* __restrict__ labels_sp, const int32
                               int32_t* __restrict__ n_new) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    assign_chain(b, frame_idx[b], labels_sp, ncl_sp, labels_st, ncl_st, counts, n_tracks, track_params, C, P, T, K, V, members,
+    assign_chain(0, 1, b, frame_idx[b], labels_sp, ncl_sp, labels_st, ncl_st, counts, n_tracks, track_params, C, P, T, K, V, members,
                  cold, init, status, n_new);
 }
 
 // One thread per chain: tracklet table after the frame's IK solves.
 // meta[b][slot] = {id, state (1 tentative, 2 confirmed), hits, length}
-__device__ __forceinline__ void commit_chain(int b, const int32_t* __restrict__ status, const int32_t* __restrict__ n_new,
+__device__ __forceinline__ void commit_chain(int lane, int nl, int b, const int32_t* __restrict__ status, const int32_t* __restrict__ n_new,
                                              const double* __restrict__ ik_params, const double* __restrict__ ik_joints, int T,
                                              int K, int n_inits, double* __restrict__ track_params,
                                              double* __restrict__ track_joints, int32_t* __restrict__ meta,
@@ -276,10 +289,17 @@ __device__ __forceinline__ void commit_chain(int b, const int32_t* __restrict__ 
         }
         // compaction only moves entries to lower slots (w <= s), and slot s's IK result is read from the
         // separate IK buffers, so the in-place copy is safe
-        for (int e = 0; e < 68; ++e) tp[w * 68 + e] = sp[e];
-        for (int e = 0; e < 54; ++e) tj[w * 54 + e] = sj[e];
-        mt[w * 4] = id; mt[w * 4 + 1] = state; mt[w * 4 + 2] = hits; mt[w * 4 + 3] = len;
-        if (slot_src) slot_src[(size_t)b * T + w] = (st == 2) ? s : -1;  // IK problem slot solved this frame
+        // every calling lane runs the same decisions; the row copies are spread over the lanes (rows move to lower or
+        // equal slots only, and a later source row is never an earlier destination)
+        if (w != s || st == 2) {
+            for (int e = lane; e < 68; e += nl) tp[w * 68 + e] = sp[e];
+            for (int e = lane; e < 54; e += nl) tj[w * 54 + e] = sj[e];
+        }
+        if (nl > 1) MVMC_WAVE_SYNC();
+        if (lane == 0) {
+            mt[w * 4] = id; mt[w * 4 + 1] = state; mt[w * 4 + 2] = hits; mt[w * 4 + 3] = len;
+            if (slot_src) slot_src[(size_t)b * T + w] = (st == 2) ? s : -1;
+        }  // IK problem slot solved this frame
         ++w;
     }
     int id = next_id[b];
@@ -288,12 +308,16 @@ __device__ __forceinline__ void commit_chain(int b, const int32_t* __restrict__ 
         if (w >= T) break;  // table full: the tracklet is dropped (sized so that this does not happen)
         const double* sp = ik_params + ((size_t)b * NP + T + k) * 68;
         const double* sj = ik_joints + ((size_t)b * NP + T + k) * 54;
-        for (int e = 0; e < 68; ++e) tp[w * 68 + e] = sp[e];
-        for (int e = 0; e < 54; ++e) tj[w * 54 + e] = sj[e];
-        mt[w * 4] = id++; mt[w * 4 + 1] = 1; mt[w * 4 + 2] = 1; mt[w * 4 + 3] = 1;
-        if (slot_src) slot_src[(size_t)b * T + w] = T + k;
+        for (int e = lane; e < 68; e += nl) tp[w * 68 + e] = sp[e];
+        for (int e = lane; e < 54; e += nl) tj[w * 54 + e] = sj[e];
+        if (lane == 0) {
+            mt[w * 4] = id; mt[w * 4 + 1] = 1; mt[w * 4 + 2] = 1; mt[w * 4 + 3] = 1;
+            if (slot_src) slot_src[(size_t)b * T + w] = T + k;
+        }
+        ++id;
         ++w;
     }
+    if (lane != 0) return;
     if (slot_src)
         for (int s = w; s < T; ++s) slot_src[(size_t)b * T + s] = -1;
     next_id[b] = id;
@@ -308,7 +332,7 @@ __global__ void commit_kernel(const int32_t* __restrict__ status, const int32_t*
                               int32_t* __restrict__ n_dead, int32_t* __restrict__ slot_src) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    commit_chain(b, status, n_new, ik_params, ik_joints, T, K, n_inits, track_params, track_joints, meta, n_tracks, next_id,
+    commit_chain(0, 1, b, status, n_new, ik_params, ik_joints, T, K, n_inits, track_params, track_joints, meta, n_tracks, next_id,
                  n_dead, slot_src);
 }
 
@@ -333,7 +357,7 @@ extern "C" int mvmc_st_affinity(const double* kps17, const int32_t* counts, cons
     const int NS = t_max + n_views * p_max;
     if (NS > MVMC_MAX_NODES) return MVMC_ERR_UNSUPPORTED;
     if (n_chains <= 0) return n_chains == 0 ? MVMC_OK : MVMC_ERR_ARG;
-    const size_t shm = (size_t)(NS * NS + 2) * sizeof(double) + (size_t)2 * NS * sizeof(int);
+    const size_t shm = (size_t)(NS * NS + 6) * sizeof(double) + (size_t)2 * NS * sizeof(int);
     hipLaunchKernelGGL(st_affinity_kernel, dim3(n_chains), dim3(64), shm, (hipStream_t)stream, kps17, counts, frame_idx,
                        track_joints, n_tracks, Pmats, F2, n_views, p_max, t_max, min_score, W, D, group_counts);
     MVMC_CHECK_LAUNCH();
