@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--nfev-warm", type=int, default=5)
     ap.add_argument("--chain-len", type=int, default=16,
                     help="frames per temporal chain (cold start at the head, warm after); 1 = every frame cold")
+    ap.add_argument("--path", default="fused", choices=["fused", "stages"],
+                    help="chain protocol: 'fused' = one persistent workgroup per chain in ONE launch (mvmc_chain_run); 'stages' = "
+                         "one launch per stage and time step (ChainTracker.step)")
     ap.add_argument("--groups", type=int, default=1,
                     help="chain groups advanced on separate HIP streams (association of one group overlaps IK of another)")
     ap.add_argument("--cpu-frames", type=int, default=1, help="frames of the CPU baseline sample (0 = skip)")
@@ -116,7 +119,7 @@ def main():
     from multiview_motion_capture_amd import synth
     from multiview_motion_capture_amd.pipeline import HotPath
     from multiview_motion_capture_amd.parallel import gather_results
-    from multiview_motion_capture_amd.tracker import run_chains
+    from multiview_motion_capture_amd.tracker import run_chains, run_chains_fused
 
     F, C, Pn = args.frames, args.views, args.people
     # same cameras on every rank (seed), a different frame shard per rank (frame_seed)
@@ -138,16 +141,23 @@ def main():
             # temporal protocol: chains of L frames, MvTracker.update_4d semantics
             e = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if timed else None
             if timed: e[0].record()
-            out = run_chains(hp, kps, counts, L, nfev_cold=args.nfev_cold, nfev_warm=args.nfev_warm,
-                             events=ik_events if timed else None, want_info=timed, n_groups=args.groups,
-                             als_events=als_events if timed else None)
+            if args.path == "fused":
+                out = run_chains_fused(hp, kps, counts, L, nfev_cold=args.nfev_cold, nfev_warm=args.nfev_warm, want_info=timed)
+                out.pop("_keepalive", None)
+            else:
+                out = run_chains(hp, kps, counts, L, nfev_cold=args.nfev_cold, nfev_warm=args.nfev_warm,
+                                 events=ik_events if timed else None, want_info=timed, n_groups=args.groups,
+                                 als_events=als_events if timed else None)
             if timed:
                 e[1].record()
                 ev["total"].append((e[0], e[1]))
             info = out.pop("ik_info", None)
+            phase = out.pop("phase_cycles", None)
+            out.pop("als_iters", None)
             if world > 1:
                 out = gather_results({k: v for k, v in out.items() if k != "n_dead"}, world)
             out["info"] = info
+            out["phase"] = phase
             return out
         e = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
         if timed: e[0].record()
@@ -184,19 +194,32 @@ def main():
 
     stage_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items() if v}
     chain = with_ik and L > 1
-    if chain:
+    fused = chain and args.path == "fused"
+    if chain and not fused:
         ik_launch_ms = [a.elapsed_time(b) for a, b in ik_events]
         als_launch_ms = [a.elapsed_time(b) for a, b in als_events]
         stage_ms["ik"] = float(np.sum(ik_launch_ms) / args.steps)     # all IK launches of one step
         stage_ms["als_temporal"] = float(np.sum(als_launch_ms) / args.steps)   # ALS on the match_spatial_time graphs
         stage_ms["other"] = stage_ms["total"] - stage_ms["ik"] - stage_ms["als_temporal"]
+    if fused and out.get("phase") is not None:
+        # one launch: the phases interleave across chains, so only per-chain shares of shader cycles can be given
+        pc = out["phase"].cpu().numpy()
+        tot = pc[:, 6].sum()
+        stage_ms["chain_cycle_shares"] = {n: float(pc[:, k].sum() / tot) for k, n in
+                                          enumerate(("graph", "als", "assign", "ik", "commit", "outputs"))}
+        stage_ms["chain_mcycles_mean_max"] = [float(pc[:, 6].mean() / 1e6), float(pc[:, 6].max() / 1e6)]
     if rank == 0:
         frames_total = F * world * args.steps
         value = frames_total / dt
         bpf = BYTES_PER_FRAME(C, Pn)
         dom = "ik" if with_ik else "assoc"
         dom_kernel = "ik1_kernel" if with_ik else "als_kernel"
-        if chain:
+        if fused:
+            # the whole step is ONE launch of chain_kernel over the rank's F frames
+            dom, dom_kernel = "chain", "chain_kernel"
+            launch_ms = stage_ms["total"]
+            achieved = bpf * F / (launch_ms * 1e-3) / 1e9
+        elif chain:
             # dominant kernel = the one with the larger share of the step; both are launched once per time step over all
             # chains, so one launch serves F/L frames
             if stage_ms["als_temporal"] > stage_ms["ik"]:
@@ -228,7 +251,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"synthetic {F} frames/GPU, C={C}, P={Pn}, J=25: affinity+ALS+DLT" +
                                    ((f"+IK, temporal chains of {L} frames (match_spatial_time + tracker; cold 50+50 nfev at the head, "
-                                     f"warm 5+5 after)" if L > 1 else "+IK, every frame cold-started (chain length 1, max_nfev 50+50)")
+                                     f"warm 5+5 after), {'one persistent workgroup per chain' if args.path == 'fused' else 'one launch per stage'}" if L > 1 else "+IK, every frame cold-started (chain length 1, max_nfev 50+50)")
                                     if with_ik else ""),
                        "frames_per_gpu": F, "views": C, "people": Pn, "chain_len": L, "seed": args.seed, "parallelism": f"frames x{world}",
                        **extra},

@@ -1,0 +1,53 @@
+"""The persistent chain kernel (mvmc_chain_run: one workgroup per chain, one launch per shard) against the launch-per-stage
+path (ChainTracker.step: mvmc_affinity / mvmc_st_affinity / mvmc_als_associate / mvmc_track_assign / mvmc_ik_solve /
+mvmc_track_commit per time step).  Same device code, different scheduling: every output must be bit-identical."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(B, L, seed=20260103, people=4):
+    from multiview_motion_capture_amd import synth
+    from multiview_motion_capture_amd.pipeline import HotPath
+    from multiview_motion_capture_amd.tracker import run_chains, run_chains_fused
+    data = synth.generate(B * L, 5, people, seed, chain_len=L)
+    hp = HotPath(data["K"], data["Rt"])
+    kps = torch.from_numpy(data["kps25"]).cuda()
+    cnt = torch.from_numpy(data["counts"]).cuda()
+    a = run_chains(hp, kps, cnt, L, want_info=True)
+    b = run_chains_fused(hp, kps, cnt, L, want_info=True)
+    torch.cuda.synchronize()
+    return ({k: v.cpu().numpy() for k, v in a.items()},
+            {k: v.cpu().numpy() for k, v in b.items() if isinstance(v, torch.Tensor)})
+
+
+@pytest.mark.parametrize("B,L,people", [(48, 8, 4), (7, 16, 3)])
+def test_fused_equals_staged_bit_for_bit(B, L, people):
+    a, b = _both(B, L, people=people)
+    for k in ("n_tracks", "meta", "n_dead"):
+        assert np.array_equal(a[k], b[k]), k
+    for k in ("params", "joints", "ik_info"):
+        assert a[k].shape == b[k].shape
+        assert np.array_equal(np.isnan(a[k]), np.isnan(b[k])), k
+        m = ~np.isnan(a[k])
+        assert np.array_equal(a[k][m], b[k][m]), k
+    assert (a["n_tracks"] > 0).all()
+    # the kernel reports where each chain spent its cycles and how many ALS iterations its graphs took
+    pc = b["phase_cycles"]
+    assert pc.shape == (B, 8) and (pc[:, :6] > 0).all() and (pc[:, 6] >= pc[:, :6].sum(1) * 0.99).all()
+    assert b["als_iters"].shape == (B, L) and (b["als_iters"] > 0).all()
+
+
+def test_sizes_outside_the_arena_are_refused():
+    from multiview_motion_capture_amd import synth
+    from multiview_motion_capture_amd._cabi import MvmcError
+    from multiview_motion_capture_amd.pipeline import HotPath
+    from multiview_motion_capture_amd.tracker import run_chains_fused
+    data = synth.generate(8, 8, 8, 20260104, chain_len=4)      # config 5 geometry: 64 nodes per frame
+    hp = HotPath(data["K"], data["Rt"])
+    with pytest.raises(MvmcError):
+        run_chains_fused(hp, torch.from_numpy(data["kps25"]).cuda(), torch.from_numpy(data["counts"]).cuda(), 4)
+    with pytest.raises(ValueError):
+        run_chains_fused(hp, torch.from_numpy(data["kps25"]).cuda(), torch.from_numpy(data["counts"]).cuda(), 3)

@@ -52,10 +52,10 @@ def main():
             w.writerow([k, len(fe[k]), "%.3f" % (sum(fe[k]) / len(fe[k])), "%.3f" % (sum(wr[k]) / max(1, len(wr[k])))])
     tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     rec = json.load(open(tp)) if os.path.exists(tp) else {}
-    unit = ("bytes per launch (one launch = one time step of all 625 chains); rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in "
+    unit = ("bytes per launch (chain_kernel: one launch = the whole step of 10,000 frames; ik1 / als4: one time step of all 625 chains); rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in "
             "separate passes, KB x 1024; accesses are 8/12-byte, so the gfx950 x2 correction for 16-B streaming reads does not "
             "apply (ingest_kernel calibrates 1:1 against its known 30 MB input)")
-    for key, kern in (("ik", "ik1_kernel<6>"), ("als", "als4_kernel<double, 32>")):
+    for key, kern in (("ik", "ik1_kernel<6>"), ("als", "als4_kernel<double, 32>"), ("chain", "chain_kernel")):
         if kern not in fe:
             continue
         kf = sum(fe[kern]) / len(fe[kern]) * 1024
