@@ -69,3 +69,38 @@ def test_chains_c8p8(c5):
     errs = np.concatenate(errs)
     print(f"C8 P8 chains: {100 * (n == P).mean():.1f}% frames with {P} tracks; median joint error {np.median(errs) * 100:.2f} cm")
     assert (n == P).mean() > 0.9 and np.median(errs) < 0.05
+
+
+def test_temporal_graph_n72_vs_oracle(c5):
+    """match_spatial_time at config-5 size (8 tracklets + 64 poses = 72 nodes, generic ALS variant): the device's graph
+    for the second frame of a chain -- distances, affinity, X_bin, cluster labels -- against the oracle, both fed the
+    tracklets the device produced on the first frame."""
+    import tracker_np as tk
+    from multiview_motion_capture_amd import device as dev
+    from multiview_motion_capture_amd.tracker import ChainTracker
+    hp, data = c5["hp"], c5["data"]
+    d = c5["kps"].device
+    T = 12
+    kps17, cnt = dev.ingest(c5["kps"][:2].contiguous(), c5["cnt"][:2].contiguous())
+    tr = ChainTracker(hp, 1, P, t_max=T)
+    tr.step(kps17[0:1].contiguous(), cnt[0:1].contiguous())
+    nt = int(tr.n_tracks[0])
+    assert nt == P
+    joints0 = tr.joints[0, :nt].cpu().numpy()
+    out = tr.step(kps17[1:2].contiguous(), cnt[1:2].contiguous(), want_debug=True)
+    k17, c1 = kps17[1].cpu().numpy(), cnt[1].cpu().numpy()
+    views = [[k17[c, p] for p in range(c1[c])] for c in range(C)]
+    Pm = hp.P.cpu().numpy()
+    D_o, dim = o.spatial_time_distance([joints0[k] for k in range(nt)], views, Pm)
+    _, S_o = o.spatial_time_affinity(D_o)
+    mm_o, xb_o = o.match_als(S_o, dim)
+    n = dim[-1]
+    assert n == 72 and out["group_counts"][0].cpu().tolist() == np.diff(dim).tolist()
+    Dg, Wg = out["D"][0, :n, :n].cpu().numpy(), out["W"][0, :n, :n].cpu().numpy()
+    assert np.array_equal(np.isnan(Dg), np.isnan(D_o))
+    assert np.nanmax(np.abs(Dg - D_o)) <= 1e-9 * np.nanmax(np.abs(D_o))
+    assert np.abs(Wg - S_o).max() < 1e-10
+    assert np.array_equal(out["st"]["x_bin"][0, :n, :n].cpu().numpy().astype(bool), xb_o)
+    assert np.array_equal(out["st"]["labels"][0, :n].cpu().numpy(), o.cluster_labels(mm_o, n))
+    # every tracklet is matched in >= 2 views and continues (status 2), no new tracklets
+    assert out["status"][0, :nt].cpu().tolist() == [2] * nt and int(out["n_new"][0]) == 0
