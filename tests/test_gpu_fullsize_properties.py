@@ -100,3 +100,24 @@ def test_stream_groups_do_not_change_results(full):
     torch.cuda.synchronize()
     for k in ("params", "joints", "meta", "n_tracks", "n_dead"):
         assert torch.equal(torch.nan_to_num(a[k].double()), torch.nan_to_num(b[k].double())), k
+
+
+def test_persistent_chain_kernel_at_full_size(full):
+    """The benchmark's default path (mvmc_chain_run, one launch for the 625 chains) at BASELINE's size: identical to the
+    launch-per-stage run, deterministic, and shard invariant (two half-shards == the whole: what the multi-GPU split
+    relies on)."""
+    from multiview_motion_capture_amd.tracker import run_chains_fused
+    hp, kps, cnt = full["hp"], full["kps"], full["cnt"]
+    a = full.get("chains") or full["run_chains"](hp, kps, cnt, L)
+    f1 = run_chains_fused(hp, kps, cnt, L)
+    f2 = run_chains_fused(hp, kps, cnt, L)
+    cut = (F // L // 2) * L
+    s0 = run_chains_fused(hp, kps[:cut].contiguous(), cnt[:cut].contiguous(), L)
+    s1 = run_chains_fused(hp, kps[cut:].contiguous(), cnt[cut:].contiguous(), L)
+    torch.cuda.synchronize()
+    for k in ("params", "joints", "meta", "n_tracks"):
+        whole = torch.nan_to_num(f1[k].double())
+        assert torch.equal(whole, torch.nan_to_num(a[k].double())), f"fused differs from staged: {k}"
+        assert torch.equal(whole, torch.nan_to_num(f2[k].double())), f"non-deterministic {k}"
+        assert torch.equal(whole, torch.nan_to_num(torch.cat([s0[k], s1[k]]).double())), f"shard-dependent {k}"
+    assert torch.equal(f1["n_dead"], a["n_dead"])
