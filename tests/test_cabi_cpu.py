@@ -41,3 +41,26 @@ def test_bad_arguments_are_reported_not_raised_in_c():
     lib = _cabi.load()
     assert lib.mvmc_fmats(None, None, 5, None, None) == 1
     assert lib.mvmc_status_string(1).decode() == "invalid argument"
+
+
+def test_chain_buffers_struct_matches_header():
+    """mvmcChainBuffers is passed by pointer: the ctypes mirror must list the header's fields in the header's order."""
+    from multiview_motion_capture_amd import _cabi
+    text = open(os.path.join(ROOT, "include", "mvmc.h")).read()
+    body = text[text.index("typedef struct mvmcChainBuffers {"):text.index("} mvmcChainBuffers;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    ints, ptrs = [], []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        if "*" in decl:
+            ptrs.append(decl.split("*")[-1].strip())
+        else:
+            assert decl.startswith("int32_t"), decl
+            ints += [n.strip() for n in decl[len("int32_t"):].split(",")]
+    assert tuple(ints) == _cabi.MvmcChainBuffers._INTS
+    assert tuple(ptrs) == _cabi.MvmcChainBuffers._PTRS
+    # 11 int32 fields: the first pointer starts at the next 8-byte boundary, as in C
+    assert _cabi.MvmcChainBuffers.kps17.offset == 48
+    assert ctypes.sizeof(_cabi.MvmcChainBuffers) == 48 + 8 * len(ptrs)
