@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--path", default="fused", choices=["fused", "stages"],
                     help="chain protocol: 'fused' = one persistent workgroup per chain in ONE launch (mvmc_chain_run); 'stages' = "
                          "one launch per stage and time step (ChainTracker.step)")
+    ap.add_argument("--parts", type=int, default=0,
+                    help="fused path: workgroups per chain (consecutive frame ranges handed over through device flags); "
+                         "0 = one per frame of the chain (default), 1 = one persistent workgroup per chain")
     ap.add_argument("--groups", type=int, default=1,
                     help="chain groups advanced on separate HIP streams (association of one group overlaps IK of another)")
     ap.add_argument("--cpu-frames", type=int, default=1, help="frames of the CPU baseline sample (0 = skip)")
@@ -134,7 +137,7 @@ def main():
 
     ev = {k: [] for k in ("assoc", "tri", "ik", "total")}
 
-    ik_events, als_events = [], []
+    ik_events, als_events, hand_over_flags = [], [], []
 
     def step(timed):
         if with_ik and L > 1:
@@ -142,8 +145,10 @@ def main():
             e = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if timed else None
             if timed: e[0].record()
             if args.path == "fused":
-                out = run_chains_fused(hp, kps, counts, L, nfev_cold=args.nfev_cold, nfev_warm=args.nfev_warm, want_info=timed)
+                out = run_chains_fused(hp, kps, counts, L, nfev_cold=args.nfev_cold, nfev_warm=args.nfev_warm, want_info=timed,
+                                       parts=args.parts or None)
                 out.pop("_keepalive", None)
+                hand_over_flags.append(out.pop("flags", None))
             else:
                 out = run_chains(hp, kps, counts, L, nfev_cold=args.nfev_cold, nfev_warm=args.nfev_warm,
                                  events=ik_events if timed else None, want_info=timed, n_groups=args.groups,
@@ -192,6 +197,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    for fl in hand_over_flags:
+        if fl is not None and int(fl[-4]) != 0:
+            raise SystemExit("chain kernel: a hand-over between the workgroups of a chain timed out; results are void")
     stage_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items() if v}
     chain = with_ik and L > 1
     fused = chain and args.path == "fused"
@@ -251,7 +259,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"synthetic {F} frames/GPU, C={C}, P={Pn}, J=25: affinity+ALS+DLT" +
                                    ((f"+IK, temporal chains of {L} frames (match_spatial_time + tracker; cold 50+50 nfev at the head, "
-                                     f"warm 5+5 after), {'one persistent workgroup per chain' if args.path == 'fused' else 'one launch per stage'}" if L > 1 else "+IK, every frame cold-started (chain length 1, max_nfev 50+50)")
+                                     f"warm 5+5 after), {('one launch, ' + (str(args.parts or L) + ' workgroup(s) per chain')) if args.path == 'fused' else 'one launch per stage'}" if L > 1 else "+IK, every frame cold-started (chain length 1, max_nfev 50+50)")
                                     if with_ik else ""),
                        "frames_per_gpu": F, "views": C, "people": Pn, "chain_len": L, "seed": args.seed, "parallelism": f"frames x{world}",
                        **extra},

@@ -234,6 +234,9 @@ int mvmc_ik_solve_stages(const mvmcSkeleton* skel_host, const double* kps17, con
  * MVMC_ERR_UNSUPPORTED otherwise (use the per-stage entry points). */
 typedef struct mvmcChainBuffers {
     int32_t n_chains, chain_len, n_views, p_max, t_max, k_max, v_max, max_nfev_cold, max_nfev_warm, n_inits, seed_len;
+    int32_t n_parts;            /* workgroups per chain: 1 = one persistent workgroup per chain; p > 1 (dividing chain_len) =
+                                   p workgroups running consecutive frame ranges of the chain one after the other, so that
+                                   the hardware dispatcher balances the load over the CUs */
     /* inputs */
     const double* kps17;        /* (F,C,P,17,3) after mvmc_ingest */
     const int32_t* counts;      /* (F,C) */
@@ -275,6 +278,8 @@ typedef struct mvmcChainBuffers {
     int32_t* out_n_tracks;      /* (F) */
     double* out_info;           /* (F,NP,8) IK info rows of the frame's problems, or NULL */
     int32_t* out_als_iters;     /* (F) ALS iterations of the frame's graph, or NULL */
+    uint32_t* flags;            /* (B + 4) u32 hand-over flags, needed when n_parts > 1 (zeroed by the call; flags[B] != 0
+                                   afterwards = a part timed out waiting for its predecessor and the results are void) */
     double* out_phase_cycles;   /* (B,8) diagnostic: shader cycles of each chain by phase {graph, ALS, assignment, IK, commit,
                                    outputs, whole chain, 0}, or NULL */
 } mvmcChainBuffers;

@@ -66,6 +66,8 @@ struct ChainArgs {
     double* out_info;         // (F,NP,8) or NULL
     int32_t* out_iters;       // (F) ALS iterations of the frame's graph, or NULL
     double* out_cycles;       // (B,8) shader cycles by phase {graph, ALS, assign, IK, commit, outputs, total}, or NULL
+    int parts;                // workgroups per chain (consecutive frame ranges, handed over through flags)
+    unsigned* flags;          // (B + 1) parts completed per chain; [B] = timeout word.  Zeroed by the launcher
 };
 
 union ChainArena {
@@ -124,16 +126,40 @@ chain_kernel(SkelDev skarg, ChainArgs A) {
     __shared__ ChainArena arena;
     __shared__ Ik1Tables tables;
     __shared__ int s_nt;
-    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+    // Workgroup (part, chain): block index = part * n_chains + chain, so every workgroup of part p is dispatched before
+    // any of part p + 1 and a waiting workgroup's predecessor is always resident or finished.  A chain's parts run one
+    // after the other (flag per chain); because later parts start wherever a slot frees up, the CUs that run slower
+    // (three chains instead of two) simply receive fewer of them -- the hardware dispatcher balances the launch.
+    const int b = blockIdx.x % A.n_chains, part = blockIdx.x / A.n_chains;
+    const int tid = threadIdx.x, wave = tid >> 6;
     const int T = A.T, NP = T + A.K;
+    const int t_lo = part * A.L / A.parts, t_hi = (part + 1) * A.L / A.parts;
+    if (part > 0) {
+        // consumer side of the hand-off (cdna_hip_programming.md Guideline 16): one lane polls the chain's flag relaxed,
+        // one agent-scope acquire, then the workgroup's barrier; the chain state is read with plain vector loads after it
+        if (tid == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(A.flags + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)part) {
+                __builtin_amdgcn_s_sleep(32);
+                if (++spins > (1u << 22)) {   // ~ seconds: dispatch did not come in block order; give up loudly
+                    __hip_atomic_store(A.flags + A.n_chains, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (__hip_atomic_load(A.flags + A.n_chains, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    }
     if (wave == 0) ik1_build_tables(tables, skarg);
     __syncthreads();
     long long cyc[6] = {0, 0, 0, 0, 0, 0}, t_prev = clock64();
     const long long t_start = t_prev;
     auto lap = [&](int k) { const long long now = clock64(); cyc[k] += now - t_prev; t_prev = now; };
-    for (int t = 0; t < A.L; ++t) {
+    for (int t = t_lo; t < t_hi; ++t) {
         const int f = b * A.L + t;
-        if (tid == 0) s_nt = A.n_tracks[b];
+        if (tid == 0) s_nt = mvmc_ld_i32(A.n_tracks + b);
         __syncthreads();
         const int nt = s_nt;
         // ---- graph + association ----
@@ -166,16 +192,27 @@ chain_kernel(SkelDev skarg, ChainArgs A) {
         if (A.out_info)
             for (int e = tid; e < NP * 8; e += 256) A.out_info[(size_t)f * NP * 8 + e] = A.ik_info[(size_t)b * NP * 8 + e];
         if (tid == 0) {
-            A.out_n[f] = A.n_tracks[b];
+            A.out_n[f] = mvmc_ld_i32(A.n_tracks + b);
             if (A.out_iters) A.out_iters[f] = nt <= 0 ? A.iters_sp[b] : A.iters_st[b];
         }
         __syncthreads();
         lap(5);
     }
-    if (A.out_cycles && tid == 0) {
-        for (int k = 0; k < 6; ++k) A.out_cycles[(size_t)b * 8 + k] = (double)cyc[k];
-        A.out_cycles[(size_t)b * 8 + 6] = (double)(clock64() - t_start);
-        A.out_cycles[(size_t)b * 8 + 7] = 0.0;
+    if (A.out_cycles && tid == 0) {   // accumulated over the chain's parts (they run one after the other)
+        double* oc = A.out_cycles + (size_t)b * 8;
+        for (int k = 0; k < 6; ++k) oc[k] = (part ? oc[k] : 0.0) + (double)cyc[k];
+        oc[6] = (part ? oc[6] : 0.0) + (double)(clock64() - t_start);
+        oc[7] = (double)(part + 1);
+    }
+    if (A.parts > 1) {
+        // producer side: every wave drains its stores, the barrier, then one lane releases at agent scope and raises the flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(A.flags + b, (unsigned)(part + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -214,7 +251,12 @@ extern "C" int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuff
     A.n_new = B.n_new; A.ik_params = B.ik_params; A.ik_joints = B.ik_joints; A.ik_info = B.ik_info; A.ik_scratch = B.ik_scratch;
     A.out_params = B.out_params; A.out_joints = B.out_joints; A.out_meta = B.out_meta; A.out_n = B.out_n_tracks;
     A.out_info = B.out_info; A.out_iters = B.out_als_iters; A.out_cycles = B.out_phase_cycles;
-    hipLaunchKernelGGL(chain_kernel, dim3(B.n_chains), dim3(256), 0, (hipStream_t)stream, sk, A);
+    A.parts = B.n_parts > 1 ? B.n_parts : 1;
+    if (A.parts > 1 && (!B.flags || B.chain_len % A.parts != 0)) return MVMC_ERR_ARG;
+    A.flags = B.flags;
+    if (A.parts > 1 && hipMemsetAsync(B.flags, 0, sizeof(unsigned) * ((size_t)B.n_chains + 4), (hipStream_t)stream) != hipSuccess)
+        return MVMC_ERR_LAUNCH;
+    hipLaunchKernelGGL(chain_kernel, dim3(B.n_chains * A.parts), dim3(256), 0, (hipStream_t)stream, sk, A);
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;
 }

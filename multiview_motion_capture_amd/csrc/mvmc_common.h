@@ -17,6 +17,12 @@
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
     } while (0)
 
+// Scalar state that another workgroup may have written earlier in the same launch (chain kernel, parts > 1): read on the
+// vector path with an agent-scope load, never through the scalar cache (which an acquire fence does not refresh).
+__device__ __forceinline__ int32_t mvmc_ld_i32(const int32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 #define MVMC_CHECK_LAUNCH()                                  \
     do {                                                     \
         if (hipGetLastError() != hipSuccess) return MVMC_ERR_LAUNCH; \

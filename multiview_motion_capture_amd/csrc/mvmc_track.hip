@@ -96,7 +96,7 @@ __device__ __forceinline__ void st_affinity_wave(double* sm, const double* __res
     int* nview = reinterpret_cast<int*>(D + NS * NS + 6);  // node -> view (-1 = tracklet)
     int* nidx = nview + NS;               // node -> tracklet slot or local pose index c*P+p
     int& s_n = reinterpret_cast<int*>(D + NS * NS + 1)[0];
-    int nt = n_tracks[b];
+    int nt = mvmc_ld_i32(n_tracks + b);
     nt = nt < 0 ? 0 : (nt > T ? T : nt);
     if (tid == 0) {
         int n = 0;
@@ -182,7 +182,7 @@ __device__ __forceinline__ void assign_chain(int lane, int nl, int b, int f, con
                                              int C, int P, int T, int K, int V, int32_t* __restrict__ members,
                                              uint8_t* __restrict__ cold, double* __restrict__ init,
                                              int32_t* __restrict__ status, int32_t* __restrict__ n_new) {
-    int nt = n_tracks[b];
+    int nt = mvmc_ld_i32(n_tracks + b);
     nt = nt < 0 ? 0 : (nt > T ? T : nt);
     const int NP = T + K;
     int32_t* mem = members + (size_t)b * NP * V;
@@ -269,7 +269,7 @@ __device__ __forceinline__ void commit_chain(int lane, int nl, int b, const int3
                                              int32_t* __restrict__ n_tracks, int32_t* __restrict__ next_id,
                                              int32_t* __restrict__ n_dead, int32_t* __restrict__ slot_src) {
     const int NP = T + K;
-    int nt = n_tracks[b];
+    int nt = mvmc_ld_i32(n_tracks + b);
     nt = nt < 0 ? 0 : (nt > T ? T : nt);
     double* tp = track_params + (size_t)b * T * 68;
     double* tj = track_joints + (size_t)b * T * 54;
@@ -302,7 +302,7 @@ __device__ __forceinline__ void commit_chain(int lane, int nl, int b, const int3
         }  // IK problem slot solved this frame
         ++w;
     }
-    int id = next_id[b];
+    int id = mvmc_ld_i32(next_id + b);
     const int nn = n_new[b];
     for (int k = 0; k < nn; ++k) {
         if (w >= T) break;  // table full: the tracklet is dropped (sized so that this does not happen)
@@ -322,7 +322,7 @@ __device__ __forceinline__ void commit_chain(int lane, int nl, int b, const int3
         for (int s = w; s < T; ++s) slot_src[(size_t)b * T + s] = -1;
     next_id[b] = id;
     n_tracks[b] = w;
-    n_dead[b] += dead;
+    n_dead[b] = mvmc_ld_i32(n_dead + b) + dead;
 }
 
 __global__ void commit_kernel(const int32_t* __restrict__ status, const int32_t* __restrict__ n_new,

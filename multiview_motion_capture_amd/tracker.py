@@ -149,10 +149,14 @@ def run_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], c
 
 
 def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], chain_len: int, t_max=8,
-                     nfev_cold=50, nfev_warm=5, want_info=False, k_max: Optional[int] = None, v_max: Optional[int] = None):
+                     nfev_cold=50, nfev_warm=5, want_info=False, k_max: Optional[int] = None, v_max: Optional[int] = None,
+                     parts: Optional[int] = None):
     """run_chains in ONE launch (mvmc_chain_run): a persistent workgroup per chain runs graph -> ALS -> assignment ->
     IK -> commit for the chain's frames, so every chain advances at its own pace instead of waiting, stage by stage,
-    for the slowest member of every launch.  Same device code and the same results as run_chains."""
+    for the slowest member of every launch.  Same device code and the same results as run_chains.
+    parts > 1 (a divisor of chain_len): every chain is run by that many workgroups, one frame range after the other
+    (hand-over through device flags), which lets the hardware dispatcher even out the load when the number of chains is
+    not a multiple of the number of workgroup slots.  res["flags"][-4] != 0 after a run means a hand-over timed out."""
     import ctypes as C
     from . import _cabi
     F, Cn, P = kps.shape[:3]
@@ -160,6 +164,8 @@ def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tens
     if F % L:
         raise ValueError("run_chains_fused: the frame count must be a multiple of the chain length")
     B = F // L
+    if parts is None:
+        parts = L   # one workgroup per chain-frame: the finest hand-over, the best balance
     T = t_max
     K = k_max or P + 2
     V = v_max or min(Cn + 1, 8)
@@ -182,17 +188,20 @@ def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tens
         ik_joints=e((B, NP, 18, 3), f64), ik_info=e((B, NP, 8), f64), ik_scratch=_chain_scratch(B, d),
         out_params=e((F, T, 68), f64), out_joints=e((F, T, 18, 3), f64), out_meta=e((F, T, 4), i32), out_n_tracks=e((F,), i32),
         out_info=e((F, NP, 8), f64) if want_info else None, out_als_iters=e((F,), i32) if want_info else None,
+        flags=z((B + 4,), torch.int32) if parts > 1 else None,
         out_phase_cycles=e((B, 8), f64) if want_info else None)
+    if parts > 1 and L % parts:
+        raise ValueError("run_chains_fused: parts must divide the chain length")
     buf = _cabi.MvmcChainBuffers()
     for name, val in dict(n_chains=B, chain_len=L, n_views=Cn, p_max=P, t_max=T, k_max=K, v_max=V, max_nfev_cold=nfev_cold,
-                          max_nfev_warm=nfev_warm, n_inits=3, seed_len=seed.numel()).items():
+                          max_nfev_warm=nfev_warm, n_inits=3, seed_len=seed.numel(), n_parts=parts).items():
         setattr(buf, name, int(val))
     for name, ten in t.items():
         setattr(buf, name, None if ten is None else ten.data_ptr())
     _cabi.check(_cabi.load().mvmc_chain_run(C.byref(hp.skeleton), C.byref(buf),
                                             C.c_void_p(torch.cuda.current_stream(d).cuda_stream)), "mvmc_chain_run")
     res = dict(params=t["out_params"], joints=t["out_joints"], meta=t["out_meta"], n_tracks=t["out_n_tracks"],
-               n_dead=t["n_dead"], _keepalive=t)
+               n_dead=t["n_dead"], flags=t["flags"], _keepalive=t)
     if want_info:
         res["ik_info"] = t["out_info"].view(B, L, NP, 8)
         res["als_iters"] = t["out_als_iters"].view(B, L)

@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _both(B, L, seed=20260103, people=4):
+def _both(B, L, seed=20260103, people=4, parts=None):
     from multiview_motion_capture_amd import synth
     from multiview_motion_capture_amd.pipeline import HotPath
     from multiview_motion_capture_amd.tracker import run_chains, run_chains_fused
@@ -17,15 +17,19 @@ def _both(B, L, seed=20260103, people=4):
     kps = torch.from_numpy(data["kps25"]).cuda()
     cnt = torch.from_numpy(data["counts"]).cuda()
     a = run_chains(hp, kps, cnt, L, want_info=True)
-    b = run_chains_fused(hp, kps, cnt, L, want_info=True)
+    b = run_chains_fused(hp, kps, cnt, L, want_info=True, parts=parts)
     torch.cuda.synchronize()
     return ({k: v.cpu().numpy() for k, v in a.items()},
             {k: v.cpu().numpy() for k, v in b.items() if isinstance(v, torch.Tensor)})
 
 
-@pytest.mark.parametrize("B,L,people", [(48, 8, 4), (7, 16, 3)])
-def test_fused_equals_staged_bit_for_bit(B, L, people):
-    a, b = _both(B, L, people=people)
+@pytest.mark.parametrize("B,L,people,parts", [(48, 8, 4, None), (7, 16, 3, 1), (300, 4, 4, 2)])
+def test_fused_equals_staged_bit_for_bit(B, L, people, parts):
+    """parts = workgroups per chain: None = one per frame (the default), 1 = one persistent workgroup per chain."""
+    a, b = _both(B, L, people=people, parts=parts)
+    if parts != 1:
+        assert int(b["flags"][B]) == 0, "a hand-over between the workgroups of a chain timed out"
+        assert (b["flags"][:B] == (parts or L)).all()
     for k in ("n_tracks", "meta", "n_dead"):
         assert np.array_equal(a[k], b[k]), k
     for k in ("params", "joints", "ik_info"):
@@ -37,6 +41,7 @@ def test_fused_equals_staged_bit_for_bit(B, L, people):
     # the kernel reports where each chain spent its cycles and how many ALS iterations its graphs took
     pc = b["phase_cycles"]
     assert pc.shape == (B, 8) and (pc[:, :6] > 0).all() and (pc[:, 6] >= pc[:, :6].sum(1) * 0.99).all()
+    assert (pc[:, 7] == (parts or L)).all()
     assert b["als_iters"].shape == (B, L) and (b["als_iters"] > 0).all()
 
 
@@ -51,3 +56,5 @@ def test_sizes_outside_the_arena_are_refused():
         run_chains_fused(hp, torch.from_numpy(data["kps25"]).cuda(), torch.from_numpy(data["counts"]).cuda(), 4)
     with pytest.raises(ValueError):
         run_chains_fused(hp, torch.from_numpy(data["kps25"]).cuda(), torch.from_numpy(data["counts"]).cuda(), 3)
+    with pytest.raises(ValueError):   # parts must divide the chain length
+        run_chains_fused(hp, torch.from_numpy(data["kps25"]).cuda(), torch.from_numpy(data["counts"]).cuda(), 4, parts=3)
