@@ -153,6 +153,70 @@ def reprojection_error(p_3d: Pose, p_2d: Pose, calib: Calib, min_valid_kps_score
     return invalid_default_error if np.isnan(e) else e
 
 
+def match_spatial_time(tlets, frames: List[FrameData], pixel_error_threshold=None) -> SpatialTimeMatch:
+    """motion_capture.py:634-826: tracklets (their last 3-D pose) and the frame's 2-D poses in one graph -- epipolar error
+    between 2-D poses of different views, reprojection error between a tracklet and a 2-D pose, NaN elsewhere -> affinity ->
+    match_als -> clusters; a cluster with a tracklet becomes spatial_time_matches[tracklet index], a 2-D-only cluster a new
+    spatial match; one pose per view, the first wins.  ``pixel_error_threshold`` is unused, as in the reference."""
+    d = _d()
+    C = len(frames)
+    T = max(len(tlets), 1)
+    ids = [list(frm.poses.keys()) for frm in frames]
+    P = max(max((len(i) for i in ids), default=0), 1)
+    kps = np.zeros((1, C, P, 17, 3))
+    cnt = np.zeros((1, C), dtype=np.int32)
+    for c, frm in enumerate(frames):
+        cnt[0, c] = len(ids[c])
+        for k, p_id in enumerate(ids[c]):
+            kps[0, c, k, :, :2] = frm.poses[p_id].keypoints
+            kps[0, c, k, :, 2] = np.asarray(frm.poses[p_id].keypoints_score).ravel()
+    tj = np.zeros((1, T, 18, 3))
+    for k, t in enumerate(tlets):
+        tj[0, k] = np.asarray(t.last_pose_3d.keypoints)
+    Pm = torch.as_tensor(np.array([f.calib.P for f in frames], np.float64), device=d).contiguous()
+    W, D, gc = _dev.st_affinity(torch.as_tensor(kps, device=d), torch.as_tensor(cnt, device=d),
+                                torch.zeros(1, dtype=torch.int32, device=d), torch.as_tensor(tj, device=d),
+                                torch.tensor([len(tlets)], dtype=torch.int32, device=d), Pm, _dev.fmats_from_projections(Pm),
+                                want_D=True)
+    dim_groups = np.concatenate([[0], np.cumsum(gc[0].cpu().numpy())]).tolist()
+    n = dim_groups[-1]
+    # compact node order = [tracklets | poses by view] with the padded slots removed
+    keep = list(range(len(tlets)))
+    for c in range(C):
+        keep += [T + c * P + k for k in range(cnt[0, c])]
+    s_mat = W[0].cpu().numpy()[:n, :n]
+    dst_mat = D[0].cpu().numpy()[:n, :n]
+    match_mat, x_bin = match_als(s_mat, dim_groups)
+    out = SpatialTimeMatch({}, [])
+    nt = len(tlets)
+    for cluster in parse_match_result(match_mat, n, dim_groups):
+        tracklet_idx = next((gi for _, _, gi in cluster if gi < nt), -1)
+        m = SpatialMatch([], [])
+        for grp, loc, gi in cluster:
+            if gi < nt:
+                continue
+            view_idx = grp - 1
+            if view_idx in m.view_idxs:
+                continue   # more than one pose of a view in the cluster: the first wins (:785-787, :803-805)
+            m.view_idxs.append(view_idx)
+            m.pose_ids.append(ids[view_idx][loc])
+            m.cost_matrix_idxs.append(gi)
+        if len(m) > 0:
+            if tracklet_idx >= 0:
+                out.spatial_time_matches[tracklet_idx] = m
+            else:
+                out.spatial_matches.append(m)
+    for c in range(C):
+        out.view_pose_matrix_idxs[c] = [(p_id, dim_groups[c + 1] + k) for k, p_id in enumerate(ids[c])]
+    out.dst_mat, out.sim_mat, out.match_mat = dst_mat, s_mat, x_bin
+    return out
+
+
+def associate_tracking(tlets, frames: List[FrameData], min_pixel_error_hard_threshold=None) -> SpatialTimeMatch:
+    """motion_capture.py:829-835."""
+    return match_spatial_time(tlets, frames, min_pixel_error_hard_threshold) if tlets else match_spatial(frames)
+
+
 class MvTracklet:
     """Host-side record of one tracklet (motion_capture.py:312-400); the numbers come from the device."""
 

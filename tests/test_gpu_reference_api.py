@@ -229,3 +229,35 @@ def test_run_main_writes_the_reference_tracklet_pickle(api, tmp_path):
     frm, pparam, pose = t0.poses[-1]
     assert pparam.root.shape == (3,) and pparam.euler_angles.shape == (18, 3) and pose.keypoints.shape == (18, 3)
     assert np.isfinite(pose.keypoints).all()
+
+
+def test_match_spatial_time_standalone_against_oracle(api):
+    """match_spatial_time / associate_tracking as standalone calls (motion_capture.py:634-835) on Shelf frames, the tracklets
+    taken from the device tracker: same tracklet matches and new matches as the oracle's associate()."""
+    import tracker_np as tk
+    mc = api["mc"]
+    tracker = mc.MvTracker(api["ik"].load_skeleton())
+    Ps = np.array([c.P for c in api["calibs"]])
+    checked = 0
+    for fi in range(1, 13):
+        frames = _frames(api, fi)
+        if tracker.tracklets:
+            got = mc.associate_tracking(tracker.tracklets, frames, 50)
+            views = [[np.concatenate([p.keypoints, p.keypoints_score], axis=1) for p in f.poses.values()] for f in frames]
+            ids = [list(f.poses.keys()) for f in frames]
+            o_tl = [tk.Tracklet(t.track_id, fi, None, np.asarray(t.last_pose_3d.keypoints)) for t in tracker.tracklets]
+            tm, nm = tk.associate(o_tl, views, Ps)
+            exp_tm = {k: ([v for v, _ in m], [ids[v][l] for v, l in m]) for k, m in tm.items()}
+            got_tm = {k: (m.view_idxs, m.pose_ids) for k, m in got.spatial_time_matches.items()}
+            assert got_tm == exp_tm, fi
+            assert [(m.view_idxs, m.pose_ids) for m in got.spatial_matches] == \
+                   [([v for v, _ in m], [ids[v][l] for v, l in m]) for m in nm], fi
+            n = got.sim_mat.shape[0]
+            assert got.dst_mat.shape == (n, n) and got.match_mat.shape == (n, n)
+            assert sorted(got.view_pose_matrix_idxs) == list(range(5))
+            checked += 1
+        else:
+            got = mc.associate_tracking([], frames, 50)     # falls back to match_spatial
+            assert got.spatial_time_matches == {} and len(got.spatial_matches) >= 1
+        tracker.update_4d(fi, frames, None)
+    assert checked >= 10
