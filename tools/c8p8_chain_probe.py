@@ -3,16 +3,19 @@ sys.path.insert(0, "/root/repo")
 from multiview_motion_capture_amd import synth
 from multiview_motion_capture_amd.pipeline import HotPath
 from multiview_motion_capture_amd.tracker import run_chains
-L, B = 8, 64
+L, B = 16, int(sys.argv[1]) if len(sys.argv) > 1 else 64
 data = synth.generate(B * L, 8, 8, 20260104, chain_len=L)
 hp = HotPath(data["K"], data["Rt"])
 kps = torch.from_numpy(data["kps25"]).cuda(); cnt = torch.from_numpy(data["counts"]).cuda()
 for rep in range(2):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    out = run_chains(hp, kps, cnt, L, t_max=8, want_info=True)
+    ev, ae = [], []
+    out = run_chains(hp, kps, cnt, L, t_max=12, want_info=True, events=ev, als_events=ae)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print("C8P8 chains: %.1f ms for %d frames -> %.0f frames/s" % (dt * 1e3, B * L, B * L / dt))
 nt = out["n_tracks"].cpu().numpy().reshape(B, L)
 print("tracks per frame: mean %.2f min %d max %d; last frame mean %.2f" % (nt.mean(), nt.min(), nt.max(), nt[:, -1].mean()))
-meta = out["meta"].cpu().numpy().reshape(B, L, 8, 4)
+meta = out["meta"].cpu().numpy().reshape(B, L, 12, 4)
 print("confirmed at last frame:", (meta[:, -1, :, 1] == 2).sum(1).mean())
+print("IK launches ms:", " ".join("%.1f" % a.elapsed_time(b) for a, b in ev))
+print("ALS (temporal graph) launches ms:", " ".join("%.1f" % a.elapsed_time(b) for a, b in ae))
