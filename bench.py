@@ -60,26 +60,51 @@ def cpu_baseline(data, n_frames, max_nfev):
                        f"oracle/oracle_np.py (NumPy + SciPy least_squares), {dt:.1f} s")
 
 
-def cpu_baseline_chain(data, L):
-    """Oracle tracker (oracle/tracker_np.py: the reference's update_4d restated) over ONE chain of L frames."""
+def _cpu_chain_worker(job):
+    """One chain of L frames through the oracle tracker (runs in a worker process; NumPy/SciPy only)."""
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_np as o
     import tracker_np as tk
-    kps25 = data["kps25"][:L].astype(np.float64)
+    kps25, K, Rt, P = job
     C, Pn = kps25.shape[1:3]
-    t0 = time.perf_counter()
-    tr = tk.OracleTracker(data["K"], data["Rt"], data["P"])
-    for f in range(L):
+    tr = tk.OracleTracker(K, Rt, P)
+    for f in range(kps25.shape[0]):
         views = []
         for c in range(C):
             poses = [o.openpose25_to_coco17(kps25[f, c, p]) for p in range(Pn)]
             views.append([p for p in poses if o.pose_is_good(p)])
         tr.update(f, views)
-    dt = time.perf_counter() - t0
     n_cold = sum(1 for s in tr.solves if s[1])
-    return dict(value=L / dt, unit="frames/s", cores=1, kind="port",
-                sample=f"one chain of {L} frames of the same synthetic workload ({n_cold} cold + {len(tr.solves) - n_cold} warm "
-                       f"IK solves), oracle/tracker_np.py + oracle_np.py (NumPy + SciPy least_squares), {dt:.1f} s")
+    return n_cold, len(tr.solves) - n_cold
+
+
+def cpu_baseline_chain(data, L, workers):
+    """Oracle tracker (oracle/tracker_np.py: the reference's update_4d restated) over `workers` chains of L frames, one chain
+    per worker process (the chains of the workload are independent, so this is how a CPU would run them in parallel)."""
+    jobs = [(data["kps25"][w * L:(w + 1) * L].astype(np.float64), data["K"], data["Rt"], data["P"]) for w in range(workers)]
+    t0 = time.perf_counter()
+    if workers > 1:
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+        env_old = os.environ.get("OMP_NUM_THREADS")
+        os.environ["OMP_NUM_THREADS"] = "1"      # inherited by the spawned workers: one thread each
+        try:
+            with ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as ex:
+                res = list(ex.map(_cpu_chain_worker, jobs))
+        finally:
+            if env_old is None:
+                os.environ.pop("OMP_NUM_THREADS", None)
+            else:
+                os.environ["OMP_NUM_THREADS"] = env_old
+    else:
+        res = [_cpu_chain_worker(jobs[0])]
+    dt = time.perf_counter() - t0
+    n_cold, n_warm = sum(r[0] for r in res), sum(r[1] for r in res)
+    return dict(value=workers * L / dt, unit="frames/s", cores=workers, kind="port",
+                sample=f"{workers} chain(s) of {L} frames of the same synthetic workload, one per worker process ({n_cold} cold + "
+                       f"{n_warm} warm IK solves), oracle/tracker_np.py + oracle_np.py (NumPy + SciPy least_squares), {dt:.1f} s "
+                       f"including worker start-up")
 
 
 def main():
@@ -104,6 +129,8 @@ def main():
     ap.add_argument("--groups", type=int, default=1,
                     help="chain groups advanced on separate HIP streams (association of one group overlaps IK of another)")
     ap.add_argument("--cpu-frames", type=int, default=1, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-workers", type=int, default=0,
+                    help="worker processes of the CPU baseline on the chain protocol (0 = min(16, host cores))")
     ap.add_argument("--seed", type=int, default=20260103)
     args = ap.parse_args()
 
@@ -272,8 +299,15 @@ def main():
                                  "bytes of the frames one launch serves / mean launch duration of the dominant kernel; see DESIGN.md"},
         }
         if args.cpu_frames > 0 and world == 1:
-            res["cpu_baseline"] = (cpu_baseline_chain(data, L) if chain else
-                                   cpu_baseline(data, args.cpu_frames, args.nfev_cold))
+            if chain:
+                workers = max(1, min(args.cpu_workers or min(16, os.cpu_count() or 1), F // L))
+                try:
+                    res["cpu_baseline"] = cpu_baseline_chain(data, L, workers)
+                except Exception as exc:   # a worker pool that cannot start must not cost the benchmark line
+                    print(f"cpu baseline: worker pool failed ({exc!r}); timing one chain in this process", file=sys.stderr)
+                    res["cpu_baseline"] = cpu_baseline_chain(data, L, 1)
+            else:
+                res["cpu_baseline"] = cpu_baseline(data, args.cpu_frames, args.nfev_cold)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
