@@ -104,7 +104,7 @@ __device__ inline void euler_to_rot_hs(const double* e, double* R, double* hs) {
 // Lane (k, r) = (lane & 15, lane >> 4) handles observed joint k in the views r, r + 4.  Returns 0.5 |f|^2.
 // ---------------------------------------------------------------------------------------------
 template <int VM>
-__device__ __noinline__ double ik1_eval(Ik1Shared<VM>& S, const Ik1Tables& T, const double* xs, int stage, bool want_jac) {
+__device__ __forceinline__ double ik1_eval(Ik1Shared<VM>& S, const Ik1Tables& T, const double* xs, int stage, bool want_jac) {
     const int lane = threadIdx.x & 63;
     double* Rl = S.tmp;
     double* off = S.tmp + 162;
