@@ -225,8 +225,8 @@ def main():
         dt = float(t.item())
 
     for fl in hand_over_flags:
-        if fl is not None and int(fl[-4]) != 0:
-            raise SystemExit("chain kernel: a hand-over between the workgroups of a chain timed out; results are void")
+        if fl is not None and (int(fl[-4]) != 0 or int(fl[-3]) != 0):
+            raise SystemExit("chain kernel: a hand-over timed out or a graph did not fit; results are void")
     stage_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items() if v}
     chain = with_ik and L > 1
     fused = chain and args.path == "fused"

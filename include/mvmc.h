@@ -230,8 +230,9 @@ int mvmc_ik_solve_stages(const mvmcSkeleton* skel_host, const double* kps17, con
  * same device code as mvmc_affinity / mvmc_st_affinity / mvmc_als_associate / mvmc_track_assign / mvmc_ik_solve /
  * mvmc_track_commit issued frame by frame, and the same results.  Chain b owns frames [b chain_len, (b+1) chain_len).
  * All pointers are device memory owned by the caller (N = n_views p_max, NS = t_max + N, NP = t_max + k_max,
- * B = n_chains, F = B chain_len).  Supported sizes: N <= 20, NS <= 32, v_max <= 6, p_max <= 8, t_max <= 8;
- * MVMC_ERR_UNSUPPORTED otherwise (use the per-stage entry points). */
+ * B = n_chains, F = B chain_len).  Supported sizes: N <= 40, NS <= 48, v_max <= 6, p_max <= 8, t_max <= 8
+ * (MVMC_ERR_UNSUPPORTED otherwise: use the per-stage entry points), and every frame's actual graph must have <= 24 nodes
+ * without tracklets and <= 32 with them -- checked on the device: flags[B + 1] != 0 after the call means a graph did not fit. */
 typedef struct mvmcChainBuffers {
     int32_t n_chains, chain_len, n_views, p_max, t_max, k_max, v_max, max_nfev_cold, max_nfev_warm, n_inits, seed_len;
     int32_t n_parts;            /* workgroups per chain: 1 = one persistent workgroup per chain; p > 1 (dividing chain_len) =
@@ -278,8 +279,9 @@ typedef struct mvmcChainBuffers {
     int32_t* out_n_tracks;      /* (F) */
     double* out_info;           /* (F,NP,8) IK info rows of the frame's problems, or NULL */
     int32_t* out_als_iters;     /* (F) ALS iterations of the frame's graph, or NULL */
-    uint32_t* flags;            /* (B + 4) u32 hand-over flags, needed when n_parts > 1 (zeroed by the call; flags[B] != 0
-                                   afterwards = a part timed out waiting for its predecessor and the results are void) */
+    uint32_t* flags;            /* (B + 4) u32, zeroed by the call: [0,B) hand-over flags of the chains; afterwards flags[B] != 0 =
+                                   a workgroup timed out waiting for its predecessor, flags[B + 1] != 0 = a graph was too large
+                                   for the kernel's ALS variant; in both cases the results are void */
     double* out_phase_cycles;   /* (B,8) diagnostic: shader cycles of each chain by phase {graph, ALS, assignment, IK, commit,
                                    outputs, whole chain, 0}, or NULL */
 } mvmcChainBuffers;

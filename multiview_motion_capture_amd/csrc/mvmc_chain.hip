@@ -74,9 +74,12 @@ union ChainArena {
     Als4Lds<32> als64;
     Als4Lds<24> als32;
     Ik1Shared<CH_VM> ik[4];
-    double graph[32 * 32 + 8 + 32];   // st_affinity_wave (NS <= 32) / affinity_wave (N <= 20: 20*51 + 400 + 24 doubles)
+    // graph scratch: st_affinity_wave needs (NS*NS + 6) doubles + 2 NS ints (NS <= 48), affinity_wave N*51 doubles + 2 N*N floats
+    // + 2 N ints + 4 words (N <= 40)
+    double graph[40 * 51 + 40 * 40 + 40 + 8];
 };
-static_assert(sizeof(double) * (20 * 51 + 20 * 20 + 24) <= sizeof(Als4Lds<24>), "affinity scratch fits the arena");
+static_assert(40 * 51 + 40 * 40 + 40 + 8 >= 48 * 48 + 6 + 48, "graph scratch covers both graph builders");
+static_assert(sizeof(ChainArena) <= 4 * sizeof(Ik1Shared<CH_VM>), "the IK blocks set the arena size");
 
 // The phases as separate (non-inlined) functions: each gets its own register allocation inside the workgroup's budget
 // of 168 VGPRs (three workgroups per CU) instead of one allocation over the union of all phases.
@@ -176,6 +179,10 @@ chain_kernel(SkelDev skarg, ChainArgs A) {
         }
         __syncthreads();
         lap(1);
+        // a graph with more nodes (or a higher rank) than the workgroup variant of the ALS holds is flagged by it (iters < 0):
+        // raise the launch's error word instead of silently tracking nobody
+        if (tid == 0 && (nt <= 0 ? A.iters_sp[b] : A.iters_st[b]) < 0)
+            __hip_atomic_store(A.flags + A.n_chains + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (wave == 0) chain_assign(A, b, f);   // clusters -> IK problems (bulk copies on the wave, the logic on lane 0)
         __syncthreads();
         lap(2);
@@ -225,13 +232,15 @@ extern "C" int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuff
         return MVMC_ERR_ARG;
     if (B.max_nfev_cold < 1 || B.max_nfev_warm < 1) return MVMC_ERR_ARG;
     // sizes the workgroup's LDS arena is built for (the launch-per-stage path covers everything else)
-    if (B.n_views * B.p_max > 20 || B.t_max + B.n_views * B.p_max > 32 || B.v_max > CH_VM || B.n_views > 16 ||
+    // (padded sizes; a frame's ACTUAL graph must have <= 24 nodes on the match_spatial path and <= 32 on the
+    //  match_spatial_time path -- checked on the device, flags[n_chains + 1])
+    if (B.n_views * B.p_max > 40 || B.t_max + B.n_views * B.p_max > 48 || B.v_max > CH_VM || B.n_views > 16 ||
         2 * B.p_max > 16 || 2 * (B.t_max > B.p_max ? B.t_max : B.p_max) > 16)
         return MVMC_ERR_UNSUPPORTED;
     const void* need[] = {B.kps17, B.counts, B.Pmats, B.Fmats, B.F2, B.seed_table, B.params, B.joints, B.meta, B.n_tracks,
                           B.next_id, B.n_dead, B.slot_src, B.S_sp, B.W_st, B.group_counts, B.labels_sp, B.labels_st, B.n_clusters_sp,
                           B.n_clusters_st, B.iters_sp, B.iters_st, B.members, B.cold, B.init, B.status, B.n_new, B.ik_params, B.ik_joints, B.ik_info, B.ik_scratch,
-                          B.out_params, B.out_joints, B.out_meta, B.out_n_tracks};
+                          B.out_params, B.out_joints, B.out_meta, B.out_n_tracks, B.flags};
     for (const void* q : need)
         if (!q) return MVMC_ERR_ARG;
     if (B.n_chains == 0) return MVMC_OK;
@@ -252,9 +261,9 @@ extern "C" int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuff
     A.out_params = B.out_params; A.out_joints = B.out_joints; A.out_meta = B.out_meta; A.out_n = B.out_n_tracks;
     A.out_info = B.out_info; A.out_iters = B.out_als_iters; A.out_cycles = B.out_phase_cycles;
     A.parts = B.n_parts > 1 ? B.n_parts : 1;
-    if (A.parts > 1 && (!B.flags || B.chain_len % A.parts != 0)) return MVMC_ERR_ARG;
+    if (A.parts > 1 && B.chain_len % A.parts != 0) return MVMC_ERR_ARG;
     A.flags = B.flags;
-    if (A.parts > 1 && hipMemsetAsync(B.flags, 0, sizeof(unsigned) * ((size_t)B.n_chains + 4), (hipStream_t)stream) != hipSuccess)
+    if (hipMemsetAsync(B.flags, 0, sizeof(unsigned) * ((size_t)B.n_chains + 4), (hipStream_t)stream) != hipSuccess)
         return MVMC_ERR_LAUNCH;
     hipLaunchKernelGGL(chain_kernel, dim3(B.n_chains * A.parts), dim3(256), 0, (hipStream_t)stream, sk, A);
     MVMC_CHECK_LAUNCH();

@@ -156,7 +156,7 @@ def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tens
     for the slowest member of every launch.  Same device code and the same results as run_chains.
     parts > 1 (a divisor of chain_len): every chain is run by that many workgroups, one frame range after the other
     (hand-over through device flags), which lets the hardware dispatcher even out the load when the number of chains is
-    not a multiple of the number of workgroup slots.  res["flags"][-4] != 0 after a run means a hand-over timed out."""
+    not a multiple of the number of workgroup slots.  check_chain_flags(res) tells whether the run is valid."""
     import ctypes as C
     from . import _cabi
     F, Cn, P = kps.shape[:3]
@@ -188,7 +188,7 @@ def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tens
         ik_joints=e((B, NP, 18, 3), f64), ik_info=e((B, NP, 8), f64), ik_scratch=_chain_scratch(B, d),
         out_params=e((F, T, 68), f64), out_joints=e((F, T, 18, 3), f64), out_meta=e((F, T, 4), i32), out_n_tracks=e((F,), i32),
         out_info=e((F, NP, 8), f64) if want_info else None, out_als_iters=e((F,), i32) if want_info else None,
-        flags=z((B + 4,), torch.int32) if parts > 1 else None,
+        flags=z((B + 4,), torch.int32),
         out_phase_cycles=e((B, 8), f64) if want_info else None)
     if parts > 1 and L % parts:
         raise ValueError("run_chains_fused: parts must divide the chain length")
@@ -207,6 +207,17 @@ def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tens
         res["als_iters"] = t["out_als_iters"].view(B, L)
         res["phase_cycles"] = t["out_phase_cycles"]
     return res
+
+
+def check_chain_flags(res) -> None:
+    """Raise if a run_chains_fused result is void (synchronises): a hand-over timed out, or a frame's graph was larger than
+    the chain kernel's association variant holds (use run_chains for such data)."""
+    fl = res["flags"][-4:].cpu().tolist()
+    if fl[0]:
+        raise RuntimeError("mvmc_chain_run: a hand-over between the workgroups of a chain timed out; results are void")
+    if fl[1]:
+        raise ValueError("mvmc_chain_run: a frame's graph has more nodes than the chain kernel supports (24 without, 32 with "
+                         "tracklets); use run_chains")
 
 
 _CHAIN_SCRATCH = {}

@@ -58,3 +58,19 @@ def test_sizes_outside_the_arena_are_refused():
         run_chains_fused(hp, torch.from_numpy(data["kps25"]).cuda(), torch.from_numpy(data["counts"]).cuda(), 3)
     with pytest.raises(ValueError):   # parts must divide the chain length
         run_chains_fused(hp, torch.from_numpy(data["kps25"]).cuda(), torch.from_numpy(data["counts"]).cuda(), 4, parts=3)
+
+
+def test_graph_larger_than_the_kernels_als_variant_is_reported():
+    """Padded sizes up to 40 nodes are accepted, but a frame whose actual graph exceeds the workgroup ALS variant (24 nodes
+    without tracklets) must raise the launch's error word -- never a silently empty result."""
+    from multiview_motion_capture_amd import synth
+    from multiview_motion_capture_amd.pipeline import HotPath
+    from multiview_motion_capture_amd.tracker import check_chain_flags, run_chains_fused
+    data = synth.generate(2 * 4, 5, 8, 20260105, chain_len=4)          # 5 views x 8 people = 40 nodes per frame
+    hp = HotPath(data["K"], data["Rt"])
+    out = run_chains_fused(hp, torch.from_numpy(data["kps25"]).cuda(), torch.from_numpy(data["counts"]).cuda(), 4)
+    with pytest.raises(ValueError):
+        check_chain_flags(out)
+    small = synth.generate(2 * 4, 5, 4, 20260105, chain_len=4)
+    hs = HotPath(small["K"], small["Rt"])
+    check_chain_flags(run_chains_fused(hs, torch.from_numpy(small["kps25"]).cuda(), torch.from_numpy(small["counts"]).cuda(), 4))

@@ -131,3 +131,29 @@ def test_shelf_end_to_end_tracker_vs_reference_log(shelf):
     assert first_div is None or first_div > 90
     assert main_ok == n_frames
     assert np.median(jd) < 1e-2
+
+
+def test_shelf_through_the_persistent_chain_kernel(shelf):
+    """Config 1 through mvmc_chain_run: the 300 Shelf frames as ONE chain (5 cameras, up to 6 people per view, padded to
+    40 graph nodes) give the same tracker tables, frame by frame, as the launch-per-stage tracker -- which the test above
+    compares with the reference's own log -- with one workgroup for the whole chain and with one per frame."""
+    from multiview_motion_capture_amd.tracker import check_chain_flags, run_chains_fused
+    hp, d, si = shelf["hp"], shelf["d"], shelf["si"]
+    P = shelf["kps17"].shape[2]
+    n_frames = 300
+    tr = shelf["ChainTracker"](hp, 1, P, t_max=8)
+    exp_meta, exp_n, exp_j = [], [], []
+    for fi in range(1, n_frames + 1):
+        tr.step(shelf["kps17"][fi:fi + 1].contiguous(), shelf["cnt"][fi:fi + 1].contiguous())
+        exp_meta.append(tr.meta[0].clone()); exp_n.append(tr.n_tracks[0].clone()); exp_j.append(tr.joints[0].clone())
+    exp_meta, exp_n, exp_j = torch.stack(exp_meta), torch.stack(exp_n), torch.stack(exp_j)
+    kps = torch.from_numpy(si["kps25"][1:n_frames + 1]).to(d)
+    cnt = torch.from_numpy(si["counts"][1:n_frames + 1].astype(np.int32)).to(d)
+    for parts in (1, n_frames):
+        out = run_chains_fused(hp, kps, cnt, n_frames, t_max=8, parts=parts)
+        check_chain_flags(out)
+        assert torch.equal(out["n_tracks"], exp_n), parts
+        live = torch.arange(8, device=d)[None, :] < exp_n[:, None]            # slots beyond n_tracks hold stale rows
+        assert torch.equal(out["meta"][live], exp_meta[live]), parts
+        assert torch.equal(out["joints"][live], exp_j[live]), parts
+        assert int(out["n_dead"][0]) == int(tr.n_dead[0])
