@@ -269,20 +269,22 @@ __device__ __noinline__ int ik1_model(Ik1Shared<VM>& S, const Ik1Tables& T, int 
         MVMC_WAVE_SYNC();  // the previous joint's broadcasts are done
         db[lane * 3] = d0; db[lane * 3 + 1] = d1; db[lane * 3 + 2] = d2;
         MVMC_WAVE_SYNC();
-        // rows in chunks of 8 behind one wave-uniform test each (d_i vanishes on the other rows of a live chunk):
-        // 12 broadcast ds_read_b128 in flight per chunk instead of one LDS round trip per row
+        // rows in chunks behind one wave-uniform test each (d_i vanishes on the other rows of a live chunk): the chunk's
+        // broadcast ds_read_b128 are in flight together instead of one LDS round trip per row.  8 rows per chunk in the
+        // 40-row instance; 4 in the 50-row one, whose 100 matrix registers leave no room for 24 more doubles of operands
+        constexpr int GR = (N > 40) ? 4 : 8, GL = GR * 3 / 2;
         const unsigned long long m = T.rowmask[stage][k];
         const unsigned mlo = __builtin_amdgcn_readfirstlane((unsigned)m), mhi = __builtin_amdgcn_readfirstlane((unsigned)(m >> 32));
 #pragma unroll
-        for (int c = 0; c < N; c += 8) {
-            const unsigned byte = c < 32 ? ((mlo >> (c & 31)) & 0xffu) : ((mhi >> (c & 31)) & 0xffu);
-            if (byte) {
-                double2 t[12];
+        for (int c = 0; c < N; c += GR) {
+            const unsigned bits = (c < 32 ? (mlo >> (c & 31)) : (mhi >> (c & 31))) & ((1u << GR) - 1u);
+            if (bits) {
+                double2 t[GL];
 #pragma unroll
-                for (int u = 0; u < 12; ++u) t[u] = *reinterpret_cast<const double2*>(&db[c * 3 + 2 * u]);
+                for (int u = 0; u < GL; ++u) t[u] = *reinterpret_cast<const double2*>(&db[c * 3 + 2 * u]);
                 const double* tt = reinterpret_cast<const double*>(t);
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+                for (int i = 0; i < GR; ++i)
                     if (c + i < N) a[c + i] += tt[3 * i] * y0 + tt[3 * i + 1] * y1 + tt[3 * i + 2] * y2;
             }
         }
