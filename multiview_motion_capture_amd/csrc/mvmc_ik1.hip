@@ -272,7 +272,7 @@ __device__ __noinline__ int ik1_model(Ik1Shared<VM>& S, const Ik1Tables& T, int 
         // rows in chunks behind one wave-uniform test each (d_i vanishes on the other rows of a live chunk): the chunk's
         // broadcast ds_read_b128 are in flight together instead of one LDS round trip per row.  8 rows per chunk in the
         // 40-row instance; 4 in the 50-row one, whose 100 matrix registers leave no room for 24 more doubles of operands
-        constexpr int GR = (N > 40) ? 4 : 8, GL = GR * 3 / 2;
+        constexpr int GR = 4, GL = GR * 3 / 2;
         const unsigned long long m = T.rowmask[stage][k];
         const unsigned mlo = __builtin_amdgcn_readfirstlane((unsigned)m), mhi = __builtin_amdgcn_readfirstlane((unsigned)(m >> 32));
 #pragma unroll
