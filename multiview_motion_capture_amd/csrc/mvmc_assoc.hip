@@ -179,6 +179,7 @@ __device__ inline double mean17(const double* d) {
 // distance of pose b's joints to the epipolar lines of pose a's joints:
 // line = normalise(F^T [x_a, 1]) (computeCorrespondEpilines(pts, 2, F)); mv_math_util.py:307-315
 __device__ __noinline__ double proj_dist(const double* pa, const double* pb, const float* F) {
+    MVMC_ASSUME_LDS(pa); MVMC_ASSUME_LDS(pb);
     double f[9];
     for (int k = 0; k < 9; ++k) f[k] = (double)F[k];
     double d[17];

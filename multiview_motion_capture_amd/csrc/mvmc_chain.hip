@@ -84,23 +84,27 @@ static_assert(sizeof(ChainArena) <= 4 * sizeof(Ik1Shared<CH_VM>), "the IK blocks
 // The phases as separate (non-inlined) functions: each gets its own register allocation inside the workgroup's budget
 // of 168 VGPRs (three workgroups per CU) instead of one allocation over the union of all phases.
 __device__ __noinline__ void chain_graph_spatial(ChainArena& arena, const ChainArgs& A, int b, int f) {
+    MVMC_ASSUME_LDS(&arena);
     const int C = A.C, P = A.P, N = C * P;
     float* S = A.S_sp + (size_t)b * N * N;
     if ((threadIdx.x >> 6) == 0) affinity_wave(arena.graph, A.kps17, A.counts, A.Fm, C, P, f, nullptr, S);
 }
 __device__ __noinline__ void chain_graph_temporal(ChainArena& arena, const ChainArgs& A, int b, int f) {
+    MVMC_ASSUME_LDS(&arena);
     const int C = A.C, P = A.P, T = A.T, NS = T + C * P;
     double* W = A.W_st + (size_t)b * NS * NS;
     st_affinity_wave<true>(arena.graph, A.kps17, A.counts, 0, f, A.joints + (size_t)b * T * 54, A.n_tracks + b, A.Pm, A.F2, C, P,
                            T, 0.1, W, nullptr, A.gc + (size_t)b * (C + 1));
 }
 __device__ __noinline__ void chain_als_spatial(ChainArena& arena, const ChainArgs& A, int b, int f) {
+    MVMC_ASSUME_LDS(&arena);
     const int C = A.C, N = C * A.P;
     // batch index 0 with pre-offset pointers: the graph, its group counts (the frame's people per view) and outputs
     als4_graph<float, 24>(arena.als32, 0, A.S_sp + (size_t)b * N * N, A.counts + (size_t)f * C, C, N, A.seed, A.seed_len, nullptr,
                           nullptr, A.labels_sp + (size_t)b * N, A.ncl_sp + b, A.iters_sp + b);
 }
 __device__ __noinline__ void chain_als_temporal(ChainArena& arena, const ChainArgs& A, int b) {
+    MVMC_ASSUME_LDS(&arena);
     const int C = A.C, NS = A.T + C * A.P;
     als4_graph<double, 32>(arena.als64, 0, A.W_st + (size_t)b * NS * NS, A.gc + (size_t)b * (C + 1), C + 1, NS, A.seed, A.seed_len,
                            nullptr, nullptr, A.labels_st + (size_t)b * NS, A.ncl_st + b, A.iters_st + b);
@@ -114,6 +118,8 @@ __device__ __noinline__ void chain_commit(const ChainArgs& A, int b) {
                  A.next_id, A.n_dead, A.slot_src);
 }
 __device__ __noinline__ void chain_ik(ChainArena& arena, const Ik1Tables& tables, const ChainArgs& A, int b) {
+    MVMC_ASSUME_LDS(&arena);
+    MVMC_ASSUME_LDS(&tables);
     const int wave = threadIdx.x >> 6, NP = A.T + A.K;
     // wave w takes the problem slots w, w + 4, ... of this chain
     for (int s = wave; s < NP; s += 4) {

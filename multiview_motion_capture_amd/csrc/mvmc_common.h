@@ -17,6 +17,14 @@
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
     } while (0)
 
+// For out-of-line device functions that receive LDS through generic pointers: tells the compiler that p is LDS, so that
+// the accesses through it become ds_ instructions instead of flat_ ones (and keep their 32-bit addresses).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MVMC_ASSUME_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void*)(p)))
+#else
+#define MVMC_ASSUME_LDS(p) ((void)0)
+#endif
+
 // Scalar state that another workgroup may have written earlier in the same launch (chain kernel, parts > 1): read on the
 // vector path with an agent-scope load, never through the scalar cache (which an acquire fence does not refresh).
 __device__ __forceinline__ int32_t mvmc_ld_i32(const int32_t* p) {

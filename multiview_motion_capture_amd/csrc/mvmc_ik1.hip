@@ -210,6 +210,10 @@ __device__ __forceinline__ double ik1_eval(Ik1Shared<VM>& S, const Ik1Tables& T,
 template <int VM, int N>
 __device__ __noinline__ int ik1_model(Ik1Shared<VM>& S, const Ik1Tables& T, int stage, bool budget_left, double gtol, double* __restrict__ hh,
                                       double* gg_out, double* ginf_out) {
+    // S and T arrive as generic pointers (the function is out of line); telling the compiler that they are LDS turns every
+    // access below into a ds_ instruction instead of a flat_ one (InferAddressSpaces uses the assumption)
+    MVMC_ASSUME_LDS(&S);
+    MVMC_ASSUME_LDS(&T);
     const int lane = threadIdx.x & 63;
     const int na = T.na[stage];
     const bool on = lane < na;
@@ -240,6 +244,13 @@ __device__ __noinline__ int ik1_model(Ik1Shared<VM>& S, const Ik1Tables& T, int 
         }
         pa0 = S.pos[ja * 3]; pa1 = S.pos[ja * 3 + 1]; pa2 = S.pos[ja * 3 + 2];
     }
+    // the lane's axis and pivot wait in LDS (the solver vectors are dead while the model is rebuilt) and are re-read per
+    // joint: six doubles less to keep in registers next to the N matrix rows
+    double* axl = S.sv;
+    axl[lane] = ax0; axl[64 + lane] = ax1; axl[128 + lane] = ax2;
+    axl[192 + lane] = pa0; axl[256 + lane] = pa1;
+    S.tmp[192 + lane] = pa2;
+    MVMC_WAVE_SYNC();
     double a[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) a[i] = 0.0;
@@ -253,8 +264,10 @@ __device__ __noinline__ int ik1_model(Ik1Shared<VM>& S, const Ik1Tables& T, int 
                 d0 = jc == 0 ? 1.0 : 0.0; d1 = jc == 1 ? 1.0 : 0.0; d2 = jc == 2 ? 1.0 : 0.0;
             } else if (kind == 1) {
                 if ((T.anc[K] >> ja) & 1) {
-                    const double r0 = S.pos[K * 3] - pa0, r1 = S.pos[K * 3 + 1] - pa1, r2 = S.pos[K * 3 + 2] - pa2;
-                    d0 = ax1 * r2 - ax2 * r1; d1 = ax2 * r0 - ax0 * r2; d2 = ax0 * r1 - ax1 * r0;
+                    const double r0 = S.pos[K * 3] - axl[192 + lane], r1 = S.pos[K * 3 + 1] - axl[256 + lane],
+                                 r2 = S.pos[K * 3 + 2] - S.tmp[192 + lane];
+                    const double x0 = axl[lane], x1 = axl[64 + lane], x2 = axl[128 + lane];
+                    d0 = x1 * r2 - x2 * r1; d1 = x2 * r0 - x0 * r2; d2 = x0 * r1 - x1 * r0;
                 }
             } else {
                 for (int j = K; j > 0; j = T.parents[j])
@@ -427,6 +440,7 @@ __device__ void ik1_trf(Ik1Shared<VM>& S, const Ik1Tables& T, int stage, int max
 // Cold start: DLT of the 18 keypoints + the reference's one-step post-optimisation; hips -> S.xn[0..6)
 template <int VM>
 __device__ __noinline__ void ik1_cold_root(Ik1Shared<VM>& S, int nv) {
+    MVMC_ASSUME_LDS(&S);
     const int lane = threadIdx.x & 63;
     double X[3] = {0, 0, 0};
     if (lane < 18) dlt_obs_point(S.pose18, S.Pm, nv, lane, 0.01, X);

@@ -210,6 +210,7 @@ __device__ inline double apply_q_w1(const double* __restrict__ hh, const double*
 template <int N>
 __device__ __noinline__ int tri_eigh_w1(const double* d, const double* e, int m, double* lam, double* __restrict__ Zg,
                                         double* dsc, double* e2sc, double* wsh) {
+    MVMC_ASSUME_LDS(d); MVMC_ASSUME_LDS(e); MVMC_ASSUME_LDS(lam); MVMC_ASSUME_LDS(dsc); MVMC_ASSUME_LDS(e2sc); MVMC_ASSUME_LDS(wsh);
     const int lane = threadIdx.x & 63;
     auto lane_value = [](double v, int src) {
         return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
