@@ -563,7 +563,12 @@ __device__ __forceinline__ void gj_chain(double (&g)[R], double* __restrict__ mu
         for (int b = p + 1; b < R; ++b) g[b] -= m * piv[b];
         if (lane < R) mul[p * R + a] = m;
     }
-    if (lane < R) dinv[a] = 1.0 / g[a];
+    // g[a] with a per-lane a: a chain of selects over static indices (a dynamic index would send the whole array through
+    // scratch memory -- eight stores and a dependent load from global memory on the critical path of every half-iteration)
+    double ga = g[0];
+#pragma unroll
+    for (int b = 1; b < R; ++b) ga = (a == b) ? g[b] : ga;
+    if (lane < R) dinv[a] = 1.0 / ga;
 }
 
 template <int R>
