@@ -127,6 +127,7 @@ __global__ void fmats_kernel(const double* __restrict__ K, const double* __restr
 // ------------------------------------------------------------------------------------------------
 // NumPy's float32 pairwise summation (loops_utils.h.src, PW_BLOCKSIZE = 128), same operation order.
 __device__ __noinline__ float np_pairwise_leaf_f32(const float* a, int n) {
+    MVMC_ASSUME_LDS(a);
     if (n < 8) {
         float r = -0.0f;
         for (int i = 0; i < n; ++i) r = faddr(r, a[i]);
@@ -143,6 +144,7 @@ __device__ __noinline__ float np_pairwise_leaf_f32(const float* a, int n) {
     return res;
 }
 __device__ __noinline__ float np_pairwise_sum_f32(const float* a, int n) {
+    MVMC_ASSUME_LDS(a);
     int s_[16], n_[16], st_[16];
     float left_[16];
     int sp = 0;
