@@ -280,7 +280,13 @@ class MvTracker:
         d = ch.hp.device
         for t in self.tracklets:
             t.time_since_update += 1
-        ch.step(torch.as_tensor(kps, device=d), torch.as_tensor(cnt, device=d))
+        k_d, c_d = torch.as_tensor(kps, device=d), torch.as_tensor(cnt, device=d)
+        n_nodes = int(cnt.sum())
+        # one launch per frame (the chain kernel) when the frame's graph fits its association variants, seven otherwise
+        if ch.fused_ok and n_nodes <= 24 and n_nodes + len(self.tracklets) <= 32:
+            ch.step_fused(k_d, c_d)
+        else:
+            ch.step(k_d, c_d)
         n = int(ch.n_tracks[0])
         meta = ch.meta[0, :n].cpu().numpy()
         params = ch.params[0, :n].cpu().numpy()

@@ -36,6 +36,7 @@ class ChainTracker:
         self.n_dead = torch.zeros((B,), dtype=torch.int32, device=d)
         self.frame_idx = torch.arange(B, dtype=torch.int32, device=d)
         self.slot_src = torch.full((B, T), -1, dtype=torch.int32, device=d)
+        self._fused = None  # workspaces of step_fused (allocated on first use)
         self.events = None  # set to a list to collect (start, end) CUDA events around every IK launch
         self.als_events = None  # same for the association (ALS) launches of the spatio-temporal graph
         self.assoc_done = None
@@ -81,6 +82,52 @@ class ChainTracker:
         if want_debug:
             out.update(D=D, W=W, st=st, sp=sp, group_counts=gc)
         return out
+
+
+    def step_fused(self, kps17: torch.Tensor, counts: torch.Tensor):
+        """The same frame update as step() in ONE launch (mvmc_chain_run with chain_len 1 on this tracker's state): what
+        the per-frame call surface (MvTracker.update_4d) uses.  Sizes outside the chain kernel's arena, or a frame whose graph
+        is too large for it, are the caller's to route to step() (ChainTracker.fused_ok, check_chain_flags)."""
+        import ctypes as C
+        from . import _cabi
+        B, Cn, P, T, K, V = self.B, self.C, self.P, self.T, self.K, self.V
+        d = kps17.device
+        N, NS, NP = Cn * P, T + Cn * P, T + K
+        if self._fused is None:
+            f64, i32 = torch.float64, torch.int32
+            e = lambda shape, dt: torch.empty(shape, dtype=dt, device=d)
+            z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=d)
+            self._fused = dict(
+                seed_table=dev.als_seed_table(_cabi.MAX_NODES * _cabi.MAX_NODES, d),
+                S_sp=e((B, N, N), torch.float32), W_st=e((B, NS, NS), f64), group_counts=e((B, Cn + 1), i32),
+                labels_sp=e((B, N), i32), labels_st=e((B, NS), i32), n_clusters_sp=z((B,), i32), n_clusters_st=z((B,), i32),
+                iters_sp=z((B,), i32), iters_st=z((B,), i32), members=e((B, NP, V), i32), cold=e((B, NP), torch.uint8),
+                init=e((B, NP, 68), f64), status=e((B, T), i32), n_new=e((B,), i32), ik_params=e((B, NP, 68), f64),
+                ik_joints=e((B, NP, 18, 3), f64), ik_info=e((B, NP, 8), f64), ik_scratch=_chain_scratch(B, d),
+                out_params=e((B, T, 68), f64), out_joints=e((B, T, 18, 3), f64), out_meta=e((B, T, 4), i32),
+                out_n_tracks=e((B,), i32), flags=z((B + 4,), i32))
+        w = self._fused
+        t = dict(w, kps17=kps17, counts=counts, Pmats=self.hp.P, Fmats=self.hp.F, F2=self.F2, params=self.params,
+                 joints=self.joints, meta=self.meta, n_tracks=self.n_tracks, next_id=self.next_id, n_dead=self.n_dead,
+                 slot_src=self.slot_src, out_info=None, out_als_iters=None, out_phase_cycles=None)
+        buf = _cabi.MvmcChainBuffers()
+        for name, val in dict(n_chains=B, chain_len=1, n_views=Cn, p_max=P, t_max=T, k_max=K, v_max=V,
+                              max_nfev_cold=self.nfev_cold, max_nfev_warm=self.nfev_warm, n_inits=3,
+                              seed_len=w["seed_table"].numel(), n_parts=1).items():
+            setattr(buf, name, int(val))
+        for name in _cabi.MvmcChainBuffers._PTRS:
+            ten = t[name]
+            setattr(buf, name, None if ten is None else ten.data_ptr())
+        _cabi.check(_cabi.load().mvmc_chain_run(C.byref(self.hp.skeleton), C.byref(buf),
+                                                C.c_void_p(torch.cuda.current_stream(d).cuda_stream)), "mvmc_chain_run")
+        return dict(members=w["members"], status=w["status"], n_new=w["n_new"], ik_params=w["ik_params"],
+                    ik_joints=w["ik_joints"], ik_info=w["ik_info"], flags=w["flags"])
+
+    @property
+    def fused_ok(self) -> bool:
+        """Whether this tracker's padded sizes fit the chain kernel (include/mvmc.h: mvmc_chain_run)."""
+        N = self.C * self.P
+        return N <= 40 and self.T + N <= 48 and self.V <= 6 and self.P <= 8 and self.T <= 8 and self.C <= 16
 
 
 def run_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], chain_len: int, t_max=8,

@@ -157,3 +157,23 @@ def test_shelf_through_the_persistent_chain_kernel(shelf):
         assert torch.equal(out["meta"][live], exp_meta[live]), parts
         assert torch.equal(out["joints"][live], exp_j[live]), parts
         assert int(out["n_dead"][0]) == int(tr.n_dead[0])
+
+
+def test_per_frame_fused_step_equals_staged_step(shelf):
+    """ChainTracker.step_fused (one launch per frame; what MvTracker.update_4d uses when the frame fits) against step()
+    (seven launches) over 60 Shelf frames: identical tracker state after every frame."""
+    from multiview_motion_capture_amd.tracker import check_chain_flags
+    hp = shelf["hp"]
+    P = shelf["kps17"].shape[2]
+    a = shelf["ChainTracker"](hp, 1, P, t_max=8)
+    b = shelf["ChainTracker"](hp, 1, P, t_max=8)
+    assert b.fused_ok
+    for fi in range(1, 61):
+        k, c = shelf["kps17"][fi:fi + 1].contiguous(), shelf["cnt"][fi:fi + 1].contiguous()
+        a.step(k, c)
+        out = b.step_fused(k, c)
+        check_chain_flags(out)
+        n = int(a.n_tracks[0])
+        assert int(b.n_tracks[0]) == n, fi
+        assert torch.equal(a.meta[0, :n], b.meta[0, :n]) and torch.equal(a.joints[0, :n], b.joints[0, :n]), fi
+        assert torch.equal(a.params[0, :n], b.params[0, :n]) and int(a.n_dead[0]) == int(b.n_dead[0]), fi
