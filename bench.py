@@ -298,6 +298,22 @@ def main():
                          "note": "latency-bound path (dependent fp64 chains), not HBM bound (SURVEY.md F6); achieved = algorithmic "
                                  "bytes of the frames one launch serves / mean launch duration of the dominant kernel; see DESIGN.md"},
         }
+        if chain and "gt_joints" in data:
+            # accuracy of the last step's output against the generator's ground truth (the parity gates against the
+            # reference are the tests'; this is the size-independent check at the benchmark's full size)
+            n_t = out["n_tracks"][:F].cpu().numpy()
+            jo = out["joints"][:F].cpu().numpy()
+            gt = data["gt_joints"]
+            errs = []
+            for f in range(0, F, 13):
+                if n_t[f] == Pn:
+                    dmat = np.linalg.norm(jo[f, :Pn, None] - gt[f][None], axis=-1).mean(axis=-1)
+                    errs.append(dmat.min(axis=1))
+            errs = np.concatenate(errs) if errs else np.array([np.nan])
+            res["accuracy"] = {"frames_with_all_people_tracked": float((n_t == Pn).mean()),
+                               "joint_error_vs_ground_truth_cm": {"median": float(np.median(errs) * 100),
+                                                                  "p95": float(np.quantile(errs, 0.95) * 100)},
+                               "note": "synthetic ground truth (2 px keypoint noise); parity with the reference: tests/"}
         if args.cpu_frames > 0 and world == 1:
             if chain:
                 workers = max(1, min(args.cpu_workers or min(16, os.cpu_count() or 1), F // L))
