@@ -25,6 +25,11 @@
 #define MVMC_ASSUME_LDS(p) ((void)0)
 #endif
 
+// A double in global memory, for pointers that travel through out-of-line functions next to LDS traffic: accesses through a
+// generic pointer are flat_ instructions, which count on the LDS counter too (a wait for an LDS result then also waits for the
+// global access); through this type they are global_ instructions.
+typedef __attribute__((address_space(1))) double mvmc_gdouble;
+
 // Scalar state that another workgroup may have written earlier in the same launch (chain kernel, parts > 1): read on the
 // vector path with an agent-scope load, never through the scalar cache (which an acquire fence does not refresh).
 __device__ __forceinline__ int32_t mvmc_ld_i32(const int32_t* p) {

@@ -208,7 +208,7 @@ __device__ __forceinline__ double ik1_eval(Ik1Shared<VM>& S, const Ik1Tables& T,
 // *gg = |g|^2, *ginf = |g|_inf.  S.sc[4..8) = {beta0, tau0, |J^T J|_1, coupling}.
 // ---------------------------------------------------------------------------------------------
 template <int VM, int N>
-__device__ __noinline__ int ik1_model(Ik1Shared<VM>& S, const Ik1Tables& T, int stage, bool budget_left, double gtol, double* __restrict__ hh,
+__device__ __noinline__ int ik1_model(Ik1Shared<VM>& S, const Ik1Tables& T, int stage, bool budget_left, double gtol, mvmc_gdouble* __restrict__ hh,
                                       double* gg_out, double* ginf_out) {
     // S and T arrive as generic pointers (the function is out of line); telling the compiler that they are LDS turns every
     // access below into a ds_ instruction instead of a flat_ one (InferAddressSpaces uses the assumption)
@@ -321,7 +321,7 @@ __device__ __noinline__ int ik1_model(Ik1Shared<VM>& S, const Ik1Tables& T, int 
     // eigensolver fallback of mvmc_ik.hip in the T basis, where suf = V^T g = beta0 * (first components).
     //   unclean collapse:  T is complete (na rows);   clean collapse: the leading block plus its coupling row.
     const int m = kk < 0 ? na : (kk < na ? kk + 1 : na);
-    double* Zg = hh + 64 * NA1;
+    mvmc_gdouble* Zg = hh + 64 * NA1;
     eightri::tri_eigh_w1<N>(S.sv + SV_D, S.sv + SV_E, m, S.sv + SV_WN, Zg, S.tmp, S.tmp + 64, S.tmp + 128);
     const double suf = lane < m ? S.sc[4] * Zg[lane] : 0.0;
     MVMC_WAVE_SYNC();
@@ -335,7 +335,7 @@ __device__ __noinline__ int ik1_model(Ik1Shared<VM>& S, const Ik1Tables& T, int 
 // in mvmc_ik.hip on one wave.
 // ---------------------------------------------------------------------------------------------
 template <int VM>
-__device__ void ik1_trf(Ik1Shared<VM>& S, const Ik1Tables& T, int stage, int max_nfev, double* __restrict__ hh, double* cost_out, int* nfev_out,
+__device__ void ik1_trf(Ik1Shared<VM>& S, const Ik1Tables& T, int stage, int max_nfev, mvmc_gdouble* __restrict__ hh, double* cost_out, int* nfev_out,
                         int* njev_out, int* status_out, int* fallbacks_out) {
     const int lane = threadIdx.x & 63;
     const int nfull = (stage == 0) ? 57 : 57 + T.n_side;
@@ -521,7 +521,7 @@ __device__ __forceinline__ void ik1_solve(Ik1Shared<VM>& S, const Ik1Tables& T, 
                                           double* __restrict__ joints_out, double* __restrict__ info_out,
                                           double* __restrict__ scratch, int stage_mask, const double* __restrict__ targets3d) {
     const int lane = threadIdx.x & 63;
-    double* hh = scratch + (size_t)b * MVMC_IK_SCRATCH_DOUBLES;   // Householder vectors [0, 3200), eigenvectors [3200, 6400)
+    mvmc_gdouble* hh = (mvmc_gdouble*)(scratch + (size_t)b * MVMC_IK_SCRATCH_DOUBLES);   // Householder vectors [0, 3200), eigenvectors [3200, 6400)
     double* info = info_out ? info_out + (size_t)b * 8 : nullptr;
     // views of this problem (the reference only solves clusters with >= 2 views: motion_capture.py:927,940)
     int q_own = -1;

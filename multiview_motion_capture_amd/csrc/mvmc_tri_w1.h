@@ -33,7 +33,7 @@ __device__ __forceinline__ double row_of(const double (&a)[N], int k) {
 // one collapses in front of a block that is not null -- the tridiagonalisation is then complete (all n rows) and
 // meant for tri_eigh_w1.
 template <int N>
-__device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, double* __restrict__ hh, int n, double* d,
+__device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, mvmc_gdouble* __restrict__ hh, int n, double* d,
                                                  double* e, double* tau, double* v0, double* vb, double* pb, double* out4) {
     static_assert(N % 2 == 0 && N <= 50, "row count");
     const int lane = threadIdx.x & 63;
@@ -170,7 +170,7 @@ __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, doub
 }
 
 // Q c for tridiag_krylov_w1 (one wave; lane j holds component j): reflectors kk-2 .. 0 from hh, then the first one.
-__device__ inline double apply_q_w1(const double* __restrict__ hh, const double* tau, const double* v0, double tau0, int kk,
+__device__ inline double apply_q_w1(const mvmc_gdouble* __restrict__ hh, const double* tau, const double* v0, double tau0, int kk,
                                     int n, double cj) {
     const int lane = threadIdx.x & 63;
     int k = kk - 2;
@@ -208,7 +208,7 @@ __device__ inline double apply_q_w1(const double* __restrict__ hh, const double*
 // it needs (apply_q_w1).
 // ---------------------------------------------------------------------------------------------------------------
 template <int N>
-__device__ __noinline__ int tri_eigh_w1(const double* d, const double* e, int m, double* lam, double* __restrict__ Zg,
+__device__ __noinline__ int tri_eigh_w1(const double* d, const double* e, int m, double* lam, mvmc_gdouble* __restrict__ Zg,
                                         double* dsc, double* e2sc, double* wsh) {
     MVMC_ASSUME_LDS(d); MVMC_ASSUME_LDS(e); MVMC_ASSUME_LDS(lam); MVMC_ASSUME_LDS(dsc); MVMC_ASSUME_LDS(e2sc); MVMC_ASSUME_LDS(wsh);
     const int lane = threadIdx.x & 63;
@@ -410,7 +410,7 @@ __device__ inline double tr_solve_eig_w1(const double* lamv, const double* sufv,
 }
 
 // y = Z c: component j to lane j (Zg as written by tri_eigh_w1, c one coefficient per lane, zero beyond m)
-__device__ inline double eig_combine_w1(const double* __restrict__ Zg, int m, double c) {
+__device__ inline double eig_combine_w1(const mvmc_gdouble* __restrict__ Zg, int m, double c) {
     const int lane = threadIdx.x & 63;
     double y = 0.0;
     int j = 0;
