@@ -1081,6 +1081,190 @@ __device__ __forceinline__ int als4_iterate(const TW* __restrict__ Wf, int ldw, 
     return iters;
 }
 
+// ------------------------------------------------------------------------------------------------
+// als6: als4 with a dedicated solver wave (rank <= 8, n <= 24).  In als4 a half-iteration is
+//   accumulate (all waves) | barrier | eliminate (wave 0) | barrier | apply | barrier,
+// although the normal matrix A^T A + ridge I needs only the factor of the previous half, not the right-hand sides.
+// Here wave 0 forms and eliminates it WHILE waves 1-3 accumulate the right-hand sides (24 columns = 6 slices of 4 on
+// their six half-waves; columns beyond n are zeros, so nothing is skipped that als4 computes): one barrier less per
+// half and the elimination chain off the critical path of the accumulation.  Same arithmetic per element; the
+// normal matrix is summed by one lane per entry (two accumulators over even / odd rows), the right-hand sides from
+// three wave partials.
+// ------------------------------------------------------------------------------------------------
+template <typename TW, int NMAX>
+__device__ __forceinline__ int als6_iterate(const TW* __restrict__ Wf, int ldw, int n, int r, const int* sGid,
+                                            const double* __restrict__ seed, double* sX, double* sA, double* sB,
+                                            double* sG, double* sMul, double* sDinv, double* sHp, double* sRed) {
+    constexpr int R = 8, NS = 4, LDX = NMAX + 1;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const bool worker = wv > 0;
+    const int tw = worker ? tid - 64 : 0;          // worker thread index 0 .. 191
+    const int i = tw & 31, h = tw >> 5;            // row, column slice (0 .. 5)
+    const bool row_ok = worker && i < n && i < NMAX;
+    double w[NS], z[NS], y[NS], xp[NS], x1[NS];
+    float w32[NS];
+    unsigned valid = 0, same = 0;
+#pragma unroll
+    for (int c = 0; c < NS; ++c) {
+        const int j = h * NS + c;
+        const bool ok = row_ok && j < n;
+        if (ok) valid |= 1u << c;
+        if (ok && sGid[i] == sGid[j]) same |= 1u << c;
+        if constexpr (sizeof(TW) == 4) {
+            const float a = ok ? (float)Wf[i * ldw + j] : 0.f, b = ok ? (float)Wf[j * ldw + i] : 0.f;
+            w32[c] = fmulr(0.5f, faddr(a, b));
+            w[c] = (double)w32[c];
+        } else {
+            const double a = ok ? (double)Wf[i * ldw + j] : 0., b = ok ? (double)Wf[j * ldw + i] : 0.;
+            w[c] = 0.5 * (a + b);
+            w32[c] = 0.f;
+        }
+        z[c] = w[c]; xp[c] = w[c]; y[c] = 0.0; x1[c] = 0.0;
+    }
+    for (int e = tid; e < NMAX * R; e += 256) {
+        const int k = e / R, a = e - k * R;
+        sA[e] = (k < n && a < r) ? seed[k * r + a] : 0.0;
+        sB[e] = 0.0;
+    }
+    __syncthreads();
+    double mu = 64.0, inv_mu = 1.0 / 64.0;  // mu = 64 * 2^k: the reciprocal is exact
+    int iters = 1000;
+#ifdef MVMC_ALS_PROFILE
+    if (threadIdx.x < 8) g_alsprof[threadIdx.x] = 0;
+    long long _tp = clock64();
+#endif
+    const int n2 = (n + 1) & ~1;  // rows beyond n are exact zeros
+    // one half-iteration: new factor rows Fout[i] = (F^T F + ridge I)^-1 (sum_k F[k] xs(k, i)), xs = the worker's entries
+    auto half = [&](const double* F, double* Fout, double ridge, bool transposed) {
+        if (!worker) {
+            // solver wave: normal matrix (one entry per lane), elimination, multipliers to LDS
+            const int a = lane / R, b = lane - a * R;
+            double g0 = (a == b) ? ridge : 0.0, g1 = 0.0;
+#pragma unroll 4
+            for (int k = 0; k < n2; k += 2) { g0 += F[k * R + a] * F[k * R + b]; g1 += F[(k + 1) * R + a] * F[(k + 1) * R + b]; }
+            sG[lane] = g0 + g1;
+            MVMC_WAVE_SYNC();
+            double g[R];
+#pragma unroll
+            for (int c = 0; c < R; ++c) g[c] = sG[(lane % R) * R + c];
+            gj_chain<R>(g, sMul, sDinv);
+        } else {
+            // workers: partial right-hand side of row i over the slice's four rows k of F
+            double hv[R];
+#pragma unroll
+            for (int a = 0; a < R; ++a) hv[a] = 0.0;
+            if (i < NMAX) {
+#pragma unroll
+                for (int c = 0; c < NS; ++c) {
+                    const int k = h * NS + c;
+                    const double xv = transposed ? sX[k * LDX + i] : x1[c];
+                    const double2* fr = reinterpret_cast<const double2*>(&F[k * R]);
+#pragma unroll
+                    for (int a = 0; a < R; a += 2) { const double2 v2 = fr[a >> 1]; hv[a] += v2.x * xv; hv[a + 1] += v2.y * xv; }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < R; ++a) hv[a] += __shfl_xor(hv[a], 32, 64);   // the two slices of the wave
+            if ((lane & 32) == 0 && i < NMAX) {
+                double2* dst = reinterpret_cast<double2*>(&sHp[((wv - 1) * NMAX + i) * R]);
+#pragma unroll
+                for (int a = 0; a < R; a += 2) dst[a >> 1] = make_double2(hv[a], hv[a + 1]);
+            }
+        }
+        __syncthreads();
+        APROF(1)
+        if (tid < NMAX) {   // (lanes of the solver wave) one lane per row: sum the three partials, apply the multipliers
+            double hv[R];
+#pragma unroll
+            for (int a = 0; a < R; a += 2) {
+                const double2 p0 = *reinterpret_cast<const double2*>(&sHp[(0 * NMAX + tid) * R + a]);
+                const double2 p1 = *reinterpret_cast<const double2*>(&sHp[(1 * NMAX + tid) * R + a]);
+                const double2 p2 = *reinterpret_cast<const double2*>(&sHp[(2 * NMAX + tid) * R + a]);
+                hv[a] = (p0.x + p1.x) + p2.x;
+                hv[a + 1] = (p0.y + p1.y) + p2.y;
+            }
+            gj_apply<R>(hv, sMul, sDinv);
+            double2* dst = reinterpret_cast<double2*>(&Fout[tid * R]);
+#pragma unroll
+            for (int a = 0; a < R; a += 2) dst[a >> 1] = make_double2(hv[a], hv[a + 1]);
+        }
+        __syncthreads();
+        APROF(3)
+    };
+    for (int it = 0; it < 1000; ++it) {
+        // ---- X1 = Z - (Y - W + beta)/mu (workers; the matrix also goes to LDS for the transposed reads) ----
+        if (worker) {
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                double v = 0.0;
+                if ((valid >> c) & 1) {
+                    if (sizeof(TW) == 4 && it == 0) v = (double)(w32[c] - faddr(-w32[c], 0.1f) / 64.f);
+                    else v = z[c] - ((y[c] - w[c]) + 0.1) * inv_mu;
+                }
+                x1[c] = v;
+                if (i < NMAX) sX[i * LDX + h * NS + c] = v;
+            }
+        }
+        __syncthreads();
+        APROF(0)
+        const double ridge = 50.0 * inv_mu;  // == 50 / mu exactly
+        half(sA, sB, ridge, true);    // B update: A^T X1[:, i]  (column i of X1: through LDS)
+        half(sB, sA, ridge, false);   // A update: B^T X1[i, :]^T (own row, own columns)
+        // ---- X = A B^T, Z, Y, residuals (workers) ----
+        double acc_p = 0.0, acc_d = 0.0;
+        if (worker) {
+            double av[R];
+            {
+                const double2* ar = reinterpret_cast<const double2*>(&sA[(i < NMAX ? i : 0) * R]);
+#pragma unroll
+                for (int a = 0; a < R; a += 2) { const double2 v2 = ar[a >> 1]; av[a] = v2.x; av[a + 1] = v2.y; }
+            }
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                const int j = h * NS + c;
+                double xa = 0.0, xb = 0.0;
+                const double2* br = reinterpret_cast<const double2*>(&sB[j * R]);
+#pragma unroll
+                for (int a = 0; a < R; a += 2) { const double2 v2 = br[a >> 1]; xa += av[a] * v2.x; xb += av[a + 1] * v2.y; }
+                const double x = xa + xb;
+                if ((valid >> c) & 1) {
+                    double zz = x + y[c] * inv_mu;
+                    if ((same >> c) & 1) zz = 0.0;
+                    if (i == j) zz = 1.0;
+                    zz = zz < 0.0 ? 0.0 : (zz > 1.0 ? 1.0 : zz);
+                    const double dz = x - zz, dx = x - xp[c];
+                    y[c] = y[c] + mu * dz;
+                    z[c] = zz;
+                    xp[c] = x;
+                    acc_p += dz * dz;
+                    acc_d += dx * dx;
+                }
+            }
+        }
+        APROF(4)
+        acc_p = wave_sum_dpp(acc_p); acc_d = wave_sum_dpp(acc_d);
+        if (worker && lane == 0) { sRed[wv - 1] = acc_p; sRed[3 + wv - 1] = acc_d; }
+        __syncthreads();
+        APROF(5)
+        const double p_res = sqrt((sRed[0] + sRed[1]) + sRed[2]) / n;
+        const double d_res = mu * sqrt((sRed[3] + sRed[4]) + sRed[5]) / n;
+        // (sRed is next written after four more barriers)
+        APROF(6)
+        if (p_res < 1e-4 && d_res < 1e-4) { iters = it + 1; break; }
+        if (p_res > 10 * d_res) { mu = 2 * mu; inv_mu = 0.5 * inv_mu; }
+        else if (d_res > 10 * p_res) { mu = mu / 2; inv_mu = 2 * inv_mu; }
+    }
+    // final X (dense n x n, leading dimension n) for the symmetrise / binarise tail
+    __syncthreads();
+    if (worker) {
+#pragma unroll
+        for (int c = 0; c < NS; ++c)
+            if ((valid >> c) & 1) sX[i * n + h * NS + c] = xp[c];
+    }
+    __syncthreads();
+    return iters;
+}
+
 template <int NMAX>
 struct Als4Lds {
     static constexpr int RMAX = 16;
@@ -1133,8 +1317,9 @@ __device__ __forceinline__ void als4_graph(Als4Lds<NMAX>& L, int f, const TW* __
         return;
     }
     const TW* Wf = W + (size_t)f * ldw * ldw;
-    const int iters = (r <= 8) ? als4_iterate<TW, NMAX, 8>(Wf, ldw, n, r, sGid, seed, sX, sA, sB, sG, sMul, sDinv, sHp, sRed)
-                               : als4_iterate<TW, NMAX, 16>(Wf, ldw, n, r, sGid, seed, sX, sA, sB, sG, sMul, sDinv, sHp, sRed);
+    const int iters = (r <= 8 && n <= 24) ? als6_iterate<TW, NMAX>(Wf, ldw, n, r, sGid, seed, sX, sA, sB, sG, sMul, sDinv, sHp, sRed)
+                      : (r <= 8)          ? als4_iterate<TW, NMAX, 8>(Wf, ldw, n, r, sGid, seed, sX, sA, sB, sG, sMul, sDinv, sHp, sRed)
+                                          : als4_iterate<TW, NMAX, 16>(Wf, ldw, n, r, sGid, seed, sX, sA, sB, sG, sMul, sDinv, sHp, sRed);
     // ---- tail: X_bin, closure (k = n-1 only), labels -- same rules as als_kernel ----
     uint8_t* sBin = reinterpret_cast<uint8_t*>(sA);
     uint8_t* sOut = reinterpret_cast<uint8_t*>(sB);
