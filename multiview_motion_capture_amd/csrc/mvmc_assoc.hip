@@ -1082,31 +1082,63 @@ __device__ __forceinline__ int als4_iterate(const TW* __restrict__ Wf, int ldw, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// als6: als4 with a dedicated solver wave (rank <= 8, n <= 24).  In als4 a half-iteration is
-//   accumulate (all waves) | barrier | eliminate (wave 0) | barrier | apply | barrier,
-// although the normal matrix A^T A + ridge I needs only the factor of the previous half, not the right-hand sides.
-// Here wave 0 forms and eliminates it WHILE waves 1-3 accumulate the right-hand sides (24 columns = 6 slices of 4 on
-// their six half-waves; columns beyond n are zeros, so nothing is skipped that als4 computes): one barrier less per
-// half and the elimination chain off the critical path of the accumulation.  Same arithmetic per element; the
-// normal matrix is summed by one lane per entry (two accumulators over even / odd rows), the right-hand sides from
-// three wave partials.
+// als7: solver wave + row-group workers (rank <= 8, n <= 24).  als4 spends a half-iteration as accumulate (all waves) | barrier |
+// eliminate (wave 0) | barrier | apply (one lane per row) | barrier.  Here:
+//  * workers own a row with EIGHT lanes (three columns each; waves 1-3 hold rows 0-7, 8-15, 16-23), so a row's right-hand side is
+//    complete inside its wave after three DPP steps -- no partials through LDS, no per-row serial back-substitution;
+//  * the solver wave turns the normal matrix into its explicit inverse (Gauss-Jordan on [G | I], lane (a, c) carries row a of G and
+//    entry (a, c) of the right half); the workers apply it as one 8-term dot product per lane (lane c of a row group makes entry c);
+//  * the inverse of A^T A + ridge I for the B update is made while the workers do the X/Z/Y update and the X1 step (A^T A is formed
+//    before the residuals are known, the ridge -- which depends on mu -- is added after), so only the inverse for the A update
+//    remains on the critical path.
 // ------------------------------------------------------------------------------------------------
+template <int P0, int P1>
+__device__ __forceinline__ void gj_inv_steps(double (&g)[8], double& e, double& dself, int lane) {
+    const int a = lane & 7;
+#pragma unroll
+    for (int p = P0; p < P1; ++p) {
+        double piv[8];
+#pragma unroll
+        for (int b = p; b < 8; ++b) {
+            const unsigned long long bits = __double_as_longlong(g[b]);
+            const unsigned lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffu), p);   // lane p: row p
+            const unsigned hi = __builtin_amdgcn_readlane((int)(bits >> 32), p);
+            piv[b] = __longlong_as_double(((unsigned long long)hi << 32) | lo);
+        }
+        const double ep = __shfl(e, (lane & ~7) | p, 64);   // row p of the right half, same column
+        const double rinv = fast_rcp(piv[p]);
+        dself = (a == p) ? rinv : dself;
+        const double m = (a == p) ? 0.0 : g[p] * rinv;
+#pragma unroll
+        for (int b = p + 1; b < 8; ++b) g[b] -= m * piv[b];
+        e -= m * ep;
+    }
+}
+// sum over the eight lanes of a row group (lanes 8q .. 8q+7); every lane gets the result
+__device__ __forceinline__ double oct_sum(double v) {
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);  // row_half_mirror: the other quad of the group
+    return v;
+}
+
 template <typename TW, int NMAX>
-__device__ __forceinline__ int als6_iterate(const TW* __restrict__ Wf, int ldw, int n, int r, const int* sGid,
+__device__ __forceinline__ int als7_iterate(const TW* __restrict__ Wf, int ldw, int n, int r, const int* sGid,
                                             const double* __restrict__ seed, double* sX, double* sA, double* sB,
-                                            double* sG, double* sMul, double* sDinv, double* sHp, double* sRed) {
-    constexpr int R = 8, NS = 4, LDX = NMAX + 1;
+                                            double* sG, double* sInvA, double* sInvB, double* sRed) {
+    constexpr int R = 8, NS = 3, LDX = NMAX + 1;
+    static_assert(NMAX >= 24, "three worker waves of eight rows");
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const bool worker = wv > 0;
-    const int tw = worker ? tid - 64 : 0;          // worker thread index 0 .. 191
-    const int i = tw & 31, h = tw >> 5;            // row, column slice (0 .. 5)
-    const bool row_ok = worker && i < n && i < NMAX;
+    const int sub = lane & 7;                                  // worker: column slice / output entry; solver: row a
+    const int i = worker ? (wv - 1) * 8 + (lane >> 3) : 0;     // worker: row 0 .. 23
+    const bool row_ok = worker && i < n;
     double w[NS], z[NS], y[NS], xp[NS], x1[NS];
     float w32[NS];
     unsigned valid = 0, same = 0;
 #pragma unroll
     for (int c = 0; c < NS; ++c) {
-        const int j = h * NS + c;
+        const int j = sub * NS + c;
         const bool ok = row_ok && j < n;
         if (ok) valid |= 1u << c;
         if (ok && sGid[i] == sGid[j]) same |= 1u << c;
@@ -1134,65 +1166,56 @@ __device__ __forceinline__ int als6_iterate(const TW* __restrict__ Wf, int ldw, 
     long long _tp = clock64();
 #endif
     const int n2 = (n + 1) & ~1;  // rows beyond n are exact zeros
-    // one half-iteration: new factor rows Fout[i] = (F^T F + ridge I)^-1 (sum_k F[k] xs(k, i)), xs = the worker's entries
-    auto half = [&](const double* F, double* Fout, double ridge, bool transposed) {
-        if (!worker) {
-            // solver wave: normal matrix (one entry per lane), elimination, multipliers to LDS
-            const int a = lane / R, b = lane - a * R;
-            double g0 = (a == b) ? ridge : 0.0, g1 = 0.0;
+    // ---- solver wave ----
+    double g0[R];   // row (lane & 7) of F^T F
+    auto form = [&](const double* F) {
+        const int a = lane >> 3, b = lane & 7;   // one entry per lane, two accumulators over even / odd rows
+        double s0 = 0.0, s1 = 0.0;
 #pragma unroll 4
-            for (int k = 0; k < n2; k += 2) { g0 += F[k * R + a] * F[k * R + b]; g1 += F[(k + 1) * R + a] * F[(k + 1) * R + b]; }
-            sG[lane] = g0 + g1;
-            MVMC_WAVE_SYNC();
-            double g[R];
+        for (int k = 0; k < n2; k += 2) { s0 += F[k * R + a] * F[k * R + b]; s1 += F[(k + 1) * R + a] * F[(k + 1) * R + b]; }
+        sG[lane] = s0 + s1;
+        MVMC_WAVE_SYNC();
+        const double2* gr = reinterpret_cast<const double2*>(&sG[(lane & 7) * R]);
 #pragma unroll
-            for (int c = 0; c < R; ++c) g[c] = sG[(lane % R) * R + c];
-            gj_chain<R>(g, sMul, sDinv);
-        } else {
-            // workers: partial right-hand side of row i over the slice's four rows k of F
-            double hv[R];
-#pragma unroll
-            for (int a = 0; a < R; ++a) hv[a] = 0.0;
-            if (i < NMAX) {
-#pragma unroll
-                for (int c = 0; c < NS; ++c) {
-                    const int k = h * NS + c;
-                    const double xv = transposed ? sX[k * LDX + i] : x1[c];
-                    const double2* fr = reinterpret_cast<const double2*>(&F[k * R]);
-#pragma unroll
-                    for (int a = 0; a < R; a += 2) { const double2 v2 = fr[a >> 1]; hv[a] += v2.x * xv; hv[a + 1] += v2.y * xv; }
-                }
-            }
-#pragma unroll
-            for (int a = 0; a < R; ++a) hv[a] += __shfl_xor(hv[a], 32, 64);   // the two slices of the wave
-            if ((lane & 32) == 0 && i < NMAX) {
-                double2* dst = reinterpret_cast<double2*>(&sHp[((wv - 1) * NMAX + i) * R]);
-#pragma unroll
-                for (int a = 0; a < R; a += 2) dst[a >> 1] = make_double2(hv[a], hv[a + 1]);
-            }
-        }
-        __syncthreads();
-        APROF(1)
-        if (tid < NMAX) {   // (lanes of the solver wave) one lane per row: sum the three partials, apply the multipliers
-            double hv[R];
-#pragma unroll
-            for (int a = 0; a < R; a += 2) {
-                const double2 p0 = *reinterpret_cast<const double2*>(&sHp[(0 * NMAX + tid) * R + a]);
-                const double2 p1 = *reinterpret_cast<const double2*>(&sHp[(1 * NMAX + tid) * R + a]);
-                const double2 p2 = *reinterpret_cast<const double2*>(&sHp[(2 * NMAX + tid) * R + a]);
-                hv[a] = (p0.x + p1.x) + p2.x;
-                hv[a + 1] = (p0.y + p1.y) + p2.y;
-            }
-            gj_apply<R>(hv, sMul, sDinv);
-            double2* dst = reinterpret_cast<double2*>(&Fout[tid * R]);
-#pragma unroll
-            for (int a = 0; a < R; a += 2) dst[a >> 1] = make_double2(hv[a], hv[a + 1]);
-        }
-        __syncthreads();
-        APROF(3)
+        for (int c = 0; c < R; c += 2) { const double2 v2 = gr[c >> 1]; g0[c] = v2.x; g0[c + 1] = v2.y; }
+        MVMC_WAVE_SYNC();
     };
+    double g[R], ge = 0.0, gd = 0.0;
+    auto inv_begin = [&](double ridge) {
+        const int a = lane & 7, c = lane >> 3;
+#pragma unroll
+        for (int b = 0; b < R; ++b) g[b] = g0[b] + ((a == b) ? ridge : 0.0);
+        ge = (a == c) ? 1.0 : 0.0;
+        gd = 0.0;
+    };
+    auto inv_store = [&](double* dst) { dst[(lane & 7) * R + (lane >> 3)] = ge * gd; };
+    // ---- workers ----
+    auto rhs = [&](const double* F, bool transposed, double (&hv)[R]) {   // sum_k F[k] xs(k, i) over the group's 24 columns
+#pragma unroll
+        for (int a = 0; a < R; ++a) hv[a] = 0.0;
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {
+            const int k = sub * NS + c;
+            const double xv = transposed ? sX[k * LDX + i] : x1[c];
+            const double2* fr = reinterpret_cast<const double2*>(&F[k * R]);
+#pragma unroll
+            for (int a = 0; a < R; a += 2) { const double2 v2 = fr[a >> 1]; hv[a] += v2.x * xv; hv[a + 1] += v2.y * xv; }
+        }
+#pragma unroll
+        for (int a = 0; a < R; ++a) hv[a] = oct_sum(hv[a]);
+    };
+    auto apply = [&](const double* inv, const double (&hv)[R], double* Fout) {   // entry `sub` of inv . hv
+        const double2* gr = reinterpret_cast<const double2*>(&inv[sub * R]);
+        double o0 = 0.0, o1 = 0.0;
+#pragma unroll
+        for (int a = 0; a < R; a += 2) { const double2 v2 = gr[a >> 1]; o0 += v2.x * hv[a]; o1 += v2.y * hv[a + 1]; }
+        Fout[i * R + sub] = o0 + o1;
+    };
+    if (!worker) form(sA);
     for (int it = 0; it < 1000; ++it) {
-        // ---- X1 = Z - (Y - W + beta)/mu (workers; the matrix also goes to LDS for the transposed reads) ----
+        const double ridge = 50.0 * inv_mu;  // == 50 / mu exactly
+        double hv[R];
+        // ---- X1 = Z - (Y - W + beta)/mu (own entries; the matrix also goes to LDS for the transposed reads) ----
         if (worker) {
 #pragma unroll
             for (int c = 0; c < NS; ++c) {
@@ -1202,26 +1225,42 @@ __device__ __forceinline__ int als6_iterate(const TW* __restrict__ Wf, int ldw, 
                     else v = z[c] - ((y[c] - w[c]) + 0.1) * inv_mu;
                 }
                 x1[c] = v;
-                if (i < NMAX) sX[i * LDX + h * NS + c] = v;
+                sX[i * LDX + sub * NS + c] = v;
             }
+        } else {
+            inv_begin(ridge);
+            gj_inv_steps<0, 3>(g, ge, gd, lane);
         }
         __syncthreads();
         APROF(0)
-        const double ridge = 50.0 * inv_mu;  // == 50 / mu exactly
-        half(sA, sB, ridge, true);    // B update: A^T X1[:, i]  (column i of X1: through LDS)
-        half(sB, sA, ridge, false);   // A update: B^T X1[i, :]^T (own row, own columns)
-        // ---- X = A B^T, Z, Y, residuals (workers) ----
+        // ---- B update: right-hand sides A^T X1[:, i] (column i of X1: through LDS) ----
+        if (worker) rhs(sA, true, hv);
+        else { gj_inv_steps<3, 8>(g, ge, gd, lane); inv_store(sInvA); }
+        __syncthreads();
+        APROF(1)
+        if (worker) apply(sInvA, hv, sB);
+        __syncthreads();
+        APROF(2)
+        // ---- A update: right-hand sides B^T X1[i, :]^T (own row, own columns) ----
+        if (worker) rhs(sB, false, hv);
+        else { form(sB); inv_begin(ridge); gj_inv_steps<0, 8>(g, ge, gd, lane); inv_store(sInvB); }
+        __syncthreads();
+        APROF(3)
+        if (worker) apply(sInvB, hv, sA);
+        __syncthreads();
+        APROF(4)
+        // ---- X = A B^T, Z, Y, residuals (workers); A^T A for the next iteration (solver) ----
         double acc_p = 0.0, acc_d = 0.0;
         if (worker) {
             double av[R];
             {
-                const double2* ar = reinterpret_cast<const double2*>(&sA[(i < NMAX ? i : 0) * R]);
+                const double2* ar = reinterpret_cast<const double2*>(&sA[i * R]);
 #pragma unroll
                 for (int a = 0; a < R; a += 2) { const double2 v2 = ar[a >> 1]; av[a] = v2.x; av[a + 1] = v2.y; }
             }
 #pragma unroll
             for (int c = 0; c < NS; ++c) {
-                const int j = h * NS + c;
+                const int j = sub * NS + c;
                 double xa = 0.0, xb = 0.0;
                 const double2* br = reinterpret_cast<const double2*>(&sB[j * R]);
 #pragma unroll
@@ -1240,15 +1279,16 @@ __device__ __forceinline__ int als6_iterate(const TW* __restrict__ Wf, int ldw, 
                     acc_d += dx * dx;
                 }
             }
+            acc_p = wave_sum_dpp(acc_p); acc_d = wave_sum_dpp(acc_d);
+            if (lane == 0) { sRed[wv - 1] = acc_p; sRed[3 + wv - 1] = acc_d; }
+        } else {
+            form(sA);
         }
-        APROF(4)
-        acc_p = wave_sum_dpp(acc_p); acc_d = wave_sum_dpp(acc_d);
-        if (worker && lane == 0) { sRed[wv - 1] = acc_p; sRed[3 + wv - 1] = acc_d; }
         __syncthreads();
         APROF(5)
         const double p_res = sqrt((sRed[0] + sRed[1]) + sRed[2]) / n;
         const double d_res = mu * sqrt((sRed[3] + sRed[4]) + sRed[5]) / n;
-        // (sRed is next written after four more barriers)
+        // (sRed is next written after five more barriers)
         APROF(6)
         if (p_res < 1e-4 && d_res < 1e-4) { iters = it + 1; break; }
         if (p_res > 10 * d_res) { mu = 2 * mu; inv_mu = 0.5 * inv_mu; }
@@ -1259,7 +1299,7 @@ __device__ __forceinline__ int als6_iterate(const TW* __restrict__ Wf, int ldw, 
     if (worker) {
 #pragma unroll
         for (int c = 0; c < NS; ++c)
-            if ((valid >> c) & 1) sX[i * n + h * NS + c] = xp[c];
+            if ((valid >> c) & 1) sX[i * n + sub * NS + c] = xp[c];
     }
     __syncthreads();
     return iters;
@@ -1317,7 +1357,7 @@ __device__ __forceinline__ void als4_graph(Als4Lds<NMAX>& L, int f, const TW* __
         return;
     }
     const TW* Wf = W + (size_t)f * ldw * ldw;
-    const int iters = (r <= 8 && n <= 24) ? als6_iterate<TW, NMAX>(Wf, ldw, n, r, sGid, seed, sX, sA, sB, sG, sMul, sDinv, sHp, sRed)
+    const int iters = (r <= 8 && n <= 24) ? als7_iterate<TW, NMAX>(Wf, ldw, n, r, sGid, seed, sX, sA, sB, sG, sHp, sHp + 64, sRed)
                       : (r <= 8)          ? als4_iterate<TW, NMAX, 8>(Wf, ldw, n, r, sGid, seed, sX, sA, sB, sG, sMul, sDinv, sHp, sRed)
                                           : als4_iterate<TW, NMAX, 16>(Wf, ldw, n, r, sGid, seed, sX, sA, sB, sG, sMul, sDinv, sHp, sRed);
     // ---- tail: X_bin, closure (k = n-1 only), labels -- same rules as als_kernel ----
