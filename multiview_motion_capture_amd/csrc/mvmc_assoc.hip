@@ -590,8 +590,12 @@ __device__ __forceinline__ void gj_apply(double (&hv)[R], const double* __restri
 #ifdef MVMC_ALS_PROFILE
 __shared__ long long g_alsprof[8];
 #define APROF(k) { const long long _t = clock64(); if (threadIdx.x == 0) g_alsprof[k] += _t - _tp; _tp = _t; }
+// als7: work / wait per phase as seen by the solver wave (thread 0, slots 0-13) and a worker wave (thread 64, slots 14-27)
+__shared__ long long g_alsprof2[28];
+#define APROF2(k) { const long long _t = clock64(); if ((threadIdx.x & 0xbf) == 0) g_alsprof2[(threadIdx.x >> 6) * 14 + (k)] += _t - _tp; _tp = _t; }
 #else
 #define APROF(k)
+#define APROF2(k)
 #endif
 template <typename TW, int NMAX, int R>
 __device__ __forceinline__ int als2_iterate(const TW* __restrict__ Wf, int ldw, int n, int r, const int* sGid,
@@ -1086,12 +1090,21 @@ __device__ __forceinline__ int als4_iterate(const TW* __restrict__ Wf, int ldw, 
 // eliminate (wave 0) | barrier | apply (one lane per row) | barrier.  Here:
 //  * workers own a row with EIGHT lanes (three columns each; waves 1-3 hold rows 0-7, 8-15, 16-23), so a row's right-hand side is
 //    complete inside its wave after three DPP steps -- no partials through LDS, no per-row serial back-substitution;
-//  * the solver wave turns the normal matrix into its explicit inverse (Gauss-Jordan on [G | I], lane (a, c) carries row a of G and
-//    entry (a, c) of the right half); the workers apply it as one 8-term dot product per lane (lane c of a row group makes entry c);
+//  * the solver wave turns the normal matrix into its explicit inverse (Gauss-Jordan on [G | I], one row of both halves per lane, the
+//    pivot row through v_readlane); the workers apply it as one 8-term dot product per lane (lane c of a row group makes entry c);
 //  * the inverse of A^T A + ridge I for the B update is made while the workers do the X/Z/Y update and the X1 step (A^T A is formed
 //    before the residuals are known, the ridge -- which depends on mu -- is added after), so only the inverse for the A update
 //    remains on the critical path.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    const unsigned long long bits = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffu), src);
+    const unsigned hi = __builtin_amdgcn_readlane((int)(bits >> 32), src);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+// Gauss-Jordan steps P0 .. P1-1 on [G | E]: lane (c, a) = (lane >> 3, lane & 7) holds row a of G in registers (eight replicas) and entry
+// (a, c) of E.  The pivot row of G travels through SGPRs (v_readlane), the pivot row of E through one ds_bpermute.  (Tried: all of E in
+// registers too, rows through v_readlane only -- 16 readlanes per step instead of 9 on average, 13% slower.)
 template <int P0, int P1>
 __device__ __forceinline__ void gj_inv_steps(double (&g)[8], double& e, double& dself, int lane) {
     const int a = lane & 7;
@@ -1099,13 +1112,8 @@ __device__ __forceinline__ void gj_inv_steps(double (&g)[8], double& e, double& 
     for (int p = P0; p < P1; ++p) {
         double piv[8];
 #pragma unroll
-        for (int b = p; b < 8; ++b) {
-            const unsigned long long bits = __double_as_longlong(g[b]);
-            const unsigned lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffu), p);   // lane p: row p
-            const unsigned hi = __builtin_amdgcn_readlane((int)(bits >> 32), p);
-            piv[b] = __longlong_as_double(((unsigned long long)hi << 32) | lo);
-        }
-        const double ep = __shfl(e, (lane & ~7) | p, 64);   // row p of the right half, same column
+        for (int b = p; b < 8; ++b) piv[b] = readlane_f64(g[b], p);   // lane p: row p
+        const double ep = __shfl(e, (lane & ~7) | p, 64);             // row p of E, same column
         const double rinv = fast_rcp(piv[p]);
         dself = (a == p) ? rinv : dself;
         const double m = (a == p) ? 0.0 : g[p] * rinv;
@@ -1113,6 +1121,12 @@ __device__ __forceinline__ void gj_inv_steps(double (&g)[8], double& e, double& 
         for (int b = p + 1; b < 8; ++b) g[b] -= m * piv[b];
         e -= m * ep;
     }
+}
+// sqrt to ~1e-13 relative (x > 0, normal range)
+__device__ __forceinline__ double fast_sqrt(double x) {
+    const double r = __builtin_amdgcn_rsq(x);
+    const double t = x * r;
+    return fma(fma(-t, t, x), 0.5 * r, t);
 }
 // sum over the eight lanes of a row group (lanes 8q .. 8q+7); every lane gets the result
 __device__ __forceinline__ double oct_sum(double v) {
@@ -1162,12 +1176,15 @@ __device__ __forceinline__ int als7_iterate(const TW* __restrict__ Wf, int ldw, 
     double mu = 64.0, inv_mu = 1.0 / 64.0;  // mu = 64 * 2^k: the reciprocal is exact
     int iters = 1000;
 #ifdef MVMC_ALS_PROFILE
-    if (threadIdx.x < 8) g_alsprof[threadIdx.x] = 0;
+    if (threadIdx.x < 28) g_alsprof2[threadIdx.x] = 0;
+    __syncthreads();
     long long _tp = clock64();
 #endif
-    const int n2 = (n + 1) & ~1;  // rows beyond n are exact zeros
+    const double tol2 = (1e-4 * n) * (1e-4 * n);
     // ---- solver wave ----
     double g0[R];   // row (lane & 7) of F^T F
+    const int n2 = (n + 1) & ~1;  // rows beyond n are exact zeros
+    // (tried: two entries per lane over half of the rows each, fully unrolled: 3% more cycles per iteration in the chain kernel)
     auto form = [&](const double* F) {
         const int a = lane >> 3, b = lane & 7;   // one entry per lane, two accumulators over even / odd rows
         double s0 = 0.0, s1 = 0.0;
@@ -1188,7 +1205,7 @@ __device__ __forceinline__ int als7_iterate(const TW* __restrict__ Wf, int ldw, 
         ge = (a == c) ? 1.0 : 0.0;
         gd = 0.0;
     };
-    auto inv_store = [&](double* dst) { dst[(lane & 7) * R + (lane >> 3)] = ge * gd; };
+    auto inv_store = [&](double* dst) { dst[(lane & 7) * R + (lane >> 3)] = ge * gd; };   // E[a][c] / pivot a
     // ---- workers ----
     auto rhs = [&](const double* F, bool transposed, double (&hv)[R]) {   // sum_k F[k] xs(k, i) over the group's 24 columns
 #pragma unroll
@@ -1231,24 +1248,29 @@ __device__ __forceinline__ int als7_iterate(const TW* __restrict__ Wf, int ldw, 
             inv_begin(ridge);
             gj_inv_steps<0, 3>(g, ge, gd, lane);
         }
+        APROF2(0)
         __syncthreads();
-        APROF(0)
+        APROF2(1)
         // ---- B update: right-hand sides A^T X1[:, i] (column i of X1: through LDS) ----
         if (worker) rhs(sA, true, hv);
         else { gj_inv_steps<3, 8>(g, ge, gd, lane); inv_store(sInvA); }
+        APROF2(2)
         __syncthreads();
-        APROF(1)
+        APROF2(3)
         if (worker) apply(sInvA, hv, sB);
+        APROF2(4)
         __syncthreads();
-        APROF(2)
+        APROF2(5)
         // ---- A update: right-hand sides B^T X1[i, :]^T (own row, own columns) ----
         if (worker) rhs(sB, false, hv);
         else { form(sB); inv_begin(ridge); gj_inv_steps<0, 8>(g, ge, gd, lane); inv_store(sInvB); }
+        APROF2(6)
         __syncthreads();
-        APROF(3)
+        APROF2(7)
         if (worker) apply(sInvB, hv, sA);
+        APROF2(8)
         __syncthreads();
-        APROF(4)
+        APROF2(9)
         // ---- X = A B^T, Z, Y, residuals (workers); A^T A for the next iteration (solver) ----
         double acc_p = 0.0, acc_d = 0.0;
         if (worker) {
@@ -1284,15 +1306,29 @@ __device__ __forceinline__ int als7_iterate(const TW* __restrict__ Wf, int ldw, 
         } else {
             form(sA);
         }
+        APROF2(10)
         __syncthreads();
-        APROF(5)
-        const double p_res = sqrt((sRed[0] + sRed[1]) + sRed[2]) / n;
-        const double d_res = mu * sqrt((sRed[3] + sRed[4]) + sRed[5]) / n;
+        APROF2(11)
+        // residuals p_res = sqrt(sP) / n, d_res = mu sqrt(sD) / n only feed thresholds (stop; mu x 2 or / 2): decide them on the squared
+        // sums (mu is a power of two, so mu^2 sD is exact), and only when a comparison is closer than 1e-9 to its threshold take the IEEE
+        // sqrt / divide path that NumPy's expressions round through (uniform over the workgroup)
+        const double sP = (sRed[0] + sRed[1]) + sRed[2], sD = (mu * mu) * ((sRed[3] + sRed[4]) + sRed[5]);
+        bool stop = sP < tol2 && sD < tol2, up = sP > 100.0 * sD, down = sD > 100.0 * sP;
+        {
+            const double eps = 1e-9;
+            const bool amb = !(sP > 1e-200) || !(sD > 1e-200) || fabs(sP - tol2) <= eps * tol2 || fabs(sD - tol2) <= eps * tol2 ||
+                             fabs(sP - 100.0 * sD) <= eps * sP || fabs(sD - 100.0 * sP) <= eps * sD;
+            if (amb) {
+                asm volatile("" ::: "memory");   // (keeps this a branch: the IEEE sqrt / divide sequences stay off the common path)
+                const double p_res = sqrt(sP) / n, d_res = mu * sqrt((sRed[3] + sRed[4]) + sRed[5]) / n;
+                stop = p_res < 1e-4 && d_res < 1e-4; up = p_res > 10 * d_res; down = d_res > 10 * p_res;
+            }
+        }
         // (sRed is next written after five more barriers)
-        APROF(6)
-        if (p_res < 1e-4 && d_res < 1e-4) { iters = it + 1; break; }
-        if (p_res > 10 * d_res) { mu = 2 * mu; inv_mu = 0.5 * inv_mu; }
-        else if (d_res > 10 * p_res) { mu = mu / 2; inv_mu = 2 * inv_mu; }
+        APROF2(12)
+        if (stop) { iters = it + 1; break; }
+        if (up) { mu = 2 * mu; inv_mu = 0.5 * inv_mu; }
+        else if (down) { mu = mu / 2; inv_mu = 2 * inv_mu; }
     }
     // final X (dense n x n, leading dimension n) for the symmetrise / binarise tail
     __syncthreads();
@@ -1409,7 +1445,8 @@ __device__ __forceinline__ void als4_graph(Als4Lds<NMAX>& L, int f, const TW* __
         iters_out[f] = iters;
 #ifdef MVMC_ALS_PROFILE
         // diagnostic build: cycles per iteration by phase {X1, accumulate G+H, eliminate, apply, X/Z/Y, reduce, residuals}
-        for (int q = 0; q < 7; ++q) lab[ldw - 7 + q] = (int)(g_alsprof[q] / iters);
+        if (r <= 8 && n <= 24 && ldw >= 28) { for (int q = 0; q < 28; ++q) lab[q] = (int)(g_alsprof2[q] / iters); }
+        else for (int q = 0; q < 7; ++q) lab[ldw - 7 + q] = (int)(g_alsprof[q] / iters);
 #endif
     }
     if (x_bin || match_mat) {

@@ -16,6 +16,14 @@ for t in range(6):
     o = tr.step(k4[:, t].contiguous(), c4[:, t].contiguous(), want_debug=True)
     st = o["st"]
     it = st["iters"].cpu().numpy(); lab = st["labels"].cpu().numpy(); gc = o["group_counts"].cpu().numpy()
+    if lab.shape[1] >= 28 and gc.sum(1).max() <= 24 and t > 0:   # als7: work / wait per phase, solver wave and a worker wave
+        print(lab.shape, it[:8], lab[0])
+        ph = np.nan_to_num(lab[it > 0][:, :28].astype(float).mean(0).round(0))
+        names = ["X1|inv0-2", "rhsB|inv3-7", "applyB", "rhsA|form+inv", "applyA", "XZY|form"]
+        print("frame", t, "iters mean %.1f" % it.mean(), " ".join(
+            "%s: solver %d+%d worker %d+%d;" % (names[k], ph[2 * k], ph[2 * k + 1], ph[14 + 2 * k], ph[14 + 2 * k + 1]) for k in range(6)),
+            "tail %d / %d; sum %d / %d" % (ph[12], ph[26], ph[:14].sum(), ph[14:].sum()))
+        continue
     ph = lab[:, -7:].astype(float)
     print("frame", t, "n nodes", gc.sum(1).mean(), "gmax", gc.max(), "iters mean %.1f max %d" % (it.mean(), it.max()),
           "cycles/iter by phase:", ph[it > 0].mean(0).round(0), "sum", ph[it > 0].sum(1).mean().round(0))
