@@ -106,6 +106,20 @@ int mvmc_als_associate(const void* W, int w_dtype, const int32_t* group_counts, 
 int mvmc_closure_labels(const uint8_t* x_bin, const int32_t* n_nodes, int n_frames, int n_max, uint8_t* match_mat,
                         int32_t* labels, int32_t* n_clusters, mvmcStream_t stream);
 
+/* match_svt (mv_association.py:321-411): ADMM with singular-value thresholding and the doubly-stochastic block projection
+ * (myproj2dpam, :15-60); the matcher match_multiview_poses can select instead of match_als.  pSelect = 1 (the reference's default).
+ *   S            (F,N,N) f32|f64 affinity in compact node order (leading dimension N <= 64); not modified (the reference zeroes
+ *                the diagonal of its argument; the symmetrised, zero-diagonal copy lives on the device here)
+ *   group_counts (F,G) nodes per group, G <= 16; g_max upper bound of any group's node count (<= 16)
+ *   alpha, lambda, mu, tol, max_iter, dual_stochastic: the reference's keyword arguments (0.1, 50, 64, 5e-4, 20, 1)
+ *   work         (F,3,N,N) f64 device workspace (Y and the two projection states)
+ *   x_bin        (F,N,N) u8 out: (X + X^T) / 2 > 0.5;  x_out (F,N,N) f64 out or NULL: X itself
+ *   iters        (F) i32 out: SVD-equivalent decompositions run (info['iter'] + 1 when the tolerance was met, else max_iter)
+ * Arithmetic is float64 for either input type.  Follow with mvmc_closure_labels for match_mat / cluster labels. */
+int mvmc_svt_associate(const void* S, int s_dtype, const int32_t* group_counts, int n_frames, int n_groups, int n_max,
+                       int g_max, double alpha, double lambda, double mu, double tol, int max_iter, int dual_stochastic,
+                       double* work, uint8_t* x_bin, double* x_out, int32_t* iters, mvmcStream_t stream);
+
 /* Turns labels into member lists: members (F,K,V) pose index q (ascending node order, -1 padded),
  * n_members (F,K).  Clusters beyond K or members beyond V are dropped (n_members still counts them). */
 int mvmc_cluster_members(const int32_t* labels, const int32_t* counts, int n_frames, int n_views, int p_max,

@@ -24,7 +24,7 @@ SYMBOLS = (
     "mvmc_abi_version", "mvmc_status_string", "mvmc_als_seed_table", "mvmc_ingest", "mvmc_fmats",
     "mvmc_affinity", "mvmc_als_associate", "mvmc_closure_labels", "mvmc_cluster_members", "mvmc_dlt", "mvmc_triangulate_postopt", "mvmc_fk", "mvmc_ik_solve",
     "mvmc_fmats_from_projections", "mvmc_st_affinity", "mvmc_track_assign", "mvmc_track_commit", "mvmc_debug_eigh",
-    "mvmc_debug_trstep", "mvmc_debug_ik_mode", "mvmc_ik_solve_stages", "mvmc_chain_run",
+    "mvmc_debug_trstep", "mvmc_debug_ik_mode", "mvmc_ik_solve_stages", "mvmc_chain_run", "mvmc_svt_associate",
 )
 
 

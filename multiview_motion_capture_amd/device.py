@@ -158,6 +158,30 @@ def als_associate(W: torch.Tensor, group_counts: torch.Tensor, g_max: int, want_
     return dict(labels=labels, n_clusters=ncl, iters=iters, x_bin=xb, match_mat=mm)
 
 
+def svt_associate(S: torch.Tensor, group_counts: torch.Tensor, g_max: int, alpha=0.1, lam=50.0, mu=64.0, tol=5e-4, max_iter=20,
+                  dual_stochastic=True, want_x=False):
+    """match_svt (mv_association.py:321-411) + transform_closure + the cluster rule.  S (F,N,N) f32|f64, group_counts (F,G) i32 ->
+    dict(x_bin, match_mat (F,N,N) u8, labels (F,N), n_clusters (F), iters (F)[, X (F,N,N) f64])."""
+    if S.dtype not in (torch.float32, torch.float64):
+        raise ValueError("svt_associate: S must be float32 or float64")
+    F, N, _ = S.shape
+    _req(S, S.dtype, "S", (F, N, N))
+    G = group_counts.shape[1]
+    _req(group_counts, torch.int32, "group_counts", (F, G))
+    dev = S.device
+    work = torch.empty((F, 3, N, N), dtype=torch.float64, device=dev)
+    xb = torch.empty((F, N, N), dtype=torch.uint8, device=dev)
+    xo = torch.empty((F, N, N), dtype=torch.float64, device=dev) if want_x else None
+    iters = torch.empty((F,), dtype=torch.int32, device=dev)
+    dt = _cabi.MVMC_F32 if S.dtype == torch.float32 else _cabi.MVMC_F64
+    check(_cabi.load().mvmc_svt_associate(_p(S), dt, _p(group_counts), F, G, N, int(g_max), C.c_double(alpha), C.c_double(lam),
+                                          C.c_double(mu), C.c_double(tol), int(max_iter), int(bool(dual_stochastic)), _p(work),
+                                          _p(xb), _p(xo), _p(iters), _stream()), "mvmc_svt_associate")
+    n_nodes = group_counts.sum(dim=1).to(torch.int32)
+    mm, labels, ncl = closure_labels(xb, n_nodes)
+    return dict(x_bin=xb, match_mat=mm, labels=labels, n_clusters=ncl, iters=iters, X=xo)
+
+
 def closure_labels(x_bin: torch.Tensor, n_nodes: torch.Tensor, want_mat=True):
     """AS-5/AS-6 alone.  x_bin (F,N,N) u8, n_nodes (F) i32 -> (match_mat (F,N,N) u8 | None, labels (F,N), n_clusters (F))."""
     F, N, _ = x_bin.shape

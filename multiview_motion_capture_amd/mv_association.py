@@ -26,6 +26,27 @@ def match_als(W: np.ndarray, dimGroup, **kwargs):
     return res["match_mat"][0].cpu().numpy().astype(bool), res["x_bin"][0].cpu().numpy().astype(bool)
 
 
+def match_svt(S, dimGroup, **kwargs):
+    """mv_association.py:321-411 -> (match_mat (n,n) bool, X_bin (n,n) bool).  Keyword arguments as in the reference (alpha, tol,
+    maxIter, _lambda, mu, dual_stochastic_SVT; verbose is accepted and ignored); pselect must be 1 and eigenvalues False.  S is not
+    modified (the reference zeroes the diagonal of the caller's array)."""
+    if kwargs.get("pselect", 1) != 1 or kwargs.get("eigenvalues", False):
+        raise ValueError("match_svt: only pselect=1, eigenvalues=False are implemented")
+    d = _d()
+    S = np.asarray(S)
+    if S.dtype not in (np.float32, np.float64):
+        S = S.astype(np.float64)
+    n = S.shape[0]
+    cnt = np.diff(np.asarray(dimGroup)).astype(np.int32)
+    if n == 0 or cnt.sum() != n:
+        raise ValueError("match_svt: dimGroup does not partition S")
+    res = dev.svt_associate(torch.as_tensor(np.ascontiguousarray(S[None]), device=d), torch.as_tensor(cnt[None], device=d),
+                            g_max=int(cnt.max()), alpha=kwargs.get("alpha", 0.1), lam=kwargs.get("_lambda", 50),
+                            mu=kwargs.get("mu", 64), tol=kwargs.get("tol", 5e-4), max_iter=kwargs.get("maxIter", 20),
+                            dual_stochastic=kwargs.get("dual_stochastic_SVT", True))
+    return res["match_mat"][0].cpu().numpy().astype(bool), res["x_bin"][0].cpu().numpy().astype(bool)
+
+
 def transform_closure(x_bin):
     """mv_association.py:99-121 (including its k = N-1 overwrite quirk) -> match_result_mat (n,n) bool."""
     d = _d()

@@ -270,6 +270,88 @@ def match_als(W, dim_group, return_iters=False):
     return match_mat, x_bin
 
 
+# ---- match_svt (mv_association.py:321-411) with its doubly-stochastic projection (:15-60) ----
+def _proj2pav(y):
+    """mv_association.py:49-60: clip negatives; a vector summing below 1 is kept, otherwise projected on the simplex."""
+    y = np.where(y < 0, 0, y).astype(y.dtype)
+    if y.sum(dtype=y.dtype) < 1:
+        return y
+    u = np.sort(y)[::-1]
+    sv = np.cumsum(u, dtype=y.dtype)
+    to_find = u > (sv - 1) / np.arange(1, len(u) + 1, dtype=y.dtype)
+    rho = np.nonzero(to_find)[0][-1]
+    theta = max(y.dtype.type(0), (sv[rho] - 1) / y.dtype.type(rho + 1))
+    return np.maximum(y - theta, 0).astype(y.dtype)
+
+
+def _proj2dpam(Y, tol):
+    """mv_association.py:15-32: alternating row / column projections with Dykstra corrections, at most 10 rounds."""
+    X0, X, I2 = Y, Y, 0
+    for _ in range(10):
+        T = X0 + I2
+        X1 = np.stack([_proj2pav(T[i]) for i in range(T.shape[0])])
+        I1 = X1 - T
+        T = X0 + I1
+        X2 = np.stack([_proj2pav(T[:, j]) for j in range(T.shape[1])], axis=1)
+        I2 = X2 - T
+        chg = np.abs(X2 - X).sum(dtype=Y.dtype) / X.size
+        X = X2
+        if chg < tol:
+            return X
+    return X
+
+
+def match_svt(S, dim_group, alpha=0.1, lam=50, mu=64, tol=5e-4, max_iter=20, dual_stochastic=True, return_info=False):
+    """mv_association.py:321-411 (pSelect = 1).  The dtype of S carries through, as with torch.from_numpy: the float32 affinity of
+    geometry_affinity keeps the whole iteration (SVD included) in float32."""
+    S = np.array(S)   # the reference writes the diagonal of its argument; the oracle works on a copy
+    dt = S.dtype.type
+    N = S.shape[0]
+    dim_group = [int(v) for v in dim_group]
+    S[np.arange(N), np.arange(N)] = 0
+    S = (S + S.T) / dt(2)
+    X = S.copy()
+    Y = np.zeros_like(S)
+    W = dt(alpha) - S
+    mu = float(mu)
+    n_iter = max_iter
+    for it in range(max_iter):
+        X0 = X
+        U, s, Vt = np.linalg.svd((dt(1.0 / mu) * Y + X).astype(S.dtype))
+        ds = np.maximum(s - dt(lam / mu), 0).astype(S.dtype)
+        Q = ((U * ds) @ Vt).astype(S.dtype)
+        X = (Q - (W + Y) / dt(mu)).astype(S.dtype)
+        for g in range(len(dim_group) - 1):
+            X[dim_group[g]:dim_group[g + 1], dim_group[g]:dim_group[g + 1]] = 0
+        X[np.arange(N), np.arange(N)] = 1
+        X[X < 0] = 0
+        X[X > 1] = 1
+        if dual_stochastic:
+            for gi in range(len(dim_group) - 1):
+                r0, r1 = dim_group[gi], dim_group[gi + 1]
+                for gj in range(len(dim_group) - 1):
+                    c0, c1 = dim_group[gj], dim_group[gj + 1]
+                    if r1 > r0 and c1 > c0:
+                        X[r0:r1, c0:c1] = _proj2dpam(X[r0:r1, c0:c1].copy(), dt(1e-2))
+        X = ((X + X.T) / dt(2)).astype(S.dtype)
+        Y = (Y + dt(mu) * (X - Q)).astype(S.dtype)
+        p_res = float(np.linalg.norm(X - Q)) / N
+        d_res = mu * float(np.linalg.norm(X - X0)) / N
+        if p_res < tol and d_res < tol:
+            n_iter = it
+            break
+        if p_res > 10 * d_res:
+            mu = 2 * mu
+        elif d_res > 10 * p_res:
+            mu = mu / 2
+    X = (X + X.T) / dt(2)
+    x_bin = X > 0.5
+    match_mat = transform_closure(x_bin)
+    if return_info:
+        return match_mat, x_bin, dict(iter=n_iter, X=X)
+    return match_mat, x_bin
+
+
 def parse_match_result(match_mat, n, dim_group):
     """motion_capture.py:417-446 -> clusters of (group, local, global)."""
     mm = np.asarray(match_mat).astype(np.float64)

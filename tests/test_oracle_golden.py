@@ -127,3 +127,16 @@ def test_ik_cases_match_reference(ik_cases):
         assert np.allclose(np.concatenate([r, e.ravel(), b]), g["s2_x"][i], rtol=0, atol=1e-7)
         assert np.allclose(joints, g["joints"][i], rtol=0, atol=1e-7)
     assert n >= 8
+
+
+def test_match_svt_oracle_against_reference_vectors():
+    """mv_association.py:321-411 restated in NumPy against X_bin / match_mat / SVD call counts recorded from the reference itself
+    (oracle/gen_golden_svt.py), float32 and float64 inputs."""
+    g = load_golden("svt_cases.npz")
+    names = sorted({k[:-2] for k in g.files if k.endswith("_S")})
+    assert len(names) == 22
+    for nm in names:
+        mm, xb, info = o.match_svt(g[nm + "_S"], g[nm + "_dim"], return_info=True)
+        assert np.array_equal(xb, g[nm + "_x_bin"]), nm
+        assert np.array_equal(mm.astype(bool), g[nm + "_match_mat"]), nm
+        assert min(info["iter"] + 1, 20) == int(g[nm + "_svd_calls"]), nm
