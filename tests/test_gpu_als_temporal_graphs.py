@@ -42,3 +42,40 @@ def test_temporal_graphs_labels_and_iterations():
     # the counts are decided by thresholds on fp64 norms (stop, and the doubling / halving of mu); rounding moves a few of them
     print(f"{n_graphs} temporal graphs: {n_diff} iteration counts differ from the oracle's, worst by {worst}")
     assert n_diff <= n_graphs // 10 and worst <= 2, (n_diff, worst)
+
+
+@pytest.mark.parametrize("sizes,dtype", [
+    ([4, 4, 4, 4, 4, 4, 4], np.float64),      # n = 28, rank 8: the four-wave form with partial sums (n > 24)
+    ([4, 4, 4, 4, 4, 4, 4], np.float32),
+    ([8, 4, 4, 4, 4, 4], np.float64),         # n = 28, rank 16
+    ([3, 6, 5, 6, 6, 6], np.float64),         # n = 32, rank 12 (padded to 16), ragged groups
+    ([4, 5, 3, 4, 4], np.float32),            # n = 20, rank 10 > 8: not the solver-wave form
+    ([2, 3, 0, 4, 3], np.float64),            # n = 12 with an empty group: the solver-wave form on a small graph
+])
+def test_workgroup_als_variants_vs_oracle(sizes, dtype):
+    """Every variant behind mvmc_als_associate's workgroup path on block-structured affinities: labels exact, iterations +-2."""
+    from multiview_motion_capture_amd import device as dev
+    rng = np.random.default_rng(20260107)
+    n, B = int(np.sum(sizes)), 12
+    dim = [0] + np.cumsum(sizes).tolist()
+    W = np.zeros((B, n, n), dtype=dtype)
+    for b in range(B):
+        ident = np.concatenate([rng.permutation(max(sizes))[:s] for s in sizes])
+        same = ident[:, None] == ident[None, :]
+        A = np.where(same, rng.uniform(0.55, 1.0, (n, n)), rng.uniform(0.0, 0.4, (n, n)))
+        A = 0.5 * (A + A.T)
+        for g in range(len(sizes)):
+            A[dim[g]:dim[g + 1], dim[g]:dim[g + 1]] = 0.0
+        W[b] = A.astype(dtype)
+    d = torch.device("cuda:0")
+    cnt = torch.tensor([sizes] * B, dtype=torch.int32, device=d)
+    res = dev.als_associate(torch.from_numpy(W).to(d), cnt, g_max=max(sizes), want_mats=True)
+    lab, it, xb = res["labels"].cpu().numpy(), res["iters"].cpu().numpy(), res["x_bin"].cpu().numpy()
+    n_diff = 0
+    for b in range(B):
+        mm_o, xb_o, it_o = o.match_als(W[b], dim, return_iters=True)
+        assert np.array_equal(xb[b].astype(bool), xb_o), b
+        assert np.array_equal(lab[b], o.cluster_labels(mm_o, n)), b
+        assert abs(int(it[b]) - it_o) <= 2, (b, it[b], it_o)
+        n_diff += int(it[b] != it_o)
+    assert n_diff <= 2, n_diff
