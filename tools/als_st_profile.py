@@ -1,4 +1,6 @@
-"""ALS on the spatio-temporal graphs of the bench workload: iterations and cycles by phase."""
+"""ALS on the spatio-temporal graphs of the bench workload: iterations and cycles by phase.
+Needs make -C multiview_motion_capture_amd/csrc prof-als; MVMC_LIB_PATH=multiview_motion_capture_amd/lib/libmvmc_prof.so.  The counters come back
+through the label rows, so the tracker loses its tracklets on every other frame: read the frames that print phases."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, "/root/repo" if os.path.exists("/root/repo/bench.py") else os.getcwd())
@@ -17,7 +19,6 @@ for t in range(6):
     st = o["st"]
     it = st["iters"].cpu().numpy(); lab = st["labels"].cpu().numpy(); gc = o["group_counts"].cpu().numpy()
     if lab.shape[1] >= 28 and gc.sum(1).max() <= 24 and t > 0:   # als7: work / wait per phase, solver wave and a worker wave
-        print(lab.shape, it[:8], lab[0])
         ph = np.nan_to_num(lab[it > 0][:, :28].astype(float).mean(0).round(0))
         names = ["X1|inv0-2", "rhsB|inv3-7", "applyB", "rhsA|form+inv", "applyA", "XZY|form"]
         print("frame", t, "iters mean %.1f" % it.mean(), " ".join(

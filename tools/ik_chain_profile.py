@@ -1,6 +1,6 @@
 """Diagnostic: cycle shares of the IK kernel's phases on the chain protocol (cold head + warm frames).
-Needs the profile build: make -C multiview_motion_capture_amd/csrc prof;
-MVMC_LIB_PATH=multiview_motion_capture_amd/lib/libmvmc_prof.so python tools/ik_chain_profile.py"""
+Needs the profile build: make -C multiview_motion_capture_amd/csrc prof-ik;
+MVMC_LIB_PATH=multiview_motion_capture_amd/lib/libmvmc_ikprof.so python tools/ik_chain_profile.py"""
 import os
 import sys
 
