@@ -1122,12 +1122,6 @@ __device__ __forceinline__ void gj_inv_steps(double (&g)[8], double& e, double& 
         e -= m * ep;
     }
 }
-// sqrt to ~1e-13 relative (x > 0, normal range)
-__device__ __forceinline__ double fast_sqrt(double x) {
-    const double r = __builtin_amdgcn_rsq(x);
-    const double t = x * r;
-    return fma(fma(-t, t, x), 0.5 * r, t);
-}
 // sum over the eight lanes of a row group (lanes 8q .. 8q+7); every lane gets the result
 __device__ __forceinline__ double oct_sum(double v) {
     v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
