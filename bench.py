@@ -128,6 +128,10 @@ def main():
                          "0 = one per frame of the chain (default), 1 = one persistent workgroup per chain")
     ap.add_argument("--groups", type=int, default=1,
                     help="chain groups advanced on separate HIP streams (association of one group overlaps IK of another)")
+    ap.add_argument("--overlap", type=int, default=2,
+                    help="steps in flight: consecutive steps (independent batches) are issued on N alternating HIP streams, so the "
+                         "tail of one launch (its slowest chains, a fifth of the workgroup slots idle) is filled by the head of the "
+                         "next; 1 = strictly one step after the other")
     ap.add_argument("--cpu-frames", type=int, default=1, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=0,
                     help="worker processes of the CPU baseline on the chain protocol (0 = min(16, host cores))")
@@ -165,6 +169,7 @@ def main():
     ev = {k: [] for k in ("assoc", "tri", "ik", "total")}
 
     ik_events, als_events, hand_over_flags = [], [], []
+    kern_events = []   # every launch of the chain kernel in this process: (timed?, start, end)
 
     def step(timed):
         if with_ik and L > 1:
@@ -172,8 +177,10 @@ def main():
             e = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if timed else None
             if timed: e[0].record()
             if args.path == "fused":
+                kev = []
                 out = run_chains_fused(hp, kps, counts, L, nfev_cold=args.nfev_cold, nfev_warm=args.nfev_warm, want_info=timed,
-                                       parts=args.parts or None)
+                                       parts=args.parts or None, kernel_events=kev)
+                kern_events.append((timed, kev[0][0], kev[0][1]))
                 out.pop("_keepalive", None)
                 hand_over_flags.append(out.pop("flags", None))
             else:
@@ -207,14 +214,22 @@ def main():
             ev["assoc"].append((e[0], e[1])); ev["tri"].append((e[1], e[2])); ev["ik"].append((e[2], e[3]))
         return out
 
-    for _ in range(args.warmup):
-        step(False)
+    streams = [torch.cuda.Stream(device=d) for _ in range(args.overlap)] if args.overlap > 1 else None
+
+    def issue(i, timed):
+        if streams is None:
+            return step(timed)
+        with torch.cuda.stream(streams[i % len(streams)]):
+            return step(timed)
+
+    for i in range(args.warmup):
+        issue(i, False)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step(True)
+    for i in range(args.steps):
+        out = issue(i, True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -224,10 +239,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # for the record: one step on its own, nothing else in flight (untimed region)
+    serial_ms = None
+    if args.overlap > 1:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        step(False)
+        e1.record()
+        torch.cuda.synchronize()
+        serial_ms = e0.elapsed_time(e1)
     for fl in hand_over_flags:
         if fl is not None and (int(fl[-4]) != 0 or int(fl[-3]) != 0):
             raise SystemExit("chain kernel: a hand-over timed out or a graph did not fit; results are void")
     stage_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items() if v}
+    if serial_ms is not None:
+        stage_ms["one_step_alone"] = serial_ms
+    if kern_events:
+        # the kernel alone (events right around its launch): the timed region's launches, and every launch of the process -- the
+        # average a profiler reports also contains the warm-up launches and the stand-alone reference launch
+        stage_ms["chain_kernel_timed_region"] = float(np.mean([a.elapsed_time(b) for tm, a, b in kern_events if tm]))
+        stage_ms["chain_kernel_all_launches"] = float(np.mean([a.elapsed_time(b) for tm, a, b in kern_events]))
     chain = with_ik and L > 1
     fused = chain and args.path == "fused"
     if chain and not fused:
@@ -252,7 +283,7 @@ def main():
         if fused:
             # the whole step is ONE launch of chain_kernel over the rank's F frames
             dom, dom_kernel = "chain", "chain_kernel"
-            launch_ms = stage_ms["total"]
+            launch_ms = stage_ms.get("chain_kernel_timed_region", stage_ms["total"])
             achieved = bpf * F / (launch_ms * 1e-3) / 1e9
         elif chain:
             # dominant kernel = the one with the larger share of the step; both are launched once per time step over all
@@ -286,17 +317,19 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"synthetic {F} frames/GPU, C={C}, P={Pn}, J=25: affinity+ALS+DLT" +
                                    ((f"+IK, temporal chains of {L} frames (match_spatial_time + tracker; cold 50+50 nfev at the head, "
-                                     f"warm 5+5 after), {('one launch, ' + (str(args.parts or L) + ' workgroup(s) per chain')) if args.path == 'fused' else 'one launch per stage'}" if L > 1 else "+IK, every frame cold-started (chain length 1, max_nfev 50+50)")
+                                     f"warm 5+5 after), {('one launch per step, ' + (str(args.parts or L) + ' workgroup(s) per chain')) if args.path == 'fused' else 'one launch per stage'}" + (f", {args.overlap} steps in flight on alternating streams" if args.overlap > 1 else "") if L > 1 else "+IK, every frame cold-started (chain length 1, max_nfev 50+50)")
                                     if with_ik else ""),
                        "frames_per_gpu": F, "views": C, "people": Pn, "chain_len": L, "seed": args.seed, "parallelism": f"frames x{world}",
-                       **extra},
+                       "steps_in_flight": args.overlap, **extra},
             "stages_ms": stage_ms,
             "roofline": {"bound": "hbm", "kernel": dom_kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "launch_ms": launch_ms,
                          "traffic": traffic, "bytes_per_frame": bpf,
                          "note": "latency-bound path (dependent fp64 chains), not HBM bound (SURVEY.md F6); achieved = algorithmic "
-                                 "bytes of the frames one launch serves / mean launch duration of the dominant kernel; see DESIGN.md"},
+                                 "bytes of the frames one launch serves / mean launch duration of the dominant kernel" +
+                                 (f" ({args.overlap} launches share the GPU, so a launch lasts longer than ms_per_step)" if args.overlap > 1 else "") +
+                                 "; see DESIGN.md"},
         }
         if chain and "gt_joints" in data:
             # accuracy of the last step's output against the generator's ground truth (the parity gates against the

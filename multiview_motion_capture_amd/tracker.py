@@ -197,13 +197,14 @@ def run_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], c
 
 def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], chain_len: int, t_max=8,
                      nfev_cold=50, nfev_warm=5, want_info=False, k_max: Optional[int] = None, v_max: Optional[int] = None,
-                     parts: Optional[int] = None):
+                     parts: Optional[int] = None, kernel_events: Optional[list] = None):
     """run_chains in ONE launch (mvmc_chain_run): a persistent workgroup per chain runs graph -> ALS -> assignment ->
     IK -> commit for the chain's frames, so every chain advances at its own pace instead of waiting, stage by stage,
     for the slowest member of every launch.  Same device code and the same results as run_chains.
     parts > 1 (a divisor of chain_len): every chain is run by that many workgroups, one frame range after the other
     (hand-over through device flags), which lets the hardware dispatcher even out the load when the number of chains is
-    not a multiple of the number of workgroup slots.  check_chain_flags(res) tells whether the run is valid."""
+    not a multiple of the number of workgroup slots.  check_chain_flags(res) tells whether the run is valid.
+    kernel_events: a list that receives the (start, end) torch.cuda.Event pair recorded right around the kernel launch."""
     import ctypes as C
     from . import _cabi
     F, Cn, P = kps.shape[:3]
@@ -245,8 +246,14 @@ def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tens
         setattr(buf, name, int(val))
     for name, ten in t.items():
         setattr(buf, name, None if ten is None else ten.data_ptr())
+    if kernel_events is not None:
+        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        k0.record()
     _cabi.check(_cabi.load().mvmc_chain_run(C.byref(hp.skeleton), C.byref(buf),
                                             C.c_void_p(torch.cuda.current_stream(d).cuda_stream)), "mvmc_chain_run")
+    if kernel_events is not None:
+        k1.record()
+        kernel_events.append((k0, k1))
     res = dict(params=t["out_params"], joints=t["out_joints"], meta=t["out_meta"], n_tracks=t["out_n_tracks"],
                n_dead=t["n_dead"], flags=t["flags"], _keepalive=t)
     if want_info:

@@ -74,3 +74,39 @@ def test_graph_larger_than_the_kernels_als_variant_is_reported():
     small = synth.generate(2 * 4, 5, 4, 20260105, chain_len=4)
     hs = HotPath(small["K"], small["Rt"])
     check_chain_flags(run_chains_fused(hs, torch.from_numpy(small["kps25"]).cuda(), torch.from_numpy(small["counts"]).cuda(), 4))
+
+
+def test_launches_in_flight_on_several_streams_do_not_interact():
+    """bench.py keeps two steps in flight on alternating streams (the head of one launch fills the slots its predecessor's slowest
+    chains leave idle).  Three launches on three streams, more workgroups than slots in every one of them: each must return exactly
+    what it returns alone, and no hand-over may time out (a waiting workgroup's predecessor is dispatched before it in its own launch,
+    whatever the other launches do)."""
+    from multiview_motion_capture_amd import synth
+    from multiview_motion_capture_amd.pipeline import HotPath
+    from multiview_motion_capture_amd.tracker import check_chain_flags, run_chains_fused
+    B, L = 200, 8
+    sets = []
+    for s in range(3):
+        data = synth.generate(B * L, 5, 4, 20260110 + s, chain_len=L)
+        hp = HotPath(data["K"], data["Rt"])
+        sets.append((hp, torch.from_numpy(data["kps25"]).cuda(), torch.from_numpy(data["counts"]).cuda()))
+    alone = []
+    for hp, kps, cnt in sets:
+        r = run_chains_fused(hp, kps, cnt, L)
+        torch.cuda.synchronize()
+        alone.append({k: r[k].clone() for k in ("params", "joints", "meta", "n_tracks")})
+    streams = [torch.cuda.Stream() for _ in sets]
+    torch.cuda.synchronize()
+    together = []
+    for rep in range(2):
+        for st, (hp, kps, cnt) in zip(streams, sets):
+            with torch.cuda.stream(st):
+                together.append(run_chains_fused(hp, kps, cnt, L))
+    torch.cuda.synchronize()
+    for i, r in enumerate(together):
+        check_chain_flags(r)
+        ref = alone[i % 3]
+        for k in ("meta", "n_tracks"):
+            assert torch.equal(r[k], ref[k]), (i, k)
+        for k in ("params", "joints"):
+            assert torch.equal(torch.nan_to_num(r[k]), torch.nan_to_num(ref[k])), (i, k)
