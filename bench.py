@@ -214,6 +214,7 @@ def main():
             ev["assoc"].append((e[0], e[1])); ev["tri"].append((e[1], e[2])); ev["ik"].append((e[2], e[3]))
         return out
 
+    torch.cuda.synchronize()   # inputs and calibration tables were made on the default stream; the steps run on side streams
     streams = [torch.cuda.Stream(device=d) for _ in range(args.overlap)] if args.overlap > 1 else None
 
     def issue(i, timed):
