@@ -6,7 +6,9 @@ on synthetic (F frames x C views x P people x 25 joints) keypoints, one process 
 
 A step = one pass of the whole hot path over this rank's F frames (inputs resident in HBM before
 the timed region).  Frames shard across ranks (weak scaling: F per GPU is fixed); each step ends
-with one RCCL all-gather of the per-frame results.  Rank 0 prints ONE JSON line.
+with one RCCL all-gather of the per-frame results.  Consecutive steps are independent batches and are issued on two
+alternating HIP streams (--overlap 2: the next launch's first frames fill the workgroup slots the slowest chains of the
+previous one leave idle; --overlap 1 = one step at a time).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json

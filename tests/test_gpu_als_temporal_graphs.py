@@ -14,7 +14,7 @@ def test_temporal_graphs_labels_and_iterations():
     from multiview_motion_capture_amd import device as dev, synth
     from multiview_motion_capture_amd.pipeline import HotPath
     from multiview_motion_capture_amd.tracker import ChainTracker
-    L, B = 4, 48
+    L, B = 5, 96
     data = synth.generate(B * L, 5, 4, 20260103, chain_len=L)
     d = torch.device("cuda:0")
     hp = HotPath(data["K"], data["Rt"], device=d)
