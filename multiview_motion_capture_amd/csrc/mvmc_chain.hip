@@ -70,15 +70,18 @@ struct ChainArgs {
     unsigned* flags;          // (B + 1) parts completed per chain; [B] = timeout word.  Zeroed by the launcher
 };
 
+constexpr int CH_EOFF = 2368;   // doubles of graph scratch in front of the pose-pair block (NS <= 48: 48 * 48 + 6 + 48 = 2358)
+
 union ChainArena {
     Als4Lds<32> als64;
     Als4Lds<24> als32;
     Ik1Shared<CH_VM> ik[4];
     // graph scratch: st_affinity_wave needs (NS*NS + 6) doubles + 2 NS ints (NS <= 48), affinity_wave N*51 doubles + 2 N*N floats
     // + 2 N ints + 4 words (N <= 40)
-    double graph[40 * 51 + 40 * 40 + 40 + 8];
+    // + the pose-pair block made ahead of the hand-over (st_pose_pairs: N * N doubles behind st_affinity_wave's part)
+    double graph[CH_EOFF + 40 * 40];
 };
-static_assert(40 * 51 + 40 * 40 + 40 + 8 >= 48 * 48 + 6 + 48, "graph scratch covers both graph builders");
+static_assert(CH_EOFF >= 48 * 48 + 6 + 48 && CH_EOFF + 40 * 40 >= 40 * 51 + 40 * 40 + 40 + 8, "graph scratch covers both graph builders");
 static_assert(sizeof(ChainArena) <= 4 * sizeof(Ik1Shared<CH_VM>), "the IK blocks set the arena size");
 
 // The phases as separate (non-inlined) functions: each gets its own register allocation inside the workgroup's budget
@@ -89,12 +92,17 @@ __device__ __noinline__ void chain_graph_spatial(ChainArena& arena, const ChainA
     float* S = A.S_sp + (size_t)b * N * N;
     if ((threadIdx.x >> 6) == 0) affinity_wave(arena.graph, A.kps17, A.counts, A.Fm, C, P, f, nullptr, S);
 }
-__device__ __noinline__ void chain_graph_temporal(ChainArena& arena, const ChainArgs& A, int b, int f) {
+__device__ __noinline__ void chain_graph_temporal(ChainArena& arena, const ChainArgs& A, int b, int f, bool pairs_ready) {
     MVMC_ASSUME_LDS(&arena);
     const int C = A.C, P = A.P, T = A.T, NS = T + C * P;
     double* W = A.W_st + (size_t)b * NS * NS;
     st_affinity_wave<true>(arena.graph, A.kps17, A.counts, 0, f, A.joints + (size_t)b * T * 54, A.n_tracks + b, A.Pm, A.F2, C, P,
-                           T, 0.1, W, nullptr, A.gc + (size_t)b * (C + 1));
+                           T, 0.1, W, nullptr, A.gc + (size_t)b * (C + 1), pairs_ready ? arena.graph + CH_EOFF : nullptr, C * P);
+}
+// the frame's 2-D / 2-D distances, made while the workgroup waits for its predecessor (they do not depend on the tracklets)
+__device__ __noinline__ void chain_pose_pairs(ChainArena& arena, const ChainArgs& A, int f) {
+    MVMC_ASSUME_LDS(&arena);
+    st_pose_pairs(arena.graph + CH_EOFF, A.kps17, A.counts, f, A.F2, A.C, A.P, 0.1);
 }
 __device__ __noinline__ void chain_als_spatial(ChainArena& arena, const ChainArgs& A, int b, int f) {
     MVMC_ASSUME_LDS(&arena);
@@ -143,6 +151,10 @@ chain_kernel(SkelDev skarg, ChainArgs A) {
     const int tid = threadIdx.x, wave = tid >> 6;
     const int T = A.T, NP = T + A.K;
     const int t_lo = part * A.L / A.parts, t_hi = (part + 1) * A.L / A.parts;
+    // work that does not depend on the chain's state comes before the hand-over: the skeleton tables and, for a workgroup that has a
+    // predecessor, the pose-pair block of its first frame's graph
+    if (wave == 0) ik1_build_tables(tables, skarg);
+    if (part > 0) chain_pose_pairs(arena, A, b * A.L + t_lo);
     if (part > 0) {
         // consumer side of the hand-off (cdna_hip_programming.md Guideline 16): one lane polls the chain's flag relaxed,
         // one agent-scope acquire, then the workgroup's barrier; the chain state is read with plain vector loads after it
@@ -161,7 +173,6 @@ chain_kernel(SkelDev skarg, ChainArgs A) {
         __syncthreads();
         if (__hip_atomic_load(A.flags + A.n_chains, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     }
-    if (wave == 0) ik1_build_tables(tables, skarg);
     __syncthreads();
     long long cyc[6] = {0, 0, 0, 0, 0, 0}, t_prev = clock64();
     const long long t_start = t_prev;
@@ -178,7 +189,7 @@ chain_kernel(SkelDev skarg, ChainArgs A) {
             lap(0);
             chain_als_spatial(arena, A, b, f);
         } else {
-            chain_graph_temporal(arena, A, b, f);
+            chain_graph_temporal(arena, A, b, f, part > 0 && t == t_lo);
             __syncthreads();
             lap(0);
             chain_als_temporal(arena, A, b);

@@ -79,13 +79,33 @@ __device__ __noinline__ double reproj_error(const double* joints, const double* 
 
 // One chain-frame (chain b, frame f) on the calling wave (WG = false) or on the whole 256-thread workgroup (WG = true:
 // every thread must call).  sm: (NS*NS + 6) doubles + 2*NS ints of LDS, NS = T + C*P.
+// The 2-D / 2-D block of the match_spatial_time graph (calc_epipolar_error per pose pair of different views, motion_capture.py:686-700)
+// depends only on the frame's own detections: a chain-frame workgroup computes it while it waits for its predecessor's tracklets.
+// E[q_i * N + q_j], q = view * P + person, N = C * P; entries of absent poses and same-view pairs are not written (never read).
+__device__ __forceinline__ void st_pose_pairs(double* E, const double* __restrict__ kps17, const int32_t* __restrict__ counts, int f,
+                                              const double* __restrict__ F2, int C, int P, double min_score) {
+    const int N = C * P;
+    const double* kf = kps17 + (size_t)f * C * P * 51;
+    for (int e = threadIdx.x; e < N * N; e += blockDim.x) {
+        const int qi = e / N, qj = e - qi * N;
+        const int ci = qi / P, cj = qj / P;
+        if (ci == cj) continue;
+        int ni = counts[f * C + ci], nj = counts[f * C + cj];
+        ni = ni < 0 ? 0 : (ni > P ? P : ni);
+        nj = nj < 0 ? 0 : (nj > P ? P : nj);
+        if (qi - ci * P >= ni || qj - cj * P >= nj) continue;
+        E[e] = epipolar_error(F2 + (ci * C + cj) * 9, kf + qi * 51, kf + qj * 51, min_score);
+    }
+}
+
 template <bool WG>
 __device__ __forceinline__ void st_affinity_wave(double* sm, const double* __restrict__ kps17, const int32_t* __restrict__ counts,
                                                  int b, int f, const double* __restrict__ track_joints,
                                                  const int32_t* __restrict__ n_tracks, const double* __restrict__ Pm,
                                                  const double* __restrict__ F2, int C, int P, int T, double min_score,
                                                  double* __restrict__ W, double* __restrict__ Dout,
-                                                 int32_t* __restrict__ group_counts) {
+                                                 int32_t* __restrict__ group_counts, const double* Epre = nullptr, int ldE = 0) {
+    // Epre: the pose-pair epipolar errors of this frame made ahead of time (st_pose_pairs; [q_i * ldE + q_j], q = view * P + person)
     const int tid = WG ? (int)threadIdx.x : (int)(threadIdx.x & 63);
     constexpr int NT = WG ? 256 : 64;
     auto sync = [] { if constexpr (WG) __syncthreads(); else MVMC_WAVE_SYNC(); };
@@ -123,7 +143,9 @@ __device__ __forceinline__ void st_affinity_wave(double* sm, const double* __res
         else {
             const int vi = nview[i], vj = nview[j];
             if (vi >= 0 && vi == vj) d = nan;
-            else if (vi >= 0 && vj >= 0) d = epipolar_error(F2 + (vi * C + vj) * 9, kf + nidx[i] * 51, kf + nidx[j] * 51, min_score);
+            else if (vi >= 0 && vj >= 0)
+                d = Epre ? Epre[nidx[i] * ldE + nidx[j]]
+                         : epipolar_error(F2 + (vi * C + vj) * 9, kf + nidx[i] * 51, kf + nidx[j] * 51, min_score);
             else if (vi >= 0) d = reproj_error(tj + nidx[j] * 54, kf + nidx[i] * 51, Pm + vi * 12, min_score);
             else if (vj >= 0) d = reproj_error(tj + nidx[i] * 54, kf + nidx[j] * 51, Pm + vj * 12, min_score);
             else d = nan;
