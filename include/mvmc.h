@@ -205,6 +205,38 @@ int mvmc_track_commit(const int32_t* status, const int32_t* n_new, const double*
                       int32_t* meta, int32_t* n_tracks, int32_t* next_id, int32_t* n_dead, int32_t* slot_src,
                       mvmcStream_t stream);
 
+/* ---- multi-GPU glue.  No counterpart in the reference: its tracker is one sequential pass
+ * (motion_capture.py:1062-1116).  A sequence is cut into chains that cold-start; contiguous chain ranges go to the GPUs; one
+ * all-gather of the packed messages below; then the identities are stitched across ALL chain boundaries on every rank. ---- */
+
+/* Message of one shard, in 4-byte words (n_chains_cap = chains the message has room for, >= the shard's own):
+ *   [0,8)   header i32 {n_chains, chain_len, t_max, rows written, rows wanted, row_cap, n_frames, 0}; rows wanted > row_cap = overflow
+ *   ids     (n_chains_cap) i32: number of local identities of each chain (the tracker's next_id)
+ *   bounds  (n_chains_cap, 2, t_max, MVMC_BOUND_WORDS): tracklet table of the chain's first / last frame:
+ *           {local id i32 or -1, 18 x 3 joints f32 (NaN when empty), pad}
+ *   rows    (row_cap, MVMC_ROW_WORDS): one row per LIVE tracklet and frame, in frame order:
+ *           {frame, slot, id, state, hits, length} i32, 54 joints f32, 68 parameters f32 */
+#define MVMC_BOUND_WORDS 56
+#define MVMC_ROW_WORDS 128
+long long mvmc_pack_message_words(int n_chains_cap, int t_max, int row_cap);   /* -1 on bad arguments */
+
+/* Packs mvmc_chain_run's per-frame outputs (out_params (F,T,68), out_joints (F,T,18,3), out_meta (F,T,4), out_n_tracks (F)) and
+ * next_id (n_chains) into `message` (mvmc_pack_message_words words).  row_offsets: (n_frames + 1) i32 device workspace.  t_max <= 16. */
+int mvmc_pack_tracks(const double* out_params, const double* out_joints, const int32_t* out_meta, const int32_t* out_n_tracks,
+                     const int32_t* next_id, int n_frames, int chain_len, int t_max, int n_chains_cap, int row_cap,
+                     int32_t* row_offsets, void* message, mvmcStream_t stream);
+
+/* Stitches the chains of `world` gathered messages (rank order = sequence order; message r at messages + r * message_words words).
+ * Chain boundary g-1 | g: optimal assignment (Kuhn-Munkres) of the last frame's tracklets of chain g-1 to the first frame's of
+ * chain g on the mean joint distance, pairs farther than max_dist (metres) dropped; matched tracklets share a global identity.
+ *   gid    (n_chains_total_cap, id_cap) i32 out: global identity of (chain, local id), -1 where the chain has fewer identities
+ *   match  (n_chains_total_cap, t_max) i32 out: slot of the previous chain's last frame matched to slot s of this chain's first, -1
+ *   info   (4) i32 out: {chains, global identities, error flag (a message overflowed or a chain has more than id_cap ids), pairs}
+ *   work   (2 * n_chains_total_cap * id_cap) i32 device workspace;  n_chains_total_cap >= world * n_chains_cap */
+int mvmc_stitch_chains(const void* messages, long long message_words, int world, int n_chains_cap, int t_max, int row_cap,
+                       int id_cap, double max_dist, int n_chains_total_cap, int32_t* gid, int32_t* match, int32_t* info,
+                       int32_t* work, mvmcStream_t stream);
+
 /* ---- diagnostics (used by the tests; not part of the hot path's call surface) ---- */
 
 /* The IK kernel's symmetric eigensolver on caller-supplied matrices: A (B,n,n) symmetric PSD, g (B,n),
@@ -237,6 +269,19 @@ int mvmc_ik_solve_stages(const mvmcSkeleton* skel_host, const double* kps17, con
                          int p_max, const double* init_params, int stage_mask, int max_nfev,
                          double* params_out, double* joints_out, double* info_out, double* scratch,
                          mvmcStream_t stream);
+
+/* TRF-faithful IK (diagnostic, never on the hot path): PoseSolver.solve (inverse_kinematics.py:380-433) with the reference's own
+ * numerical method -- scipy.optimize.least_squares defaults as called at inverse_kinematics.py:236,274: 2-point finite-difference
+ * Jacobians (step sqrt(eps) sign(x) max(1,|x|)), an SVD of J and solve_lsq_trust_region -- instead of the production solver's analytic
+ * Jacobian and Krylov step; the cold start triangulates with post_optimize=True through the same least_squares restatement
+ * (mv_math_util.py:189-210).  Used to measure the band in which independent implementations of the reference's algorithm land.
+ * Arguments as mvmc_ik_solve, plus stage_mask (1 = solve_pose_reproj only, 2 = solve_pose_bone_lens_reproj only, 3 = both);
+ *   work  (B, MVMC_IK_FD_WORK_DOUBLES) f64 device workspace.  v_max <= 8. */
+#define MVMC_IK_FD_WORK_DOUBLES 40960
+int mvmc_debug_ik_solve_fd(const mvmcSkeleton* skel_host, const double* kps17, const double* Pmats, const int32_t* members,
+                           int n_problems, int v_max, int n_views, int p_max, const double* init_params, const uint8_t* cold,
+                           int max_nfev_cold, int max_nfev_warm, int stage_mask, double* params_out, double* joints_out,
+                           double* info_out, double* work, mvmcStream_t stream);
 
 /* The whole temporal hot path of a shard in ONE launch: a persistent 256-thread workgroup per chain runs
  * graph (match_spatial where the chain has no tracklet, match_spatial_time otherwise) -> ALS -> assignment -> IK ->

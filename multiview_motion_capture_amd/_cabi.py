@@ -18,13 +18,15 @@ MVMC_F32, MVMC_F64 = 0, 1
 N_PARAM = 68
 MAX_NODES = 80
 IK_SCRATCH_DOUBLES = 7680
+IK_FD_WORK_DOUBLES = 40960
+BOUND_WORDS, ROW_WORDS = 56, 128
 
 # every symbol declared in include/mvmc.h
 SYMBOLS = (
     "mvmc_abi_version", "mvmc_status_string", "mvmc_als_seed_table", "mvmc_ingest", "mvmc_fmats",
     "mvmc_affinity", "mvmc_als_associate", "mvmc_closure_labels", "mvmc_cluster_members", "mvmc_dlt", "mvmc_triangulate_postopt", "mvmc_fk", "mvmc_ik_solve",
     "mvmc_fmats_from_projections", "mvmc_st_affinity", "mvmc_track_assign", "mvmc_track_commit", "mvmc_debug_eigh",
-    "mvmc_debug_trstep", "mvmc_debug_ik_mode", "mvmc_ik_solve_stages", "mvmc_chain_run", "mvmc_svt_associate",
+    "mvmc_debug_trstep", "mvmc_debug_ik_mode", "mvmc_ik_solve_stages", "mvmc_chain_run", "mvmc_svt_associate", "mvmc_debug_ik_solve_fd", "mvmc_pack_message_words", "mvmc_pack_tracks", "mvmc_stitch_chains",
 )
 
 
@@ -88,10 +90,15 @@ def load():
     lib.mvmc_debug_ik_mode.argtypes = [i32]
     lib.mvmc_chain_run.argtypes = [C.POINTER(MvmcSkeleton), C.POINTER(MvmcChainBuffers), vp]
     lib.mvmc_ik_solve_stages.argtypes = [C.POINTER(MvmcSkeleton), vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp]
+    lib.mvmc_debug_ik_solve_fd.argtypes = [C.POINTER(MvmcSkeleton), vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.mvmc_pack_message_words.argtypes = [i32, i32, i32]
+    lib.mvmc_pack_tracks.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
+    lib.mvmc_stitch_chains.argtypes = [vp, C.c_longlong, i32, i32, i32, i32, i32, f64, i32, vp, vp, vp, vp, vp]
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError if the library does not export it
-        if name not in ("mvmc_status_string",):
+        if name not in ("mvmc_status_string", "mvmc_pack_message_words"):
             getattr(lib, name).restype = C.c_int
+    lib.mvmc_pack_message_words.restype = C.c_longlong
     _lib = lib
     return lib
 

@@ -84,6 +84,15 @@ __device__ inline void post_optimize_wave(double* X, const double* obs_j, int st
         lam[k] = on ? fmax(B[k][k], 0.0) : 1.0;
         suf[k] = on ? Vm[0][k] * g[0] + Vm[1][k] * g[1] + Vm[2][k] * g[2] : 0.0;
     }
+    // A joint that fewer than three views score has a rank-deficient block (one residual per view): its null direction is an exact
+    // zero singular value with a zero projection in the reference's SVD of J.  In the normal-equation form the same direction shows
+    // up as rounding noise (lam ~ 1e-16 lam_max with a noise gradient component), and because alpha ends near 0 whenever the
+    // Gauss-Newton step is shorter than Delta, noise / (noise + alpha) would dominate the normalised step: drop it explicitly.
+    {
+        const double lmax = fmax(lam[0], fmax(lam[1], lam[2]));
+        for (int k = 0; k < 3; ++k)
+            if (lam[k] <= 1e-12 * lmax) { lam[k] = 0.0; suf[k] = 0.0; }
+    }
     const int m = nv * J, n = 3 * J;
     double smax = 0.0, smin = 1e300;
     for (int k = 0; k < 3; ++k)
@@ -98,6 +107,7 @@ __device__ inline void post_optimize_wave(double* X, const double* obs_j, int st
         if (sqrt(wave_sum(pn)) <= Delta) done = true;  // Gauss-Newton step inside the region
     }
     if (!done) {
+        const double sufn = sqrt(wave_sum(suf[0] * suf[0] + suf[1] * suf[1] + suf[2] * suf[2]));
         auto phi_of = [&](double alpha, double* phi_prime) {
             double a = 0.0, b = 0.0;
             for (int k = 0; k < 3; ++k) {
@@ -108,7 +118,7 @@ __device__ inline void post_optimize_wave(double* X, const double* obs_j, int st
             *phi_prime = -wave_sum(b) / pn;
             return pn - Delta;
         };
-        double alpha_upper = sqrt(wave_sum(suf[0] * suf[0] + suf[1] * suf[1] + suf[2] * suf[2])) / Delta;
+        double alpha_upper = sufn / Delta;
         double alpha_lower = 0.0;
         if (full_rank) {
             double pp;
@@ -127,6 +137,9 @@ __device__ inline void post_optimize_wave(double* X, const double* obs_j, int st
             alpha -= (phi + Delta) * ratio / Delta;
             if (fabs(phi) < 0.01 * Delta) break;
         }
+        // a last Newton update that overshoots below zero is clamped (mvmc_trf_faithful.h, solve_lsq_trust_region: SciPy's LAPACK
+        // noise triplets stop it at ~ -1e-20): the step is then the minimum-norm Gauss-Newton step stretched to |p| = Delta
+        if (!full_rank && alpha < 0.0) alpha = 0.0;
         double pn = 0.0;
         for (int k = 0; k < 3; ++k) {
             coef[k] = (on && suf[k] != 0.0) ? -suf[k] / (lam[k] + alpha) : 0.0;

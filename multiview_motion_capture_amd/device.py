@@ -306,6 +306,35 @@ def ik_solve_stages(init_params: torch.Tensor, stage_mask: int, max_nfev: int, k
     return params, joints, info
 
 
+def ik_solve_fd(kps17: torch.Tensor, Pmats: torch.Tensor, members: torch.Tensor, init_params: Optional[torch.Tensor] = None,
+                cold: Optional[torch.Tensor] = None, max_nfev_cold=50, max_nfev_warm=5, stage_mask=3,
+                skeleton: Optional[MvmcSkeleton] = None):
+    """Diagnostic: the same problems as ik_solve through the TRF-faithful solver (finite-difference Jacobian, SVD step;
+    mvmc_debug_ik_solve_fd).  -> params (B,68), joints (B,18,3), info (B,8)."""
+    sk = skeleton if skeleton is not None else make_skeleton()
+    F, Cn, P = kps17.shape[:3]
+    _req(kps17, torch.float64, "kps17", (F, Cn, P, 17, 3))
+    _req(Pmats, torch.float64, "Pmats", (Cn, 3, 4))
+    _req(members, torch.int32, "members")
+    B, V = members.shape
+    dev = kps17.device
+    if init_params is not None:
+        _req(init_params, torch.float64, "init_params", (B, 68))
+    if cold is not None:
+        _req(cold, torch.uint8, "cold", (B,))
+    if init_params is None and cold is not None:
+        raise ValueError("ik_solve_fd: warm problems need init_params")
+    params = torch.empty((B, 68), dtype=torch.float64, device=dev)
+    joints = torch.empty((B, 18, 3), dtype=torch.float64, device=dev)
+    info = torch.empty((B, 8), dtype=torch.float64, device=dev)
+    work = torch.empty((B, _cabi.IK_FD_WORK_DOUBLES), dtype=torch.float64, device=dev)
+    check(_cabi.load().mvmc_debug_ik_solve_fd(C.byref(sk), _p(kps17), _p(Pmats), _p(members), B, V, Cn, P, _p(init_params),
+                                              _p(cold if init_params is not None else None), int(max_nfev_cold),
+                                              int(max_nfev_warm), int(stage_mask), _p(params), _p(joints), _p(info), _p(work),
+                                              _stream()), "mvmc_debug_ik_solve_fd")
+    return params, joints, info
+
+
 # ----------------------------------------------------------------------------
 # temporal layer (match_spatial_time + tracker), batched over chains
 # ----------------------------------------------------------------------------

@@ -1,57 +1,154 @@
 """Frame sharding across the GPUs of one node (one process per GPU, torch.distributed).
 
-Spatial association, DLT and cold-started IK are independent per frame, so frames
-shard as contiguous ranges with no data-path collective; one all-gather (RCCL over xGMI with the
-"nccl" backend, gloo on CPU) brings every shard's per-frame results to every rank, after which
-identities are stitched across shard boundaries on the host (the reference's tracker is a single
-sequential pass, motion_capture.py:1062-1116, so this step has no counterpart there).
+A sequence is cut into chains (sub-sequences of ``chain_len`` frames that cold-start); chains are independent,
+so contiguous chain ranges go to the ranks with **no data-path collective**.  Each rank packs its results into one message (live
+tracklets only, float32: ~0.5 KB per tracklet-frame), ONE all-gather (RCCL over xGMI under the "nccl" backend,
+gloo on CPU) brings every shard's message to every rank, and a device kernel stitches the identities across all chain boundaries --
+shard boundaries are chain boundaries like any other.  The reference has no counterpart: its tracker is a single sequential pass
+(motion_capture.py:1062-1116).
+
+Pack, gather and stitch are issued on a communication stream behind an event, so they overlap the next step's compute.
 """
 from __future__ import annotations
 
-from typing import Dict
+import ctypes as C
+from typing import Callable, Dict, Optional
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
+ID_CAP = 16          # local identities per chain the stitch has room for
+MAX_DIST = 0.5       # metres: pairs farther apart (mean joint distance) are not the same person
 
-def shard_range(n_frames: int, rank: int, world: int):
-    """Contiguous frame range [lo, hi) of ``rank``; ranges differ by at most one frame."""
-    base, rem = divmod(n_frames, world)
+
+def shard_range(n_units: int, rank: int, world: int):
+    """Contiguous range [lo, hi) of ``rank``; ranges differ by at most one unit (units = chains, or frames)."""
+    base, rem = divmod(n_units, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_results(out: Dict[str, torch.Tensor], world: int) -> Dict[str, torch.Tensor]:
-    """All-gather every per-frame tensor of ``out`` along dim 0 (equal shard sizes).  One fused
-    collective: the tensors are packed into a single byte buffer so RCCL sees one large message."""
-    keys = sorted(k for k, v in out.items() if isinstance(v, torch.Tensor))
+def chains_cap(n_chains_total: int, world: int) -> int:
+    """Chains a message must have room for: the largest shard."""
+    return -(-n_chains_total // world)
+
+
+def message_words(b_cap: int, t_max: int, row_cap: int) -> int:
+    from . import _cabi
+    n = int(_cabi.load().mvmc_pack_message_words(int(b_cap), int(t_max), int(row_cap)))
+    if n < 0:
+        raise ValueError("message_words: unsupported sizes")
+    return n
+
+
+def pack_tracks(out: Dict[str, torch.Tensor], next_id: torch.Tensor, chain_len: int, b_cap: int, row_cap: int) -> torch.Tensor:
+    """The shard's message (int32 words, include/mvmc.h: mvmc_pack_tracks) from run_chains_fused's result; asynchronous on the
+    current stream."""
+    from . import _cabi
+    from .device import _p, _stream
+    F, T = out["params"].shape[:2]
+    d = out["params"].device
+    msg = torch.empty((message_words(b_cap, T, row_cap),), dtype=torch.int32, device=d)
+    offs = torch.empty((F + 1,), dtype=torch.int32, device=d)
+    _cabi.check(_cabi.load().mvmc_pack_tracks(_p(out["params"]), _p(out["joints"]), _p(out["meta"]), _p(out["n_tracks"]), _p(next_id), F,
+                                              int(chain_len), T, int(b_cap), int(row_cap), _p(offs), _p(msg), _stream()),
+                "mvmc_pack_tracks")
+    return msg
+
+
+def stitch_chains(messages: torch.Tensor, b_cap: int, t_max: int, row_cap: int, max_dist: float = MAX_DIST, id_cap: int = ID_CAP):
+    """messages (world, words) int32 on the device -> dict(gid (Btot_cap, id_cap), match (Btot_cap, T), info (4)); asynchronous."""
+    from . import _cabi
+    from .device import _p, _stream
+    world, words = messages.shape
+    d = messages.device
+    cap = world * b_cap
+    gid = torch.full((cap, id_cap), -1, dtype=torch.int32, device=d)
+    match = torch.full((cap, t_max), -1, dtype=torch.int32, device=d)
+    info = torch.zeros((4,), dtype=torch.int32, device=d)
+    work = torch.empty((2 * cap * id_cap,), dtype=torch.int32, device=d)
+    _cabi.check(_cabi.load().mvmc_stitch_chains(_p(messages), C.c_longlong(words), world, int(b_cap), int(t_max), int(row_cap), int(id_cap),
+                                                float(max_dist), cap, _p(gid), _p(match), _p(info), _p(work), _stream()),
+                "mvmc_stitch_chains")
+    return dict(gid=gid, match=match, info=info, _work=work)
+
+
+def all_gather_messages(msg: torch.Tensor, world: int) -> torch.Tensor:
+    """(world, words) from every rank's (words,) message: one collective."""
     if world == 1:
+        return msg.view(1, -1)
+    if dist.get_backend() == "nccl":
+        out = torch.empty((world, msg.numel()), dtype=msg.dtype, device=msg.device)
+        dist.all_gather_into_tensor(out.view(-1), msg)
         return out
-    flat = [out[k].contiguous().view(torch.uint8).reshape(-1) for k in keys]
-    sizes = [f.numel() for f in flat]
-    send = torch.cat(flat)
-    recv = torch.empty(world * send.numel(), dtype=torch.uint8, device=send.device)
-    dist.all_gather_into_tensor(recv, send)
-    recv = recv.view(world, -1)
-    res, off = {}, 0
-    for k, n in zip(keys, sizes):
-        t = out[k]
-        part = recv[:, off:off + n].contiguous().view(t.dtype).reshape((world * t.shape[0],) + tuple(t.shape[1:]))
-        res[k] = part
-        off += n
-    return res
+    # gloo (CPU tests, or several ranks sharing one GPU): host tensors
+    host = msg.cpu()
+    parts = [torch.empty_like(host) for _ in range(world)]
+    dist.all_gather(parts, host)
+    return torch.stack(parts).to(msg.device)
 
 
-def stitch_identities(joints_prev: np.ndarray, joints_next: np.ndarray, max_dist=0.5):
-    """Match the people of the last frame of one shard to the first frame of the next shard.
-    joints_* (K,18,3) with NaN rows for empty slots -> list of (i_prev, i_next) pairs
-    (Hungarian assignment on the mean joint distance, pairs farther than max_dist dropped)."""
-    from scipy.optimize import linear_sum_assignment
-    ok_p = np.nonzero(~np.isnan(joints_prev).any(axis=(1, 2)))[0]
-    ok_n = np.nonzero(~np.isnan(joints_next).any(axis=(1, 2)))[0]
-    if len(ok_p) == 0 or len(ok_n) == 0:
-        return []
-    cost = np.linalg.norm(joints_prev[ok_p][:, None] - joints_next[ok_n][None], axis=-1).mean(axis=-1)
-    r, c = linear_sum_assignment(cost)
-    return [(int(ok_p[i]), int(ok_n[j])) for i, j in zip(r, c) if cost[i, j] <= max_dist]
+def unpack_message(msg: np.ndarray, b_cap: int, t_max: int, row_cap: int) -> dict:
+    """Host view of one message (int32 words): header, ids, bounds (B,2,T,56), rows -- for consumers and tests."""
+    msg = np.ascontiguousarray(msg).view(np.int32)
+    h = msg[:8]
+    o_ids = 8
+    o_b = o_ids + b_cap
+    o_r = o_b + b_cap * 2 * t_max * 56
+    n_rows = int(h[3])
+    bounds = msg[o_b:o_r].reshape(b_cap, 2, t_max, 56)
+    rows = msg[o_r:o_r + n_rows * 128].reshape(n_rows, 128)
+    return dict(n_chains=int(h[0]), chain_len=int(h[1]), t_max=int(h[2]), n_rows=n_rows, rows_wanted=int(h[4]), n_frames=int(h[6]),
+                ids=msg[o_ids:o_ids + int(h[0])].copy(), bound_ids=bounds[:int(h[0]), :, :, 0].copy(),
+                bound_joints=bounds[:int(h[0]), :, :, 1:55].copy().view(np.float32).reshape(int(h[0]), 2, t_max, 18, 3),
+                row_meta=rows[:, :6].copy(), row_joints=rows[:, 6:60].copy().view(np.float32).reshape(n_rows, 18, 3),
+                row_params=rows[:, 60:128].copy().view(np.float32))
+
+
+def run_sharded(compute: Callable[[], Dict[str, torch.Tensor]], chain_len: int, n_chains_total: int, rank: int, world: int,
+                rows_per_frame: int, comm_stream=None, pack: Optional[Callable] = None, stitch: Optional[Callable] = None,
+                gather: Optional[Callable] = None, max_dist: float = MAX_DIST):
+    """One step of the sharded path on this rank: compute() (the shard's chains: tracker.run_chains_fused) -> pack -> ONE all-gather ->
+    stitch.  ``rows_per_frame`` sizes the message (live tracklets per frame it has room for: the people in the scene; an overflow is
+    reported in info[2], never silent).  pack / stitch / gather default to the device kernels and torch.distributed; the CPU tests
+    inject host implementations of the same message format.  Returns dict(local=compute's result, messages (world, words),
+    gid, match, info, done=event or None).  With a CUDA ``comm_stream`` the pack/gather/stitch tail runs there, behind an event."""
+    pack = pack or pack_tracks
+    stitch = stitch or stitch_chains
+    gather = gather or all_gather_messages
+    out = compute()
+    F, T = out["params"].shape[:2]
+    b_cap = chains_cap(n_chains_total, world)
+    lo, hi = shard_range(n_chains_total, rank, world)
+    if F != (hi - lo) * chain_len:
+        raise ValueError(f"run_sharded: rank {rank} computed {F} frames, its shard is chains [{lo}, {hi}) x {chain_len}")
+    row_cap = b_cap * chain_len * rows_per_frame
+    use_stream = comm_stream is not None and out["params"].is_cuda
+    if use_stream:
+        ready = torch.cuda.Event()
+        ready.record()
+        ctx = torch.cuda.stream(comm_stream)
+        comm_stream.wait_event(ready)
+    else:
+        import contextlib
+        ctx = contextlib.nullcontext()
+    with ctx:
+        msg = pack(out, out["next_id"], chain_len, b_cap, row_cap)
+        msgs = gather(msg, world)
+        st = stitch(msgs, b_cap, T, row_cap, max_dist)
+        done = None
+        if use_stream:
+            done = torch.cuda.Event()
+            done.record()
+            for t in (msg, msgs) + tuple(v for v in st.values() if isinstance(v, torch.Tensor)) + tuple(
+                    v for v in out.values() if isinstance(v, torch.Tensor)):
+                t.record_stream(comm_stream)
+    return dict(local=out, message=msg, messages=msgs, b_cap=b_cap, row_cap=row_cap, done=done, **{k: v for k, v in st.items()})
+
+
+def check_stitch_info(res) -> None:
+    """Raise if the stitched result is void (synchronises)."""
+    info = res["info"].cpu().tolist()
+    if info[2]:
+        raise RuntimeError("stitch: a message overflowed its row capacity or a chain has more local identities than ID_CAP")

@@ -255,7 +255,7 @@ def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tens
         k1.record()
         kernel_events.append((k0, k1))
     res = dict(params=t["out_params"], joints=t["out_joints"], meta=t["out_meta"], n_tracks=t["out_n_tracks"],
-               n_dead=t["n_dead"], flags=t["flags"], _keepalive=t)
+               n_dead=t["n_dead"], next_id=t["next_id"], flags=t["flags"], _keepalive=t)
     if want_info:
         res["ik_info"] = t["out_info"].view(B, L, NP, 8)
         res["als_iters"] = t["out_als_iters"].view(B, L)

@@ -46,3 +46,61 @@ def ulp_diff_f32(a, b):
     a = np.asarray(a, np.float32)
     b = np.asarray(b, np.float32)
     return np.abs(a.astype(np.float64) - b.astype(np.float64)) / np.spacing(np.abs(b).astype(np.float32)).astype(np.float64)
+
+
+def postopt_step_noise_share(projs, poses18):
+    """For triangulate(..., post_optimize=True) (mv_math_util.py:189-210; least_squares(max_nfev=2) = ONE trust-region trial step):
+    the share of that step's squared length that lies along singular vectors of the Jacobian whose singular value is rounding noise
+    (< 1e-10 s_max).  J is rank deficient (one residual per point and view for three unknowns per point), SciPy then normalises the
+    step to |p| = Delta = |x0|, its Newton iteration drives alpha to ~ +-1e-20, and a LAPACK noise singular value of ~1e-16 then carries
+    a coefficient s u^T f / (s^2 + alpha) ~ 1e6 x the genuine ones: the trial point is defined by rounding noise.  It is almost always
+    rejected (cost goes up); where it is accepted, no other implementation can reproduce the reference's point."""
+    import trf_np as t
+    projs = np.asarray(projs, float)
+    groups = [np.asarray(g, float) for g in poses18]
+
+    def res(x):
+        X = x.reshape((-1, 3))
+        homo = np.concatenate([X, np.ones((X.shape[0], 1))], axis=-1).T
+        d = []
+        for v in range(len(projs)):
+            h = projs[v] @ homo
+            uv = (h[:2] / (h[2] + 1e-6)).T
+            d.append(np.linalg.norm(uv - groups[v][:, :2], axis=-1) * groups[v][:, -1])
+        return np.array(d).flatten()
+
+    x0 = o.triangulate_groups(projs, groups, 0.01, False)[:, :3].ravel()
+    f = res(x0)
+    J = t.fd_jacobian(res, x0, f)
+    U, s, Vt = np.linalg.svd(J, full_matrices=False)
+    uf = U.T @ f
+    _, alpha, _ = t.solve_tr_svd(J.shape[1], J.shape[0], uf, s, Vt.T, np.linalg.norm(x0), initial_alpha=0.0)
+    with np.errstate(all="ignore"):
+        c = np.where(s * uf != 0, s * uf / (s ** 2 + alpha), 0.0)
+    noise = s < 1e-10 * s[0]
+    return float((c[noise] ** 2).sum() / (c ** 2).sum())
+
+
+def cpu_twin():
+    """ctypes handle of the C++ CPU twin (oracle/cpu_twin/libmvmc_cpu.so, built by __graft_entry__.build() / make -C oracle)."""
+    import ctypes
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "cpu_twin", "libmvmc_cpu.so")
+    if not os.path.exists(path):
+        raise RuntimeError("oracle/cpu_twin/libmvmc_cpu.so is not built: run make -C oracle")
+    return ctypes.CDLL(path)
+
+
+def twin_postopt_root(projs, poses18):
+    """Root (midpoint of the post-optimised hips) from the HOST build of csrc/mvmc_trf_faithful.h -- the same source the device's
+    TRF-faithful solver is compiled from."""
+    import ctypes
+    lib = cpu_twin()
+    pose = np.ascontiguousarray(np.array(poses18, dtype=np.float64))
+    Pm = np.ascontiguousarray(np.asarray(projs, dtype=np.float64))
+    x = np.ascontiguousarray(o.triangulate_groups(Pm, list(pose), 0.01, False)[:, :3].ravel())
+    out = np.zeros(4)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lib.trf_check_postopt(p(pose), p(Pm), len(pose), 18, 2, p(x), p(out))
+    X = x.reshape(18, 3)
+    return 0.5 * (X[11] + X[12])

@@ -1,0 +1,179 @@
+"""GPU: the multi-GPU glue kernels (mvmc_pack_tracks, mvmc_stitch_chains) against their host restatement (oracle/stitch_np.py) on
+real output of the chain kernel, identities against the generator's ground truth, and parallel.run_sharded end to end in two
+processes that share the one GPU of the test box (gloo; the RCCL path differs only in the collective call)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+import stitch_np as sn
+
+pytestmark = pytest.mark.gpu
+
+L, F, C, P, T = 8, 96, 5, 4, 8
+SEED = 77
+
+
+def _sequence(d):
+    """A CONTINUOUS synthetic scene (one random walk over all frames) processed in chains of L frames: every chain cold-starts, so
+    identities must be stitched at every chain boundary."""
+    from multiview_motion_capture_amd import synth
+    from multiview_motion_capture_amd.pipeline import HotPath
+    data = synth.generate(F, C, P, SEED, chain_len=0)
+    hp = HotPath(data["K"], data["Rt"], device=d)
+    return data, hp, torch.from_numpy(data["kps25"]).to(d), torch.from_numpy(data["counts"]).to(d)
+
+
+def _host(out):
+    return {k: out[k].cpu().numpy() for k in ("params", "joints", "meta", "n_tracks", "next_id")}
+
+
+@pytest.fixture(scope="module")
+def run():
+    from multiview_motion_capture_amd.tracker import check_chain_flags, run_chains_fused
+    d = torch.device("cuda:0")
+    data, hp, kps, counts = _sequence(d)
+    out = run_chains_fused(hp, kps, counts, L)
+    torch.cuda.synchronize()
+    check_chain_flags(out)
+    return dict(data=data, out=out, host=_host(out), d=d)
+
+
+def test_pack_kernel_is_bit_identical_to_host_restatement(run):
+    from multiview_motion_capture_amd import parallel as par
+    h, out = run["host"], run["out"]
+    B = F // L
+    for b_cap, row_cap in ((B, F * P), (B + 3, F * T), (B, 7)):      # exact fit, roomy, overflowing
+        msg = par.pack_tracks(out, out["next_id"], L, b_cap, row_cap)
+        torch.cuda.synchronize()
+        got = msg.cpu().numpy()
+        exp = sn.pack_np(h["params"], h["joints"], h["meta"], h["n_tracks"], h["next_id"], L, b_cap, row_cap)
+        u = par.unpack_message(got, b_cap, T, row_cap)
+        assert u["n_chains"] == B and u["rows_wanted"] == int(np.clip(h["n_tracks"], 0, T).sum())
+        o_b = 8 + b_cap
+        o_r = o_b + b_cap * 2 * T * 56
+        n_written = min(u["rows_wanted"], row_cap)
+        assert np.array_equal(got[:8], exp[:8])
+        assert np.array_equal(got[8:8 + B], exp[8:8 + B])
+        gb, eb = got[o_b:o_r].reshape(b_cap, 2, T, 56)[:B], exp[o_b:o_r].reshape(b_cap, 2, T, 56)[:B]
+        assert np.array_equal(gb[..., :55], eb[..., :55])            # ids + joints (NaN bit patterns included)
+        assert np.array_equal(got[o_r:o_r + n_written * 128], exp[o_r:o_r + n_written * 128])
+    # 2 KB per frame at P = 4: 512 B per live tracklet-frame instead of the (T = 8)-padded float64 tables
+    assert par.message_words(B, T, F * P) * 4 / F < 2.6e3
+
+
+def _split_messages(run, world):
+    """the run's chains as `world` shards' messages (device tensors)"""
+    from multiview_motion_capture_amd import parallel as par
+    out = run["out"]
+    B = F // L
+    b_cap = par.chains_cap(B, world)
+    row_cap = b_cap * L * P
+    msgs = []
+    for r in range(world):
+        lo, hi = par.shard_range(B, r, world)
+        sl = {k: out[k][lo * L:hi * L].contiguous() for k in ("params", "joints", "meta", "n_tracks")}
+        msgs.append(par.pack_tracks(sl, out["next_id"][lo:hi].contiguous(), L, b_cap, row_cap))
+    return torch.stack(msgs), b_cap, row_cap
+
+
+@pytest.mark.parametrize("world", [1, 2, 5])
+def test_stitch_kernel_equals_host_restatement(run, world):
+    from multiview_motion_capture_amd import parallel as par
+    msgs, b_cap, row_cap = _split_messages(run, world)
+    st = par.stitch_chains(msgs, b_cap, T, row_cap)
+    torch.cuda.synchronize()
+    exp = sn.stitch_np(msgs.cpu().numpy(), b_cap, T, row_cap)
+    B = F // L
+    assert np.array_equal(st["info"].cpu().numpy(), exp["info"]) and exp["info"][0] == B and exp["info"][2] == 0
+    assert np.array_equal(st["match"].cpu().numpy()[:B], exp["match"][:B])
+    assert np.array_equal(st["gid"].cpu().numpy()[:B], exp["gid"][:B])
+    if world > 1:    # sharding does not change the identities
+        one_msgs, bc1, rc1 = _split_messages(run, 1)
+        one = sn.stitch_np(one_msgs.cpu().numpy(), bc1, T, rc1)
+        assert np.array_equal(one["gid"][:B], exp["gid"][:B])
+
+
+def test_global_identities_follow_the_ground_truth_people(run):
+    """Every tracked person keeps one global identity over the whole continuous sequence (12 cold-started chains)."""
+    from multiview_motion_capture_amd import parallel as par
+    msgs, b_cap, row_cap = _split_messages(run, 3)
+    st = par.stitch_chains(msgs, b_cap, T, row_cap)
+    torch.cuda.synchronize()
+    gid = st["gid"].cpu().numpy()
+    h, gt = run["host"], run["data"]["gt_joints"]
+    seen = {}
+    n_rows = 0
+    for f in range(F):
+        g = f // L
+        for s in range(h["n_tracks"][f]):
+            person = int(np.argmin(np.linalg.norm(gt[f] - h["joints"][f, s][None], axis=-1).mean(axis=-1)))
+            err = np.linalg.norm(gt[f, person] - h["joints"][f, s], axis=-1).mean()
+            if err < 0.1:
+                seen.setdefault(person, set()).add(int(gid[g, h["meta"][f, s, 0]]))
+                n_rows += 1
+    assert n_rows > 0.9 * F * P
+    print("global identities per ground-truth person:", {k: sorted(v) for k, v in seen.items()}, "| total", st["info"].cpu().tolist())
+    assert len(seen) == P and all(len(v) == 1 for v in seen.values())
+    assert len({next(iter(v)) for v in seen.values()}) == P
+
+
+def test_stitch_flags_overflow(run):
+    from multiview_motion_capture_amd import parallel as par
+    out = run["out"]
+    B = F // L
+    msg = par.pack_tracks(out, out["next_id"], L, B, 5)     # far too few rows
+    st = par.stitch_chains(msg.view(1, -1), B, T, 5)
+    torch.cuda.synchronize()
+    assert int(st["info"][2]) == 1
+    with pytest.raises(RuntimeError):
+        par.check_stitch_info(st)
+
+
+def _rank_main(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    import torch.distributed as dist
+    from multiview_motion_capture_amd import parallel as par
+    from multiview_motion_capture_amd.tracker import run_chains_fused
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = torch.device("cuda:0")
+    data, hp, kps, counts = _sequence(d)
+    B = F // L
+    lo, hi = par.shard_range(B, rank, world)
+    comm = torch.cuda.Stream(device=d)
+    res = par.run_sharded(lambda: run_chains_fused(hp, kps[lo * L:hi * L].contiguous(), counts[lo * L:hi * L].contiguous(), L),
+                          L, B, rank, world, rows_per_frame=P, comm_stream=comm)
+    res["done"].synchronize()
+    par.check_stitch_info(res)
+    q.put((rank, res["gid"].cpu().numpy()[:B].tobytes(), res["info"].cpu().tolist(), res["match"].cpu().numpy()[:B].tobytes()))
+    dist.destroy_process_group()
+
+
+def test_run_sharded_two_processes_one_gpu(run):
+    """run_sharded with the real kernels in two processes (gloo): same identities as the single-process run."""
+    import torch.multiprocessing as mp
+    from multiview_motion_capture_amd import parallel as par
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert [r[0] for r in res] == [0, 1]
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
+    msgs, b_cap, row_cap = _split_messages(run, 1)
+    one = par.stitch_chains(msgs, b_cap, T, row_cap)
+    torch.cuda.synchronize()
+    B = F // L
+    assert np.array_equal(np.frombuffer(res[0][1], dtype=np.int32).reshape(B, -1), one["gid"].cpu().numpy()[:B])
+    assert res[0][2] == one["info"].cpu().tolist()
