@@ -5,6 +5,10 @@ TEST INFRASTRUCTURE (build container only).  Runs the reference's own code from 
 
     PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden_ikconv.py [--shelf-frames 150] [--max-nfev 400] [--procs 8]
 
+Runs with single-threaded BLAS (set below, before NumPy loads): eight worker processes with eight OpenBLAS threads each spend their
+time spinning (45 min instead of 30 s), and LAPACK's rounding depends on the thread count -- the CPU tests that compare the oracle
+bit for bit with these fixtures limit BLAS to one thread the same way (tests/test_synth_pins_cpu.py).
+
 Fixtures written under tests/golden:
   ik_converged.npz      the reference's ``solve_pose_reproj`` followed by ``solve_pose_bone_lens_reproj``
                         (inverse_kinematics.py:202-277) run with ``n_max_iter`` large enough for both least_squares calls
@@ -22,7 +26,10 @@ import os
 import sys
 import time
 
-import numpy as np
+os.environ["OPENBLAS_NUM_THREADS"] = "1"
+os.environ["OMP_NUM_THREADS"] = "1"
+
+import numpy as np  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
