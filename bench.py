@@ -5,12 +5,19 @@ on synthetic (F frames x C views x P people x 25 joints) keypoints, one process 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = one pass of the whole hot path over this rank's F frames (inputs resident in HBM before
-the timed region).  Frames shard across ranks (weak scaling: F per GPU is fixed); each step ends
-with one RCCL all-gather of the per-frame results.  Consecutive steps are independent batches and are issued on two
-alternating HIP streams (--overlap 2: the next launch's first frames fill the workgroup slots the slowest chains of the
-previous one leave idle; --overlap 1 = one step at a time).  Rank 0 prints ONE JSON line.
+the timed region).  Frames shard across ranks as contiguous chain ranges (weak scaling: F per GPU is fixed) with no data-path
+collective; each step ends with the multi-GPU tail of parallel.run_sharded on a communication stream: pack the live tracklets
+(float32, ~0.5 KB per tracklet-frame) -> ONE all-gather (RCCL) -> stitch the identities across all chain boundaries on the device.
+The tail runs at N = 1 too (the stitch over the shard's own chain boundaries), so the per-N values compare like with like.
+Consecutive steps are independent batches and are issued on two alternating HIP streams (--overlap 2: the next launch's first
+frames fill the workgroup slots the slowest chains of the previous one leave idle; --overlap 1 = one step at a time).
+
+`python bench.py --gpus N` started WITHOUT torch.distributed.run launches its N ranks itself, as fresh child processes, before this
+process touches the GPU; under torch.distributed.run (RANK / WORLD_SIZE in the environment) it is one of the ranks.
+Rank 0 prints ONE JSON line.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -71,6 +78,7 @@ def _cpu_chain_worker(job):
     kps25, K, Rt, P = job
     C, Pn = kps25.shape[1:3]
     tr = tk.OracleTracker(K, Rt, P)
+    t0 = time.perf_counter()          # inside the worker, after the imports: interpreter / NumPy / SciPy start-up is not timed
     for f in range(kps25.shape[0]):
         views = []
         for c in range(C):
@@ -78,7 +86,7 @@ def _cpu_chain_worker(job):
             views.append([p for p in poses if o.pose_is_good(p)])
         tr.update(f, views)
     n_cold = sum(1 for s in tr.solves if s[1])
-    return n_cold, len(tr.solves) - n_cold
+    return n_cold, len(tr.solves) - n_cold, time.perf_counter() - t0
 
 
 def cpu_baseline_chain(data, L, workers):
@@ -101,12 +109,50 @@ def cpu_baseline_chain(data, L, workers):
                 os.environ["OMP_NUM_THREADS"] = env_old
     else:
         res = [_cpu_chain_worker(jobs[0])]
-    dt = time.perf_counter() - t0
+    wall = time.perf_counter() - t0
     n_cold, n_warm = sum(r[0] for r in res), sum(r[1] for r in res)
-    return dict(value=workers * L / dt, unit="frames/s", cores=workers, kind="port",
+    busy = max(r[2] for r in res)      # the workers run side by side: the job lasts as long as the slowest chain
+    one = float(np.mean([r[2] for r in res]))
+    return dict(value=workers * L / busy, unit="frames/s", cores=workers, kind="port",
+                one_core_frames_per_s=L / one,
                 sample=f"{workers} chain(s) of {L} frames of the same synthetic workload, one per worker process ({n_cold} cold + "
-                       f"{n_warm} warm IK solves), oracle/tracker_np.py + oracle_np.py (NumPy + SciPy least_squares), {dt:.1f} s "
-                       f"including worker start-up")
+                       f"{n_warm} warm IK solves), oracle/tracker_np.py + oracle_np.py (NumPy + SciPy least_squares, one BLAS thread "
+                       f"each); timed inside the workers after their imports: slowest chain {busy:.1f} s, mean {one:.1f} s "
+                       f"({wall:.1f} s wall including worker start-up)")
+
+
+def kernel_sources_sha() -> str:
+    """Hash of the HIP sources the library is built from (stamps profiles/pmc_traffic.json records)."""
+    import hashlib
+    src = os.path.join(ROOT, "multiview_motion_capture_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(src, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def launch_ranks(n: int) -> int:
+    """Start n ranks of this script (one per GPU, env as torch.distributed.run sets it) and wait; returns the exit code.
+    Children are fresh interpreters (subprocess), so no process that has initialised the GPU is ever replaced or forked."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
 
 
 def main():
@@ -138,23 +184,35 @@ def main():
     ap.add_argument("--cpu-workers", type=int, default=0,
                     help="worker processes of the CPU baseline on the chain protocol (0 = min(16, host cores))")
     ap.add_argument("--seed", type=int, default=20260103)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the one all-gather: nccl = RCCL over xGMI (one rank per GPU); gloo only to "
+                         "rehearse several ranks on a box with one GPU (host-staged)")
+    ap.add_argument("--walk", default="chains", choices=["chains", "continuous"],
+                    help="synthetic scene: 'chains' restarts the people's random walk at every chain head (the workload the round-1 "
+                         "numbers were measured on); 'continuous' is one walk over all frames, so the stitch has identities to find")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks as fresh child processes.  Nothing in this process has touched the GPU
+        # (no HIP call, no torch.cuda call), and it never does: it only waits and passes rank 0's line through.
+        raise SystemExit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}: launch N ranks for --gpus N")
     import torch.distributed as dist
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     d = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=d)
+        dist.init_process_group(args.backend, rank=rank, world_size=world, **({"device_id": d} if args.backend == "nccl" else {}))
 
     from multiview_motion_capture_amd import synth
     from multiview_motion_capture_amd.pipeline import HotPath
-    from multiview_motion_capture_amd.parallel import gather_results
+    from multiview_motion_capture_amd import parallel as par
     from multiview_motion_capture_amd.tracker import run_chains, run_chains_fused
 
     F, C, Pn = args.frames, args.views, args.people
@@ -162,7 +220,7 @@ def main():
     L = args.chain_len
     if F % L:
         raise SystemExit("--frames must be a multiple of --chain-len")
-    data = synth.generate(F, C, Pn, args.seed, chain_len=L, frame_seed=args.seed + 1000 * rank)
+    data = synth.generate(F, C, Pn, args.seed, chain_len=L if args.walk == "chains" else 0, frame_seed=args.seed + 1000 * rank)
     hp = HotPath(data["K"], data["Rt"], device=d)
     kps = torch.from_numpy(data["kps25"]).to(d)
     counts = torch.from_numpy(data["counts"]).to(d)
@@ -195,8 +253,6 @@ def main():
             info = out.pop("ik_info", None)
             phase = out.pop("phase_cycles", None)
             out.pop("als_iters", None)
-            if world > 1:
-                out = gather_results({k: v for k, v in out.items() if k != "n_dead"}, world)
             out["info"] = info
             out["phase"] = phase
             return out
@@ -210,8 +266,6 @@ def main():
         if with_ik:
             out.update(hp.solve_cold(assoc, tri, args.nfev_cold))
         if timed: e[3].record()
-        if world > 1:
-            out = gather_results(out, world)
         if timed:
             ev["assoc"].append((e[0], e[1])); ev["tri"].append((e[1], e[2])); ev["ik"].append((e[2], e[3]))
         return out
@@ -219,11 +273,27 @@ def main():
     torch.cuda.synchronize()   # inputs and calibration tables were made on the default stream; the steps run on side streams
     streams = [torch.cuda.Stream(device=d) for _ in range(args.overlap)] if args.overlap > 1 else None
 
+    sharded = with_ik and L > 1       # the temporal protocol ends every step with pack -> all-gather -> stitch
+    comm = torch.cuda.Stream(device=d) if sharded else None
+    tail_events, stitched = [], []
+
     def issue(i, timed):
-        if streams is None:
+        def compute():
             return step(timed)
-        with torch.cuda.stream(streams[i % len(streams)]):
-            return step(timed)
+        ctx = torch.cuda.stream(streams[i % len(streams)]) if streams is not None else contextlib.nullcontext()
+        with ctx:
+            if not sharded:
+                return compute()
+            res = par.run_sharded(compute, L, (F // L) * world, rank, world, rows_per_frame=min(Pn + 1, 8), comm_stream=comm,
+                                  timing=timed)
+            if timed:
+                tail_events.append(res["tail_events"])
+            stitched.append(res)
+            if len(stitched) > 3:
+                stitched.pop(0)
+            out = res["local"]
+            out["stitch"] = res
+            return out
 
     for i in range(args.warmup):
         issue(i, False)
@@ -237,10 +307,15 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    per_rank_ms = [dt / args.steps * 1e3]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=d)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.tensor([dt], dtype=torch.float64, device=d if args.backend == "nccl" else "cpu")
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        per_rank_ms = [float(x.item()) / args.steps * 1e3 for x in parts]
+        dt = max(float(x.item()) for x in parts)
+    for res in stitched:
+        par.check_stitch_info(res)     # a message overflowed / too many identities in a chain: the step's stitch is void
 
     # for the record: one step on its own, nothing else in flight (untimed region)
     serial_ms = None
@@ -257,6 +332,9 @@ def main():
     stage_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items() if v}
     if serial_ms is not None:
         stage_ms["one_step_alone"] = serial_ms
+    if tail_events:
+        te = np.array([[a.elapsed_time(b) for a, b in zip(e, e[1:])] for e in tail_events])
+        stage_ms["tail_pack_gather_stitch"] = [float(x) for x in te.mean(axis=0)]
     if kern_events:
         # the kernel alone (events right around its launch): the timed region's launches, and every launch of the process -- the
         # average a profiler reports also contains the warm-up launches and the stand-alone reference launch
@@ -307,16 +385,20 @@ def main():
             ok = ~torch.isnan(inf[:, 1])
             extra = dict(ik_solves_per_step=int(ok.sum()), mean_nfev=float((inf[ok, 1] + inf[ok, 4]).mean()),
                          mean_njev=float(inf[ok, 6].mean()), eigensolver_fallbacks_per_solve=float(inf[ok, 7].mean()))
-        traffic = None
+        # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; tools/aggregate_profiles.py)
+        # of THIS command, recorded with a hash of the kernel sources: a record made from other sources is stale and reported as null
+        traffic, traffic_note = None, "no PMC record for this workload"
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tp):
-            rec = json.load(open(tp))
-            key = f"{dom}:{F}x{C}x{Pn}"
-            traffic = (rec.get(key) or {}).get("bytes")  # measured offline: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+            rec = (json.load(open(tp)).get(f"{dom}:{F}x{C}x{Pn}") or {})
+            if rec.get("src_sha") == kernel_sources_sha():
+                traffic, traffic_note = rec.get("bytes"), f"profiles/{rec.get('source')}"
+            elif rec:
+                traffic_note = f"stale: profiles/{rec.get('source')} was measured on other kernel sources"
         res = {
             "metric": "frames/s (assoc+triangulate+IK) at C=5,P=4,J=25" if with_ik else "frames/s (assoc+triangulate)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "per_rank_ms_per_step": per_rank_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"synthetic {F} frames/GPU, C={C}, P={Pn}, J=25: affinity+ALS+DLT" +
                                    ((f"+IK, temporal chains of {L} frames (match_spatial_time + tracker; cold 50+50 nfev at the head, "
@@ -328,7 +410,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom_kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "launch_ms": launch_ms,
-                         "traffic": traffic, "bytes_per_frame": bpf,
+                         "traffic": traffic, "traffic_source": traffic_note, "bytes_per_frame": bpf,
                          "note": "latency-bound path (dependent fp64 chains), not HBM bound (SURVEY.md F6); achieved = algorithmic "
                                  "bytes of the frames one launch serves / mean launch duration of the dominant kernel" +
                                  (f" ({args.overlap} launches share the GPU, so a launch lasts longer than ms_per_step)" if args.overlap > 1 else "") +

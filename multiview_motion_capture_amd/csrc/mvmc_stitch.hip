@@ -130,24 +130,27 @@ struct StitchArgs {
     int32_t* rank_of;         // (Btot * id_cap) workspace
 };
 
-__global__ void __launch_bounds__(1024)
-stitch_kernel(StitchArgs A) {
-    __shared__ int s_first[64 + 1];     // first global chain of each rank
-    __shared__ int part[1024];
-    __shared__ int s_flag, s_pairs;
-    const int tid = threadIdx.x;
-    const int T = A.lay.t_max, IC = A.id_cap;
-    if (tid == 0) {
-        int acc = 0, flag = 0;
-        for (int r = 0; r < A.world; ++r) {
-            const int32_t* h = reinterpret_cast<const int32_t*>(A.msgs + (size_t)r * A.msg_words);
-            s_first[r] = acc;
-            acc += h[0];
-            if (h[4] > h[5] || h[0] > A.lay.b_cap || h[2] != T) flag = 1;   // rows dropped / layout mismatch
-        }
-        s_first[A.world] = acc;
-        s_flag = flag; s_pairs = 0;
+// first global chain of every rank (world <= 64) and the layout checks; every thread computes the same
+__device__ __forceinline__ int chain_starts(const StitchArgs& A, int* first, int* flag) {
+    int acc = 0, fl = 0;
+    for (int r = 0; r < A.world; ++r) {
+        const int32_t* h = reinterpret_cast<const int32_t*>(A.msgs + (size_t)r * A.msg_words);
+        first[r] = acc;
+        acc += h[0];
+        if (h[4] > h[5] || h[0] > A.lay.b_cap || h[2] != A.lay.t_max) fl = 1;   // rows dropped / layout mismatch
     }
+    first[A.world] = acc;
+    *flag = fl;
+    return acc;
+}
+
+// phase A: one thread per chain boundary (many workgroups: the assignments are independent)
+__global__ void __launch_bounds__(64)
+stitch_match_kernel(StitchArgs A) {
+    __shared__ int s_first[64 + 1];
+    __shared__ int s_flag;
+    const int T = A.lay.t_max, IC = A.id_cap;
+    if (threadIdx.x == 0) { int fl; chain_starts(A, s_first, &fl); s_flag = fl; }
     __syncthreads();
     const int Btot = s_first[A.world];
     auto chain_msg = [&](int g, int* b_local) {
@@ -156,57 +159,66 @@ stitch_kernel(StitchArgs A) {
         *b_local = g - s_first[r];
         return A.msgs + (size_t)r * A.msg_words;
     };
-    // ---- phase A: one thread per chain boundary ----
-    int my_pairs = 0, my_flag = 0;
-    for (int g = tid; g < Btot; g += 1024) {
-        int bl;
-        const uint32_t* mn = chain_msg(g, &bl);
-        const int n_ids = reinterpret_cast<const int32_t*>(mn + A.lay.off_ids())[bl];
-        if (n_ids > IC) my_flag = 1;
-        const uint32_t* nx = mn + A.lay.off_bounds() + ((size_t)bl * 2 + 0) * T * MVMC_BOUND_WORDS;
-        for (int l = 0; l < IC; ++l) A.ptr[(size_t)g * IC + l] = l < n_ids ? g * IC + l : -1;
-        for (int s = 0; s < T; ++s) A.match[(size_t)g * T + s] = -1;
-        if (g == 0) continue;
-        int bp;
-        const uint32_t* mp = chain_msg(g - 1, &bp);
-        const uint32_t* pv = mp + A.lay.off_bounds() + ((size_t)bp * 2 + 1) * T * MVMC_BOUND_WORDS;
-        int ip[ST_T], in[ST_T], np = 0, nn = 0;
-        for (int s = 0; s < T; ++s) {
-            if ((int32_t)pv[(size_t)s * MVMC_BOUND_WORDS] >= 0) ip[np++] = s;
-            if ((int32_t)nx[(size_t)s * MVMC_BOUND_WORDS] >= 0) in[nn++] = s;
-        }
-        if (np == 0 || nn == 0) continue;
-        double cost[ST_T][ST_T];   // rows = the smaller side
-        const bool swap = np > nn;
-        const int nr = swap ? nn : np, nc = swap ? np : nn;
-        for (int i = 0; i < np; ++i)
-            for (int j = 0; j < nn; ++j) {
-                const uint32_t* a = pv + (size_t)ip[i] * MVMC_BOUND_WORDS + 1;
-                const uint32_t* b = nx + (size_t)in[j] * MVMC_BOUND_WORDS + 1;
-                double sum = 0.0;
-                for (int k = 0; k < 18; ++k) {
-                    const double dx = (double)__uint_as_float(a[3 * k]) - (double)__uint_as_float(b[3 * k]);
-                    const double dy = (double)__uint_as_float(a[3 * k + 1]) - (double)__uint_as_float(b[3 * k + 1]);
-                    const double dz = (double)__uint_as_float(a[3 * k + 2]) - (double)__uint_as_float(b[3 * k + 2]);
-                    sum += sqrt(dx * dx + dy * dy + dz * dz);
-                }
-                const double c = sum / 18.0;
-                if (swap) cost[j][i] = c; else cost[i][j] = c;
-            }
-        int col_of[ST_T];
-        assign_rows(cost, nr, nc, col_of);
-        for (int r = 0; r < nr; ++r) {
-            const int i = swap ? col_of[r] : r, j = swap ? r : col_of[r];
-            if (!(cost[r][col_of[r]] <= A.max_dist)) continue;
-            A.match[(size_t)g * T + in[j]] = ip[i];
-            const int lid_n = (int32_t)nx[(size_t)in[j] * MVMC_BOUND_WORDS], lid_p = (int32_t)pv[(size_t)ip[i] * MVMC_BOUND_WORDS];
-            if (lid_n < IC && lid_p < IC) A.ptr[(size_t)g * IC + lid_n] = (g - 1) * IC + lid_p;
-            ++my_pairs;
-        }
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && s_flag) atomicOr(A.info + 2, 1);
+    if (g >= Btot) return;
+    int bl;
+    const uint32_t* mn = chain_msg(g, &bl);
+    const int n_ids = reinterpret_cast<const int32_t*>(mn + A.lay.off_ids())[bl];
+    if (n_ids > IC) atomicOr(A.info + 2, 1);
+    const uint32_t* nx = mn + A.lay.off_bounds() + ((size_t)bl * 2 + 0) * T * MVMC_BOUND_WORDS;
+    for (int l = 0; l < IC; ++l) A.ptr[(size_t)g * IC + l] = l < n_ids ? g * IC + l : -1;
+    for (int s = 0; s < T; ++s) A.match[(size_t)g * T + s] = -1;
+    if (g == 0) return;
+    int bp;
+    const uint32_t* mp = chain_msg(g - 1, &bp);
+    const uint32_t* pv = mp + A.lay.off_bounds() + ((size_t)bp * 2 + 1) * T * MVMC_BOUND_WORDS;
+    int ip[ST_T], in[ST_T], np = 0, nn = 0;
+    for (int s = 0; s < T; ++s) {
+        if ((int32_t)pv[(size_t)s * MVMC_BOUND_WORDS] >= 0) ip[np++] = s;
+        if ((int32_t)nx[(size_t)s * MVMC_BOUND_WORDS] >= 0) in[nn++] = s;
     }
-    if (my_flag) atomicOr(&s_flag, 1);
-    atomicAdd(&s_pairs, my_pairs);
+    if (np == 0 || nn == 0) return;
+    double cost[ST_T][ST_T];   // rows = the smaller side
+    const bool swap = np > nn;
+    const int nr = swap ? nn : np, nc = swap ? np : nn;
+    for (int i = 0; i < np; ++i)
+        for (int j = 0; j < nn; ++j) {
+            const uint32_t* a = pv + (size_t)ip[i] * MVMC_BOUND_WORDS + 1;
+            const uint32_t* b = nx + (size_t)in[j] * MVMC_BOUND_WORDS + 1;
+            double sum = 0.0;
+            for (int k = 0; k < 18; ++k) {
+                const double dx = (double)__uint_as_float(a[3 * k]) - (double)__uint_as_float(b[3 * k]);
+                const double dy = (double)__uint_as_float(a[3 * k + 1]) - (double)__uint_as_float(b[3 * k + 1]);
+                const double dz = (double)__uint_as_float(a[3 * k + 2]) - (double)__uint_as_float(b[3 * k + 2]);
+                sum += sqrt(dx * dx + dy * dy + dz * dz);
+            }
+            const double c = sum / 18.0;
+            if (swap) cost[j][i] = c; else cost[i][j] = c;
+        }
+    int col_of[ST_T];
+    assign_rows(cost, nr, nc, col_of);
+    int pairs = 0;
+    for (int r = 0; r < nr; ++r) {
+        const int i = swap ? col_of[r] : r, j = swap ? r : col_of[r];
+        if (!(cost[r][col_of[r]] <= A.max_dist)) continue;
+        A.match[(size_t)g * T + in[j]] = ip[i];
+        const int lid_n = (int32_t)nx[(size_t)in[j] * MVMC_BOUND_WORDS], lid_p = (int32_t)pv[(size_t)ip[i] * MVMC_BOUND_WORDS];
+        if (lid_n < IC && lid_p < IC) A.ptr[(size_t)g * IC + lid_n] = (g - 1) * IC + lid_p;
+        ++pairs;
+    }
+    if (pairs) atomicAdd(A.info + 3, pairs);
+}
+
+// phases B-D on one workgroup: roots numbered in chain order, pointer jumping, global identities
+__global__ void __launch_bounds__(1024)
+stitch_ids_kernel(StitchArgs A) {
+    __shared__ int s_first[64 + 1];
+    __shared__ int part[1024];
+    const int tid = threadIdx.x, IC = A.id_cap;
+    if (tid == 0) { int fl; chain_starts(A, s_first, &fl); }
     __syncthreads();
+    const int Btot = s_first[A.world];
     // ---- phase B: roots (tracklets without a predecessor) numbered in chain order ----
     const int n_nodes = Btot * IC;
     const int per = (n_nodes + 1023) / 1024;
@@ -237,7 +249,7 @@ stitch_kernel(StitchArgs A) {
         const int p = A.ptr[k];
         A.gid[k] = p >= 0 ? A.rank_of[p] : -1;
     }
-    if (tid == 0) { A.info[0] = Btot; A.info[1] = part[1023]; A.info[2] = s_flag; A.info[3] = s_pairs; }
+    if (tid == 0) { A.info[0] = Btot; A.info[1] = part[1023]; }
 }
 
 }  // namespace
@@ -280,7 +292,10 @@ extern "C" int mvmc_stitch_chains(const void* messages, long long message_words,
     A.msgs = (const uint32_t*)messages; A.msg_words = (size_t)message_words; A.world = world; A.id_cap = id_cap; A.lay = lay;
     A.max_dist = max_dist; A.gid = gid; A.match = match; A.info = info;
     A.ptr = work; A.rank_of = work + (size_t)n_chains_total_cap * id_cap;
-    hipLaunchKernelGGL(stitch_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, A);
+    if (hipMemsetAsync(info, 0, 4 * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return MVMC_ERR_LAUNCH;
+    const int cap = world * n_chains_cap;
+    if (cap > 0) hipLaunchKernelGGL(stitch_match_kernel, dim3((cap + 63) / 64), dim3(64), 0, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(stitch_ids_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, A);
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;
 }

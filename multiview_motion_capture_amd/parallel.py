@@ -108,12 +108,13 @@ def unpack_message(msg: np.ndarray, b_cap: int, t_max: int, row_cap: int) -> dic
 
 def run_sharded(compute: Callable[[], Dict[str, torch.Tensor]], chain_len: int, n_chains_total: int, rank: int, world: int,
                 rows_per_frame: int, comm_stream=None, pack: Optional[Callable] = None, stitch: Optional[Callable] = None,
-                gather: Optional[Callable] = None, max_dist: float = MAX_DIST):
+                gather: Optional[Callable] = None, max_dist: float = MAX_DIST, timing: bool = False):
     """One step of the sharded path on this rank: compute() (the shard's chains: tracker.run_chains_fused) -> pack -> ONE all-gather ->
     stitch.  ``rows_per_frame`` sizes the message (live tracklets per frame it has room for: the people in the scene; an overflow is
     reported in info[2], never silent).  pack / stitch / gather default to the device kernels and torch.distributed; the CPU tests
     inject host implementations of the same message format.  Returns dict(local=compute's result, messages (world, words),
-    gid, match, info, done=event or None).  With a CUDA ``comm_stream`` the pack/gather/stitch tail runs there, behind an event."""
+    gid, match, info, done=event or None, tail_events = [start, packed, gathered, stitched] with timing=True).  With a CUDA
+    ``comm_stream`` the pack/gather/stitch tail runs there, behind an event."""
     pack = pack or pack_tracks
     stitch = stitch or stitch_chains
     gather = gather or all_gather_messages
@@ -134,9 +135,16 @@ def run_sharded(compute: Callable[[], Dict[str, torch.Tensor]], chain_len: int, 
         import contextlib
         ctx = contextlib.nullcontext()
     with ctx:
+        t_tail = None
+        if use_stream and timing:
+            t_tail = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            t_tail[0].record()
         msg = pack(out, out["next_id"], chain_len, b_cap, row_cap)
+        if t_tail: t_tail[1].record()
         msgs = gather(msg, world)
+        if t_tail: t_tail[2].record()
         st = stitch(msgs, b_cap, T, row_cap, max_dist)
+        if t_tail: t_tail[3].record()
         done = None
         if use_stream:
             done = torch.cuda.Event()
@@ -144,7 +152,8 @@ def run_sharded(compute: Callable[[], Dict[str, torch.Tensor]], chain_len: int, 
             for t in (msg, msgs) + tuple(v for v in st.values() if isinstance(v, torch.Tensor)) + tuple(
                     v for v in out.values() if isinstance(v, torch.Tensor)):
                 t.record_stream(comm_stream)
-    return dict(local=out, message=msg, messages=msgs, b_cap=b_cap, row_cap=row_cap, done=done, **{k: v for k, v in st.items()})
+    return dict(local=out, message=msg, messages=msgs, b_cap=b_cap, row_cap=row_cap, done=done, tail_events=t_tail,
+                **{k: v for k, v in st.items()})
 
 
 def check_stitch_info(res) -> None:

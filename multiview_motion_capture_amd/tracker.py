@@ -154,6 +154,7 @@ def run_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], c
     out_m = torch.empty((B, L, t_max, 4), dtype=torch.int32, device=d)
     out_n = torch.empty((B, L), dtype=torch.int32, device=d)
     n_dead = torch.empty((B,), dtype=torch.int32, device=d)
+    next_id = torch.empty((B,), dtype=torch.int32, device=d)
     bounds = [B * g // G for g in range(G + 1)]
     main = torch.cuda.current_stream(d)
     streams = [main] if G == 1 else [torch.cuda.Stream(device=d) for _ in range(G)]
@@ -186,10 +187,11 @@ def run_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], c
     for g in range(G):
         with torch.cuda.stream(streams[g]):
             n_dead[bounds[g]:bounds[g + 1]] = trackers[g].n_dead
+            next_id[bounds[g]:bounds[g + 1]] = trackers[g].next_id
         if streams[g] is not main:
             main.wait_stream(streams[g])
     res = dict(params=out_p.view(F, t_max, 68), joints=out_j.view(F, t_max, 18, 3), meta=out_m.view(F, t_max, 4),
-               n_tracks=out_n.view(F), n_dead=n_dead)
+               n_tracks=out_n.view(F), n_dead=n_dead, next_id=next_id)
     if want_info:
         res["ik_info"] = torch.cat([torch.stack(i, 1) for i in infos], 0)
     return res

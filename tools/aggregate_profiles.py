@@ -2,7 +2,10 @@
 profiles/:  kernel stats (from --kernel-trace --stats) and HBM traffic per launch (from two --pmc passes,
 FETCH_SIZE and WRITE_SIZE, which rocprofv3 reports in KB per dispatch).
 
-  python tools/aggregate_profiles.py <stats_dir> <pmc_fetch_dir> <pmc_write_dir> <tag>
+  python tools/aggregate_profiles.py <stats_dir> <pmc_fetch_dir> <pmc_write_dir> <tag> [workload key, default 10000x5x4]
+
+Every record written to profiles/pmc_traffic.json carries the hash of the kernel sources it was measured on (bench.kernel_sources_sha);
+bench.py reports roofline.traffic = null for a record whose hash is not the current one.
 """
 import collections
 import csv
@@ -30,6 +33,9 @@ def pmc(dirname, counter):
 
 def main():
     stats_dir, fdir, wdir, tag = sys.argv[1:5]
+    wkey = sys.argv[5] if len(sys.argv) > 5 else "10000x5x4"
+    sys.path.insert(0, ROOT)
+    from bench import kernel_sources_sha
     f = glob.glob(os.path.join(stats_dir, "*", "*kernel_stats.csv"))[0]
     out = os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv")
     rows = list(csv.DictReader(open(f)))
@@ -60,8 +66,8 @@ def main():
             continue
         kf = sum(fe[kern]) / len(fe[kern]) * 1024
         kw = sum(wr[kern]) / len(wr[kern]) * 1024
-        rec[f"{key}:10000x5x4"] = {"kernel": kern, "fetch_bytes": kf, "write_bytes": kw, "bytes": kf + kw,
-                                   "source": os.path.basename(out2), "unit": unit}
+        rec[f"{key}:{wkey}"] = {"kernel": kern, "fetch_bytes": kf, "write_bytes": kw, "bytes": kf + kw,
+                                "source": os.path.basename(out2), "src_sha": kernel_sources_sha(), "unit": unit}
     json.dump(rec, open(tp, "w"), indent=1)
     print(open(out).read())
     print(open(out2).read())
