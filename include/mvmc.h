@@ -289,9 +289,11 @@ int mvmc_debug_ik_solve_fd(const mvmcSkeleton* skel_host, const double* kps17, c
  * same device code as mvmc_affinity / mvmc_st_affinity / mvmc_als_associate / mvmc_track_assign / mvmc_ik_solve /
  * mvmc_track_commit issued frame by frame, and the same results.  Chain b owns frames [b chain_len, (b+1) chain_len).
  * All pointers are device memory owned by the caller (N = n_views p_max, NS = t_max + N, NP = t_max + k_max,
- * B = n_chains, F = B chain_len).  Supported sizes: N <= 40, NS <= 48, v_max <= 6, p_max <= 8, t_max <= 8
- * (MVMC_ERR_UNSUPPORTED otherwise: use the per-stage entry points), and every frame's actual graph must have <= 24 nodes
- * without tracklets and <= 32 with them -- checked on the device: flags[B + 1] != 0 after the call means a graph did not fit. */
+ * B = n_chains, F = B chain_len).  Two LDS layouts (MVMC_ERR_UNSUPPORTED outside them: use the per-stage entry points), both with
+ * p_max <= 8, t_max <= 8:
+ *   small  N <= 40, NS <= 48, v_max <= 6 (configs 1-4; three workgroups per CU); every frame's actual graph must have <= 24 nodes
+ *          without tracklets and <= 32 with them -- checked on the device: flags[B + 1] != 0 after the call means a graph did not fit;
+ *   big    N <= 64, NS <= 72, v_max <= 8 (config 5, C8 P8; two workgroups per CU); every graph of those sizes fits. */
 typedef struct mvmcChainBuffers {
     int32_t n_chains, chain_len, n_views, p_max, t_max, k_max, v_max, max_nfev_cold, max_nfev_warm, n_inits, seed_len;
     int32_t n_parts;            /* workgroups per chain: 1 = one persistent workgroup per chain; p > 1 (dividing chain_len) =

@@ -314,24 +314,36 @@ __device__ inline void gauss_jordan(double* M, int r, int ld) {
     }
 }
 
-template <typename TW, int NMAX, int RMAX, int NT>
-__global__ void __launch_bounds__(NT)
-als_kernel(const TW* __restrict__ W, const int32_t* __restrict__ gcounts, int G, int ldw,
-           const double* __restrict__ seed, int seed_len, uint8_t* __restrict__ x_bin,
-           uint8_t* __restrict__ match_mat, int32_t* __restrict__ labels, int32_t* __restrict__ n_clusters,
-           int32_t* __restrict__ iters_out) {
-    constexpr int T = (NMAX * NMAX + NT - 1) / NT;
-    __shared__ double sX[NMAX * NMAX];
-    __shared__ double sA[NMAX * RMAX];
-    __shared__ double sB[NMAX * RMAX];
-    __shared__ double sM[RMAX * (RMAX + NMAX)];
-    __shared__ double sRed[NT / 64 + 1];
-    __shared__ int sGid[NMAX];
-    __shared__ uint8_t sVis[NMAX];
-    __shared__ int sKeep[NMAX];
-    __shared__ int s_n, s_r;
+// LDS of the generic ALS (any n <= NMAX, rank <= RMAX): X1 as a dense matrix, both factors, the augmented normal matrix
+template <int NMAX, int RMAX, int NT>
+struct AlsGenLds {
+    double sX[NMAX * NMAX];
+    double sA[NMAX * RMAX];
+    double sB[NMAX * RMAX];
+    double sM[RMAX * (RMAX + NMAX)];
+    double sRed[NT / 64 + 1];
+    int sGid[NMAX];
+    uint8_t sVis[NMAX];
+    int sKeep[NMAX];
+    int s_n, s_r;
+};
 
-    const int f = blockIdx.x, tid = threadIdx.x;
+// One graph (index f of the batch) on an NT-thread workgroup; every thread of the workgroup must call it.  als_kernel is the
+// stand-alone wrapper; the chain kernel's large layout (C8 P8) calls it from its persistent workgroup.
+template <typename TW, int NMAX, int RMAX, int NT>
+__device__ __forceinline__ void als_gen_graph(AlsGenLds<NMAX, RMAX, NT>& L, int f, const TW* __restrict__ W,
+                                              const int32_t* __restrict__ gcounts, int G, int ldw,
+                                              const double* __restrict__ seed, int seed_len, uint8_t* __restrict__ x_bin,
+                                              uint8_t* __restrict__ match_mat, int32_t* __restrict__ labels,
+                                              int32_t* __restrict__ n_clusters, int32_t* __restrict__ iters_out) {
+    constexpr int T = (NMAX * NMAX + NT - 1) / NT;
+    double *sX = L.sX, *sA = L.sA, *sB = L.sB, *sM = L.sM, *sRed = L.sRed;
+    int *sGid = L.sGid, *sKeep = L.sKeep;
+    uint8_t* sVis = L.sVis;
+    int &s_n = L.s_n, &s_r = L.s_r;
+    const int tid = threadIdx.x;
+    __syncthreads();   // the LDS may still be in use by the caller's previous phase
+
     if (tid == 0) {
         int n = 0, total = 0, gmax = 0;
         for (int g = 0; g < G; ++g) {
@@ -527,6 +539,17 @@ als_kernel(const TW* __restrict__ W, const int32_t* __restrict__ gcounts, int G,
             if (match_mat) match_mat[(size_t)f * ldw * ldw + e] = in ? sOut[i * n + j] : 0;
         }
     }
+}
+
+template <typename TW, int NMAX, int RMAX, int NT>
+__global__ void __launch_bounds__(NT)
+als_kernel(const TW* __restrict__ W, const int32_t* __restrict__ gcounts, int G, int ldw,
+           const double* __restrict__ seed, int seed_len, uint8_t* __restrict__ x_bin,
+           uint8_t* __restrict__ match_mat, int32_t* __restrict__ labels, int32_t* __restrict__ n_clusters,
+           int32_t* __restrict__ iters_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char als_gen_lds[];
+    auto& L = *reinterpret_cast<AlsGenLds<NMAX, RMAX, NT>*>(als_gen_lds);
+    als_gen_graph<TW, NMAX, RMAX, NT>(L, blockIdx.x, W, gcounts, G, ldw, seed, seed_len, x_bin, match_mat, labels, n_clusters, iters_out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1464,6 +1487,441 @@ als4_kernel(const TW* __restrict__ W, const int32_t* __restrict__ gcounts, int G
 }
 
 // ------------------------------------------------------------------------------------------------
+// ALS for the large graphs of config 5 (C8 P8: n <= 72 nodes, rank <= 16) on one 256-thread workgroup
+// (match_als, mv_association.py:263-312; same iteration as als_kernel / als4_graph, restated for this size).
+//   * W, Z, Y and the previous X live in REGISTERS: thread (ti, tj) of a 24 x 9 grid owns the 3 x 8 tile of elements
+//     rows 3 ti .., columns 8 tj .. (216 of the 256 threads; the kernel runs one workgroup per CU, 512 VGPRs per thread);
+//   * X1 = Z - (Y - W + beta) / mu is a dense n x n matrix in LDS (row stride NMAX), read by both factor updates;
+//   * a factor update  B = (inv(A^T A + rho I) (A^T X1))^T : threads 0..191 form H = A^T X1 with a 1 x 6 register tile each
+//     (one factor entry + three 16-byte reads of an X1 row per six FMAs) while wave 3 forms the 16 x 16 normal matrix and
+//     inverts it by Gauss-Jordan in LDS (the reference forms explicit inverses too: np.linalg.inv); then inv(G) H;
+//   * X = A B^T on the 3 x 8 tiles (A rows in registers, one 128-byte B row per column), the Z / Y update and the residual sums
+//     in the same pass.
+// Seven workgroup barriers per iteration; no state in scratch memory.
+// ------------------------------------------------------------------------------------------------
+template <int NMAX>
+struct Als5Lds {
+    __attribute__((aligned(16))) double sX[NMAX * NMAX];
+    __attribute__((aligned(16))) double sA[NMAX * 16];
+    __attribute__((aligned(16))) double sB[NMAX * 16];
+    __attribute__((aligned(16))) double sH[16 * NMAX];
+    __attribute__((aligned(16))) double sG[16 * 34];   // rows padded to 34 doubles: a column walk does not stay on one bank
+    double sRed[16];
+    int sGid[NMAX];
+    uint8_t sVis[NMAX];
+    int sKeep[NMAX];
+    int s_n, s_r;
+};
+
+// wave 3: G = F^T F + rho I over the n rows of the factor F (NMAX x 16 in LDS), then [G | I] -> [I | inv(G)] in sG (16 x 32, row stride 34)
+__device__ __forceinline__ void als5_normal_inverse(const double* __restrict__ sF, int n, int r, double rho, double* __restrict__ sG) {
+    const int lane = threadIdx.x & 63;
+    {
+        const int a = lane & 15, b0 = (lane >> 4) * 4;
+        double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
+        for (int k0 = 0; k0 < n; k0 += 4) {     // rows beyond n are zero; four rows of loads in flight (one wave per SIMD: nothing
+            double fa[4];                       // else hides the LDS latency)
+            double2 f01[4], f23[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                fa[u] = sF[(k0 + u) * 16 + a];
+                f01[u] = *reinterpret_cast<const double2*>(&sF[(k0 + u) * 16 + b0]);
+                f23[u] = *reinterpret_cast<const double2*>(&sF[(k0 + u) * 16 + b0 + 2]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { g0 += fa[u] * f01[u].x; g1 += fa[u] * f01[u].y; g2 += fa[u] * f23[u].x; g3 += fa[u] * f23[u].y; }
+        }
+        double g[4] = {g0, g1, g2, g3};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int b = b0 + q;
+            double v = g[q];
+            if (a == b) v += rho;
+            if (a >= r || b >= r) v = a == b ? 1.0 : 0.0;   // unused rank slots: identity block
+            sG[a * 34 + b] = v;
+            sG[a * 34 + 16 + b] = a == b ? 1.0 : 0.0;
+        }
+    }
+    MVMC_WAVE_SYNC();
+    const int c = lane & 31, h = lane >> 5;
+    for (int p = 0; p < 16; ++p) {
+        const double f = sG[p * 34 + c] / sG[p * 34 + p];   // (IEEE division: the inverse feeds the factors directly)
+        double col[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) col[q] = sG[(h * 8 + q) * 34 + p];
+        double cur[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cur[q] = sG[(h * 8 + q) * 34 + c];
+        MVMC_WAVE_SYNC();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int row = h * 8 + q;
+            sG[row * 34 + c] = row == p ? f : cur[q] - col[q] * f;
+        }
+        MVMC_WAVE_SYNC();
+    }
+}
+
+// One graph (index f of the batch) on a 256-thread workgroup; every thread of the workgroup must call it.
+template <typename TW, int NMAX>
+__device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __restrict__ W,
+                                           const int32_t* __restrict__ gcounts, int G, int ldw,
+                                           const double* __restrict__ seed, int seed_len, uint8_t* __restrict__ x_bin,
+                                           uint8_t* __restrict__ match_mat, int32_t* __restrict__ labels,
+                                           int32_t* __restrict__ n_clusters, int32_t* __restrict__ iters_out) {
+    static_assert(NMAX == 72, "tile grid: 24 x 9 tiles of 3 x 8 elements");
+    constexpr int NT5 = 256, TR = 3, TC = 8, LD = NMAX;
+    double *sX = L.sX, *sA = L.sA, *sB = L.sB, *sH = L.sH, *sG = L.sG, *sRed = L.sRed;
+    int *sGid = L.sGid, *sKeep = L.sKeep;
+    uint8_t* sVis = L.sVis;
+    int &s_n = L.s_n, &s_r = L.s_r;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    __syncthreads();   // the LDS may still be in use by the caller's previous phase
+    if (tid == 0) {
+        int n = 0, total = 0, gmax = 0;
+        for (int g = 0; g < G; ++g) {
+            int c = gcounts[f * G + g];
+            c = c < 0 ? 0 : c;
+            total += c;
+            for (int k = 0; k < c && n < NMAX; ++k) sGid[n++] = g;
+            if (c > gmax) gmax = c;
+        }
+        s_n = total;
+        const int r = 2 * gmax;
+        s_r = r < total ? r : total;
+    }
+    __syncthreads();
+    const int n = s_n, r = s_r;
+    int32_t* lab = labels + (size_t)f * ldw;
+    if (n == 0 || n > NMAX || n > ldw || r > 16 || n * r > seed_len) {
+        for (int i = tid; i < ldw; i += NT5) lab[i] = -1;
+        if (tid == 0) { n_clusters[f] = 0; iters_out[f] = (n == 0) ? 0 : -1; }
+        return;
+    }
+    const TW* Wf = W + (size_t)f * ldw * ldw;
+    // ---- element tiles ----
+    const bool own = tid < 24 * 9;
+    const int i0 = own ? (tid / 9) * TR : 0, j0 = own ? (tid % 9) * TC : 0;
+    double w[TR][TC], z[TR][TC], y[TR][TC], xp[TR][TC];
+    float w32[TR][TC];
+    unsigned same_grp = 0;      // bit (a * TC + b): nodes of one group (view / tracklet block), or an element beyond n: Z forced to 0
+    unsigned on_diag = 0;       // bit (a * TC + b): i == j: Z forced to 1
+#pragma unroll
+    for (int a = 0; a < TR; ++a)
+#pragma unroll
+        for (int b = 0; b < TC; ++b) {
+            const int i = i0 + a, j = j0 + b;
+            const bool ok = own && i < n && j < n;
+            if constexpr (sizeof(TW) == 4) {
+                const float p = ok ? (float)Wf[i * ldw + j] : 0.f, q = ok ? (float)Wf[j * ldw + i] : 0.f;
+                w32[a][b] = fmulr(0.5f, faddr(p, q));
+                w[a][b] = (double)w32[a][b];
+            } else {
+                const double p = ok ? (double)Wf[i * ldw + j] : 0., q = ok ? (double)Wf[j * ldw + i] : 0.;
+                w[a][b] = 0.5 * (p + q);
+                w32[a][b] = 0.f;
+            }
+            z[a][b] = w[a][b]; xp[a][b] = w[a][b]; y[a][b] = 0.0;
+            if (!ok || sGid[i] == sGid[j]) same_grp |= 1u << (a * TC + b);
+            if (ok && i == j) on_diag |= 1u << (a * TC + b);
+        }
+    for (int e = tid; e < NMAX * 16; e += NT5) {
+        const int k = e >> 4, a = e & 15;
+        sA[e] = (k < n && a < r) ? seed[k * r + a] : 0.0;
+        sB[e] = 0.0;
+    }
+    for (int e = tid; e < NMAX * NMAX; e += NT5) sX[e] = 0.0;   // rows / columns beyond n are read (times zero factors) by the 4-row loops
+    // factor-update roles: threads 0..191 = (rank slot fa, block of six columns fj0..fj0+5)
+    const int fa = tid & 15, fj0 = (tid >> 4) * 6;
+    __syncthreads();
+
+    double mu = 64.0;
+    int iters = 1000;
+#ifdef MVMC_ALS_PROFILE
+    __shared__ long long prof5[16];
+    if (tid < 16) prof5[tid] = 0;
+    long long _t5 = clock64();
+#define A5PROF(k) { const long long _t = clock64(); if ((tid & 63) == 0 && (wave == 0 || wave == 3)) prof5[(wave == 3 ? 8 : 0) + (k)] += _t - _t5; _t5 = _t; }
+#else
+#define A5PROF(k)
+#endif
+    for (int it = 0; it < 1000; ++it) {
+        // ---- X1 = Z - (Y - W + beta) / mu      (float32 arithmetic on iteration 1 when W is f32) ----
+        const double inv_mu = 1.0 / mu;      // mu = 64 * 2^k: the reciprocal is exact, x * inv_mu == x / mu bit for bit
+        if (own) {
+#pragma unroll
+            for (int a = 0; a < TR; ++a) {
+                double x1[TC];
+#pragma unroll
+                for (int b = 0; b < TC; ++b) {
+                    if (sizeof(TW) == 4 && it == 0) {
+                        const float q = faddr(-w32[a][b], 0.1f) / 64.f;
+                        x1[b] = (double)(w32[a][b] - q);
+                    } else {
+                        x1[b] = z[a][b] - ((y[a][b] - w[a][b]) + 0.1) * inv_mu;
+                    }
+                }
+                if (i0 + a < n) {
+#pragma unroll
+                    for (int b = 0; b < TC; b += 2) *reinterpret_cast<double2*>(&sX[(i0 + a) * LD + j0 + b]) = make_double2(x1[b], x1[b + 1]);
+                }
+            }
+        }
+        A5PROF(0)
+        __syncthreads();
+        A5PROF(1)
+        const double rho = 50.0 / mu;
+        // ================= B = (inv(A^T A + rho I) (A^T X1))^T =================
+        if (wave == 3) {
+            als5_normal_inverse(sA, n, r, rho, sG);
+        } else {
+            double h[6] = {0, 0, 0, 0, 0, 0};
+            for (int k0 = 0; k0 < n; k0 += 4) {
+                double av[4];
+                double2 x01[4], x23[4], x45[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    av[u] = sA[(k0 + u) * 16 + fa];
+                    x01[u] = *reinterpret_cast<const double2*>(&sX[(k0 + u) * LD + fj0]);
+                    x23[u] = *reinterpret_cast<const double2*>(&sX[(k0 + u) * LD + fj0 + 2]);
+                    x45[u] = *reinterpret_cast<const double2*>(&sX[(k0 + u) * LD + fj0 + 4]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    h[0] += av[u] * x01[u].x; h[1] += av[u] * x01[u].y; h[2] += av[u] * x23[u].x; h[3] += av[u] * x23[u].y;
+                    h[4] += av[u] * x45[u].x; h[5] += av[u] * x45[u].y;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 6; q += 2) *reinterpret_cast<double2*>(&sH[fa * LD + fj0 + q]) = make_double2(h[q], h[q + 1]);
+        }
+        A5PROF(2)
+        __syncthreads();
+        A5PROF(3)
+        if (wave < 3) {
+            double gi[16];
+#pragma unroll
+            for (int b = 0; b < 16; b += 2) {
+                const double2 g2 = *reinterpret_cast<const double2*>(&sG[fa * 34 + 16 + b]);
+                gi[b] = g2.x; gi[b + 1] = g2.y;
+            }
+            double o[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int b0 = 0; b0 < 16; b0 += 4) {
+                double2 h01[4], h23[4], h45[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    h01[u] = *reinterpret_cast<const double2*>(&sH[(b0 + u) * LD + fj0]);
+                    h23[u] = *reinterpret_cast<const double2*>(&sH[(b0 + u) * LD + fj0 + 2]);
+                    h45[u] = *reinterpret_cast<const double2*>(&sH[(b0 + u) * LD + fj0 + 4]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double gv = gi[b0 + u];
+                    o[0] += gv * h01[u].x; o[1] += gv * h01[u].y; o[2] += gv * h23[u].x; o[3] += gv * h23[u].y; o[4] += gv * h45[u].x; o[5] += gv * h45[u].y;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                if (fj0 + q < n) sB[(fj0 + q) * 16 + fa] = o[q];
+        }
+        __syncthreads();
+        A5PROF(4)
+        // ================= A = (inv(B^T B + rho I) (B^T X1^T))^T =================
+        if (wave == 3) {
+            als5_normal_inverse(sB, n, r, rho, sG);
+        } else {
+            // H2[a][i] = sum_k B[k][a] X1[i][k] for six rows i = fj0 .. fj0 + 5; two k per step (one 16-byte read per row)
+            double h[6] = {0, 0, 0, 0, 0, 0};
+            for (int k = 0; k < n; k += 4) {      // X1 columns and B rows beyond n are zero
+                double bv[4];
+                double2 xa[6], xb[6];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bv[u] = sB[(k + u) * 16 + fa];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    xa[q] = *reinterpret_cast<const double2*>(&sX[(fj0 + q) * LD + k]);
+                    xb[q] = *reinterpret_cast<const double2*>(&sX[(fj0 + q) * LD + k + 2]);
+                }
+#pragma unroll
+                for (int q = 0; q < 6; ++q) h[q] += (bv[0] * xa[q].x + bv[1] * xa[q].y) + (bv[2] * xb[q].x + bv[3] * xb[q].y);
+            }
+#pragma unroll
+            for (int q = 0; q < 6; q += 2) *reinterpret_cast<double2*>(&sH[fa * LD + fj0 + q]) = make_double2(h[q], h[q + 1]);
+        }
+        A5PROF(2)
+        __syncthreads();
+        A5PROF(3)
+        if (wave < 3) {
+            double gi[16];
+#pragma unroll
+            for (int b = 0; b < 16; b += 2) {
+                const double2 g2 = *reinterpret_cast<const double2*>(&sG[fa * 34 + 16 + b]);
+                gi[b] = g2.x; gi[b + 1] = g2.y;
+            }
+            double o[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int b0 = 0; b0 < 16; b0 += 4) {
+                double2 h01[4], h23[4], h45[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    h01[u] = *reinterpret_cast<const double2*>(&sH[(b0 + u) * LD + fj0]);
+                    h23[u] = *reinterpret_cast<const double2*>(&sH[(b0 + u) * LD + fj0 + 2]);
+                    h45[u] = *reinterpret_cast<const double2*>(&sH[(b0 + u) * LD + fj0 + 4]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double gv = gi[b0 + u];
+                    o[0] += gv * h01[u].x; o[1] += gv * h01[u].y; o[2] += gv * h23[u].x; o[3] += gv * h23[u].y; o[4] += gv * h45[u].x; o[5] += gv * h45[u].y;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                if (fj0 + q < n) sA[(fj0 + q) * 16 + fa] = o[q];
+        }
+        __syncthreads();
+        A5PROF(4)
+        // ================= X = A B^T ; Z ; Y ; residuals =================
+        double acc_p = 0.0, acc_d = 0.0;
+        if (own) {
+            // A rows in registers; the B row of column b + 1 is loaded while column b is computed (one wave per SIMD: the loads have
+            // to be in flight early); elements beyond n have zero factors, zero state and the forced-zero bit: branch-free, they add 0
+            double ar[TR][16];
+#pragma unroll
+            for (int a = 0; a < TR; ++a)
+#pragma unroll
+                for (int q = 0; q < 16; q += 2) {
+                    const double2 v = *reinterpret_cast<const double2*>(&sA[(i0 + a) * 16 + q]);
+                    ar[a][q] = v.x; ar[a][q + 1] = v.y;
+                }
+            double2 bn[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) bn[q] = *reinterpret_cast<const double2*>(&sB[j0 * 16 + 2 * q]);
+#pragma unroll
+            for (int b = 0; b < TC; ++b) {
+                double br[16];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { br[2 * q] = bn[q].x; br[2 * q + 1] = bn[q].y; }
+                if (b + 1 < TC) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) bn[q] = *reinterpret_cast<const double2*>(&sB[(j0 + b + 1) * 16 + 2 * q]);
+                }
+#pragma unroll
+                for (int a = 0; a < TR; ++a) {
+                    // two partial sums: half the length of the dependent FMA chain
+                    double x0 = 0.0, x1 = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 16; q += 2) { x0 += ar[a][q] * br[q]; x1 += ar[a][q + 1] * br[q + 1]; }
+                    const double x = x0 + x1;
+                    const unsigned bit = 1u << (a * TC + b);
+                    double zz = x + y[a][b] * inv_mu;
+                    zz = zz < 0.0 ? 0.0 : (zz > 1.0 ? 1.0 : zz);
+                    zz = (same_grp & bit) ? 0.0 : zz;
+                    zz = (on_diag & bit) ? 1.0 : zz;
+                    const double dz = x - zz, dx = x - xp[a][b];
+                    y[a][b] = y[a][b] + mu * dz;
+                    z[a][b] = zz;
+                    xp[a][b] = x;
+                    acc_p += dz * dz;
+                    acc_d += dx * dx;
+                }
+            }
+        }
+        A5PROF(5)
+        acc_p = wave_sum_dpp(acc_p);
+        acc_d = wave_sum_dpp(acc_d);
+        if ((tid & 63) == 0) { sRed[wave] = acc_p; sRed[4 + wave] = acc_d; }
+        __syncthreads();
+        A5PROF(6)
+        const double p_res = sqrt(sRed[0] + sRed[1] + sRed[2] + sRed[3]) / n;
+        const double d_res = mu * sqrt(sRed[4] + sRed[5] + sRed[6] + sRed[7]) / n;
+        if (p_res < 1e-4 && d_res < 1e-4) { iters = it + 1; break; }
+        if (p_res > 10 * d_res) mu = 2 * mu;
+        else if (d_res > 10 * p_res) mu = mu / 2;
+    }
+    // ---- tail: X_bin = (X + X^T) / 2 > 0.5, closure (k = n-1 only), labels -- same rules as als_kernel ----
+    __syncthreads();
+    if (own) {
+#pragma unroll
+        for (int a = 0; a < TR; ++a)
+#pragma unroll
+            for (int b = 0; b < TC; ++b)
+                if (i0 + a < n && j0 + b < n) sX[(i0 + a) * LD + j0 + b] = xp[a][b];
+    }
+    uint8_t* sBin = reinterpret_cast<uint8_t*>(sA);
+    uint8_t* sOut = reinterpret_cast<uint8_t*>(sB);
+    uint8_t* sTmp = reinterpret_cast<uint8_t*>(sH);
+    __syncthreads();
+    for (int e = tid; e < n * n; e += NT5) {
+        const int i = e / n, j = e - i * n;
+        sBin[e] = (0.5 * (sX[i * LD + j] + sX[j * LD + i])) > 0.5;
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += NT5) {
+        const int i = e / n, j = e - i * n;
+        sOut[e] = 0;
+        sTmp[e] = sBin[e] | (sBin[i * n + (n - 1)] & sBin[(n - 1) * n + j]);
+    }
+    for (int i = tid; i < n; i += NT5) sVis[i] = 0;
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+        const bool skip = sVis[i] != 0;
+        __syncthreads();
+        if (!skip)
+            for (int j = tid; j < n; j += NT5)
+                if (sTmp[i * n + j]) { sVis[j] = 1; sOut[j * n + i] = 1; }
+        __syncthreads();
+    }
+    for (int c = tid; c < n; c += NT5) {
+        int sc = 0;
+        for (int j = 0; j < n; ++j) sc += sOut[j * n + c];
+        sKeep[c] = sc >= 2;
+    }
+    __syncthreads();
+    for (int row = tid; row < ldw; row += NT5) {
+        int label = -1;
+        if (row < n) {
+            int ord = 0;
+            for (int c = 0; c < n; ++c) {
+                if (!sKeep[c]) continue;
+                if (sOut[row * n + c]) { label = ord; break; }
+                ++ord;
+            }
+        }
+        lab[row] = label;
+    }
+    if (tid == 0) {
+        int k = 0;
+        for (int c = 0; c < n; ++c) k += sKeep[c];
+        n_clusters[f] = k;
+        iters_out[f] = iters;
+#ifdef MVMC_ALS_PROFILE
+        // diagnostic build: cycles per iteration {X1, barrier, H (wave 0) | G + inverse (wave 3), barrier wait, apply + barrier, X/Z/Y, reduce}
+        for (int q = 0; q < 16; ++q) lab[q] = (int)(prof5[q] / iters);
+#endif
+    }
+    if (x_bin || match_mat) {
+        for (int e = tid; e < ldw * ldw; e += NT5) {
+            const int i = e / ldw, j = e - i * ldw;
+            const bool in = i < n && j < n;
+            if (x_bin) x_bin[(size_t)f * ldw * ldw + e] = in ? sBin[i * n + j] : 0;
+            if (match_mat) match_mat[(size_t)f * ldw * ldw + e] = in ? sOut[i * n + j] : 0;
+        }
+    }
+}
+
+template <typename TW, int NMAX>
+__global__ void __launch_bounds__(256, 1)
+als5_kernel(const TW* __restrict__ W, const int32_t* __restrict__ gcounts, int G, int ldw,
+            const double* __restrict__ seed, int seed_len, uint8_t* __restrict__ x_bin,
+            uint8_t* __restrict__ match_mat, int32_t* __restrict__ labels, int32_t* __restrict__ n_clusters,
+            int32_t* __restrict__ iters_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char als5_lds[];
+    auto& L = *reinterpret_cast<Als5Lds<NMAX>*>(als5_lds);
+    als5_graph<TW, NMAX>(L, blockIdx.x, W, gcounts, G, ldw, seed, seed_len, x_bin, match_mat, labels, n_clusters, iters_out);
+}
+
+// ------------------------------------------------------------------------------------------------
 // standalone closure + labelling (transform_closure, mv_association.py:99-121; the cluster rule of
 // parse_match_result, motion_capture.py:419-425) for callers that bring their own binary matrix
 // ------------------------------------------------------------------------------------------------
@@ -1600,8 +2058,14 @@ template <typename TW>
 static int launch_als(const TW* W, const int32_t* gc, int F, int G, int n_max, int r_max, const double* seed,
                       int seed_len, uint8_t* xb, uint8_t* mm, int32_t* lab, int32_t* nc, int32_t* it, hipStream_t s) {
 #define MVMC_ALS(NM, RM, NT)                                                                              \
-    hipLaunchKernelGGL((als_kernel<TW, NM, RM, NT>), dim3(F), dim3(NT), 0, s, W, gc, G, n_max, seed,    \
-                       seed_len, xb, mm, lab, nc, it)
+    do {                                                                                                  \
+        const size_t lds = sizeof(AlsGenLds<NM, RM, NT>);                                                 \
+        if (lds > 65536 && hipFuncSetAttribute((const void*)als_kernel<TW, NM, RM, NT>,                   \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            return MVMC_ERR_LAUNCH;                                                                       \
+        hipLaunchKernelGGL((als_kernel<TW, NM, RM, NT>), dim3(F), dim3(NT), lds, s, W, gc, G, n_max, seed, \
+                           seed_len, xb, mm, lab, nc, it);                                                \
+    } while (0)
 #define MVMC_ALS2(NM)                                                                                     \
     hipLaunchKernelGGL((als2_kernel<TW, NM>), dim3(F), dim3(64), 0, s, W, gc, G, n_max, seed, seed_len, xb, mm, \
                        lab, nc, it)
@@ -1617,6 +2081,12 @@ static int launch_als(const TW* W, const int32_t* gc, int F, int G, int n_max, i
     else if (n_max <= 32 && r_max <= 16) { if (few) MVMC_ALS4(32); else MVMC_ALS2(32); }
     else if (n_max <= 24) MVMC_ALS(24, 24, 64);
     else if (n_max <= 32) MVMC_ALS(32, 32, 128);
+    else if (n_max <= 72 && r_max <= 16 && few) {   // config 5 (C8 P8, + 8 tracklets): the workgroup form the chain kernel's BIG layout runs
+        const size_t lds = sizeof(Als5Lds<72>);
+        if (hipFuncSetAttribute((const void*)als5_kernel<TW, 72>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return MVMC_ERR_LAUNCH;
+        hipLaunchKernelGGL((als5_kernel<TW, 72>), dim3(F), dim3(256), lds, s, W, gc, G, n_max, seed, seed_len, xb, mm, lab, nc, it);
+    }
     else if (n_max <= 64) MVMC_ALS(64, 16, 256);
     else if (n_max <= 80) MVMC_ALS(80, 16, 512);
     else return MVMC_ERR_UNSUPPORTED;

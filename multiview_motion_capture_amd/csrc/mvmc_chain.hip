@@ -19,7 +19,13 @@
 
 namespace {
 
-constexpr int CH_VM = 6;   // views per IK problem (v_max <= 6)
+// Two layouts.  SMALL (configs 1-4: N = C P <= 40 nodes, <= 6 views per person): the rank-8 workgroup ALS variants, 52 KB of LDS,
+// three workgroups per CU.  BIG (config 5, C8 P8: N <= 64, N + T <= 72, <= 8 views per person): the generic workgroup ALS (rank
+// <= 16: als5_graph, X1 as a dense n x n matrix in LDS, the element state in registers), 74 KB of LDS in a dynamic allocation, one
+// workgroup per CU (512 VGPRs per thread).
+template <bool BIG> struct ChainCfg;
+template <> struct ChainCfg<false> { static constexpr int VM = 6, N_MAX = 40, NS_MAX = 48, WG_PER_CU = 3; };
+template <> struct ChainCfg<true> { static constexpr int VM = 8, N_MAX = 64, NS_MAX = 72, WG_PER_CU = 1; };
 
 struct ChainArgs {
     // inputs
@@ -70,52 +76,72 @@ struct ChainArgs {
     unsigned* flags;          // (B + 1) parts completed per chain; [B] = timeout word.  Zeroed by the launcher
 };
 
-constexpr int CH_EOFF = 2368;   // doubles of graph scratch in front of the pose-pair block (NS <= 48: 48 * 48 + 6 + 48 = 2358)
+constexpr int CH_EOFF = 2368;   // SMALL: doubles of graph scratch in front of the pose-pair block (NS <= 48: 48 * 48 + 6 + 48 = 2358)
 
-union ChainArena {
-    Als4Lds<32> als64;
-    Als4Lds<24> als32;
-    Ik1Shared<CH_VM> ik[4];
+template <bool BIG> union ChainArena;
+template <> union ChainArena<false> {
+    Als4Lds<32> als_st;
+    Als4Lds<24> als_sp;
+    Ik1Shared<6> ik[4];
     // graph scratch: st_affinity_wave needs (NS*NS + 6) doubles + 2 NS ints (NS <= 48), affinity_wave N*51 doubles + 2 N*N floats
     // + 2 N ints + 4 words (N <= 40)
     // + the pose-pair block made ahead of the hand-over (st_pose_pairs: N * N doubles behind st_affinity_wave's part)
     double graph[CH_EOFF + 40 * 40];
 };
+template <> union ChainArena<true> {
+    Als5Lds<72> als;
+    Ik1Shared<8> ik[4];
+    double graph[64 * 51 + 64 * 64 + 64 + 16];   // affinity_wave at N = 64 (st_affinity_wave at NS = 72 needs 72 * 72 + 6 + 72)
+};
 static_assert(CH_EOFF >= 48 * 48 + 6 + 48 && CH_EOFF + 40 * 40 >= 40 * 51 + 40 * 40 + 40 + 8, "graph scratch covers both graph builders");
-static_assert(sizeof(ChainArena) <= 4 * sizeof(Ik1Shared<CH_VM>), "the IK blocks set the arena size");
+static_assert(sizeof(ChainArena<false>) <= 4 * sizeof(Ik1Shared<6>), "SMALL: the IK blocks set the arena size");
+static_assert(64 * 51 + 64 * 64 + 64 + 16 >= 72 * 72 + 6 + 72, "BIG: graph scratch covers both graph builders");
+static_assert(sizeof(ChainArena<true>) <= 80 * 1024, "BIG: half of a CU's LDS");
 
 // The phases as separate (non-inlined) functions: each gets its own register allocation inside the workgroup's budget
 // of 168 VGPRs (three workgroups per CU) instead of one allocation over the union of all phases.
-__device__ __noinline__ void chain_graph_spatial(ChainArena& arena, const ChainArgs& A, int b, int f) {
+template <bool BIG>
+__device__ __noinline__ void chain_graph_spatial(ChainArena<BIG>& arena, const ChainArgs& A, int b, int f) {
     MVMC_ASSUME_LDS(&arena);
     const int C = A.C, P = A.P, N = C * P;
     float* S = A.S_sp + (size_t)b * N * N;
     if ((threadIdx.x >> 6) == 0) affinity_wave(arena.graph, A.kps17, A.counts, A.Fm, C, P, f, nullptr, S);
 }
-__device__ __noinline__ void chain_graph_temporal(ChainArena& arena, const ChainArgs& A, int b, int f, bool pairs_ready) {
+template <bool BIG>
+__device__ __noinline__ void chain_graph_temporal(ChainArena<BIG>& arena, const ChainArgs& A, int b, int f, bool pairs_ready) {
     MVMC_ASSUME_LDS(&arena);
     const int C = A.C, P = A.P, T = A.T, NS = T + C * P;
     double* W = A.W_st + (size_t)b * NS * NS;
     st_affinity_wave<true>(arena.graph, A.kps17, A.counts, 0, f, A.joints + (size_t)b * T * 54, A.n_tracks + b, A.Pm, A.F2, C, P,
-                           T, 0.1, W, nullptr, A.gc + (size_t)b * (C + 1), pairs_ready ? arena.graph + CH_EOFF : nullptr, C * P);
+                           T, 0.1, W, nullptr, A.gc + (size_t)b * (C + 1), (!BIG && pairs_ready) ? arena.graph + CH_EOFF : nullptr, C * P);
 }
 // the frame's 2-D / 2-D distances, made while the workgroup waits for its predecessor (they do not depend on the tracklets)
-__device__ __noinline__ void chain_pose_pairs(ChainArena& arena, const ChainArgs& A, int f) {
+__device__ __noinline__ void chain_pose_pairs(ChainArena<false>& arena, const ChainArgs& A, int f) {
     MVMC_ASSUME_LDS(&arena);
     st_pose_pairs(arena.graph + CH_EOFF, A.kps17, A.counts, f, A.F2, A.C, A.P, 0.1);
 }
-__device__ __noinline__ void chain_als_spatial(ChainArena& arena, const ChainArgs& A, int b, int f) {
+template <bool BIG>
+__device__ __noinline__ void chain_als_spatial(ChainArena<BIG>& arena, const ChainArgs& A, int b, int f) {
     MVMC_ASSUME_LDS(&arena);
     const int C = A.C, N = C * A.P;
     // batch index 0 with pre-offset pointers: the graph, its group counts (the frame's people per view) and outputs
-    als4_graph<float, 24>(arena.als32, 0, A.S_sp + (size_t)b * N * N, A.counts + (size_t)f * C, C, N, A.seed, A.seed_len, nullptr,
-                          nullptr, A.labels_sp + (size_t)b * N, A.ncl_sp + b, A.iters_sp + b);
+    if constexpr (BIG)
+        als5_graph<float, 72>(arena.als, 0, A.S_sp + (size_t)b * N * N, A.counts + (size_t)f * C, C, N, A.seed, A.seed_len,
+                                          nullptr, nullptr, A.labels_sp + (size_t)b * N, A.ncl_sp + b, A.iters_sp + b);
+    else
+        als4_graph<float, 24>(arena.als_sp, 0, A.S_sp + (size_t)b * N * N, A.counts + (size_t)f * C, C, N, A.seed, A.seed_len, nullptr,
+                              nullptr, A.labels_sp + (size_t)b * N, A.ncl_sp + b, A.iters_sp + b);
 }
-__device__ __noinline__ void chain_als_temporal(ChainArena& arena, const ChainArgs& A, int b) {
+template <bool BIG>
+__device__ __noinline__ void chain_als_temporal(ChainArena<BIG>& arena, const ChainArgs& A, int b) {
     MVMC_ASSUME_LDS(&arena);
     const int C = A.C, NS = A.T + C * A.P;
-    als4_graph<double, 32>(arena.als64, 0, A.W_st + (size_t)b * NS * NS, A.gc + (size_t)b * (C + 1), C + 1, NS, A.seed, A.seed_len,
-                           nullptr, nullptr, A.labels_st + (size_t)b * NS, A.ncl_st + b, A.iters_st + b);
+    if constexpr (BIG)
+        als5_graph<double, 72>(arena.als, 0, A.W_st + (size_t)b * NS * NS, A.gc + (size_t)b * (C + 1), C + 1, NS, A.seed,
+                                           A.seed_len, nullptr, nullptr, A.labels_st + (size_t)b * NS, A.ncl_st + b, A.iters_st + b);
+    else
+        als4_graph<double, 32>(arena.als_st, 0, A.W_st + (size_t)b * NS * NS, A.gc + (size_t)b * (C + 1), C + 1, NS, A.seed, A.seed_len,
+                               nullptr, nullptr, A.labels_st + (size_t)b * NS, A.ncl_st + b, A.iters_st + b);
 }
 __device__ __noinline__ void chain_assign(const ChainArgs& A, int b, int f) {
     assign_chain(threadIdx.x & 63, 64, b, f, A.labels_sp, A.ncl_sp, A.labels_st, A.ncl_st, A.counts, A.n_tracks, A.params, A.C, A.P, A.T, A.K, A.V,
@@ -125,22 +151,25 @@ __device__ __noinline__ void chain_commit(const ChainArgs& A, int b) {
     commit_chain(threadIdx.x & 63, 64, b, A.status, A.n_new, A.ik_params, A.ik_joints, A.T, A.K, A.n_inits, A.params, A.joints, A.meta, A.n_tracks,
                  A.next_id, A.n_dead, A.slot_src);
 }
-__device__ __noinline__ void chain_ik(ChainArena& arena, const Ik1Tables& tables, const ChainArgs& A, int b) {
+template <bool BIG>
+__device__ __noinline__ void chain_ik(ChainArena<BIG>& arena, const Ik1Tables& tables, const ChainArgs& A, int b) {
     MVMC_ASSUME_LDS(&arena);
     MVMC_ASSUME_LDS(&tables);
     const int wave = threadIdx.x >> 6, NP = A.T + A.K;
     // wave w takes the problem slots w, w + 4, ... of this chain
     for (int s = wave; s < NP; s += 4) {
         const int p = b * NP + s;
-        ik1_solve<CH_VM>(arena.ik[wave], tables, A.kps17, A.Pm, A.members, p, A.V, A.C, A.P, A.init, A.cold, A.nfev_cold,
+        ik1_solve<ChainCfg<BIG>::VM>(arena.ik[wave], tables, A.kps17, A.Pm, A.members, p, A.V, A.C, A.P, A.init, A.cold, A.nfev_cold,
                          A.nfev_warm, A.ik_params, A.ik_joints, A.ik_info,
                          A.ik_scratch + (ptrdiff_t)(b * 4 + wave - p) * MVMC_IK_SCRATCH_DOUBLES, 3, nullptr);
     }
 }
 
-__global__ void __launch_bounds__(256, 3)
+template <bool BIG>
+__global__ void __launch_bounds__(256, ChainCfg<BIG>::WG_PER_CU)
 chain_kernel(SkelDev skarg, ChainArgs A) {
-    __shared__ ChainArena arena;
+    extern __shared__ __attribute__((aligned(16))) unsigned char chain_lds[];   // the arena (BIG: 72 KB, beyond the static limit)
+    ChainArena<BIG>& arena = *reinterpret_cast<ChainArena<BIG>*>(chain_lds);
     __shared__ Ik1Tables tables;
     __shared__ int s_nt;
     // Workgroup (part, chain): block index = part * n_chains + chain, so every workgroup of part p is dispatched before
@@ -154,7 +183,7 @@ chain_kernel(SkelDev skarg, ChainArgs A) {
     // work that does not depend on the chain's state comes before the hand-over: the skeleton tables and, for a workgroup that has a
     // predecessor, the pose-pair block of its first frame's graph
     if (wave == 0) ik1_build_tables(tables, skarg);
-    if (part > 0) chain_pose_pairs(arena, A, b * A.L + t_lo);
+    if constexpr (!BIG) { if (part > 0) chain_pose_pairs(arena, A, b * A.L + t_lo); }
     if (part > 0) {
         // consumer side of the hand-off (cdna_hip_programming.md Guideline 16): one lane polls the chain's flag relaxed,
         // one agent-scope acquire, then the workgroup's barrier; the chain state is read with plain vector loads after it
@@ -184,15 +213,15 @@ chain_kernel(SkelDev skarg, ChainArgs A) {
         const int nt = s_nt;
         // ---- graph + association ----
         if (nt <= 0) {   // no live tracklets: match_spatial (motion_capture.py:597-631), f32 affinity
-            chain_graph_spatial(arena, A, b, f);
+            chain_graph_spatial<BIG>(arena, A, b, f);
             __syncthreads();
             lap(0);
-            chain_als_spatial(arena, A, b, f);
+            chain_als_spatial<BIG>(arena, A, b, f);
         } else {
-            chain_graph_temporal(arena, A, b, f, part > 0 && t == t_lo);
+            chain_graph_temporal<BIG>(arena, A, b, f, part > 0 && t == t_lo);
             __syncthreads();
             lap(0);
-            chain_als_temporal(arena, A, b);
+            chain_als_temporal<BIG>(arena, A, b);
         }
         __syncthreads();
         lap(1);
@@ -203,7 +232,7 @@ chain_kernel(SkelDev skarg, ChainArgs A) {
         if (wave == 0) chain_assign(A, b, f);   // clusters -> IK problems (bulk copies on the wave, the logic on lane 0)
         __syncthreads();
         lap(2);
-        chain_ik(arena, tables, A, b);
+        chain_ik<BIG>(arena, tables, A, b);
         __syncthreads();
         lap(3);
         if (wave == 0) chain_commit(A, b);      // tracklet table after the frame
@@ -248,12 +277,14 @@ extern "C" int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuff
     if (B.n_chains < 0 || B.chain_len <= 0 || B.n_views <= 0 || B.p_max <= 0 || B.t_max <= 0 || B.k_max <= 0 || B.v_max <= 0)
         return MVMC_ERR_ARG;
     if (B.max_nfev_cold < 1 || B.max_nfev_warm < 1) return MVMC_ERR_ARG;
-    // sizes the workgroup's LDS arena is built for (the launch-per-stage path covers everything else)
-    // (padded sizes; a frame's ACTUAL graph must have <= 24 nodes on the match_spatial path and <= 32 on the
-    //  match_spatial_time path -- checked on the device, flags[n_chains + 1])
-    if (B.n_views * B.p_max > 40 || B.t_max + B.n_views * B.p_max > 48 || B.v_max > CH_VM || B.n_views > 16 ||
-        2 * B.p_max > 16 || 2 * (B.t_max > B.p_max ? B.t_max : B.p_max) > 16)
-        return MVMC_ERR_UNSUPPORTED;
+    // sizes the two LDS layouts are built for (the launch-per-stage path covers everything else).  SMALL: padded sizes N <= 40,
+    // N + T <= 48, and a frame's ACTUAL graph must have <= 24 nodes on the match_spatial path and <= 32 on the match_spatial_time
+    // path -- checked on the device, flags[n_chains + 1].  BIG (C8 P8): N <= 64, N + T <= 72: every graph of those sizes fits.
+    const int N = B.n_views * B.p_max, NS = B.t_max + N;
+    if (B.n_views > 16 || 2 * B.p_max > 16 || 2 * (B.t_max > B.p_max ? B.t_max : B.p_max) > 16) return MVMC_ERR_UNSUPPORTED;
+    const bool small = N <= ChainCfg<false>::N_MAX && NS <= ChainCfg<false>::NS_MAX && B.v_max <= ChainCfg<false>::VM;
+    const bool big = N <= ChainCfg<true>::N_MAX && NS <= ChainCfg<true>::NS_MAX && B.v_max <= ChainCfg<true>::VM;
+    if (!small && !big) return MVMC_ERR_UNSUPPORTED;
     const void* need[] = {B.kps17, B.counts, B.Pmats, B.Fmats, B.F2, B.seed_table, B.params, B.joints, B.meta, B.n_tracks,
                           B.next_id, B.n_dead, B.slot_src, B.S_sp, B.W_st, B.group_counts, B.labels_sp, B.labels_st, B.n_clusters_sp,
                           B.n_clusters_st, B.iters_sp, B.iters_st, B.members, B.cold, B.init, B.status, B.n_new, B.ik_params, B.ik_joints, B.ik_info, B.ik_scratch,
@@ -282,7 +313,18 @@ extern "C" int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuff
     A.flags = B.flags;
     if (hipMemsetAsync(B.flags, 0, sizeof(unsigned) * ((size_t)B.n_chains + 4), (hipStream_t)stream) != hipSuccess)
         return MVMC_ERR_LAUNCH;
-    hipLaunchKernelGGL(chain_kernel, dim3(B.n_chains * A.parts), dim3(256), 0, (hipStream_t)stream, sk, A);
+    if (small) {
+        hipLaunchKernelGGL(chain_kernel<false>, dim3(B.n_chains * A.parts), dim3(256), sizeof(ChainArena<false>), (hipStream_t)stream, sk, A);
+    } else {
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)chain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)sizeof(ChainArena<true>)) != hipSuccess)
+                return MVMC_ERR_LAUNCH;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(chain_kernel<true>, dim3(B.n_chains * A.parts), dim3(256), sizeof(ChainArena<true>), (hipStream_t)stream, sk, A);
+    }
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;
 }

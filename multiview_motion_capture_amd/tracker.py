@@ -127,7 +127,9 @@ class ChainTracker:
     def fused_ok(self) -> bool:
         """Whether this tracker's padded sizes fit the chain kernel (include/mvmc.h: mvmc_chain_run)."""
         N = self.C * self.P
-        return N <= 40 and self.T + N <= 48 and self.V <= 6 and self.P <= 8 and self.T <= 8 and self.C <= 16
+        small = N <= 40 and self.T + N <= 48 and self.V <= 6
+        big = N <= 64 and self.T + N <= 72 and self.V <= 8
+        return (small or big) and self.P <= 8 and self.T <= 8 and self.C <= 16
 
 
 def run_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], chain_len: int, t_max=8,
@@ -272,8 +274,8 @@ def check_chain_flags(res) -> None:
     if fl[0]:
         raise RuntimeError("mvmc_chain_run: a hand-over between the workgroups of a chain timed out; results are void")
     if fl[1]:
-        raise ValueError("mvmc_chain_run: a frame's graph has more nodes than the chain kernel supports (24 without, 32 with "
-                         "tracklets); use run_chains")
+        raise ValueError("mvmc_chain_run: a frame's graph has more nodes than the chain kernel's layout supports (small layout: 24 "
+                         "without, 32 with tracklets); use run_chains")
 
 
 _CHAIN_SCRATCH = {}

@@ -50,7 +50,7 @@ def test_sizes_outside_the_arena_are_refused():
     from multiview_motion_capture_amd._cabi import MvmcError
     from multiview_motion_capture_amd.pipeline import HotPath
     from multiview_motion_capture_amd.tracker import run_chains_fused
-    data = synth.generate(8, 8, 8, 20260104, chain_len=4)      # config 5 geometry: 64 nodes per frame
+    data = synth.generate(8, 12, 8, 20260104, chain_len=4)     # 96 nodes per frame: beyond both layouts (config 5's 64 fit the BIG one)
     hp = HotPath(data["K"], data["Rt"])
     with pytest.raises(MvmcError):
         run_chains_fused(hp, torch.from_numpy(data["kps25"]).cuda(), torch.from_numpy(data["counts"]).cuda(), 4)

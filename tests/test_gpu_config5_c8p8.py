@@ -104,3 +104,50 @@ def test_temporal_graph_n72_vs_oracle(c5):
     assert np.array_equal(out["st"]["labels"][0, :n].cpu().numpy(), o.cluster_labels(mm_o, n))
     # every tracklet is matched in >= 2 views and continues (status 2), no new tracklets
     assert out["status"][0, :nt].cpu().tolist() == [2] * nt and int(out["n_new"][0]) == 0
+
+
+def test_chain_kernel_big_layout_is_bit_identical_to_the_staged_path(c5):
+    """Config 5 on the persistent chain kernel (mvmc_chain_run, BIG layout: N = 64, N + T = 72, rank 16, 8 views per person): the
+    same device functions as the launch-per-stage path, so the same results bit for bit -- and that path is the one the tests above
+    and below compare with the oracle."""
+    from multiview_motion_capture_amd.tracker import check_chain_flags, run_chains, run_chains_fused
+    a = run_chains(c5["hp"], c5["kps"], c5["cnt"], L, t_max=8, want_info=True)
+    for parts in (None, 1, 4):
+        b = run_chains_fused(c5["hp"], c5["kps"], c5["cnt"], L, t_max=8, want_info=True, parts=parts)
+        torch.cuda.synchronize()
+        check_chain_flags(b)
+        assert torch.equal(a["n_tracks"], b["n_tracks"]) and torch.equal(a["meta"], b["meta"]) and torch.equal(a["n_dead"], b["n_dead"])
+        n = a["n_tracks"].cpu().numpy()
+        ja, jb, pa, pb = a["joints"].cpu().numpy(), b["joints"].cpu().numpy(), a["params"].cpu().numpy(), b["params"].cpu().numpy()
+        for f in range(F):
+            assert np.array_equal(ja[f, :n[f]], jb[f, :n[f]]) and np.array_equal(pa[f, :n[f]], pb[f, :n[f]]), f
+    joints, gt = b["joints"].cpu().numpy(), c5["data"]["gt_joints"]
+    errs = np.concatenate([np.linalg.norm(joints[f, :P, None] - gt[f][None], axis=-1).mean(axis=-1).min(axis=1) for f in range(F) if n[f] == P])
+    it = b["als_iters"].cpu().numpy()
+    print(f"C8 P8 fused: {100 * (n == P).mean():.1f}% frames with {P} tracks; median joint error {np.median(errs) * 100:.2f} cm; "
+          f"ALS iterations heads mean {it[:, 0].mean():.0f}, later frames mean {it[:, 1:].mean():.0f} max {it.max()}")
+    assert (n == P).mean() > 0.9 and np.median(errs) < 0.05
+
+
+def test_temporal_graph_n72_t8_vs_oracle(c5):
+    """The 72-node graph of the BIG layout (8 tracklets + 64 poses; the 256-thread generic ALS, n <= 72) against the oracle."""
+    from multiview_motion_capture_amd import device as dev
+    from multiview_motion_capture_amd.tracker import ChainTracker
+    hp = c5["hp"]
+    kps17, cnt = dev.ingest(c5["kps"][16:18].contiguous(), c5["cnt"][16:18].contiguous())
+    tr = ChainTracker(hp, 1, P, t_max=8)
+    tr.step(kps17[0:1].contiguous(), cnt[0:1].contiguous())
+    nt = int(tr.n_tracks[0])
+    assert nt == P
+    joints0 = tr.joints[0, :nt].cpu().numpy()
+    out = tr.step(kps17[1:2].contiguous(), cnt[1:2].contiguous(), want_debug=True)
+    k17, c1 = kps17[1].cpu().numpy(), cnt[1].cpu().numpy()
+    views = [[k17[c, p] for p in range(c1[c])] for c in range(C)]
+    D_o, dim = o.spatial_time_distance([joints0[k] for k in range(nt)], views, hp.P.cpu().numpy())
+    _, S_o = o.spatial_time_affinity(D_o)
+    mm_o, xb_o, it_o = o.match_als(S_o, dim, return_iters=True)
+    n = dim[-1]
+    assert n == 72
+    assert np.array_equal(out["st"]["x_bin"][0, :n, :n].cpu().numpy().astype(bool), xb_o)
+    assert np.array_equal(out["st"]["labels"][0, :n].cpu().numpy(), o.cluster_labels(mm_o, n))
+    assert abs(int(out["st"]["iters"][0]) - it_o) <= 2
