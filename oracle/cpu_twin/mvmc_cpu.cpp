@@ -1,10 +1,643 @@
-// TEST INFRASTRUCTURE: host build of csrc/mvmc_trf_faithful.h for checks against SciPy (tests/test_trf_faithful_cpu.py)
-#include <vector>
+// C++ CPU twin of the hot path (TEST INFRASTRUCTURE -- never linked into the product library).
+//
+// The second CPU restatement of the reference's per-frame path next to oracle/oracle_np.py + tracker_np.py: plain C++17, -O3,
+// OpenMP over the independent chains of the benchmark protocol, host pointers, the same stage semantics as include/mvmc.h's entry
+// points.  bench.py times it as the second cpu_baseline (what a compiled CPU implementation of the reference's algorithm achieves on
+// the box's host cores); tests/test_cpu_twin.py checks it against the same golden fixtures as the NumPy oracle.
+//
+// Follows (reference file:line): ingest pose_def.py:262-270 + motion_capture.py:1023-1043; F-matrices mv_math_util.py:267-285;
+// affinity mv_math_util.py:288-351; match_als mv_association.py:222-318 with transform_closure :99-121 and the cluster rule of
+// parse_match_result motion_capture.py:417-446; match_spatial_time motion_capture.py:634-826 with calc_epipolar_error
+// mv_math_util.py:57-115 and reprojection_error motion_capture.py:403-414; DLT + post-optimisation mv_math_util.py:152-240;
+// PoseSolver.solve inverse_kinematics.py:351-433 -- the least_squares calls through csrc/mvmc_trf_faithful.h, the literal restatement
+// of SciPy's TRF (2-point finite differences, SVD step); tracker MvTracklet / MvTracker.update_4d motion_capture.py:312-400,873-963.
+#include <math.h>
+#include <omp.h>
+#include <stdint.h>
 #include <string.h>
+
+#include <algorithm>
+#include <random>
+#include <vector>
+
 #include "../../multiview_motion_capture_amd/csrc/mvmc_trf_faithful.h"
+
 using namespace trf_faithful;
-extern "C" int trf_check_ik(const double* dirs, const int* parents, const int* side_map, int n_side, const double* pose18, const double* Pm,
-                            int nv, const double* side_fixed, int stage, int max_nfev, double* x, double* out4) {
+
+namespace {
+
+const int kOp25ToCoco17[17] = {0, 16, 15, 18, 17, 5, 2, 6, 3, 7, 4, 12, 9, 13, 10, 14, 11};
+const double kSkelOffsets[18][3] = {{0, 0, 0}, {0.15, 0, 0}, {0, 0, -0.5}, {0, 0, -0.5}, {-0.15, 0, 0}, {0, 0, -0.5}, {0, 0, -0.5},
+                                    {0, 0, 0.3}, {0, 0, 0.3}, {0.2, 0, 0}, {0.3, 0, 0}, {0.3, 0, 0}, {-0.2, 0, 0}, {-0.3, 0, 0},
+                                    {-0.3, 0, 0}, {0, -0.02, 0.15}, {0.07, 0.02, 0.1}, {-0.07, 0.02, 0.1}};
+const int kParents[18] = {-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 9, 10, 8, 12, 13, 8, 15, 15};
+const int kSideMap[18] = {7, 0, 1, 2, 0, 1, 2, 8, 9, 3, 4, 5, 3, 4, 5, 10, 6, 6};
+const int kSideJoints[11] = {1, 2, 3, 9, 10, 11, 16, 0, 7, 8, 15};
+const int kRpSkel[15] = {1, 2, 3, 4, 5, 6, 9, 10, 11, 12, 13, 14, 15, 16, 17};
+const int kRpCoco[15] = {11, 13, 15, 12, 14, 16, 5, 7, 9, 6, 8, 10, 0, 3, 4};
+
+struct SkelConst {
+    Skel sk;
+    double ref_side[11];
+    SkelConst() {
+        for (int j = 0; j < 18; ++j) {
+            const double* o = kSkelOffsets[j];
+            const double len = sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
+            for (int k = 0; k < 3; ++k) sk.dirs[j][k] = j == 0 ? o[k] : o[k] / len;
+            sk.parents[j] = kParents[j];
+            sk.side_map[j] = kSideMap[j];
+        }
+        sk.n_side = 11;
+        for (int s = 0; s < 11; ++s) {
+            const double* o = kSkelOffsets[kSideJoints[s]];
+            ref_side[s] = sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
+        }
+    }
+};
+const SkelConst& skel() { static SkelConst s; return s; }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// IN-1 / IN-2
+// ---------------------------------------------------------------------------------------------------------------------------------
+bool pose_is_good(const double* k17) {
+    int valid = 0;
+    double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+    for (int j = 0; j < 17; ++j)
+        if (k17[j * 3 + 2] > 0.01) {
+            ++valid;
+            for (int c = 0; c < 2; ++c) { lo[c] = std::min(lo[c], k17[j * 3 + c]); hi[c] = std::max(hi[c], k17[j * 3 + c]); }
+        }
+    if (valid < 4) return false;
+    return !(hi[0] - lo[0] < 5.0 || hi[1] - lo[1] < 5.0);
+}
+
+// one frame: -> per view the kept poses (17 x 3 doubles each)
+template <class T>
+void ingest_frame(const T* kps, const int32_t* counts, int C, int P, int Jin, std::vector<std::vector<double>>& views) {
+    views.assign(C, {});
+    for (int c = 0; c < C; ++c) {
+        const int cnt = counts ? std::min(std::max(counts[c], 0), P) : P;
+        for (int p = 0; p < cnt; ++p) {
+            double k17[51];
+            const T* src = kps + ((size_t)c * P + p) * Jin * 3;
+            for (int j = 0; j < 17; ++j) {
+                const int sj = Jin == 25 ? kOp25ToCoco17[j] : j;
+                for (int e = 0; e < 3; ++e) k17[j * 3 + e] = (double)src[sj * 3 + e];
+            }
+            if (pose_is_good(k17)) views[c].insert(views[c].end(), k17, k17 + 51);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// AS-1
+// ---------------------------------------------------------------------------------------------------------------------------------
+void m3mul(const double* A, const double* B, double* O) {
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) O[r * 3 + c] = A[r * 3] * B[c] + A[r * 3 + 1] * B[3 + c] + A[r * 3 + 2] * B[6 + c];
+}
+void m3t(const double* A, double* O) { for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) O[r * 3 + c] = A[c * 3 + r]; }
+void m3v(const double* A, const double* x, double* o) { for (int r = 0; r < 3; ++r) o[r] = A[r * 3] * x[0] + A[r * 3 + 1] * x[1] + A[r * 3 + 2] * x[2]; }
+void m3inv(const double* A, double* O) {
+    const double det = A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+    const double id = 1.0 / det;
+    O[0] = (A[4] * A[8] - A[5] * A[7]) * id; O[1] = (A[2] * A[7] - A[1] * A[8]) * id; O[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+    O[3] = (A[5] * A[6] - A[3] * A[8]) * id; O[4] = (A[0] * A[8] - A[2] * A[6]) * id; O[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+    O[6] = (A[3] * A[7] - A[4] * A[6]) * id; O[7] = (A[1] * A[6] - A[0] * A[7]) * id; O[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+}
+
+void fmats(const double* K, const double* Rt, int C, float* F) {
+    for (int i = 0; i < C; ++i)
+        for (int j = 0; j < C; ++j) {
+            double R0[9], R1[9], T0[3], T1[3];
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c) { R0[r * 3 + c] = Rt[i * 12 + r * 4 + c]; R1[r * 3 + c] = Rt[j * 12 + r * 4 + c]; }
+                T0[r] = Rt[i * 12 + r * 4 + 3]; T1[r] = Rt[j * 12 + r * 4 + 3];
+            }
+            const double *K0 = K + i * 9, *K1 = K + j * 9;
+            double R1t[9], R0t[9], R01[9], K0i[9], K0it[9], K1t[9], t[3], v[3], m[9], m2[9], m3[9], sk[9], f[9];
+            m3t(R1, R1t); m3t(R0, R0t); m3mul(R0, R1t, R01);
+            m3v(R01, T1, t);
+            for (int k = 0; k < 3; ++k) t[k] = T0[k] - t[k];
+            m3mul(K1, R1, m); m3mul(m, R0t, m2); m3v(m2, t, v);
+            sk[0] = 0; sk[1] = -v[2]; sk[2] = v[1]; sk[3] = v[2]; sk[4] = 0; sk[5] = -v[0]; sk[6] = -v[1]; sk[7] = v[0]; sk[8] = 0;
+            m3inv(K0, K0i); m3t(K0i, K0it); m3t(K1, K1t);
+            m3mul(K0it, R01, m); m3mul(m, K1t, m3); m3mul(m3, sk, f);
+            float* o = F + ((size_t)i * C + j) * 9;
+            float sum = 0.f;
+            for (int k = 0; k < 9; ++k) { o[k] = (float)f[k]; sum += o[k]; }
+            if (sum == 0.f) for (int k = 0; k < 9; ++k) o[k] += 1e-12f;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// AS-2 / AS-3 (operation order of NumPy, as csrc/mvmc_assoc.hip restates it; this file is built with -ffp-contract=off)
+// ---------------------------------------------------------------------------------------------------------------------------------
+float np_pairwise_sum_f32(const float* a, int n) {
+    if (n < 8) {
+        float r = -0.0f;
+        for (int i = 0; i < n; ++i) r = r + a[i];
+        return r;
+    }
+    if (n <= 128) {
+        float r[8];
+        for (int k = 0; k < 8; ++k) r[k] = a[k];
+        int i = 8;
+        for (; i < n - (n % 8); i += 8) for (int k = 0; k < 8; ++k) r[k] = r[k] + a[i + k];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res = res + a[i];
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum_f32(a, n2) + np_pairwise_sum_f32(a + n2, n - n2);
+}
+
+double proj_dist(const double* pa, const double* pb, const float* F) {
+    double f[9], d[17];
+    for (int k = 0; k < 9; ++k) f[k] = (double)F[k];
+    for (int j = 0; j < 17; ++j) {
+        const double x = pa[j * 3], y = pa[j * 3 + 1];
+        double a = (f[0] * x + f[3] * y) + f[6];
+        double b = (f[1] * x + f[4] * y) + f[7];
+        double c = (f[2] * x + f[5] * y) + f[8];
+        const double nu = a * a + b * b;
+        const double sc = nu != 0.0 ? 1.0 / sqrt(nu) : 1.0;
+        a = a * sc; b = b * sc; c = c * sc;
+        d[j] = fabs((a * pb[j * 3] + b * pb[j * 3 + 1]) + c);
+    }
+    double r[8];
+    for (int k = 0; k < 8; ++k) r[k] = d[k] + d[8 + k];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    res = res + d[16];
+    return res / 17.0;
+}
+
+// nodes: n poses (51 doubles each) with their view; D, S (n x n) f32
+void geometry_affinity(const std::vector<const double*>& pose, const std::vector<int>& view, const float* F, int C, float* D, float* S) {
+    const int n = (int)pose.size();
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) D[i * n + j] = i == j ? 0.f : 50.f;
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j) {
+            const int a = view[i], b = view[j];
+            if (a == b) continue;
+            const double dab = proj_dist(pose[i], pose[j], F + ((size_t)a * C + b) * 9);
+            const double dba = proj_dist(pose[j], pose[i], F + ((size_t)b * C + a) * 9);
+            const float v = (float)(0.5 * (dab + dba));
+            D[i * n + j] = v; D[j * n + i] = v;
+        }
+    const int nn = n * n;
+    if (nn == 0) return;
+    const float mean = np_pairwise_sum_f32(D, nn) / (float)nn;
+    std::vector<float> tmp(nn);
+    for (int e = 0; e < nn; ++e) { const float x = D[e] - mean; tmp[e] = x * x; }
+    const float sd = sqrtf(np_pairwise_sum_f32(tmp.data(), nn) / (float)nn);
+    for (int e = 0; e < nn; ++e) {
+        const float a = -(D[e] - mean) / sd;
+        const float t = -5.f * a;
+        S[e] = 1.f / (1.f + (float)exp((double)t));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// AS-4 / AS-5 / AS-6
+// ---------------------------------------------------------------------------------------------------------------------------------
+const double* als_seed() {   // numpy.random.RandomState(0).rand(): MT19937, 53-bit doubles
+    static std::vector<double> t;
+    if (t.empty()) {
+        std::mt19937 g(0);
+        t.resize(80 * 80);
+        for (double& v : t) { const uint32_t a = g() >> 5, b = g() >> 6; v = (a * 67108864.0 + b) / 9007199254740992.0; }
+    }
+    return t.data();
+}
+
+void inv_small(double* M, int r) {   // in place, Gauss-Jordan with partial pivoting (the reference: np.linalg.inv)
+    std::vector<double> I((size_t)r * r, 0.0);
+    for (int i = 0; i < r; ++i) I[i * r + i] = 1.0;
+    for (int p = 0; p < r; ++p) {
+        int best = p;
+        for (int i = p + 1; i < r; ++i) if (fabs(M[i * r + p]) > fabs(M[best * r + p])) best = i;
+        if (best != p) for (int c = 0; c < r; ++c) { std::swap(M[p * r + c], M[best * r + c]); std::swap(I[p * r + c], I[best * r + c]); }
+        const double inv = 1.0 / M[p * r + p];
+        for (int c = 0; c < r; ++c) { M[p * r + c] *= inv; I[p * r + c] *= inv; }
+        for (int i = 0; i < r; ++i) {
+            if (i == p) continue;
+            const double f = M[i * r + p];
+            if (f == 0.0) continue;
+            for (int c = 0; c < r; ++c) { M[i * r + c] -= f * M[p * r + c]; I[i * r + c] -= f * I[p * r + c]; }
+        }
+    }
+    memcpy(M, I.data(), sizeof(double) * r * r);
+}
+
+// W (n x n, leading dimension ldw; f32 keeps iteration 1's X update in float32 as NumPy's dtype propagation does); group sizes gc[G]
+// -> x_bin, match_mat (n x n u8, may be null), labels (n), returns iterations (-1: nothing to do)
+template <class TW>
+int match_als(const TW* Win, int ldw, const int* gc, int G, uint8_t* x_bin, uint8_t* match_mat, int32_t* labels, int* n_clusters) {
+    int n = 0, gmax = 0;
+    std::vector<int> gid;
+    for (int g = 0; g < G; ++g) { for (int k = 0; k < gc[g]; ++k) gid.push_back(g); n += gc[g]; gmax = std::max(gmax, gc[g]); }
+    if (n_clusters) *n_clusters = 0;
+    if (n == 0) return 0;
+    const int r = std::min(n, 2 * gmax);
+    std::vector<double> W((size_t)n * n), X(W.size()), Z(W.size()), Y(W.size(), 0.0), X0(W.size()), A((size_t)n * r), B((size_t)n * r),
+        Gm((size_t)r * r), H((size_t)r * n);
+    std::vector<float> W32((size_t)n * n);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            if (sizeof(TW) == 4) { W32[i * n + j] = 0.5f * ((float)Win[i * ldw + j] + (float)Win[j * ldw + i]); W[i * n + j] = (double)W32[i * n + j]; }
+            else W[i * n + j] = 0.5 * ((double)Win[i * ldw + j] + (double)Win[j * ldw + i]);
+        }
+    X = W; Z = W;
+    const double* seed = als_seed();
+    for (int e = 0; e < n * r; ++e) A[e] = seed[e];
+    double mu = 64.0;
+    int iters = 1000;
+    auto factor = [&](const std::vector<double>& Fa, std::vector<double>& Out, bool transpose_x) {
+        // Out = (inv(Fa^T Fa + rho I) (Fa^T X'))^T, X' = X (transpose_x false) or X^T
+        const double rho = 50.0 / mu;
+        for (int a = 0; a < r; ++a)
+            for (int b = 0; b < r; ++b) {
+                double s = 0.0;
+                for (int k = 0; k < n; ++k) s += Fa[k * r + a] * Fa[k * r + b];
+                Gm[a * r + b] = s + (a == b ? rho : 0.0);
+            }
+        inv_small(Gm.data(), r);
+        for (int a = 0; a < r; ++a)
+            for (int j = 0; j < n; ++j) {
+                double s = 0.0;
+                for (int k = 0; k < n; ++k) s += Fa[k * r + a] * (transpose_x ? X[j * n + k] : X[k * n + j]);
+                H[a * n + j] = s;
+            }
+        for (int j = 0; j < n; ++j)
+            for (int a = 0; a < r; ++a) {
+                double s = 0.0;
+                for (int b = 0; b < r; ++b) s += Gm[a * r + b] * H[b * n + j];
+                Out[j * r + a] = s;
+            }
+    };
+    for (int it = 0; it < 1000; ++it) {
+        X0 = X;
+        for (int e = 0; e < n * n; ++e) {
+            if (sizeof(TW) == 4 && it == 0) { const float q = (-W32[e] + 0.1f) / 64.f; X[e] = (double)(W32[e] - q); }
+            else X[e] = Z[e] - ((Y[e] - W[e]) + 0.1) / mu;
+        }
+        factor(A, B, false);
+        factor(B, A, true);
+        double ap = 0.0, ad = 0.0;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                double x = 0.0;
+                for (int a = 0; a < r; ++a) x += A[i * r + a] * B[j * r + a];
+                double zz = x + Y[i * n + j] / mu;
+                if (gid[i] == gid[j]) zz = 0.0;
+                if (i == j) zz = 1.0;
+                zz = zz < 0.0 ? 0.0 : (zz > 1.0 ? 1.0 : zz);
+                const double dz = x - zz, dx = x - X0[i * n + j];
+                Y[i * n + j] += mu * dz;
+                Z[i * n + j] = zz;
+                X[i * n + j] = x;
+                ap += dz * dz; ad += dx * dx;
+            }
+        const double p_res = sqrt(ap) / n, d_res = mu * sqrt(ad) / n;
+        if (p_res < 1e-4 && d_res < 1e-4) { iters = it + 1; break; }
+        if (p_res > 10 * d_res) mu = 2 * mu;
+        else if (d_res > 10 * p_res) mu = mu / 2;
+    }
+    std::vector<uint8_t> xb((size_t)n * n), tmp((size_t)n * n), out((size_t)n * n, 0), vis(n, 0);
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) xb[i * n + j] = 0.5 * (X[i * n + j] + X[j * n + i]) > 0.5;
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) tmp[i * n + j] = xb[i * n + j] | (xb[i * n + n - 1] & xb[(n - 1) * n + j]);
+    for (int i = 0; i < n; ++i) {
+        if (vis[i]) continue;
+        for (int j = 0; j < n; ++j) if (tmp[i * n + j]) { vis[j] = 1; out[j * n + i] = 1; }
+    }
+    std::vector<int> keep(n);
+    int nk = 0;
+    for (int c = 0; c < n; ++c) { int s = 0; for (int j = 0; j < n; ++j) s += out[j * n + c]; keep[c] = s >= 2; nk += keep[c]; }
+    for (int row = 0; row < n; ++row) {
+        int label = -1, ord = 0;
+        for (int c = 0; c < n; ++c) { if (!keep[c]) continue; if (out[row * n + c]) { label = ord; break; } ++ord; }
+        labels[row] = label;
+    }
+    if (n_clusters) *n_clusters = nk;
+    if (x_bin) memcpy(x_bin, xb.data(), xb.size());
+    if (match_mat) memcpy(match_mat, out.data(), out.size());
+    return iters;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// AS-7 / AS-8 / AS-9
+// ---------------------------------------------------------------------------------------------------------------------------------
+double det4(const double* r0, const double* r1, const double* r2, const double* r3) {
+    const double s0 = r0[0] * r1[1] - r0[1] * r1[0], s1 = r0[0] * r1[2] - r0[2] * r1[0], s2 = r0[0] * r1[3] - r0[3] * r1[0];
+    const double s3 = r0[1] * r1[2] - r0[2] * r1[1], s4 = r0[1] * r1[3] - r0[3] * r1[1], s5 = r0[2] * r1[3] - r0[3] * r1[2];
+    const double c5 = r2[2] * r3[3] - r2[3] * r3[2], c4 = r2[1] * r3[3] - r2[3] * r3[1], c3 = r2[1] * r3[2] - r2[2] * r3[1];
+    const double c2 = r2[0] * r3[3] - r2[3] * r3[0], c1 = r2[0] * r3[2] - r2[2] * r3[0], c0 = r2[0] * r3[1] - r2[1] * r3[0];
+    return s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+}
+void fmats_p(const double* Pm, int C, double* F2) {
+    const int rp[3][2] = {{1, 2}, {2, 0}, {0, 1}};
+    for (int a = 0; a < C; ++a)
+        for (int b = 0; b < C; ++b)
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j)
+                    F2[((size_t)a * C + b) * 9 + i * 3 + j] =
+                        det4(Pm + a * 12 + rp[j][0] * 4, Pm + a * 12 + rp[j][1] * 4, Pm + b * 12 + rp[i][0] * 4, Pm + b * 12 + rp[i][1] * 4);
+}
+double epipolar_error(const double* F, const double* k1, const double* k2, double min_score) {
+    double total = 0.0;
+    int cnt = 0;
+    for (int j = 0; j < 17; ++j) {
+        const double x1 = k1[j * 3], y1 = k1[j * 3 + 1], x2 = k2[j * 3], y2 = k2[j * 3 + 1];
+        if (!(k1[j * 3 + 2] * k2[j * 3 + 2] > min_score)) continue;
+        double a = F[0] * x1 + F[1] * y1 + F[2], b = F[3] * x1 + F[4] * y1 + F[5], c = F[6] * x1 + F[7] * y1 + F[8];
+        double nu = a * a + b * b, sc = nu != 0.0 ? 1.0 / sqrt(nu) : 1.0;
+        a *= sc; b *= sc; c *= sc;
+        const double d1 = fabs(a * x2 + b * y2 + c) / sqrt(a * a + b * b);
+        a = F[0] * x2 + F[3] * y2 + F[6]; b = F[1] * x2 + F[4] * y2 + F[7]; c = F[2] * x2 + F[5] * y2 + F[8];
+        nu = a * a + b * b; sc = nu != 0.0 ? 1.0 / sqrt(nu) : 1.0;
+        a *= sc; b *= sc; c *= sc;
+        const double d2 = fabs(a * x1 + b * y1 + c) / sqrt(a * a + b * b);
+        total = total + 0.5 * (d1 + d2);
+        ++cnt;
+    }
+    return cnt ? total / cnt : NAN;
+}
+double reproj_error(const double* joints, const double* k2, const double* P, double min_score) {
+    double total = 0.0;
+    int cnt = 0;
+    for (int m = 0; m < 15; ++m) {
+        const double* X = joints + kRpSkel[m] * 3;
+        const double* kp = k2 + kRpCoco[m] * 3;
+        if (!(kp[2] > min_score)) continue;
+        const double h0 = P[0] * X[0] + P[1] * X[1] + P[2] * X[2] + P[3], h1 = P[4] * X[0] + P[5] * X[1] + P[6] * X[2] + P[7];
+        const double h2 = P[8] * X[0] + P[9] * X[1] + P[10] * X[2] + P[11];
+        const double du = h0 / (1e-5 + h2) - kp[0], dv = h1 / (1e-5 + h2) - kp[1];
+        total += sqrt(du * du + dv * dv);
+        ++cnt;
+    }
+    return cnt ? total / cnt : NAN;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// IK-1 .. IK-4
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct Tracklet {
+    int id, state, hits, length;
+    double params[68], joints[54];
+};
+
+void add_mid_spine(const double* k17, double* k18) {
+    memcpy(k18, k17, 51 * sizeof(double));
+    for (int c = 0; c < 2; ++c) {
+        const double mid_sh = 0.5 * (k17[5 * 3 + c] + k17[6 * 3 + c]), mid_hip = 0.5 * (k17[11 * 3 + c] + k17[12 * 3 + c]);
+        k18[51 + c] = 0.5 * (mid_sh + mid_hip);
+    }
+    double sc = k17[5 * 3 + 2] * k17[6 * 3 + 2];
+    sc *= k17[11 * 3 + 2] * k17[12 * 3 + 2];
+    k18[53] = sc;
+}
+
+// poses: nv x 51, Pm: nv x 12; init null = cold.  -> params (68), joints (54); info {cost1, nfev1, status1, cost2, nfev2, status2}
+void pose_solver_solve(const std::vector<const double*>& poses, const std::vector<const double*>& projs, const double* init, int nfev_cold,
+                       int nfev_warm, double* params, double* joints, double* info, std::vector<double>& work) {
+    const int nv = (int)poses.size();
+    std::vector<double> pose18((size_t)nv * 54), Pm((size_t)nv * 12);
+    for (int v = 0; v < nv; ++v) { add_mid_spine(poses[v], &pose18[v * 54]); memcpy(&Pm[v * 12], projs[v], 12 * sizeof(double)); }
+    const SkelConst& S = skel();
+    double x[68], side0[11];
+    const int m = 32 * nv;
+    work.resize(std::max(work_doubles(m, 68), work_doubles(18 * nv, 54) + 54));
+    int max_nfev;
+    if (!init) {
+        double* p3d = work.data() + work_doubles(18 * nv, 54);
+        triangulate_postopt18(Serial(), pose18.data(), Pm.data(), nv, p3d, work.data());
+        for (int c = 0; c < 3; ++c) x[c] = 0.5 * (p3d[11 * 3 + c] + p3d[12 * 3 + c]);
+        for (int e = 0; e < 54; ++e) x[3 + e] = 0.0;
+        for (int s = 0; s < 11; ++s) x[57 + s] = S.ref_side[s];
+        max_nfev = nfev_cold;
+    } else {
+        memcpy(x, init, 68 * sizeof(double));
+        max_nfev = nfev_warm;
+    }
+    memcpy(side0, x + 57, 11 * sizeof(double));
+    IkResidual f1{&S.sk, pose18.data(), Pm.data(), side0, nv, 0};
+    const Result r1 = trf(Serial(), f1, 57, m, x, max_nfev, work.data());
+    IkResidual f2{&S.sk, pose18.data(), Pm.data(), side0, nv, 1};
+    const Result r2 = trf(Serial(), f2, 68, m, x, max_nfev, work.data());
+    memcpy(params, x, 68 * sizeof(double));
+    forward_kinematics(S.sk, x, x + 3, x + 57, joints);
+    if (info) { info[0] = r1.cost; info[1] = r1.nfev; info[2] = r1.status; info[3] = r2.cost; info[4] = r2.nfev; info[5] = r2.status; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// TK-1: MvTracker.update_4d for one chain-frame
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct ChainState {
+    std::vector<Tracklet> tracks;
+    int next_id = 0, n_dead = 0;
+};
+
+struct Calib {
+    int C;
+    const double* K;
+    const double* Rt;
+    std::vector<double> P, F2;
+    std::vector<float> F;
+};
+
+int update_frame(ChainState& st, const std::vector<std::vector<double>>& views, const Calib& cal, int nfev_cold, int nfev_warm,
+                 std::vector<double>& work) {
+    const int C = cal.C, T = (int)st.tracks.size();
+    // graph nodes: tracklets, then 2-D poses by view
+    std::vector<const double*> pose;
+    std::vector<int> view, local;
+    std::vector<int> gc;
+    if (T > 0) gc.push_back(T);
+    for (int c = 0; c < C; ++c) {
+        const int cnt = (int)views[c].size() / 51;
+        gc.push_back(cnt);
+        for (int p = 0; p < cnt; ++p) { pose.push_back(&views[c][p * 51]); view.push_back(c); local.push_back(p); }
+    }
+    const int n2 = (int)pose.size(), n = T + n2;
+    std::vector<int32_t> labels(std::max(n, 1), -1);
+    int ncl = 0;
+    if (T == 0) {
+        if (n2 > 0) {
+            std::vector<float> D((size_t)n2 * n2), S((size_t)n2 * n2);
+            geometry_affinity(pose, view, cal.F.data(), C, D.data(), S.data());
+            match_als<float>(S.data(), n2, gc.data(), (int)gc.size(), nullptr, nullptr, labels.data(), &ncl);
+        }
+    } else {
+        std::vector<double> D((size_t)n * n, 0.0), W((size_t)n * n);
+        double mx = -1e300;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                if (i == j) continue;
+                const int vi = i < T ? -1 : view[i - T], vj = j < T ? -1 : view[j - T];
+                double d;
+                if (vi >= 0 && vi == vj) d = NAN;
+                else if (vi >= 0 && vj >= 0) d = epipolar_error(&cal.F2[((size_t)vi * C + vj) * 9], pose[i - T], pose[j - T], 0.1);
+                else if (vi >= 0) d = reproj_error(st.tracks[j].joints, pose[i - T], &cal.P[vi * 12], 0.1);
+                else if (vj >= 0) d = reproj_error(st.tracks[i].joints, pose[j - T], &cal.P[vj * 12], 0.1);
+                else d = NAN;
+                D[i * n + j] = d;
+                if (d == d && d > mx) mx = d;
+            }
+        if (mx < 0.0) mx = 0.0;     // the diagonal's zeros take part in nanmax
+        for (int e = 0; e < n * n; ++e) {
+            double d = D[e];
+            if (!(d == d)) d = mx + 1.0;
+            double s = 1.0 / (1.0 + exp(5.0 * ((d - 15.0) / 30.0)));
+            if (s < 1e-3) s = 0.0;
+            if (s > 1.0) s = 1.0;
+            W[e] = s;
+        }
+        match_als<double>(W.data(), n, gc.data(), (int)gc.size(), nullptr, nullptr, labels.data(), &ncl);
+    }
+    // clusters -> matches (motion_capture.py:763-808, :618-626)
+    std::vector<std::vector<int>> tmatch(T);   // per tracklet: 2-D node indices (one per view, first wins)
+    std::vector<bool> tseen(T, false);
+    std::vector<std::vector<int>> fresh;
+    for (int k = 0; k < ncl; ++k) {
+        int tracklet = -1;
+        for (int t = 0; t < T; ++t) if (labels[t] == k) { tracklet = t; break; }
+        std::vector<int> mem;
+        std::vector<bool> used(C, false);
+        for (int q = 0; q < n2; ++q)
+            if (labels[T + q] == k) {
+                if (T > 0) { if (used[view[q]]) continue; used[view[q]] = true; }   // match_spatial keeps every member
+                mem.push_back(q);
+            }
+        if (tracklet >= 0) { if (!mem.empty()) { tmatch[tracklet] = mem; tseen[tracklet] = true; } }
+        else if (mem.size() >= 2) fresh.push_back(mem);
+    }
+    int n_solves = 0;
+    std::vector<Tracklet> next;
+    auto solve = [&](const std::vector<int>& mem, const double* init, Tracklet& tl) {
+        std::vector<const double*> ps, pr;
+        for (int q : mem) { ps.push_back(pose[q]); pr.push_back(&cal.P[view[q] * 12]); }
+        pose_solver_solve(ps, pr, init, nfev_cold, nfev_warm, tl.params, tl.joints, nullptr, work);
+        ++n_solves;
+    };
+    for (int t = 0; t < T; ++t) {
+        Tracklet tl = st.tracks[t];
+        if (!tseen[t]) { ++st.n_dead; continue; }            // max_age = 0: any miss kills
+        if (tmatch[t].size() >= 2) {
+            solve(tmatch[t], st.tracks[t].params, tl);
+            ++tl.hits; ++tl.length;
+            if (tl.state == 1 && tl.hits >= 3) tl.state = 2;
+        }
+        next.push_back(tl);
+    }
+    for (const auto& mem : fresh) {
+        Tracklet tl;
+        tl.id = st.next_id++; tl.state = 1; tl.hits = 1; tl.length = 1;
+        solve(mem, nullptr, tl);
+        next.push_back(tl);
+    }
+    st.tracks.swap(next);
+    return n_solves;
+}
+
+}  // namespace
+
+// =================================================================================================================================
+// C entry points (host pointers)
+// =================================================================================================================================
+extern "C" {
+
+int mvmc_cpu_fmats(const double* K, const double* Rt, int n_views, float* F) { fmats(K, Rt, n_views, F); return 0; }
+
+// one frame: kps17 (C,P,17,3) f64 (already ingested), counts (C) -> D, S (n,n) f32 compact; returns n
+int mvmc_cpu_affinity(const double* kps17, const int32_t* counts, const float* F, int C, int P, float* D, float* S) {
+    std::vector<const double*> pose;
+    std::vector<int> view;
+    for (int c = 0; c < C; ++c) for (int p = 0; p < counts[c]; ++p) { pose.push_back(kps17 + ((size_t)c * P + p) * 51); view.push_back(c); }
+    geometry_affinity(pose, view, F, C, D, S);
+    return (int)pose.size();
+}
+
+// W (n,n) dtype 0 = f32, 1 = f64; group sizes gc (G) -> x_bin, match_mat (n,n) u8, labels (n); returns iterations
+int mvmc_cpu_als(const void* W, int dtype, int n, const int32_t* gc, int G, uint8_t* x_bin, uint8_t* match_mat, int32_t* labels, int32_t* n_clusters) {
+    std::vector<int> g(gc, gc + G);
+    int ncl = 0;
+    const int it = dtype == 0 ? match_als<float>((const float*)W, n, g.data(), G, x_bin, match_mat, labels, &ncl)
+                              : match_als<double>((const double*)W, n, g.data(), G, x_bin, match_mat, labels, &ncl);
+    if (n_clusters) *n_clusters = ncl;
+    return it;
+}
+
+// one PoseSolver.solve: poses (nv,17,3), projs (nv,3,4), init (68) or null -> params (68), joints (54), info (6)
+int mvmc_cpu_pose_solve(const double* poses, const double* projs, int nv, const double* init, int nfev_cold, int nfev_warm, double* params,
+                        double* joints, double* info) {
+    std::vector<const double*> ps, pr;
+    for (int v = 0; v < nv; ++v) { ps.push_back(poses + v * 51); pr.push_back(projs + v * 12); }
+    std::vector<double> work;
+    pose_solver_solve(ps, pr, init, nfev_cold, nfev_warm, params, joints, info, work);
+    return 0;
+}
+
+// The benchmark protocol: chains of chain_len frames, MvTracker.update_4d per chain, OpenMP over the chains.
+//   kps (F,C,P,J_in,3) f32 (dtype 0) or f64 (1); counts (F,C) or null; outputs: the tracklet table after every frame
+//   out_params (F,T,68), out_joints (F,T,18,3), out_meta (F,T,4) {id, state, hits, length}, out_n_tracks (F), out_n_dead (F),
+//   out_n_solves (F).  n_threads <= 0: OpenMP's default.  Returns the number of threads used.
+int mvmc_cpu_chain_run(const double* K, const double* Rt, const void* kps, int dtype, const int32_t* counts, int n_frames, int n_views,
+                       int p_max, int n_joints_in, int chain_len, int t_max, int nfev_cold, int nfev_warm, int n_threads, double* out_params,
+                       double* out_joints, int32_t* out_meta, int32_t* out_n_tracks, int32_t* out_n_dead, int32_t* out_n_solves) {
+    const int C = n_views, P = p_max, L = chain_len, B = n_frames / L;
+    Calib cal;
+    cal.C = C; cal.K = K; cal.Rt = Rt;
+    cal.P.resize((size_t)C * 12);
+    for (int c = 0; c < C; ++c)
+        for (int r = 0; r < 3; ++r)
+            for (int k = 0; k < 4; ++k) {
+                double s = 0.0;
+                for (int q = 0; q < 3; ++q) s += K[c * 9 + r * 3 + q] * Rt[c * 12 + q * 4 + k];
+                cal.P[c * 12 + r * 4 + k] = s;
+            }
+    cal.F.resize((size_t)C * C * 9);
+    fmats(K, Rt, C, cal.F.data());
+    cal.F2.resize((size_t)C * C * 9);
+    fmats_p(cal.P.data(), C, cal.F2.data());
+    als_seed();
+    skel();
+    int used = 1;
+    const size_t frame_elems = (size_t)C * P * n_joints_in * 3;
+#pragma omp parallel num_threads(n_threads > 0 ? n_threads : omp_get_max_threads())
+    {
+#pragma omp single
+        used = omp_get_num_threads();
+        std::vector<double> work;
+        std::vector<std::vector<double>> views;
+#pragma omp for schedule(dynamic, 1)
+        for (int b = 0; b < B; ++b) {
+            ChainState st;
+            for (int t = 0; t < L; ++t) {
+                const int f = b * L + t;
+                const int32_t* cnt = counts ? counts + (size_t)f * C : nullptr;
+                if (dtype == 0) ingest_frame((const float*)kps + f * frame_elems, cnt, C, P, n_joints_in, views);
+                else ingest_frame((const double*)kps + f * frame_elems, cnt, C, P, n_joints_in, views);
+                const int ns = update_frame(st, views, cal, nfev_cold, nfev_warm, work);
+                const int nt = std::min((int)st.tracks.size(), t_max);
+                for (int s = 0; s < nt; ++s) {
+                    const Tracklet& tl = st.tracks[s];
+                    if (out_params) memcpy(out_params + ((size_t)f * t_max + s) * 68, tl.params, 68 * sizeof(double));
+                    if (out_joints) memcpy(out_joints + ((size_t)f * t_max + s) * 54, tl.joints, 54 * sizeof(double));
+                    if (out_meta) { int32_t* m = out_meta + ((size_t)f * t_max + s) * 4; m[0] = tl.id; m[1] = tl.state; m[2] = tl.hits; m[3] = tl.length; }
+                }
+                if (out_n_tracks) out_n_tracks[f] = (int)st.tracks.size();
+                if (out_n_dead) out_n_dead[f] = st.n_dead;
+                if (out_n_solves) out_n_solves[f] = ns;
+            }
+        }
+    }
+    return used;
+}
+
+// ---- checks of csrc/mvmc_trf_faithful.h built for the host (tests/test_trf_faithful_cpu.py) ----
+int trf_check_ik(const double* dirs, const int* parents, const int* side_map, int n_side, const double* pose18, const double* Pm,
+                 int nv, const double* side_fixed, int stage, int max_nfev, double* x, double* out4) {
     Skel sk;
     memcpy(sk.dirs, dirs, sizeof(sk.dirs));
     for (int j = 0; j < 18; ++j) { sk.parents[j] = parents[j]; sk.side_map[j] = side_map[j]; }
@@ -16,7 +649,7 @@ extern "C" int trf_check_ik(const double* dirs, const int* parents, const int* s
     out4[0] = r.cost; out4[1] = r.nfev; out4[2] = r.status; out4[3] = r.njev;
     return 0;
 }
-extern "C" int trf_check_postopt(const double* pose, const double* Pm, int nv, int n_pts, int max_nfev, double* x, double* out4) {
+int trf_check_postopt(const double* pose, const double* Pm, int nv, int n_pts, int max_nfev, double* x, double* out4) {
     PostoptResidual fun{pose, Pm, nv, n_pts};
     const int n = 3 * n_pts, m = fun.m();
     std::vector<double> work(work_doubles(m, n));
@@ -24,15 +657,11 @@ extern "C" int trf_check_postopt(const double* pose, const double* Pm, int nv, i
     out4[0] = r.cost; out4[1] = r.nfev; out4[2] = r.status; out4[3] = r.njev;
     return 0;
 }
-extern "C" int trf_check_svd(int m, int n, double* A /* col-major, ld = max(m,n) */, double* f, double* s, double* suf, double* V) {
-    const int mm = m > n ? m : n;
-    std::vector<double> fq(f, f + mm);
-    svd_pieces(Serial(), m, n, A, mm, fq.data(), s, suf, V);
-    return 0;
-}
-extern "C" int trf_check_triangulate18(const double* pose18, const double* Pm, int nv, double* x54, double* dlt54) {
+int trf_check_triangulate18(const double* pose18, const double* Pm, int nv, double* x54, double* dlt54) {
     for (int j = 0; j < 18; ++j) dlt_point(pose18, Pm, nv, j, 0.01, dlt54 + 3 * j);
     std::vector<double> work(work_doubles(18 * nv, 54));
     triangulate_postopt18(Serial(), pose18, Pm, nv, x54, work.data());
     return 0;
 }
+
+}  // extern "C"
