@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVMC_ABI_VERSION 1
+#define MVMC_ABI_VERSION 2
 
 enum {
     MVMC_OK = 0,
@@ -189,21 +189,24 @@ int mvmc_st_affinity(const double* kps17, const int32_t* counts, const int32_t* 
  * Chains without tracklets read labels_sp (B,C*P) (match_spatial, every member kept); the others read
  * labels_st (B,T+C*P) (tracklet-anchored clusters, one pose per view, first wins).
  *   members (B,T+K,V) pose indices; cold (B,T+K) u8; init_params (B,T+K,68);
- *   status (B,T) i32: 0 unmatched (dies), 1 one view (kept, not updated), 2 updated; n_new (B) new tracklets */
+ *   status (B,T) i32: 0 unmatched (dies), 1 one view (kept, not updated), 2 updated; n_new (B) new tracklets;
+ *   overflow (B) i32 in/out or NULL: bit 0 is OR-ed in where a cluster (more than k_max new ones) or a member (more than v_max
+ *   views) was dropped for lack of room -- the reference has no such caps */
 int mvmc_track_assign(const int32_t* labels_sp, const int32_t* ncl_sp, const int32_t* labels_st,
                       const int32_t* ncl_st, const int32_t* counts, const int32_t* frame_idx,
                       const int32_t* n_tracks, const double* track_params, int n_chains, int n_views, int p_max,
                       int t_max, int k_max, int v_max, int32_t* members, uint8_t* cold, double* init_params,
-                      int32_t* status, int32_t* n_new, mvmcStream_t stream);
+                      int32_t* status, int32_t* n_new, int32_t* overflow, mvmcStream_t stream);
 
 /* TK-1, second half (MvTracklet.update / mark_missed / __init__, motion_capture.py:352-391, :924-963):
  * applies the frame's IK results to the tracklet table (order kept, survivors first, new ones appended).
  *   meta (B,T,4) i32 = {id, state (1 tentative, 2 confirmed), hits, length}; n_inits = 3 in the reference;
- *   slot_src (B,T) i32 out or NULL: IK problem slot each table entry was solved in this frame (-1 = not solved) */
+ *   slot_src (B,T) i32 out or NULL: IK problem slot each table entry was solved in this frame (-1 = not solved);
+ *   overflow (B) i32 in/out or NULL: bit 1 is OR-ed in where a new tracklet did not fit the table of t_max slots */
 int mvmc_track_commit(const int32_t* status, const int32_t* n_new, const double* ik_params, const double* ik_joints,
                       int n_chains, int t_max, int k_max, int n_inits, double* track_params, double* track_joints,
                       int32_t* meta, int32_t* n_tracks, int32_t* next_id, int32_t* n_dead, int32_t* slot_src,
-                      mvmcStream_t stream);
+                      int32_t* overflow, mvmcStream_t stream);
 
 /* ---- multi-GPU glue.  No counterpart in the reference: its tracker is one sequential pass
  * (motion_capture.py:1062-1116).  A sequence is cut into chains that cold-start; contiguous chain ranges go to the GPUs; one
@@ -342,7 +345,9 @@ typedef struct mvmcChainBuffers {
     int32_t* out_als_iters;     /* (F) ALS iterations of the frame's graph, or NULL */
     uint32_t* flags;            /* (B + 4) u32, zeroed by the call: [0,B) hand-over flags of the chains; afterwards flags[B] != 0 =
                                    a workgroup timed out waiting for its predecessor, flags[B + 1] != 0 = a graph was too large
-                                   for the kernel's ALS variant; in both cases the results are void */
+                                   for the kernel's ALS variant, flags[B + 2] != 0 = a capacity was exceeded (bit 0: more than
+                                   k_max new clusters or v_max views in a frame, bit 1: more than t_max tracklets); in every
+                                   case the results are void */
     double* out_phase_cycles;   /* (B,8) diagnostic: shader cycles of each chain by phase {graph, ALS, assignment, IK, commit,
                                    outputs, whole chain, 0}, or NULL */
 } mvmcChainBuffers;

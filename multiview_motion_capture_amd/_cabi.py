@@ -83,8 +83,8 @@ def load():
                                   vp, vp, vp, vp, vp]
     lib.mvmc_fmats_from_projections.argtypes = [vp, i32, vp, vp]
     lib.mvmc_st_affinity.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f64, vp, vp, vp, vp]
-    lib.mvmc_track_assign.argtypes = [vp] * 8 + [i32] * 6 + [vp] * 6
-    lib.mvmc_track_commit.argtypes = [vp] * 4 + [i32] * 4 + [vp] * 8
+    lib.mvmc_track_assign.argtypes = [vp] * 8 + [i32] * 6 + [vp] * 7
+    lib.mvmc_track_commit.argtypes = [vp] * 4 + [i32] * 4 + [vp] * 9
     lib.mvmc_debug_eigh.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp]
     lib.mvmc_debug_trstep.argtypes = [vp, vp, i32, i32, i32, C.c_double, C.c_double, vp, vp, vp, vp]
     lib.mvmc_debug_ik_mode.argtypes = [i32]

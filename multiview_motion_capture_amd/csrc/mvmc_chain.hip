@@ -145,11 +145,11 @@ __device__ __noinline__ void chain_als_temporal(ChainArena<BIG>& arena, const Ch
 }
 __device__ __noinline__ void chain_assign(const ChainArgs& A, int b, int f) {
     assign_chain(threadIdx.x & 63, 64, b, f, A.labels_sp, A.ncl_sp, A.labels_st, A.ncl_st, A.counts, A.n_tracks, A.params, A.C, A.P, A.T, A.K, A.V,
-                 A.members, A.cold, A.init, A.status, A.n_new);
+                 A.members, A.cold, A.init, A.status, A.n_new, reinterpret_cast<int32_t*>(A.flags + A.n_chains + 2));
 }
 __device__ __noinline__ void chain_commit(const ChainArgs& A, int b) {
     commit_chain(threadIdx.x & 63, 64, b, A.status, A.n_new, A.ik_params, A.ik_joints, A.T, A.K, A.n_inits, A.params, A.joints, A.meta, A.n_tracks,
-                 A.next_id, A.n_dead, A.slot_src);
+                 A.next_id, A.n_dead, A.slot_src, reinterpret_cast<int32_t*>(A.flags + A.n_chains + 2));
 }
 template <bool BIG>
 __device__ __noinline__ void chain_ik(ChainArena<BIG>& arena, const Ik1Tables& tables, const ChainArgs& A, int b) {
@@ -187,20 +187,29 @@ chain_kernel(SkelDev skarg, ChainArgs A) {
     if (part > 0) {
         // consumer side of the hand-off (cdna_hip_programming.md Guideline 16): one lane polls the chain's flag relaxed,
         // one agent-scope acquire, then the workgroup's barrier; the chain state is read with plain vector loads after it
+        __shared__ int s_abort;
         if (tid == 0) {
-            unsigned spins = 0;
+            // bounded by wall time (~4 s at the 100 MHz constant clock), not by a spin count; a time-out anywhere in the launch
+            // (the error word) also ends this wait, so a chain of waiting parts does not pay the time-out once per part
+            const unsigned long long t0 = wall_clock64();
+            int abort = 0;
             while (__hip_atomic_load(A.flags + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)part) {
                 __builtin_amdgcn_s_sleep(32);
-                if (++spins > (1u << 22)) {   // ~ seconds: dispatch did not come in block order; give up loudly
+                if (__hip_atomic_load(A.flags + A.n_chains, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { abort = 1; break; }
+                if (wall_clock64() - t0 > 400000000ull) {   // dispatch did not come in block order; give up loudly
                     __hip_atomic_store(A.flags + A.n_chains, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    abort = 1;
                     break;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_abort = abort;     // ONE lane decides; the whole workgroup branches on the same value
+            if (abort)           // release the successors: they must not wait for this part's flag
+                __hip_atomic_store(A.flags + b, (unsigned)(part + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        if (__hip_atomic_load(A.flags + A.n_chains, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+        if (s_abort) return;
     }
     __syncthreads();
     long long cyc[6] = {0, 0, 0, 0, 0, 0}, t_prev = clock64();

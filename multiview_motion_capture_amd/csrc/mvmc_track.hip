@@ -203,7 +203,9 @@ __device__ __forceinline__ void assign_chain(int lane, int nl, int b, int f, con
                                              const int32_t* __restrict__ n_tracks, const double* __restrict__ track_params,
                                              int C, int P, int T, int K, int V, int32_t* __restrict__ members,
                                              uint8_t* __restrict__ cold, double* __restrict__ init,
-                                             int32_t* __restrict__ status, int32_t* __restrict__ n_new) {
+                                             int32_t* __restrict__ status, int32_t* __restrict__ n_new, int32_t* ovf = nullptr) {
+    // ovf (one word, may be shared by several chains: atomic OR): bit 0 = a cluster or a member was dropped here for lack of room
+    // (more than K new tracklets, more than V views) -- the reference has no such caps, so the results of the frame are not its own
     int nt = mvmc_ld_i32(n_tracks + b);
     nt = nt < 0 ? 0 : (nt > T ? T : nt);
     const int NP = T + K;
@@ -234,9 +236,12 @@ __device__ __forceinline__ void assign_chain(int lane, int nl, int b, int f, con
             for (int c = 0; c < C; ++c)
                 for (int p = 0; p < cnt[c]; ++p, ++node)
                     if (lab[node] == k && m < 64) tmp[m++] = (f * C + c) * P + p;
-            if (m >= 2 && created < K) {
-                for (int v = 0; v < m && v < V; ++v) mem[(T + created) * V + v] = tmp[v];
-                ++created;
+            if (m >= 2) {
+                if (ovf && m > V) atomicOr(ovf, 1);
+                if (created < K) {
+                    for (int v = 0; v < m && v < V; ++v) mem[(T + created) * V + v] = tmp[v];
+                    ++created;
+                } else if (ovf) atomicOr(ovf, 1);
             }
         }
     } else {
@@ -254,15 +259,18 @@ __device__ __forceinline__ void assign_chain(int lane, int nl, int b, int f, con
                 for (int p = 0; p < cnt[c]; ++p, ++node)
                     if (lab[node] == k && !used && m < 16) { tmp[m++] = (f * C + c) * P + p; used = true; }
             }
+            if (ovf && m >= 2 && m > V) atomicOr(ovf, 1);
             if (tracklet >= 0) {
                 if (m > 0) {
                     status[(size_t)b * T + tracklet] = m >= 2 ? 2 : 1;
                     if (m >= 2)
                         for (int v = 0; v < m && v < V; ++v) mem[tracklet * V + v] = tmp[v];
                 }
-            } else if (m >= 2 && created < K) {
-                for (int v = 0; v < m && v < V; ++v) mem[(T + created) * V + v] = tmp[v];
-                ++created;
+            } else if (m >= 2) {
+                if (created < K) {
+                    for (int v = 0; v < m && v < V; ++v) mem[(T + created) * V + v] = tmp[v];
+                    ++created;
+                } else if (ovf) atomicOr(ovf, 1);
             }
         }
     }
@@ -275,11 +283,11 @@ __global__ void assign_kernel(const int32_t* __restrict__ labels_sp, const int32
                               const int32_t* __restrict__ n_tracks, const double* __restrict__ track_params, int B,
                               int C, int P, int T, int K, int V, int32_t* __restrict__ members,
                               uint8_t* __restrict__ cold, double* __restrict__ init, int32_t* __restrict__ status,
-                              int32_t* __restrict__ n_new) {
+                              int32_t* __restrict__ n_new, int32_t* __restrict__ overflow) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     assign_chain(0, 1, b, frame_idx[b], labels_sp, ncl_sp, labels_st, ncl_st, counts, n_tracks, track_params, C, P, T, K, V, members,
-                 cold, init, status, n_new);
+                 cold, init, status, n_new, overflow ? overflow + b : nullptr);
 }
 
 // One thread per chain: tracklet table after the frame's IK solves.
@@ -289,7 +297,8 @@ __device__ __forceinline__ void commit_chain(int lane, int nl, int b, const int3
                                              int K, int n_inits, double* __restrict__ track_params,
                                              double* __restrict__ track_joints, int32_t* __restrict__ meta,
                                              int32_t* __restrict__ n_tracks, int32_t* __restrict__ next_id,
-                                             int32_t* __restrict__ n_dead, int32_t* __restrict__ slot_src) {
+                                             int32_t* __restrict__ n_dead, int32_t* __restrict__ slot_src, int32_t* ovf = nullptr) {
+    // ovf bit 1: a new tracklet did not fit the table of T slots
     const int NP = T + K;
     int nt = mvmc_ld_i32(n_tracks + b);
     nt = nt < 0 ? 0 : (nt > T ? T : nt);
@@ -327,7 +336,7 @@ __device__ __forceinline__ void commit_chain(int lane, int nl, int b, const int3
     int id = mvmc_ld_i32(next_id + b);
     const int nn = n_new[b];
     for (int k = 0; k < nn; ++k) {
-        if (w >= T) break;  // table full: the tracklet is dropped (sized so that this does not happen)
+        if (w >= T) { if (ovf && lane == 0) atomicOr(ovf, 2); break; }  // table full: dropped, and reported
         const double* sp = ik_params + ((size_t)b * NP + T + k) * 68;
         const double* sj = ik_joints + ((size_t)b * NP + T + k) * 54;
         for (int e = lane; e < 68; e += nl) tp[w * 68 + e] = sp[e];
@@ -351,11 +360,11 @@ __global__ void commit_kernel(const int32_t* __restrict__ status, const int32_t*
                               const double* __restrict__ ik_params, const double* __restrict__ ik_joints, int B, int T,
                               int K, int n_inits, double* __restrict__ track_params, double* __restrict__ track_joints,
                               int32_t* __restrict__ meta, int32_t* __restrict__ n_tracks, int32_t* __restrict__ next_id,
-                              int32_t* __restrict__ n_dead, int32_t* __restrict__ slot_src) {
+                              int32_t* __restrict__ n_dead, int32_t* __restrict__ slot_src, int32_t* __restrict__ overflow) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     commit_chain(0, 1, b, status, n_new, ik_params, ik_joints, T, K, n_inits, track_params, track_joints, meta, n_tracks, next_id,
-                 n_dead, slot_src);
+                 n_dead, slot_src, overflow ? overflow + b : nullptr);
 }
 
 }  // namespace
@@ -390,7 +399,7 @@ extern "C" int mvmc_track_assign(const int32_t* labels_sp, const int32_t* ncl_sp
                                  const int32_t* ncl_st, const int32_t* counts, const int32_t* frame_idx,
                                  const int32_t* n_tracks, const double* track_params, int n_chains, int n_views,
                                  int p_max, int t_max, int k_max, int v_max, int32_t* members, uint8_t* cold,
-                                 double* init_params, int32_t* status, int32_t* n_new, mvmcStream_t stream) {
+                                 double* init_params, int32_t* status, int32_t* n_new, int32_t* overflow, mvmcStream_t stream) {
     if (!labels_sp || !ncl_sp || !labels_st || !ncl_st || !counts || !frame_idx || !n_tracks || !track_params ||
         !members || !cold || !init_params || !status || !n_new)
         return MVMC_ERR_ARG;
@@ -399,7 +408,7 @@ extern "C" int mvmc_track_assign(const int32_t* labels_sp, const int32_t* ncl_sp
     if (n_chains <= 0) return n_chains == 0 ? MVMC_OK : MVMC_ERR_ARG;
     hipLaunchKernelGGL(assign_kernel, dim3((n_chains + 63) / 64), dim3(64), 0, (hipStream_t)stream, labels_sp, ncl_sp,
                        labels_st, ncl_st, counts, frame_idx, n_tracks, track_params, n_chains, n_views, p_max, t_max,
-                       k_max, v_max, members, cold, init_params, status, n_new);
+                       k_max, v_max, members, cold, init_params, status, n_new, overflow);
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;
 }
@@ -407,7 +416,7 @@ extern "C" int mvmc_track_assign(const int32_t* labels_sp, const int32_t* ncl_sp
 extern "C" int mvmc_track_commit(const int32_t* status, const int32_t* n_new, const double* ik_params,
                                  const double* ik_joints, int n_chains, int t_max, int k_max, int n_inits,
                                  double* track_params, double* track_joints, int32_t* meta, int32_t* n_tracks,
-                                 int32_t* next_id, int32_t* n_dead, int32_t* slot_src, mvmcStream_t stream) {
+                                 int32_t* next_id, int32_t* n_dead, int32_t* slot_src, int32_t* overflow, mvmcStream_t stream) {
     if (!status || !n_new || !ik_params || !ik_joints || !track_params || !track_joints || !meta || !n_tracks ||
         !next_id || !n_dead)
         return MVMC_ERR_ARG;
@@ -415,7 +424,7 @@ extern "C" int mvmc_track_commit(const int32_t* status, const int32_t* n_new, co
     if (n_chains <= 0) return n_chains == 0 ? MVMC_OK : MVMC_ERR_ARG;
     hipLaunchKernelGGL(commit_kernel, dim3((n_chains + 63) / 64), dim3(64), 0, (hipStream_t)stream, status, n_new,
                        ik_params, ik_joints, n_chains, t_max, k_max, n_inits, track_params, track_joints, meta,
-                       n_tracks, next_id, n_dead, slot_src);
+                       n_tracks, next_id, n_dead, slot_src, overflow);
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;
 }

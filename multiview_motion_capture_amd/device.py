@@ -368,8 +368,9 @@ def st_affinity(kps17, counts, frame_idx, track_joints, n_tracks, Pmats, F2, wan
     return W, D, gc
 
 
-def track_assign(labels_sp, ncl_sp, labels_st, ncl_st, counts, frame_idx, n_tracks, track_params, p_max, k_max, v_max):
-    """TK-1 first half -> members (B,T+K,V), cold (B,T+K), init (B,T+K,68), status (B,T), n_new (B)."""
+def track_assign(labels_sp, ncl_sp, labels_st, ncl_st, counts, frame_idx, n_tracks, track_params, p_max, k_max, v_max, overflow=None):
+    """TK-1 first half -> members (B,T+K,V), cold (B,T+K), init (B,T+K,68), status (B,T), n_new (B).
+    overflow (B) i32 in/out: bit 0 set where a cluster or member did not fit (k_max new clusters, v_max views)."""
     B, T = track_params.shape[:2]
     Cn = counts.shape[1]
     dev_ = track_params.device
@@ -384,17 +385,17 @@ def track_assign(labels_sp, ncl_sp, labels_st, ncl_st, counts, frame_idx, n_trac
     n_new = torch.empty((B,), dtype=torch.int32, device=dev_)
     check(_cabi.load().mvmc_track_assign(_p(labels_sp), _p(ncl_sp), _p(labels_st), _p(ncl_st), _p(counts), _p(frame_idx),
                                          _p(n_tracks), _p(track_params), B, Cn, p_max, T, k_max, v_max, _p(mem), _p(cold),
-                                         _p(init), _p(status), _p(n_new), _stream()), "mvmc_track_assign")
+                                         _p(init), _p(status), _p(n_new), _p(overflow), _stream()), "mvmc_track_assign")
     return mem, cold, init, status, n_new
 
 
 def track_commit(status, n_new, ik_params, ik_joints, track_params, track_joints, meta, n_tracks, next_id, n_dead,
-                 k_max, n_inits=3, slot_src=None):
-    """TK-1 second half: updates the tracklet table tensors in place."""
+                 k_max, n_inits=3, slot_src=None, overflow=None):
+    """TK-1 second half: updates the tracklet table tensors in place (overflow bit 1: a new tracklet did not fit t_max slots)."""
     B, T = track_params.shape[:2]
     _req(ik_params, torch.float64, "ik_params", (B, T + k_max, 68))
     _req(ik_joints, torch.float64, "ik_joints", (B, T + k_max, 18, 3))
     _req(meta, torch.int32, "meta", (B, T, 4))
     check(_cabi.load().mvmc_track_commit(_p(status), _p(n_new), _p(ik_params), _p(ik_joints), B, T, k_max, n_inits,
                                          _p(track_params), _p(track_joints), _p(meta), _p(n_tracks), _p(next_id),
-                                         _p(n_dead), _p(slot_src), _stream()), "mvmc_track_commit")
+                                         _p(n_dead), _p(slot_src), _p(overflow), _stream()), "mvmc_track_commit")

@@ -287,6 +287,7 @@ class MvTracker:
             ch.step_fused(k_d, c_d)
         else:
             ch.step(k_d, c_d)
+        ch.check()     # a frame that exceeds p_max / t_max / the cluster capacity raises instead of silently losing people
         n = int(ch.n_tracks[0])
         meta = ch.meta[0, :n].cpu().numpy()
         params = ch.params[0, :n].cpu().numpy()

@@ -69,8 +69,13 @@ def batched_fk(root: np.ndarray, euler: np.ndarray, side_lens: np.ndarray) -> np
 
 
 def generate(n_frames: int, n_views: int, n_people: int, seed: int, chain_len: int = 0, dtype=np.float32,
-             drop=0.05, pix_sigma=2.0, shuffle=True, frame_seed=None):
+             drop=0.05, pix_sigma=2.0, shuffle=True, frame_seed=None, occlusion=0.0, spurious=0.0):
     """-> dict(kps25 (F,C,P,25,3), counts (F,C) int32, K, Rt, P, gt_joints (F,P,18,3), gt_order (F,C,P)).
+
+    occlusion: probability that a person is missed entirely by a view in a frame (the view's list gets shorter: ragged counts,
+    tracklets seen by one view or none, deaths and re-births); spurious: probability that such a freed slot holds a false
+    detection instead (a random pose of plausible size that matches nobody).  gt_order is -1 for slots that hold no real person.
+    Both default to 0, which leaves the output of earlier versions bit for bit unchanged.
 
     chain_len > 0 restarts the random walk every chain_len frames (independent sub-sequences).
     Cameras depend on ``seed`` only; ``frame_seed`` (default: seed) drives people, noise and shuffles,
@@ -118,5 +123,21 @@ def generate(n_frames: int, n_views: int, n_people: int, seed: int, chain_len: i
         order = rng.permuted(order, axis=-1)
         kps = np.take_along_axis(kps, order[..., None, None], axis=2)
     counts = np.full((F, C), Pn, dtype=np.int32)
+    if occlusion > 0.0 or spurious > 0.0:
+        rng2 = np.random.default_rng([seed if frame_seed is None else frame_seed, 2])
+        gone = rng2.uniform(size=(F, C, Pn)) < occlusion
+        ghost = gone & (rng2.uniform(size=(F, C, Pn)) < (spurious / max(occlusion, 1e-12)))
+        centre = rng2.uniform([100.0, 100.0], [900.0, 650.0], size=(F, C, Pn, 1, 2))
+        fake = np.concatenate([centre + rng2.normal(0, 60.0, size=(F, C, Pn, 25, 2)), rng2.uniform(0.3, 0.9, size=(F, C, Pn, 25, 1))], axis=-1)
+        kps = np.where(ghost[..., None, None], fake, kps)
+        order = np.where(gone, -1, order)
+        keep = ~gone | ghost
+        # compact every view's list (kept slots first, their order preserved), zero the rest
+        idx = np.argsort(~keep, axis=-1, kind="stable")
+        kps = np.take_along_axis(kps, idx[..., None, None], axis=2)
+        order = np.take_along_axis(order, idx, axis=2)
+        counts = keep.sum(axis=-1).astype(np.int32)
+        kps[np.arange(Pn)[None, None, :] >= counts[..., None]] = 0.0
+        order = np.where(np.arange(Pn)[None, None, :] >= counts[..., None], -1, order)
     return dict(kps25=np.ascontiguousarray(kps.astype(dtype)), counts=counts, K=K, Rt=Rt, P=Pm,
                 gt_joints=joints, gt_order=order.astype(np.int32))

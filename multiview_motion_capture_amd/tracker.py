@@ -26,6 +26,9 @@ class ChainTracker:
         self.K = k_max or p_max + 2
         self.V = v_max or min(C + 1, 8)
         self.nfev_cold, self.nfev_warm = nfev_cold, nfev_warm
+        if 2 * p_max > 16 or C * p_max + t_max > 80:
+            raise ValueError(f"ChainTracker: p_max={p_max}, t_max={t_max}, views={C}: the association kernels hold rank 2 p_max <= 16 "
+                             "and p_max views + t_max <= 80 graph nodes (more than 8 LIVE tracklets in a frame is reported by check())")
         self.F2 = dev.fmats_from_projections(hp.P)
         B, T = n_chains, t_max
         self.params = torch.zeros((B, T, 68), dtype=torch.float64, device=d)
@@ -36,6 +39,9 @@ class ChainTracker:
         self.n_dead = torch.zeros((B,), dtype=torch.int32, device=d)
         self.frame_idx = torch.arange(B, dtype=torch.int32, device=d)
         self.slot_src = torch.full((B, T), -1, dtype=torch.int32, device=d)
+        # per chain: bit 0 cluster / view capacity, bit 1 tracklet table, bit 2 a graph the association kernel could not hold
+        # (iters < 0); accumulated on the device, read by check() -- a non-zero word voids the chain's results
+        self.overflow = torch.zeros((B,), dtype=torch.int32, device=d)
         self._fused = None  # workspaces of step_fused (allocated on first use)
         self.events = None  # set to a list to collect (start, end) CUDA events around every IK launch
         self.als_events = None  # same for the association (ALS) launches of the spatio-temporal graph
@@ -60,9 +66,10 @@ class ChainTracker:
         if self.als_events is not None:
             a1.record()
             self.als_events.append((a0, a1))
+        self.overflow |= (((sp["iters"] < 0) | (st["iters"] < 0)).to(torch.int32) * 4)
         mem, cold, init, status, n_new = dev.track_assign(sp["labels"], sp["n_clusters"], st["labels"],
                                                           st["n_clusters"], counts, self.frame_idx, self.n_tracks,
-                                                          self.params, P, K, V)
+                                                          self.params, P, K, V, overflow=self.overflow)
         NP = T + K
         if self.assoc_done is not None:   # one-shot marker for run_chains' stream stagger
             self.assoc_done.record()
@@ -77,7 +84,7 @@ class ChainTracker:
             self.events.append((e0, e1))
         p, j = p.reshape(B, NP, 68), j.reshape(B, NP, 18, 3)
         dev.track_commit(status, n_new, p, j, self.params, self.joints, self.meta, self.n_tracks, self.next_id,
-                         self.n_dead, K, slot_src=self.slot_src)
+                         self.n_dead, K, slot_src=self.slot_src, overflow=self.overflow)
         out = dict(members=mem, status=status, n_new=n_new, ik_params=p, ik_joints=j, ik_info=info.reshape(B, NP, 8))
         if want_debug:
             out.update(D=D, W=W, st=st, sp=sp, group_counts=gc)
@@ -120,8 +127,24 @@ class ChainTracker:
             setattr(buf, name, None if ten is None else ten.data_ptr())
         _cabi.check(_cabi.load().mvmc_chain_run(C.byref(self.hp.skeleton), C.byref(buf),
                                                 C.c_void_p(torch.cuda.current_stream(d).cuda_stream)), "mvmc_chain_run")
+        # the launch zeroes its flag words: fold this frame's error words into the tracker's own (read by check())
+        self.overflow |= (w["flags"][-3].clamp(max=1) * 4 + w["flags"][-2]).to(torch.int32)
         return dict(members=w["members"], status=w["status"], n_new=w["n_new"], ik_params=w["ik_params"],
                     ik_joints=w["ik_joints"], ik_info=w["ik_info"], flags=w["flags"])
+
+    def check(self) -> None:
+        """Raise if a capacity was exceeded in any step so far (synchronises): the reference has no such caps, so a frame that
+        hits one is not tracked the way the reference would."""
+        ov = int(self.overflow.max()) if self.overflow.numel() else 0
+        if self._fused is not None:
+            fl = self._fused["flags"][-4:].cpu().tolist()
+            if fl[0]:
+                raise RuntimeError("mvmc_chain_run: a hand-over between the workgroups of a chain timed out; results are void")
+            ov |= (4 if fl[1] else 0) | int(fl[2])
+        if ov:
+            what = [m for bit, m in ((1, "more than k_max new clusters or v_max views in a frame"), (2, "more than t_max live tracklets"),
+                                     (4, "a graph larger than the association kernel holds")) if ov & bit]
+            raise ValueError("ChainTracker: capacity exceeded (" + "; ".join(what) + "): results are void, use larger p_max / t_max / k_max")
 
     @property
     def fused_ok(self) -> bool:
@@ -133,7 +156,8 @@ class ChainTracker:
 
 
 def run_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], chain_len: int, t_max=8,
-               nfev_cold=50, nfev_warm=5, events=None, want_info=False, n_groups=1, als_events=None):
+               nfev_cold=50, nfev_warm=5, events=None, want_info=False, n_groups=1, als_events=None, k_max: Optional[int] = None,
+               v_max: Optional[int] = None):
     """Whole shard: frames [c*L, (c+1)*L) form chain c (F must be a multiple of L).  Returns per-frame
     tracklet tables: params (F,T,68), joints (F,T,18,3), meta (F,T,4), n_tracks (F).
 
@@ -157,6 +181,7 @@ def run_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], c
     out_n = torch.empty((B, L), dtype=torch.int32, device=d)
     n_dead = torch.empty((B,), dtype=torch.int32, device=d)
     next_id = torch.empty((B,), dtype=torch.int32, device=d)
+    overflow = torch.empty((B,), dtype=torch.int32, device=d)
     bounds = [B * g // G for g in range(G + 1)]
     main = torch.cuda.current_stream(d)
     streams = [main] if G == 1 else [torch.cuda.Stream(device=d) for _ in range(G)]
@@ -166,7 +191,7 @@ def run_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], c
     for g in range(G):
         with torch.cuda.stream(streams[g]):
             streams[g].wait_event(ready)
-            tr = ChainTracker(hp, bounds[g + 1] - bounds[g], P, t_max, nfev_cold=nfev_cold, nfev_warm=nfev_warm)
+            tr = ChainTracker(hp, bounds[g + 1] - bounds[g], P, t_max, k_max=k_max, v_max=v_max, nfev_cold=nfev_cold, nfev_warm=nfev_warm)
             tr.events = events
             tr.als_events = als_events
             trackers.append(tr)
@@ -190,10 +215,11 @@ def run_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], c
         with torch.cuda.stream(streams[g]):
             n_dead[bounds[g]:bounds[g + 1]] = trackers[g].n_dead
             next_id[bounds[g]:bounds[g + 1]] = trackers[g].next_id
+            overflow[bounds[g]:bounds[g + 1]] = trackers[g].overflow
         if streams[g] is not main:
             main.wait_stream(streams[g])
     res = dict(params=out_p.view(F, t_max, 68), joints=out_j.view(F, t_max, 18, 3), meta=out_m.view(F, t_max, 4),
-               n_tracks=out_n.view(F), n_dead=n_dead, next_id=next_id)
+               n_tracks=out_n.view(F), n_dead=n_dead, next_id=next_id, overflow=overflow)
     if want_info:
         res["ik_info"] = torch.cat([torch.stack(i, 1) for i in infos], 0)
     return res
@@ -268,14 +294,24 @@ def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tens
 
 
 def check_chain_flags(res) -> None:
-    """Raise if a run_chains_fused result is void (synchronises): a hand-over timed out, or a frame's graph was larger than
-    the chain kernel's association variant holds (use run_chains for such data)."""
+    """Raise if a run_chains_fused / run_chains result is void (synchronises): a hand-over timed out, a frame's graph was larger
+    than the chain kernel's association variant holds (use run_chains for such data), or a capacity (k_max, v_max, t_max) was
+    exceeded -- the reference has no such caps."""
+    if "flags" not in res:      # run_chains: per-chain words {1: clusters / views, 2: tracklet table, 4: graph too large}
+        ov = int(res["overflow"].max()) if res["overflow"].numel() else 0
+        if ov:
+            raise ValueError(f"run_chains: capacity exceeded (word {ov}: 1 = k_max / v_max, 2 = t_max, 4 = graph larger than the "
+                             "association kernel holds): results are void")
+        return
     fl = res["flags"][-4:].cpu().tolist()
     if fl[0]:
         raise RuntimeError("mvmc_chain_run: a hand-over between the workgroups of a chain timed out; results are void")
     if fl[1]:
         raise ValueError("mvmc_chain_run: a frame's graph has more nodes than the chain kernel's layout supports (small layout: 24 "
                          "without, 32 with tracklets); use run_chains")
+    if fl[2]:
+        raise ValueError("mvmc_chain_run: capacity exceeded (" + ("more than k_max new clusters or v_max views in a frame; " if fl[2] & 1 else "")
+                         + ("more than t_max live tracklets" if fl[2] & 2 else "") + "): results are void")
 
 
 _CHAIN_SCRATCH = {}
