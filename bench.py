@@ -199,7 +199,9 @@ def main():
     ap.add_argument("--frames", type=int, default=10000, help="frames per GPU")
     ap.add_argument("--views", type=int, default=5)
     ap.add_argument("--people", type=int, default=4)
-    ap.add_argument("--workload", default="full", choices=["full", "assoc_dlt"])
+    ap.add_argument("--workload", default="full", choices=["full", "assoc_dlt", "dlt"],
+                    help="full = config 4 (the headline); assoc_dlt = config 3 (affinity + ALS + DLT, every frame independent); "
+                         "dlt = config 2 (triangulation only: ingest + DLT of one cluster per person; use --people 1)")
     ap.add_argument("--nfev-cold", type=int, default=50)
     ap.add_argument("--nfev-warm", type=int, default=5)
     ap.add_argument("--chain-len", type=int, default=16,
@@ -256,11 +258,18 @@ def main():
     L = args.chain_len
     if F % L:
         raise SystemExit("--frames must be a multiple of --chain-len")
-    data = synth.generate(F, C, Pn, args.seed, chain_len=L if args.walk == "chains" else 0, frame_seed=args.seed + 1000 * rank)
+    data = synth.generate(F, C, Pn, args.seed, chain_len=L if args.walk == "chains" else 0, frame_seed=args.seed + 1000 * rank,
+                          shuffle=args.workload != "dlt")
     hp = HotPath(data["K"], data["Rt"], device=d)
     kps = torch.from_numpy(data["kps25"]).to(d)
     counts = torch.from_numpy(data["counts"]).to(d)
     with_ik = args.workload == "full"
+    dlt_members = None
+    if args.workload == "dlt":      # cluster (f, p) = person slot p of every view (the generator's unshuffled order)
+        f_i = torch.arange(F, device=d, dtype=torch.int32)[:, None, None]
+        p_i = torch.arange(Pn, device=d, dtype=torch.int32)[None, :, None]
+        c_i = torch.arange(C, device=d, dtype=torch.int32)[None, None, :]
+        dlt_members = ((f_i * C + c_i) * Pn + p_i).reshape(F * Pn, C).contiguous()
 
     ev = {k: [] for k in ("assoc", "tri", "ik", "total")}
 
@@ -292,6 +301,18 @@ def main():
             out["info"] = info
             out["phase"] = phase
             return out
+        if args.workload == "dlt":
+            # config 2: every person's views are one cluster (no association): ingest + DLT
+            from multiview_motion_capture_amd import device as dev
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if timed else None
+            if timed: e[0].record()
+            k17, c17 = dev.ingest(kps, counts)
+            if timed: e[1].record()
+            pts = dev.dlt(k17, hp.P, dlt_members)
+            if timed:
+                e[2].record()
+                ev["assoc"].append((e[0], e[1])); ev["tri"].append((e[1], e[2]))
+            return dict(pts3d=pts)
         e = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
         if timed: e[0].record()
         assoc = hp.associate(kps, counts)
@@ -411,6 +432,12 @@ def main():
             else:
                 launch_ms = float(np.mean(ik_launch_ms))
             achieved = bpf * (F // L) / (launch_ms * 1e-3) / 1e9
+        elif args.workload == "dlt":
+            # config 2: 12 C P J bytes read + 16 P J written per frame; the DLT kernel dominates
+            dom, dom_kernel = "tri", "dlt_kernel"
+            bpf = 12 * C * Pn * 25 + 16 * Pn * 25
+            launch_ms = stage_ms["tri"]
+            achieved = bpf * F / (launch_ms * 1e-3) / 1e9
         else:
             launch_ms = stage_ms[dom]
             achieved = bpf * F / (launch_ms * 1e-3) / 1e9
@@ -432,11 +459,13 @@ def main():
             elif rec:
                 traffic_note = f"stale: profiles/{rec.get('source')} was measured on other kernel sources"
         res = {
-            "metric": "frames/s (assoc+triangulate+IK) at C=5,P=4,J=25" if with_ik else "frames/s (assoc+triangulate)",
+            "metric": "frames/s (assoc+triangulate+IK) at C=5,P=4,J=25" if with_ik else
+                      ("frames/s (triangulate)" if args.workload == "dlt" else "frames/s (assoc+triangulate)"),
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "per_rank_ms_per_step": per_rank_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"synthetic {F} frames/GPU, C={C}, P={Pn}, J=25: affinity+ALS+DLT" +
+            "config": {"workload": f"synthetic {F} frames/GPU, C={C}, P={Pn}, J=25: " + ("ingest + DLT of one cluster per person (config 2)"
+                                    if args.workload == "dlt" else "affinity+ALS+DLT") +
                                    ((f"+IK, temporal chains of {L} frames (match_spatial_time + tracker; cold 50+50 nfev at the head, "
                                      f"warm 5+5 after), {('one launch per step, ' + (str(args.parts or L) + ' workgroup(s) per chain')) if args.path == 'fused' else 'one launch per stage'}" + (f", {args.overlap} steps in flight on alternating streams" if args.overlap > 1 else "") if L > 1 else "+IK, every frame cold-started (chain length 1, max_nfev 50+50)")
                                     if with_ik else ""),

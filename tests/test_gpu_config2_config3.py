@@ -1,0 +1,113 @@
+"""GPU: BASELINE.json configs 2 and 3 at their full sizes (the other two single-GPU configurations besides the benchmark's config 4).
+  config 2: synthetic 10 k frames, C5 P1 J25, triangulation only (seed 20260101) -- ingest + DLT
+  config 3: synthetic 10 k frames, C5 P4, affinity + ALS + DLT (seed 20260102)
+Each: the oracle on a 64-frame subset (1e-4), and size-independent properties on all 10 k frames."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_np as o
+from helpers import frame_nodes, oracle_ingest
+
+pytestmark = pytest.mark.gpu
+F = 10000
+
+
+def test_config2_triangulation_only_10k_c5p1():
+    from multiview_motion_capture_amd import device as dev, synth
+    C, P = 5, 1
+    data = synth.generate(F, C, P, 20260101)
+    d = torch.device("cuda:0")
+    kps, cnt, Pm = torch.from_numpy(data["kps25"]).to(d), torch.from_numpy(data["counts"]).to(d), torch.from_numpy(data["P"]).to(d)
+    k17, c17 = dev.ingest(kps, cnt)
+    mem = (torch.arange(F, device=d, dtype=torch.int32)[:, None] * C + torch.arange(C, device=d, dtype=torch.int32)[None]).contiguous()
+    pts = dev.dlt(k17, Pm, mem)                 # one cluster per frame: the person's five views
+    torch.cuda.synchronize()
+    pts = pts.cpu().numpy()
+    assert pts.shape == (F, 17, 4) and np.isfinite(pts).all() and (c17.cpu().numpy() == 1).all()
+    # oracle on a 64-frame subset: DLT within 1e-4 relative (north star), the mean score exactly
+    k17_o, _ = oracle_ingest(data["kps25"][:64].astype(np.float64), data["counts"][:64])
+    worst = 0.0
+    for f in range(64):
+        ref = o.triangulate_groups(data["P"], [k17_o[f, c, 0] for c in range(C)], 0.01, False)
+        worst = max(worst, np.abs(pts[f, :, :3] - ref[:, :3]).max() / np.abs(ref[:, :3]).max())
+        assert np.array_equal(pts[f, :, 3], ref[:, 3])
+    print("config 2: DLT vs oracle on 64 frames, worst relative error %.2e" % worst)
+    assert worst < 1e-4
+    # full size: against the generator's ground truth (2 px noise -> about a centimetre), joints seen by >= 2 views
+    gt = data["gt_joints"][:, 0]            # (F,18,3)
+    coco_from_skel = {0: 15, 3: 16, 4: 17, 5: 9, 6: 12, 7: 10, 8: 13, 9: 11, 10: 14, 11: 1, 12: 4, 13: 2, 14: 5, 15: 3, 16: 6}
+    k17h = k17.cpu().numpy()[:, :, 0]       # (F,C,17,3)
+    err = []
+    for cj, sj in coco_from_skel.items():
+        seen = (k17h[:, :, cj, 2] >= 0.01).sum(axis=1) >= 2
+        err.append(np.linalg.norm(pts[seen, cj, :3] - gt[seen, sj], axis=-1))
+    err = np.concatenate(err)
+    print("config 2 at 10 k frames: joint error vs ground truth median %.2f cm, p99 %.2f cm over %d points" %
+          (np.median(err) * 100, np.quantile(err, 0.99) * 100, len(err)))
+    assert np.median(err) < 0.02 and np.quantile(err, 0.99) < 0.1
+    # shard invariance: two halves == the whole
+    h = F // 2
+    p0 = dev.dlt(k17[:h].contiguous(), Pm, mem[:h].contiguous())
+    p1 = dev.dlt(k17[h:].contiguous(), Pm, (mem[h:] - h * C).contiguous())
+    assert torch.equal(torch.cat([p0, p1]), torch.from_numpy(pts).to(d))
+
+
+def test_config3_association_and_triangulation_10k_c5p4():
+    from multiview_motion_capture_amd import synth
+    from multiview_motion_capture_amd.pipeline import HotPath
+    C, P = 5, 4
+    data = synth.generate(F, C, P, 20260102)
+    d = torch.device("cuda:0")
+    hp = HotPath(data["K"], data["Rt"], device=d)
+    kps, cnt = torch.from_numpy(data["kps25"]).to(d), torch.from_numpy(data["counts"]).to(d)
+    assoc = hp.associate(kps, cnt, want_mats=True)
+    tri = hp.triangulate(assoc)
+    torch.cuda.synchronize()
+    lab = assoc["labels"].cpu().numpy()
+    mem, nm, pts = tri["members"].cpu().numpy(), tri["n_members"].cpu().numpy(), tri["pts3d"].cpu().numpy()
+    # oracle on a 64-frame subset: association exact, DLT of every cluster within 1e-4
+    k17_o, cnt_o = oracle_ingest(data["kps25"][:64].astype(np.float64), data["counts"][:64])
+    F_o = hp.F.cpu().numpy()
+    worst = 0.0
+    for f in range(64):
+        pts_o, _, dim, q = frame_nodes(k17_o[f], cnt_o[f])
+        D_o, S_o = o.geometry_affinity(pts_o, F_o, dim)
+        assert np.array_equal(assoc["D"][f].cpu().numpy()[:len(q), :len(q)], D_o)
+        mm_o, xb_o = o.match_als(assoc["S"][f, :len(q), :len(q)].cpu().numpy(), dim)
+        lab_o = o.cluster_labels(mm_o, len(q))
+        assert np.array_equal(assoc["x_bin"][f, :len(q), :len(q)].cpu().numpy().astype(bool), xb_o)
+        assert np.array_equal(lab[f, :len(q)], lab_o)
+        for k in range(lab_o.max() + 1):
+            nodes = np.nonzero(lab_o == k)[0]
+            if len(nodes) < 2:
+                continue
+            cams = [q[i] // P for i in nodes]
+            ref = o.triangulate_groups(data["P"][cams], [k17_o[f, q[i] // P, q[i] % P] for i in nodes], 0.01, False)
+            got = pts[f, k]
+            assert [int(m % (C * P)) for m in mem[f, k, :len(nodes)]] == [q[i] for i in nodes]
+            worst = max(worst, np.abs(got[:, :3] - ref[:, :3]).max() / np.abs(ref[:, :3]).max())
+    print("config 3: association exact on 64 frames; DLT of the clusters vs oracle worst relative error %.2e" % worst)
+    assert worst < 1e-4
+    # full size: identities against the generator's truth and 3-D accuracy of the triangulated clusters
+    order, gt = data["gt_order"], data["gt_joints"]
+    good = 0
+    err = []
+    for f in range(0, F, 5):
+        l = lab[f].reshape(C, P)
+        pl = {}
+        ok = True
+        for c in range(C):
+            for s in range(P):
+                if l[c, s] < 0 or pl.setdefault(order[f, c, s], l[c, s]) != l[c, s]:
+                    ok = False
+        ok = ok and len(set(pl.values())) == P
+        good += ok
+        if ok:
+            for p, k in pl.items():
+                if nm[f, k] >= 2:
+                    err.append(np.linalg.norm(pts[f, k, 11, :3] - gt[f, p, 1]))      # left hip (COCO 11 = skeleton joint 1)
+    err = np.array(err)
+    print("config 3 at 10 k frames: %d / %d sampled frames with every pose in its person's cluster; hip error median %.2f cm" %
+          (good, len(range(0, F, 5)), np.median(err) * 100))
+    assert good >= 0.97 * len(range(0, F, 5)) and np.median(err) < 0.02
