@@ -17,17 +17,8 @@
 #include "mvmc_track.hip"
 #include "mvmc_ik1.hip"
 
-namespace {
-
-// Two layouts.  SMALL (configs 1-4: N = C P <= 40 nodes, <= 6 views per person): the rank-8 workgroup ALS variants, 52 KB of LDS,
-// three workgroups per CU.  BIG (config 5, C8 P8: N <= 64, N + T <= 72, <= 8 views per person): the generic workgroup ALS (rank
-// <= 16: als5_graph, X1 as a dense n x n matrix in LDS, the element state in registers), 74 KB of LDS in a dynamic allocation, one
-// workgroup per CU (512 VGPRs per thread).
-template <bool BIG> struct ChainCfg;
-template <> struct ChainCfg<false> { static constexpr int VM = 6, N_MAX = 40, NS_MAX = 48, WG_PER_CU = 3; };
-template <> struct ChainCfg<true> { static constexpr int VM = 8, N_MAX = 64, NS_MAX = 72, WG_PER_CU = 1; };
-
-struct ChainArgs {
+// kernel arguments (a named type with external linkage: the BIG layout's launcher lives in another translation unit)
+struct MvmcChainArgs {
     // inputs
     const double* kps17;      // (F,C,P,17,3), F = n_chains * L, chain b owns frames [b L, (b+1) L)
     const int32_t* counts;    // (F,C)
@@ -75,6 +66,19 @@ struct ChainArgs {
     int parts;                // workgroups per chain (consecutive frame ranges, handed over through flags)
     unsigned* flags;          // (B + 1) parts completed per chain; [B] = timeout word.  Zeroed by the launcher
 };
+
+namespace {
+
+using ChainArgs = MvmcChainArgs;
+
+// Two layouts.  SMALL (configs 1-4: N = C P <= 40 nodes, <= 6 views per person): the rank-8 workgroup ALS variants, 52 KB of LDS,
+// three workgroups per CU.  BIG (config 5, C8 P8: N <= 64, N + T <= 72, <= 8 views per person): the generic workgroup ALS (rank
+// <= 16: als5_graph, X1 as a dense n x n matrix in LDS, the element state in registers), 74 KB of LDS in a dynamic allocation, one
+// workgroup per CU (512 VGPRs per thread).
+template <bool BIG> struct ChainCfg;
+template <> struct ChainCfg<false> { static constexpr int VM = 6, N_MAX = 40, NS_MAX = 48, WG_PER_CU = 3; };
+template <> struct ChainCfg<true> { static constexpr int VM = 8, N_MAX = 64, NS_MAX = 72, WG_PER_CU = 1; };
+
 
 constexpr int CH_EOFF = 2368;   // SMALL: doubles of graph scratch in front of the pose-pair block (NS <= 48: 48 * 48 + 6 + 48 = 2358)
 
@@ -193,8 +197,12 @@ chain_kernel(SkelDev skarg, ChainArgs A) {
             // (the error word) also ends this wait, so a chain of waiting parts does not pay the time-out once per part
             const unsigned long long t0 = wall_clock64();
             int abort = 0;
+            unsigned spins = 0;
             while (__hip_atomic_load(A.flags + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)part) {
                 __builtin_amdgcn_s_sleep(32);
+                // the launch-wide error word is ONE address for every waiting workgroup of the launch: looked at once in 1024 polls
+                // (hundreds of pollers on one line cost the whole chip memory bandwidth: measured 370 k -> 331 k frames/s)
+                if ((++spins & 1023u) != 0u) continue;
                 if (__hip_atomic_load(A.flags + A.n_chains, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { abort = 1; break; }
                 if (wall_clock64() - t0 > 400000000ull) {   // dispatch did not come in block order; give up loudly
                     __hip_atomic_store(A.flags + A.n_chains, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -280,6 +288,26 @@ chain_kernel(SkelDev skarg, ChainArgs A) {
 
 }  // namespace
 
+// The two layouts are compiled in SEPARATE translation units (mvmc_chain_big.hip includes this file with MVMC_CHAIN_BIG_TU): the
+// out-of-line device functions both kernels call (proj_dist, the pairwise sums, assign / commit, the IK model ...) take their register
+// budget from the loosest kernel that reaches them, so in one unit the BIG kernel (one workgroup per CU, 512 VGPRs) let them grow to
+// 248 VGPRs and dropped the SMALL kernel from three workgroups per CU to one (measured: 370 k -> 167 k frames/s on config 4).
+int mvmc_chain_launch_big(const SkelDev& sk, const MvmcChainArgs& A, int n_blocks, hipStream_t stream);
+
+#ifdef MVMC_CHAIN_BIG_TU
+int mvmc_chain_launch_big(const SkelDev& sk, const MvmcChainArgs& A, int n_blocks, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)chain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)sizeof(ChainArena<true>)) != hipSuccess)
+            return MVMC_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(chain_kernel<true>, dim3(n_blocks), dim3(256), sizeof(ChainArena<true>), stream, sk, A);
+    MVMC_CHECK_LAUNCH();
+    return MVMC_OK;
+}
+#else
 extern "C" int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuffers* buf, mvmcStream_t stream) {
     if (!skel_host || !buf) return MVMC_ERR_ARG;
     const mvmcChainBuffers& B = *buf;
@@ -322,18 +350,9 @@ extern "C" int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuff
     A.flags = B.flags;
     if (hipMemsetAsync(B.flags, 0, sizeof(unsigned) * ((size_t)B.n_chains + 4), (hipStream_t)stream) != hipSuccess)
         return MVMC_ERR_LAUNCH;
-    if (small) {
-        hipLaunchKernelGGL(chain_kernel<false>, dim3(B.n_chains * A.parts), dim3(256), sizeof(ChainArena<false>), (hipStream_t)stream, sk, A);
-    } else {
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)chain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)sizeof(ChainArena<true>)) != hipSuccess)
-                return MVMC_ERR_LAUNCH;
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(chain_kernel<true>, dim3(B.n_chains * A.parts), dim3(256), sizeof(ChainArena<true>), (hipStream_t)stream, sk, A);
-    }
+    if (!small) return mvmc_chain_launch_big(sk, A, B.n_chains * A.parts, (hipStream_t)stream);
+    hipLaunchKernelGGL(chain_kernel<false>, dim3(B.n_chains * A.parts), dim3(256), sizeof(ChainArena<false>), (hipStream_t)stream, sk, A);
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;
 }
+#endif  // MVMC_CHAIN_BIG_TU
