@@ -335,7 +335,7 @@ typedef struct mvmcChainBuffers {
     double* ik_params;          /* (B,NP,68) */
     double* ik_joints;          /* (B,NP,18,3) */
     double* ik_info;            /* (B,NP,8) */
-    double* ik_scratch;         /* (B,4,MVMC_IK_SCRATCH_DOUBLES) */
+    double* ik_scratch;         /* (B,8,MVMC_IK_SCRATCH_DOUBLES) */
     /* per-frame outputs: the tracklet table after every frame */
     double* out_params;         /* (F,T,68) */
     double* out_joints;         /* (F,T,18,3) */

@@ -1487,25 +1487,33 @@ als4_kernel(const TW* __restrict__ W, const int32_t* __restrict__ gcounts, int G
 }
 
 // ------------------------------------------------------------------------------------------------
-// ALS for the large graphs of config 5 (C8 P8: n <= 72 nodes, rank <= 16) on one 256-thread workgroup
+// ALS for the large graphs of config 5 (C8 P8: n <= 72 nodes, rank <= 16) on one 512-thread workgroup
 // (match_als, mv_association.py:263-312; same iteration as als_kernel / als4_graph, restated for this size).
-//   * W, Z, Y and the previous X live in REGISTERS: thread (ti, tj) of a 24 x 9 grid owns the 3 x 8 tile of elements
-//     rows 3 ti .., columns 8 tj .. (216 of the 256 threads; the kernel runs one workgroup per CU, 512 VGPRs per thread);
+//   * W, Z, Y and the previous X live in REGISTERS: thread (ti, tj) of a 24 x 18 grid owns the 3 x 4 tile of elements
+//     rows 3 ti .., columns 4 tj .. (432 of the 512 threads; eight waves per CU: two per SIMD, so one wave's LDS round trips and
+//     dependent fp64 chains are covered by the other's work);
 //   * X1 = Z - (Y - W + beta) / mu is a dense n x n matrix in LDS (row stride NMAX), read by both factor updates;
-//   * a factor update  B = (inv(A^T A + rho I) (A^T X1))^T : threads 0..191 form H = A^T X1 with a 1 x 6 register tile each
-//     (one factor entry + three 16-byte reads of an X1 row per six FMAs) while wave 3 forms the 16 x 16 normal matrix and
-//     inverts it by Gauss-Jordan in LDS (the reference forms explicit inverses too: np.linalg.inv); then inv(G) H;
-//   * X = A B^T on the 3 x 8 tiles (A rows in registers, one 128-byte B row per column), the Z / Y update and the residual sums
-//     in the same pass.
+//   * a factor update  B = (inv(A^T A + rho I) (A^T X1))^T : threads 0..287 form H = A^T X1 with a 1 x 4 register tile each
+//     (one factor entry + two 16-byte reads of an X1 row per four FMAs, four rows of loads in flight) while the last wave forms the
+//     16 x 16 normal matrix and inverts it by Gauss-Jordan in LDS (the reference forms explicit inverses too: np.linalg.inv);
+//     then inv(G) H;
+//   * X = A B^T on the 3 x 4 tiles (A rows in registers, one 128-byte B row per column, the next column's row prefetched), the
+//     Z / Y update and the residual sums in the same pass.
 // Seven workgroup barriers per iteration; no state in scratch memory.
 // ------------------------------------------------------------------------------------------------
 template <int NMAX>
 struct Als5Lds {
-    __attribute__((aligned(16))) double sX[NMAX * NMAX];
-    __attribute__((aligned(16))) double sA[NMAX * 16];
-    __attribute__((aligned(16))) double sB[NMAX * 16];
-    __attribute__((aligned(16))) double sH[16 * NMAX];
-    __attribute__((aligned(16))) double sG[16 * 34];   // rows padded to 34 doubles: a column walk does not stay on one bank
+    // Row strides chosen against LDS bank conflicts (64 banks of 4 bytes): the matrices are walked by rows 3 or 4 apart (the tiles),
+    // and a stride of 72 or 16 doubles would put every such row on the same banks (an 18-way conflict on the factor rows)
+    static constexpr int LD = NMAX + 2;     // X1 / W / H rows: 74 doubles
+    static constexpr int FS = 18;           // factor rows: 16 rank slots + 2
+    __attribute__((aligned(16))) double sX[NMAX * LD];
+    __attribute__((aligned(16))) double sW[NMAX * LD];      // the symmetrised affinity (constant over the iteration): LDS, not registers
+    __attribute__((aligned(16))) double sA[NMAX * FS];
+    __attribute__((aligned(16))) double sB[NMAX * FS];
+    __attribute__((aligned(16))) double sH[16 * LD];
+    __attribute__((aligned(16))) double sG[16 * 34];   // inverse of the normal matrix in columns 16..31 (rows padded to 34 doubles)
+    __attribute__((aligned(16))) double sGin[16 * 16]; // the normal matrix on its way to the solver wave
     double sRed[16];
     int sGid[NMAX];
     uint8_t sVis[NMAX];
@@ -1513,65 +1521,131 @@ struct Als5Lds {
     int s_n, s_r;
 };
 
-// wave 3: G = F^T F + rho I over the n rows of the factor F (NMAX x 16 in LDS), then [G | I] -> [I | inv(G)] in sG (16 x 32, row stride 34)
-__device__ __forceinline__ void als5_normal_inverse(const double* __restrict__ sF, int n, int r, double rho, double* __restrict__ sG) {
-    const int lane = threadIdx.x & 63;
-    {
-        const int a = lane & 15, b0 = (lane >> 4) * 4;
-        double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
-        for (int k0 = 0; k0 < n; k0 += 4) {     // rows beyond n are zero; four rows of loads in flight (one wave per SIMD: nothing
-            double fa[4];                       // else hides the LDS latency)
-            double2 f01[4], f23[4];
+// G = F^T F (+ rho on the diagonal; identity on the unused rank slots) over the n rows of the factor F (NMAX x FSG in LDS) into
+// sGin (16 x 16).  NTH = 256: one entry per thread (rows in groups of four so that the LDS round trips overlap).  NTH = 64 (the
+// solver wave): lane (a2, b2) = (lane & 7, lane >> 3) owns the 2 x 2 block rows 2 a2.., columns 2 b2.. -- two 16-byte factor reads
+// per row for four FMAs.  add_rho = false leaves the raw Gram matrix (rho is not known yet).
+template <int NTH, int FSG>
+__device__ __forceinline__ void als5_gram(const double* __restrict__ sF, int n, int r, double rho, bool add_rho, double* __restrict__ sGin, int t) {
+    if constexpr (NTH == 64) {
+        const int a0 = (t & 7) * 2, b0 = (t >> 3) * 2;
+        double g00 = 0.0, g01 = 0.0, g10 = 0.0, g11 = 0.0;
+        for (int k0 = 0; k0 < n; k0 += 4) {
+            double2 fa[4], fb[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                fa[u] = sF[(k0 + u) * 16 + a];
-                f01[u] = *reinterpret_cast<const double2*>(&sF[(k0 + u) * 16 + b0]);
-                f23[u] = *reinterpret_cast<const double2*>(&sF[(k0 + u) * 16 + b0 + 2]);
+                fa[u] = *reinterpret_cast<const double2*>(&sF[(k0 + u) * FSG + a0]);
+                fb[u] = *reinterpret_cast<const double2*>(&sF[(k0 + u) * FSG + b0]);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { g0 += fa[u] * f01[u].x; g1 += fa[u] * f01[u].y; g2 += fa[u] * f23[u].x; g3 += fa[u] * f23[u].y; }
+            for (int u = 0; u < 4; ++u) { g00 += fa[u].x * fb[u].x; g01 += fa[u].x * fb[u].y; g10 += fa[u].y * fb[u].x; g11 += fa[u].y * fb[u].y; }
         }
-        double g[4] = {g0, g1, g2, g3};
+        const double g[2][2] = {{g00, g01}, {g10, g11}};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int b = b0 + q;
-            double v = g[q];
-            if (a == b) v += rho;
-            if (a >= r || b >= r) v = a == b ? 1.0 : 0.0;   // unused rank slots: identity block
-            sG[a * 34 + b] = v;
-            sG[a * 34 + 16 + b] = a == b ? 1.0 : 0.0;
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int a = a0 + i, bb = b0 + j;
+                double v = g[i][j];
+                if (add_rho) {
+                    if (a == bb) v += rho;
+                    if (a >= r || bb >= r) v = a == bb ? 1.0 : 0.0;
+                }
+                sGin[a * 16 + bb] = v;
+            }
+    } else {
+        const int a = t & 15, bb = t >> 4;
+        double g = 0.0;
+        for (int k0 = 0; k0 < n; k0 += 4) {
+            double fa[4], fb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { fa[u] = sF[(k0 + u) * FSG + a]; fb[u] = sF[(k0 + u) * FSG + bb]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) g += fa[u] * fb[u];
         }
-    }
-    MVMC_WAVE_SYNC();
-    const int c = lane & 31, h = lane >> 5;
-    for (int p = 0; p < 16; ++p) {
-        const double f = sG[p * 34 + c] / sG[p * 34 + p];   // (IEEE division: the inverse feeds the factors directly)
-        double col[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) col[q] = sG[(h * 8 + q) * 34 + p];
-        double cur[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) cur[q] = sG[(h * 8 + q) * 34 + c];
-        MVMC_WAVE_SYNC();
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int row = h * 8 + q;
-            sG[row * 34 + c] = row == p ? f : cur[q] - col[q] * f;
+        if (add_rho) {
+            if (a == bb) g += rho;
+            if (a >= r || bb >= r) g = a == bb ? 1.0 : 0.0;
         }
-        MVMC_WAVE_SYNC();
+        sGin[a * 16 + bb] = g;
     }
 }
 
-// One graph (index f of the batch) on a 256-thread workgroup; every thread of the workgroup must call it.
+// the solver wave: [G | I] -> [I | inv(G)] by Gauss-Jordan IN REGISTERS (G is symmetric positive definite: no pivoting; the
+// reference forms the explicit inverse too, np.linalg.inv).  Lane (c, h) = (lane & 31, lane >> 5) holds rows 8 h .. 8 h + 7 of column
+// c of the 16 x 32 augmented matrix in cur[8].  Per pivot p (unrolled: every register index is a constant): the pivot row's entry of
+// my column comes from my own registers or from lane ^ 32, the pivot itself by v_readlane, the pivot column's entries of my rows by
+// crossbar broadcasts (ds_bpermute) of lane p of my half -- no LDS memory, no waits on stores.  In three pieces (load, a range of
+// pivots, store) because the sixteen dependent pivots are spread over several phases of the iteration (als5_graph).
+// rho_fix: add rho to the diagonal and put the identity on the unused rank slots while loading (the Gram matrix was stored raw).
+__device__ __forceinline__ double als5_bcast_half(double v, int src_in_half) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    const int src = ((threadIdx.x & 32) | src_in_half) << 2;
+    lo = __builtin_amdgcn_ds_bpermute(src, lo);
+    hi = __builtin_amdgcn_ds_bpermute(src, hi);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void als5_inv_load(double (&cur)[8], const double* __restrict__ sGin, int r, double rho, bool rho_fix) {
+    const int lane = threadIdx.x & 63;
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int row = h * 8 + q;
+        double v;
+        if (c < 16) {
+            v = sGin[row * 16 + c];
+            if (rho_fix) {
+                if (row == c) v += rho;
+                if (row >= r || c >= r) v = row == c ? 1.0 : 0.0;
+            }
+        } else {
+            v = row == c - 16 ? 1.0 : 0.0;
+        }
+        cur[q] = v;
+    }
+}
+template <int P0, int P1>
+__device__ __forceinline__ void als5_inv_pivots(double (&cur)[8]) {
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int p = P0; p < P1; ++p) {
+        const int ph = p >> 3, pq = p & 7;
+        const double mine = cur[pq];
+        const double other = __shfl_xor(mine, 32, 64);
+        const double prow = h == ph ? mine : other;                 // M[p][c]
+        const double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine), p + 32 * ph),
+                                            __builtin_amdgcn_readlane(__double2loint(mine), p + 32 * ph));   // M[p][p]
+        double col[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) col[q] = als5_bcast_half(cur[q], p);   // M[8 h + q][p]
+        const double f = prow / piv;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int row = h * 8 + q;
+            cur[q] = row == p ? f : cur[q] - col[q] * f;
+        }
+    }
+}
+__device__ __forceinline__ void als5_inv_store(const double (&cur)[8], double* __restrict__ sG) {
+    const int lane = threadIdx.x & 63;
+    const int c = lane & 31, h = lane >> 5;
+    if (c >= 16) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sG[(h * 8 + q) * 34 + c] = cur[q];
+    }
+}
+
+// One graph (index f of the batch) on a 512-thread workgroup; every thread of the workgroup must call it.
 template <typename TW, int NMAX>
 __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __restrict__ W,
                                            const int32_t* __restrict__ gcounts, int G, int ldw,
                                            const double* __restrict__ seed, int seed_len, uint8_t* __restrict__ x_bin,
                                            uint8_t* __restrict__ match_mat, int32_t* __restrict__ labels,
                                            int32_t* __restrict__ n_clusters, int32_t* __restrict__ iters_out) {
-    static_assert(NMAX == 72, "tile grid: 24 x 9 tiles of 3 x 8 elements");
-    constexpr int NT5 = 256, TR = 3, TC = 8, LD = NMAX;
-    double *sX = L.sX, *sA = L.sA, *sB = L.sB, *sH = L.sH, *sG = L.sG, *sRed = L.sRed;
+    static_assert(NMAX == 72, "tile grid: 24 x 18 tiles of 3 x 4 elements");
+    constexpr int NT5 = 512, TR = 3, TC = 4, LD = Als5Lds<NMAX>::LD, FS = Als5Lds<NMAX>::FS, NW5 = NT5 / 64, SOLVER = NW5 - 1, NWORK = 16 * (NMAX / 4);
+    double *sX = L.sX, *sW = L.sW, *sA = L.sA, *sB = L.sB, *sH = L.sH, *sG = L.sG, *sGin = L.sGin, *sRed = L.sRed;
     int *sGid = L.sGid, *sKeep = L.sKeep;
     uint8_t* sVis = L.sVis;
     int &s_n = L.s_n, &s_r = L.s_r;
@@ -1600,40 +1674,58 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
     }
     const TW* Wf = W + (size_t)f * ldw * ldw;
     // ---- element tiles ----
-    const bool own = tid < 24 * 9;
-    const int i0 = own ? (tid / 9) * TR : 0, j0 = own ? (tid % 9) * TC : 0;
-    double w[TR][TC], z[TR][TC], y[TR][TC], xp[TR][TC];
-    float w32[TR][TC];
+    const bool own = tid < 24 * 18;
+    // consecutive lanes own consecutive row triples of one column block: a wave reads ~3 distinct B rows (broadcasts) and 24 A rows
+    // that the factor stride spreads over the banks
+    const int i0 = own ? (tid % 24) * TR : 0, j0 = own ? (tid / 24) * TC : 0;
+    double z[TR][TC], y[TR][TC], xp[TR][TC];
     unsigned same_grp = 0;      // bit (a * TC + b): nodes of one group (view / tracklet block), or an element beyond n: Z forced to 0
     unsigned on_diag = 0;       // bit (a * TC + b): i == j: Z forced to 1
+    for (int e = tid; e < NMAX * LD; e += NT5) { sX[e] = 0.0; sW[e] = 0.0; }   // rows / columns beyond n are read (times zero factors)
+    __syncthreads();
 #pragma unroll
     for (int a = 0; a < TR; ++a)
 #pragma unroll
         for (int b = 0; b < TC; ++b) {
             const int i = i0 + a, j = j0 + b;
             const bool ok = own && i < n && j < n;
+            double wv, x1;
             if constexpr (sizeof(TW) == 4) {
+                // float32 affinity: W is symmetrised in float32 and the FIRST X1 = Z - (Y - W + beta) / mu is float32 arithmetic too
+                // (NumPy's dtype propagation in mv_association.py:263-277); everything after it is float64
                 const float p = ok ? (float)Wf[i * ldw + j] : 0.f, q = ok ? (float)Wf[j * ldw + i] : 0.f;
-                w32[a][b] = fmulr(0.5f, faddr(p, q));
-                w[a][b] = (double)w32[a][b];
+                const float w32 = fmulr(0.5f, faddr(p, q));
+                wv = (double)w32;
+                const float qq = faddr(-w32, 0.1f) / 64.f;
+                x1 = (double)(w32 - qq);
             } else {
                 const double p = ok ? (double)Wf[i * ldw + j] : 0., q = ok ? (double)Wf[j * ldw + i] : 0.;
-                w[a][b] = 0.5 * (p + q);
-                w32[a][b] = 0.f;
+                wv = 0.5 * (p + q);
+                x1 = wv - ((0.0 - wv) + 0.1) / 64.0;
             }
-            z[a][b] = w[a][b]; xp[a][b] = w[a][b]; y[a][b] = 0.0;
+            z[a][b] = wv; xp[a][b] = wv; y[a][b] = 0.0;
+            if (ok) { sW[i * LD + j] = wv; sX[i * LD + j] = x1; }
             if (!ok || sGid[i] == sGid[j]) same_grp |= 1u << (a * TC + b);
             if (ok && i == j) on_diag |= 1u << (a * TC + b);
         }
-    for (int e = tid; e < NMAX * 16; e += NT5) {
-        const int k = e >> 4, a = e & 15;
+    for (int e = tid; e < NMAX * FS; e += NT5) {
+        const int k = e / FS, a = e - k * FS;
         sA[e] = (k < n && a < r) ? seed[k * r + a] : 0.0;
         sB[e] = 0.0;
     }
-    for (int e = tid; e < NMAX * NMAX; e += NT5) sX[e] = 0.0;   // rows / columns beyond n are read (times zero factors) by the 4-row loops
-    // factor-update roles: threads 0..191 = (rank slot fa, block of six columns fj0..fj0+5)
-    const int fa = tid & 15, fj0 = (tid >> 4) * 6;
+    // factor-update roles: threads 0..287 = (rank slot fa, block of four columns fj0..fj0+3); the last wave is the solver
+    const bool worker = tid < NWORK;
+    const int fa = tid & 15, fj0 = worker ? (tid >> 4) * 4 : 0;
     __syncthreads();
+    // The solver wave (its 16 dependent pivots are the longest chain of an iteration, so they never stand alone):
+    //   phase H   workers: H = A^T X1            | solver: inverts A^T A + rho I (raw Gram matrix from the previous XZY phase + rho)
+    //   phase H2  workers: H2 = B^T X1^T         | solver: inverts B^T B + rho I (Gram matrix formed by 256 threads in a short phase)
+    //   phase XZY tile owners: X = A B^T, Z, Y   | solver: forms the raw A^T A of the next iteration (rho is added once mu is decided)
+    if (tid < 256) als5_gram<256, FS>(sA, n, r, 50.0 / 64.0, true, sGin, tid);
+    __syncthreads();
+    // the solver wave shares its SIMD with a worker wave and is the younger of the two: at equal priority it only gets the issue slots
+    // the worker leaves (MI355X_MICROARCH.md, two waves per SIMD) -- but it is the critical path, the worker waits for it
+    if (wave == SOLVER) __builtin_amdgcn_s_setprio(3);
 
     double mu = 64.0;
     int iters = 1000;
@@ -1641,205 +1733,245 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
     __shared__ long long prof5[16];
     if (tid < 16) prof5[tid] = 0;
     long long _t5 = clock64();
-#define A5PROF(k) { const long long _t = clock64(); if ((tid & 63) == 0 && (wave == 0 || wave == 3)) prof5[(wave == 3 ? 8 : 0) + (k)] += _t - _t5; _t5 = _t; }
+#define A5PROF(k) { const long long _t = clock64(); if ((tid & 63) == 0 && (wave == 0 || wave == SOLVER)) prof5[(wave == SOLVER ? 8 : 0) + (k)] += _t - _t5; _t5 = _t; }
 #else
 #define A5PROF(k)
 #endif
-    for (int it = 0; it < 1000; ++it) {
-        // ---- X1 = Z - (Y - W + beta) / mu      (float32 arithmetic on iteration 1 when W is f32) ----
-        const double inv_mu = 1.0 / mu;      // mu = 64 * 2^k: the reciprocal is exact, x * inv_mu == x / mu bit for bit
-        if (own) {
+    if (wave == SOLVER) {
+        // ---- the solver wave's own loop: the same seven barriers per iteration and the same decisions as the workers' loop below (two
+        // loops, so that neither's registers are live in the other's code: the tile state does not spill around the unrolled inversion) ----
+        // (Tried and dropped, each within noise of this form or slower: the pivots of inv(A^T A + rho I) spread speculatively over the
+        // XZY / X1 / H phases -- they crawl beside the tiles' LDS traffic --; the pivot column through v_readlane instead of the LDS
+        // crossbar -- 32 scalar moves per pivot cost more than 16 crossbar reads.)
+        bool gram_raw = false;      // sGin holds A^T A without rho / identity padding (formed during XZY)
+        double cur[8];
+        for (int it = 0; it < 1000; ++it) {
+            const double rho = 50.0 / mu;
+            als5_inv_load(cur, sGin, r, rho, gram_raw);            // inv(A^T A + rho I) while the workers form H
+            als5_inv_pivots<0, 16>(cur);
+            als5_inv_store(cur, sG);
+            A5PROF(2)
+            __syncthreads();
+            A5PROF(3)
+            __syncthreads();                                       // (workers: B = inv H)
+            A5PROF(4)
+            __syncthreads();                                       // (256 threads: B^T B + rho I)
+            als5_inv_load(cur, sGin, r, rho, false);               // inv(B^T B + rho I) while the workers form H2
+            als5_inv_pivots<0, 16>(cur);
+            als5_inv_store(cur, sG);
+            A5PROF(2)
+            __syncthreads();
+            A5PROF(3)
+            __syncthreads();                                       // (workers: A = inv H2)
+            A5PROF(4)
+            als5_gram<64, FS>(sA, n, r, 0.0, false, sGin, tid & 63);   // raw A^T A of the next iteration while the tiles are updated
+            gram_raw = true;
+            A5PROF(5)
+            if ((tid & 63) == 0) { sRed[wave] = 0.0; sRed[8 + wave] = 0.0; }
+            __syncthreads();
+            A5PROF(6)
+            double sum_p = 0.0, sum_d = 0.0;
 #pragma unroll
-            for (int a = 0; a < TR; ++a) {
-                double x1[TC];
-#pragma unroll
-                for (int b = 0; b < TC; ++b) {
-                    if (sizeof(TW) == 4 && it == 0) {
-                        const float q = faddr(-w32[a][b], 0.1f) / 64.f;
-                        x1[b] = (double)(w32[a][b] - q);
-                    } else {
-                        x1[b] = z[a][b] - ((y[a][b] - w[a][b]) + 0.1) * inv_mu;
+            for (int q = 0; q < NW5; ++q) { sum_p += sRed[q]; sum_d += sRed[8 + q]; }
+            const double p_res = sqrt(sum_p) / n;
+            const double d_res = mu * sqrt(sum_d) / n;
+            if (p_res < 1e-4 && d_res < 1e-4) { iters = it + 1; break; }
+            if (p_res > 10 * d_res) mu = 2 * mu;
+            else if (d_res > 10 * p_res) mu = mu / 2;
+            A5PROF(0)
+            __syncthreads();                                       // (tile owners: X1 of the next iteration)
+            A5PROF(1)
+        }
+    } else {
+        for (int it = 0; it < 1000; ++it) {
+            // (X1 = Z - (Y - W + beta) / mu of this iteration is in sX: written before the loop, then at the end of the previous iteration)
+            const double inv_mu = 1.0 / mu;      // mu = 64 * 2^k: the reciprocal is exact, x * inv_mu == x / mu bit for bit
+            const double rho = 50.0 / mu;
+            // ================= B = (inv(A^T A + rho I) (A^T X1))^T =================
+            if (worker) {
+                double h[4] = {0, 0, 0, 0};
+                for (int k0 = 0; k0 < n; k0 += 4) {
+                    double av[4];
+                    double2 x01[4], x23[4];
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        av[u] = sA[(k0 + u) * FS + fa];
+                        x01[u] = *reinterpret_cast<const double2*>(&sX[(k0 + u) * LD + fj0]);
+                        x23[u] = *reinterpret_cast<const double2*>(&sX[(k0 + u) * LD + fj0 + 2]);
+                    }
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) { h[0] += av[u] * x01[u].x; h[1] += av[u] * x01[u].y; h[2] += av[u] * x23[u].x; h[3] += av[u] * x23[u].y; }
+                }
+                *reinterpret_cast<double2*>(&sH[fa * LD + fj0]) = make_double2(h[0], h[1]);
+                *reinterpret_cast<double2*>(&sH[fa * LD + fj0 + 2]) = make_double2(h[2], h[3]);
+            }
+            A5PROF(2)
+            __syncthreads();
+            A5PROF(3)
+            if (worker) {
+                double gi[16];
+    #pragma unroll
+                for (int b = 0; b < 16; b += 2) {
+                    const double2 g2 = *reinterpret_cast<const double2*>(&sG[fa * 34 + 16 + b]);
+                    gi[b] = g2.x; gi[b + 1] = g2.y;
+                }
+                double o[4] = {0, 0, 0, 0};
+    #pragma unroll
+                for (int b0 = 0; b0 < 16; b0 += 4) {
+                    double2 h01[4], h23[4];
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        h01[u] = *reinterpret_cast<const double2*>(&sH[(b0 + u) * LD + fj0]);
+                        h23[u] = *reinterpret_cast<const double2*>(&sH[(b0 + u) * LD + fj0 + 2]);
+                    }
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const double gv = gi[b0 + u];
+                        o[0] += gv * h01[u].x; o[1] += gv * h01[u].y; o[2] += gv * h23[u].x; o[3] += gv * h23[u].y;
                     }
                 }
-                if (i0 + a < n) {
-#pragma unroll
-                    for (int b = 0; b < TC; b += 2) *reinterpret_cast<double2*>(&sX[(i0 + a) * LD + j0 + b]) = make_double2(x1[b], x1[b + 1]);
-                }
+    #pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (fj0 + q < n) sB[(fj0 + q) * FS + fa] = o[q];
             }
+            __syncthreads();
+            A5PROF(4)
+            // ================= A = (inv(B^T B + rho I) (B^T X1^T))^T =================
+            if (tid < 256) als5_gram<256, FS>(sB, n, r, rho, true, sGin, tid);
+            __syncthreads();
+            if (worker) {
+                // H2[a][i] = sum_k B[k][a] X1[i][k] for four rows i = fj0 .. fj0 + 3; four k per step (two 16-byte reads per row)
+                double h[4] = {0, 0, 0, 0};
+                for (int k = 0; k < n; k += 4) {      // X1 columns and B rows beyond n are zero
+                    double bv[4];
+                    double2 xa[4], xb[4];
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) bv[u] = sB[(k + u) * FS + fa];
+    #pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        xa[q] = *reinterpret_cast<const double2*>(&sX[(fj0 + q) * LD + k]);
+                        xb[q] = *reinterpret_cast<const double2*>(&sX[(fj0 + q) * LD + k + 2]);
+                    }
+    #pragma unroll
+                    for (int q = 0; q < 4; ++q) h[q] += (bv[0] * xa[q].x + bv[1] * xa[q].y) + (bv[2] * xb[q].x + bv[3] * xb[q].y);
+                }
+                *reinterpret_cast<double2*>(&sH[fa * LD + fj0]) = make_double2(h[0], h[1]);
+                *reinterpret_cast<double2*>(&sH[fa * LD + fj0 + 2]) = make_double2(h[2], h[3]);
+            }
+            A5PROF(2)
+            __syncthreads();
+            A5PROF(3)
+            if (worker) {
+                double gi[16];
+    #pragma unroll
+                for (int b = 0; b < 16; b += 2) {
+                    const double2 g2 = *reinterpret_cast<const double2*>(&sG[fa * 34 + 16 + b]);
+                    gi[b] = g2.x; gi[b + 1] = g2.y;
+                }
+                double o[4] = {0, 0, 0, 0};
+    #pragma unroll
+                for (int b0 = 0; b0 < 16; b0 += 4) {
+                    double2 h01[4], h23[4];
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        h01[u] = *reinterpret_cast<const double2*>(&sH[(b0 + u) * LD + fj0]);
+                        h23[u] = *reinterpret_cast<const double2*>(&sH[(b0 + u) * LD + fj0 + 2]);
+                    }
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const double gv = gi[b0 + u];
+                        o[0] += gv * h01[u].x; o[1] += gv * h01[u].y; o[2] += gv * h23[u].x; o[3] += gv * h23[u].y;
+                    }
+                }
+    #pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (fj0 + q < n) sA[(fj0 + q) * FS + fa] = o[q];
+            }
+            __syncthreads();
+            A5PROF(4)
+
+            // ================= X = A B^T ; Z ; Y ; residuals =================
+            double acc_p = 0.0, acc_d = 0.0;
+            if (own) {
+                // X = A B^T on the 3 x 4 tile in four passes over the rank (four slots each): 14 16-byte loads in flight per pass and 28
+                // doubles of operands next to the 48 of state -- more of the rank at once does not fit 256 VGPRs (two waves per SIMD) and
+                // a spilled state costs a global-memory round trip per phase.  Elements beyond n have zero factors, zero state and the
+                // forced-zero bit: branch-free, they add 0
+                double x[TR][TC];
+    #pragma unroll
+                for (int a = 0; a < TR; ++a)
+    #pragma unroll
+                    for (int b = 0; b < TC; ++b) x[a][b] = 0.0;
+    #pragma unroll
+                for (int part = 0; part < 4; ++part) {
+                    double2 ar[TR][2], bq[TC][2];
+    #pragma unroll
+                    for (int a = 0; a < TR; ++a)
+    #pragma unroll
+                        for (int q = 0; q < 2; ++q) ar[a][q] = *reinterpret_cast<const double2*>(&sA[(i0 + a) * FS + part * 4 + 2 * q]);
+    #pragma unroll
+                    for (int b = 0; b < TC; ++b)
+    #pragma unroll
+                        for (int q = 0; q < 2; ++q) bq[b][q] = *reinterpret_cast<const double2*>(&sB[(j0 + b) * FS + part * 4 + 2 * q]);
+    #pragma unroll
+                    for (int a = 0; a < TR; ++a)
+    #pragma unroll
+                        for (int b = 0; b < TC; ++b)
+                            x[a][b] += (ar[a][0].x * bq[b][0].x + ar[a][0].y * bq[b][0].y) + (ar[a][1].x * bq[b][1].x + ar[a][1].y * bq[b][1].y);
+                }
+    #pragma unroll
+                for (int a = 0; a < TR; ++a)
+    #pragma unroll
+                    for (int b = 0; b < TC; ++b) {
+                        const unsigned bit = 1u << (a * TC + b);
+                        const double xv = x[a][b];
+                        double zz = xv + y[a][b] * inv_mu;
+                        zz = zz < 0.0 ? 0.0 : (zz > 1.0 ? 1.0 : zz);
+                        zz = (same_grp & bit) ? 0.0 : zz;
+                        zz = (on_diag & bit) ? 1.0 : zz;
+                        const double dz = xv - zz, dx = xv - xp[a][b];
+                        y[a][b] = y[a][b] + mu * dz;
+                        z[a][b] = zz;
+                        xp[a][b] = xv;
+                        acc_p += dz * dz;
+                        acc_d += dx * dx;
+                    }
+            }
+            A5PROF(5)
+            acc_p = wave_sum_dpp(acc_p);
+            acc_d = wave_sum_dpp(acc_d);
+            if ((tid & 63) == 0) { sRed[wave] = acc_p; sRed[8 + wave] = acc_d; }
+            __syncthreads();
+            A5PROF(6)
+            double sum_p = 0.0, sum_d = 0.0;
+    #pragma unroll
+            for (int q = 0; q < NW5; ++q) { sum_p += sRed[q]; sum_d += sRed[8 + q]; }
+            const double p_res = sqrt(sum_p) / n;
+            const double d_res = mu * sqrt(sum_d) / n;
+            if (p_res < 1e-4 && d_res < 1e-4) { iters = it + 1; break; }
+            if (p_res > 10 * d_res) mu = 2 * mu;
+            else if (d_res > 10 * p_res) mu = mu / 2;
+            // ---- X1 of the next iteration (sX is free: both factor updates are done) ----
+            if (own) {
+                const double inv_next = 1.0 / mu;
+    #pragma unroll
+                for (int a = 0; a < TR; ++a)
+                    if (i0 + a < n) {
+                        const double2 w01 = *reinterpret_cast<const double2*>(&sW[(i0 + a) * LD + j0]);
+                        const double2 w23 = *reinterpret_cast<const double2*>(&sW[(i0 + a) * LD + j0 + 2]);
+                        const double x0 = z[a][0] - ((y[a][0] - w01.x) + 0.1) * inv_next, x1 = z[a][1] - ((y[a][1] - w01.y) + 0.1) * inv_next;
+                        const double x2 = z[a][2] - ((y[a][2] - w23.x) + 0.1) * inv_next, x3 = z[a][3] - ((y[a][3] - w23.y) + 0.1) * inv_next;
+                        *reinterpret_cast<double2*>(&sX[(i0 + a) * LD + j0]) = make_double2(x0, x1);
+                        *reinterpret_cast<double2*>(&sX[(i0 + a) * LD + j0 + 2]) = make_double2(x2, x3);
+                    }
+            }
+            A5PROF(0)
+            __syncthreads();
+            A5PROF(1)
         }
-        A5PROF(0)
-        __syncthreads();
-        A5PROF(1)
-        const double rho = 50.0 / mu;
-        // ================= B = (inv(A^T A + rho I) (A^T X1))^T =================
-        if (wave == 3) {
-            als5_normal_inverse(sA, n, r, rho, sG);
-        } else {
-            double h[6] = {0, 0, 0, 0, 0, 0};
-            for (int k0 = 0; k0 < n; k0 += 4) {
-                double av[4];
-                double2 x01[4], x23[4], x45[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    av[u] = sA[(k0 + u) * 16 + fa];
-                    x01[u] = *reinterpret_cast<const double2*>(&sX[(k0 + u) * LD + fj0]);
-                    x23[u] = *reinterpret_cast<const double2*>(&sX[(k0 + u) * LD + fj0 + 2]);
-                    x45[u] = *reinterpret_cast<const double2*>(&sX[(k0 + u) * LD + fj0 + 4]);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    h[0] += av[u] * x01[u].x; h[1] += av[u] * x01[u].y; h[2] += av[u] * x23[u].x; h[3] += av[u] * x23[u].y;
-                    h[4] += av[u] * x45[u].x; h[5] += av[u] * x45[u].y;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 6; q += 2) *reinterpret_cast<double2*>(&sH[fa * LD + fj0 + q]) = make_double2(h[q], h[q + 1]);
-        }
-        A5PROF(2)
-        __syncthreads();
-        A5PROF(3)
-        if (wave < 3) {
-            double gi[16];
-#pragma unroll
-            for (int b = 0; b < 16; b += 2) {
-                const double2 g2 = *reinterpret_cast<const double2*>(&sG[fa * 34 + 16 + b]);
-                gi[b] = g2.x; gi[b + 1] = g2.y;
-            }
-            double o[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int b0 = 0; b0 < 16; b0 += 4) {
-                double2 h01[4], h23[4], h45[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    h01[u] = *reinterpret_cast<const double2*>(&sH[(b0 + u) * LD + fj0]);
-                    h23[u] = *reinterpret_cast<const double2*>(&sH[(b0 + u) * LD + fj0 + 2]);
-                    h45[u] = *reinterpret_cast<const double2*>(&sH[(b0 + u) * LD + fj0 + 4]);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const double gv = gi[b0 + u];
-                    o[0] += gv * h01[u].x; o[1] += gv * h01[u].y; o[2] += gv * h23[u].x; o[3] += gv * h23[u].y; o[4] += gv * h45[u].x; o[5] += gv * h45[u].y;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-                if (fj0 + q < n) sB[(fj0 + q) * 16 + fa] = o[q];
-        }
-        __syncthreads();
-        A5PROF(4)
-        // ================= A = (inv(B^T B + rho I) (B^T X1^T))^T =================
-        if (wave == 3) {
-            als5_normal_inverse(sB, n, r, rho, sG);
-        } else {
-            // H2[a][i] = sum_k B[k][a] X1[i][k] for six rows i = fj0 .. fj0 + 5; two k per step (one 16-byte read per row)
-            double h[6] = {0, 0, 0, 0, 0, 0};
-            for (int k = 0; k < n; k += 4) {      // X1 columns and B rows beyond n are zero
-                double bv[4];
-                double2 xa[6], xb[6];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) bv[u] = sB[(k + u) * 16 + fa];
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    xa[q] = *reinterpret_cast<const double2*>(&sX[(fj0 + q) * LD + k]);
-                    xb[q] = *reinterpret_cast<const double2*>(&sX[(fj0 + q) * LD + k + 2]);
-                }
-#pragma unroll
-                for (int q = 0; q < 6; ++q) h[q] += (bv[0] * xa[q].x + bv[1] * xa[q].y) + (bv[2] * xb[q].x + bv[3] * xb[q].y);
-            }
-#pragma unroll
-            for (int q = 0; q < 6; q += 2) *reinterpret_cast<double2*>(&sH[fa * LD + fj0 + q]) = make_double2(h[q], h[q + 1]);
-        }
-        A5PROF(2)
-        __syncthreads();
-        A5PROF(3)
-        if (wave < 3) {
-            double gi[16];
-#pragma unroll
-            for (int b = 0; b < 16; b += 2) {
-                const double2 g2 = *reinterpret_cast<const double2*>(&sG[fa * 34 + 16 + b]);
-                gi[b] = g2.x; gi[b + 1] = g2.y;
-            }
-            double o[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int b0 = 0; b0 < 16; b0 += 4) {
-                double2 h01[4], h23[4], h45[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    h01[u] = *reinterpret_cast<const double2*>(&sH[(b0 + u) * LD + fj0]);
-                    h23[u] = *reinterpret_cast<const double2*>(&sH[(b0 + u) * LD + fj0 + 2]);
-                    h45[u] = *reinterpret_cast<const double2*>(&sH[(b0 + u) * LD + fj0 + 4]);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const double gv = gi[b0 + u];
-                    o[0] += gv * h01[u].x; o[1] += gv * h01[u].y; o[2] += gv * h23[u].x; o[3] += gv * h23[u].y; o[4] += gv * h45[u].x; o[5] += gv * h45[u].y;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-                if (fj0 + q < n) sA[(fj0 + q) * 16 + fa] = o[q];
-        }
-        __syncthreads();
-        A5PROF(4)
-        // ================= X = A B^T ; Z ; Y ; residuals =================
-        double acc_p = 0.0, acc_d = 0.0;
-        if (own) {
-            // A rows in registers; the B row of column b + 1 is loaded while column b is computed (one wave per SIMD: the loads have
-            // to be in flight early); elements beyond n have zero factors, zero state and the forced-zero bit: branch-free, they add 0
-            double ar[TR][16];
-#pragma unroll
-            for (int a = 0; a < TR; ++a)
-#pragma unroll
-                for (int q = 0; q < 16; q += 2) {
-                    const double2 v = *reinterpret_cast<const double2*>(&sA[(i0 + a) * 16 + q]);
-                    ar[a][q] = v.x; ar[a][q + 1] = v.y;
-                }
-            double2 bn[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) bn[q] = *reinterpret_cast<const double2*>(&sB[j0 * 16 + 2 * q]);
-#pragma unroll
-            for (int b = 0; b < TC; ++b) {
-                double br[16];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { br[2 * q] = bn[q].x; br[2 * q + 1] = bn[q].y; }
-                if (b + 1 < TC) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) bn[q] = *reinterpret_cast<const double2*>(&sB[(j0 + b + 1) * 16 + 2 * q]);
-                }
-#pragma unroll
-                for (int a = 0; a < TR; ++a) {
-                    // two partial sums: half the length of the dependent FMA chain
-                    double x0 = 0.0, x1 = 0.0;
-#pragma unroll
-                    for (int q = 0; q < 16; q += 2) { x0 += ar[a][q] * br[q]; x1 += ar[a][q + 1] * br[q + 1]; }
-                    const double x = x0 + x1;
-                    const unsigned bit = 1u << (a * TC + b);
-                    double zz = x + y[a][b] * inv_mu;
-                    zz = zz < 0.0 ? 0.0 : (zz > 1.0 ? 1.0 : zz);
-                    zz = (same_grp & bit) ? 0.0 : zz;
-                    zz = (on_diag & bit) ? 1.0 : zz;
-                    const double dz = x - zz, dx = x - xp[a][b];
-                    y[a][b] = y[a][b] + mu * dz;
-                    z[a][b] = zz;
-                    xp[a][b] = x;
-                    acc_p += dz * dz;
-                    acc_d += dx * dx;
-                }
-            }
-        }
-        A5PROF(5)
-        acc_p = wave_sum_dpp(acc_p);
-        acc_d = wave_sum_dpp(acc_d);
-        if ((tid & 63) == 0) { sRed[wave] = acc_p; sRed[4 + wave] = acc_d; }
-        __syncthreads();
-        A5PROF(6)
-        const double p_res = sqrt(sRed[0] + sRed[1] + sRed[2] + sRed[3]) / n;
-        const double d_res = mu * sqrt(sRed[4] + sRed[5] + sRed[6] + sRed[7]) / n;
-        if (p_res < 1e-4 && d_res < 1e-4) { iters = it + 1; break; }
-        if (p_res > 10 * d_res) mu = 2 * mu;
-        else if (d_res > 10 * p_res) mu = mu / 2;
     }
     // ---- tail: X_bin = (X + X^T) / 2 > 0.5, closure (k = n-1 only), labels -- same rules as als_kernel ----
+    if (wave == SOLVER) __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     if (own) {
 #pragma unroll
@@ -1911,7 +2043,7 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
 }
 
 template <typename TW, int NMAX>
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(512, 2)
 als5_kernel(const TW* __restrict__ W, const int32_t* __restrict__ gcounts, int G, int ldw,
             const double* __restrict__ seed, int seed_len, uint8_t* __restrict__ x_bin,
             uint8_t* __restrict__ match_mat, int32_t* __restrict__ labels, int32_t* __restrict__ n_clusters,
@@ -2085,7 +2217,7 @@ static int launch_als(const TW* W, const int32_t* gc, int F, int G, int n_max, i
         const size_t lds = sizeof(Als5Lds<72>);
         if (hipFuncSetAttribute((const void*)als5_kernel<TW, 72>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return MVMC_ERR_LAUNCH;
-        hipLaunchKernelGGL((als5_kernel<TW, 72>), dim3(F), dim3(256), lds, s, W, gc, G, n_max, seed, seed_len, xb, mm, lab, nc, it);
+        hipLaunchKernelGGL((als5_kernel<TW, 72>), dim3(F), dim3(512), lds, s, W, gc, G, n_max, seed, seed_len, xb, mm, lab, nc, it);
     }
     else if (n_max <= 64) MVMC_ALS(64, 16, 256);
     else if (n_max <= 80) MVMC_ALS(80, 16, 512);

@@ -54,7 +54,7 @@ struct MvmcChainArgs {
     double* ik_params;        // (B,NP,68)
     double* ik_joints;        // (B,NP,54)
     double* ik_info;          // (B,NP,8)
-    double* ik_scratch;       // (B,4,MVMC_IK_SCRATCH_DOUBLES)
+    double* ik_scratch;       // (B,8,MVMC_IK_SCRATCH_DOUBLES): one block per IK wave (4 in the SMALL layout, 8 in the BIG one)
     // per-frame outputs
     double* out_params;       // (F,T,68)
     double* out_joints;       // (F,T,54)
@@ -73,11 +73,11 @@ using ChainArgs = MvmcChainArgs;
 
 // Two layouts.  SMALL (configs 1-4: N = C P <= 40 nodes, <= 6 views per person): the rank-8 workgroup ALS variants, 52 KB of LDS,
 // three workgroups per CU.  BIG (config 5, C8 P8: N <= 64, N + T <= 72, <= 8 views per person): the generic workgroup ALS (rank
-// <= 16: als5_graph, X1 as a dense n x n matrix in LDS, the element state in registers), 74 KB of LDS in a dynamic allocation, one
-// workgroup per CU (512 VGPRs per thread).
+// <= 16: als5_graph, X1 as a dense n x n matrix in LDS, the element state in registers) on a 512-thread workgroup -- eight waves, so the
+// eight people of a frame are solved side by side -- with 112 KB of LDS in a dynamic allocation, one workgroup per CU.
 template <bool BIG> struct ChainCfg;
-template <> struct ChainCfg<false> { static constexpr int VM = 6, N_MAX = 40, NS_MAX = 48, WG_PER_CU = 3; };
-template <> struct ChainCfg<true> { static constexpr int VM = 8, N_MAX = 64, NS_MAX = 72, WG_PER_CU = 1; };
+template <> struct ChainCfg<false> { static constexpr int VM = 6, N_MAX = 40, NS_MAX = 48, NT = 256, WG_PER_CU = 3, WAVES_PER_SIMD = 3; };
+template <> struct ChainCfg<true> { static constexpr int VM = 8, N_MAX = 64, NS_MAX = 72, NT = 512, WG_PER_CU = 1, WAVES_PER_SIMD = 2; };
 
 
 constexpr int CH_EOFF = 2368;   // SMALL: doubles of graph scratch in front of the pose-pair block (NS <= 48: 48 * 48 + 6 + 48 = 2358)
@@ -94,13 +94,13 @@ template <> union ChainArena<false> {
 };
 template <> union ChainArena<true> {
     Als5Lds<72> als;
-    Ik1Shared<8> ik[4];
+    Ik1Shared<8> ik[8];         // eight waves: the eight people of config 5 are solved side by side
     double graph[64 * 51 + 64 * 64 + 64 + 16];   // affinity_wave at N = 64 (st_affinity_wave at NS = 72 needs 72 * 72 + 6 + 72)
 };
-static_assert(CH_EOFF >= 48 * 48 + 6 + 48 && CH_EOFF + 40 * 40 >= 40 * 51 + 40 * 40 + 40 + 8, "graph scratch covers both graph builders");
+static_assert(CH_EOFF >= 48 * 48 + 10 + 48 && CH_EOFF + 40 * 40 >= 40 * 51 + 40 * 40 + 40 + 8, "graph scratch covers both graph builders");
 static_assert(sizeof(ChainArena<false>) <= 4 * sizeof(Ik1Shared<6>), "SMALL: the IK blocks set the arena size");
-static_assert(64 * 51 + 64 * 64 + 64 + 16 >= 72 * 72 + 6 + 72, "BIG: graph scratch covers both graph builders");
-static_assert(sizeof(ChainArena<true>) <= 80 * 1024, "BIG: half of a CU's LDS");
+static_assert(64 * 51 + 64 * 64 + 64 + 16 >= 72 * 72 + 10 + 72, "BIG: graph scratch covers both graph builders");
+static_assert(sizeof(ChainArena<true>) <= 150 * 1024, "BIG: one workgroup per CU");
 
 // The phases as separate (non-inlined) functions: each gets its own register allocation inside the workgroup's budget
 // of 168 VGPRs (three workgroups per CU) instead of one allocation over the union of all phases.
@@ -116,7 +116,7 @@ __device__ __noinline__ void chain_graph_temporal(ChainArena<BIG>& arena, const 
     MVMC_ASSUME_LDS(&arena);
     const int C = A.C, P = A.P, T = A.T, NS = T + C * P;
     double* W = A.W_st + (size_t)b * NS * NS;
-    st_affinity_wave<true>(arena.graph, A.kps17, A.counts, 0, f, A.joints + (size_t)b * T * 54, A.n_tracks + b, A.Pm, A.F2, C, P,
+    st_affinity_wave<ChainCfg<BIG>::NT>(arena.graph, A.kps17, A.counts, 0, f, A.joints + (size_t)b * T * 54, A.n_tracks + b, A.Pm, A.F2, C, P,
                            T, 0.1, W, nullptr, A.gc + (size_t)b * (C + 1), (!BIG && pairs_ready) ? arena.graph + CH_EOFF : nullptr, C * P);
 }
 // the frame's 2-D / 2-D distances, made while the workgroup waits for its predecessor (they do not depend on the tracklets)
@@ -159,18 +159,19 @@ template <bool BIG>
 __device__ __noinline__ void chain_ik(ChainArena<BIG>& arena, const Ik1Tables& tables, const ChainArgs& A, int b) {
     MVMC_ASSUME_LDS(&arena);
     MVMC_ASSUME_LDS(&tables);
+    constexpr int NW = ChainCfg<BIG>::NT / 64;
     const int wave = threadIdx.x >> 6, NP = A.T + A.K;
-    // wave w takes the problem slots w, w + 4, ... of this chain
-    for (int s = wave; s < NP; s += 4) {
+    // wave w takes the problem slots w, w + NW, ... of this chain
+    for (int s = wave; s < NP; s += NW) {
         const int p = b * NP + s;
         ik1_solve<ChainCfg<BIG>::VM>(arena.ik[wave], tables, A.kps17, A.Pm, A.members, p, A.V, A.C, A.P, A.init, A.cold, A.nfev_cold,
                          A.nfev_warm, A.ik_params, A.ik_joints, A.ik_info,
-                         A.ik_scratch + (ptrdiff_t)(b * 4 + wave - p) * MVMC_IK_SCRATCH_DOUBLES, 3, nullptr);
+                         A.ik_scratch + (ptrdiff_t)(b * NW + wave - p) * MVMC_IK_SCRATCH_DOUBLES, 3, nullptr);
     }
 }
 
 template <bool BIG>
-__global__ void __launch_bounds__(256, ChainCfg<BIG>::WG_PER_CU)
+__global__ void __launch_bounds__(ChainCfg<BIG>::NT, ChainCfg<BIG>::WAVES_PER_SIMD)
 chain_kernel(SkelDev skarg, ChainArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char chain_lds[];   // the arena (BIG: 72 KB, beyond the static limit)
     ChainArena<BIG>& arena = *reinterpret_cast<ChainArena<BIG>*>(chain_lds);
@@ -256,11 +257,11 @@ chain_kernel(SkelDev skarg, ChainArgs A) {
         __syncthreads();
         lap(4);
         // ---- per-frame outputs ----
-        for (int e = tid; e < T * 68; e += 256) A.out_params[(size_t)f * T * 68 + e] = A.params[(size_t)b * T * 68 + e];
-        for (int e = tid; e < T * 54; e += 256) A.out_joints[(size_t)f * T * 54 + e] = A.joints[(size_t)b * T * 54 + e];
-        for (int e = tid; e < T * 4; e += 256) A.out_meta[(size_t)f * T * 4 + e] = A.meta[(size_t)b * T * 4 + e];
+        for (int e = tid; e < T * 68; e += ChainCfg<BIG>::NT) A.out_params[(size_t)f * T * 68 + e] = A.params[(size_t)b * T * 68 + e];
+        for (int e = tid; e < T * 54; e += ChainCfg<BIG>::NT) A.out_joints[(size_t)f * T * 54 + e] = A.joints[(size_t)b * T * 54 + e];
+        for (int e = tid; e < T * 4; e += ChainCfg<BIG>::NT) A.out_meta[(size_t)f * T * 4 + e] = A.meta[(size_t)b * T * 4 + e];
         if (A.out_info)
-            for (int e = tid; e < NP * 8; e += 256) A.out_info[(size_t)f * NP * 8 + e] = A.ik_info[(size_t)b * NP * 8 + e];
+            for (int e = tid; e < NP * 8; e += ChainCfg<BIG>::NT) A.out_info[(size_t)f * NP * 8 + e] = A.ik_info[(size_t)b * NP * 8 + e];
         if (tid == 0) {
             A.out_n[f] = mvmc_ld_i32(A.n_tracks + b);
             if (A.out_iters) A.out_iters[f] = nt <= 0 ? A.iters_sp[b] : A.iters_st[b];
@@ -303,7 +304,7 @@ int mvmc_chain_launch_big(const SkelDev& sk, const MvmcChainArgs& A, int n_block
             return MVMC_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(chain_kernel<true>, dim3(n_blocks), dim3(256), sizeof(ChainArena<true>), stream, sk, A);
+    hipLaunchKernelGGL(chain_kernel<true>, dim3(n_blocks), dim3(ChainCfg<true>::NT), sizeof(ChainArena<true>), stream, sk, A);
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;
 }

@@ -77,8 +77,8 @@ __device__ __noinline__ double reproj_error(const double* joints, const double* 
     return cnt ? total / cnt : __longlong_as_double(0x7ff8000000000000LL);
 }
 
-// One chain-frame (chain b, frame f) on the calling wave (WG = false) or on the whole 256-thread workgroup (WG = true:
-// every thread must call).  sm: (NS*NS + 6) doubles + 2*NS ints of LDS, NS = T + C*P.
+// One chain-frame (chain b, frame f) on the calling wave (NT = 64) or on the whole NT-thread workgroup (NT = 256 / 512:
+// every thread must call).  sm: (NS*NS + 10) doubles + 2*NS ints of LDS, NS = T + C*P.
 // The 2-D / 2-D block of the match_spatial_time graph (calc_epipolar_error per pose pair of different views, motion_capture.py:686-700)
 // depends only on the frame's own detections: a chain-frame workgroup computes it while it waits for its predecessor's tracklets.
 // E[q_i * N + q_j], q = view * P + person, N = C * P; entries of absent poses and same-view pairs are not written (never read).
@@ -98,7 +98,7 @@ __device__ __forceinline__ void st_pose_pairs(double* E, const double* __restric
     }
 }
 
-template <bool WG>
+template <int NT>
 __device__ __forceinline__ void st_affinity_wave(double* sm, const double* __restrict__ kps17, const int32_t* __restrict__ counts,
                                                  int b, int f, const double* __restrict__ track_joints,
                                                  const int32_t* __restrict__ n_tracks, const double* __restrict__ Pm,
@@ -106,14 +106,14 @@ __device__ __forceinline__ void st_affinity_wave(double* sm, const double* __res
                                                  double* __restrict__ W, double* __restrict__ Dout,
                                                  int32_t* __restrict__ group_counts, const double* Epre = nullptr, int ldE = 0) {
     // Epre: the pose-pair epipolar errors of this frame made ahead of time (st_pose_pairs; [q_i * ldE + q_j], q = view * P + person)
+    constexpr bool WG = NT > 64;
     const int tid = WG ? (int)threadIdx.x : (int)(threadIdx.x & 63);
-    constexpr int NT = WG ? 256 : 64;
     auto sync = [] { if constexpr (WG) __syncthreads(); else MVMC_WAVE_SYNC(); };
     const int NS = T + C * P;
     double* D = sm;                       // [NS*NS]
     double& s_max = D[NS * NS];
-    double* s_part = D + NS * NS + 2;     // per-wave maxima
-    int* nview = reinterpret_cast<int*>(D + NS * NS + 6);  // node -> view (-1 = tracklet)
+    double* s_part = D + NS * NS + 2;     // per-wave maxima (up to 8 waves)
+    int* nview = reinterpret_cast<int*>(D + NS * NS + 10);  // node -> view (-1 = tracklet)
     int* nidx = nview + NS;               // node -> tracklet slot or local pose index c*P+p
     int& s_n = reinterpret_cast<int*>(D + NS * NS + 1)[0];
     int nt = mvmc_ld_i32(n_tracks + b);
@@ -161,7 +161,7 @@ __device__ __forceinline__ void st_affinity_wave(double* sm, const double* __res
     sync();
     if (tid == 0) {
         double mm = s_part[0];
-        if constexpr (WG) { for (int w = 1; w < 4; ++w) mm = s_part[w] > mm ? s_part[w] : mm; }
+        if constexpr (WG) { for (int w = 1; w < NT / 64; ++w) mm = s_part[w] > mm ? s_part[w] : mm; }
         s_max = mm;
     }
     sync();
@@ -190,7 +190,7 @@ st_affinity_kernel(const double* __restrict__ kps17, const int32_t* __restrict__
                    int32_t* __restrict__ group_counts) {
     extern __shared__ double sm[];
     const int b = blockIdx.x;
-    st_affinity_wave<false>(sm, kps17, counts, b, frame_idx[b], track_joints, n_tracks, Pm, F2, C, P, T, min_score, W, Dout,
+    st_affinity_wave<64>(sm, kps17, counts, b, frame_idx[b], track_joints, n_tracks, Pm, F2, C, P, T, min_score, W, Dout,
                      group_counts);
 }
 
@@ -388,7 +388,7 @@ extern "C" int mvmc_st_affinity(const double* kps17, const int32_t* counts, cons
     const int NS = t_max + n_views * p_max;
     if (NS > MVMC_MAX_NODES) return MVMC_ERR_UNSUPPORTED;
     if (n_chains <= 0) return n_chains == 0 ? MVMC_OK : MVMC_ERR_ARG;
-    const size_t shm = (size_t)(NS * NS + 6) * sizeof(double) + (size_t)2 * NS * sizeof(int);
+    const size_t shm = (size_t)(NS * NS + 10) * sizeof(double) + (size_t)2 * NS * sizeof(int);
     hipLaunchKernelGGL(st_affinity_kernel, dim3(n_chains), dim3(64), shm, (hipStream_t)stream, kps17, counts, frame_idx,
                        track_joints, n_tracks, Pmats, F2, n_views, p_max, t_max, min_score, W, D, group_counts);
     MVMC_CHECK_LAUNCH();

@@ -322,6 +322,6 @@ def _chain_scratch(n_chains: int, d) -> torch.Tensor:
     buf = _CHAIN_SCRATCH.get(key)
     if buf is None or buf.shape[0] < n_chains:
         from . import _cabi
-        buf = torch.empty((n_chains, 4, _cabi.IK_SCRATCH_DOUBLES), dtype=torch.float64, device=d)
+        buf = torch.empty((n_chains, 8, _cabi.IK_SCRATCH_DOUBLES), dtype=torch.float64, device=d)
         _CHAIN_SCRATCH[key] = buf
     return buf
