@@ -707,3 +707,45 @@ def ik_stage2_3d(obs_pose_3d, root, euler, side_blens, max_nfev, bone_dirs=None)
         return ik_residual_3d(x[:3], x[3:n3].reshape(-1, 3), x[n3:], target, bone_dirs)
     r = least_squares(fun, np.concatenate([np.ravel(root), np.ravel(euler), np.ravel(side_blens)]), max_nfev=max_nfev)
     return r.x[:3], r.x[3:n3].reshape(-1, 3), r.x[n3:], r
+
+
+# ---- match_eig (mv_association.py:179-219): restated only to show why it cannot be pinned (tests/test_match_eig_cpu.py) ----
+def _biparti(sim):
+    """mv_association.py:179-184: 0/1 matrix of the maximum-weight bipartite assignment of a block."""
+    from scipy.optimize import linear_sum_assignment
+    rows, cols = linear_sum_assignment(sim, maximize=True)
+    p = np.zeros_like(sim)
+    p[rows, cols] = 1
+    return p
+
+
+def match_eig(s_mat, dim_group, return_eig=False):
+    """mv_association.py:187-219.  The reference keeps the FIRST d columns of np.linalg.eig -- LAPACK geev's order, which is
+    neither sorted nor invariant under a relabelling of the nodes -- so the result is a property of the LAPACK build, not of the
+    algorithm.  Complex eigenpairs, where geev returns them, are kept as NumPy gives them."""
+    s_mat = np.asarray(s_mat)
+    dim_group = [int(v) for v in dim_group]
+    n, d = len(dim_group) - 1, int(max(np.diff(dim_group)))
+    z = np.zeros_like(s_mat)
+    for i in range(n):
+        for j in range(n):
+            z[dim_group[i]:dim_group[i + 1], dim_group[j]:dim_group[j + 1]] = _biparti(
+                s_mat[dim_group[i]:dim_group[i + 1], dim_group[j]:dim_group[j + 1]])
+    lam, u = np.linalg.eig(z)
+    lam_d, u_d = lam[:d], u[:, :d]
+    with np.errstate(all="ignore"):
+        u_d = u_d * np.sqrt(lam_d)
+    z_out = np.zeros_like(s_mat)
+    for i in range(n):
+        for j in range(n):
+            if i == j:
+                continue
+            with np.errstate(all="ignore"):
+                zb = np.real(u_d[dim_group[i]:dim_group[i + 1]] @ u_d[dim_group[j]:dim_group[j + 1]].T)
+            zb = np.nan_to_num(zb)
+            zb[zb < 0] = 0
+            z_out[dim_group[i]:dim_group[i + 1], dim_group[j]:dim_group[j + 1]] = _biparti(zb)
+    mm = transform_closure(z_out)
+    if return_eig:
+        return mm, z_out, lam
+    return mm, z_out
