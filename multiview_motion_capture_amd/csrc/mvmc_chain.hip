@@ -104,28 +104,35 @@ static_assert(sizeof(ChainArena<true>) <= 150 * 1024, "BIG: one workgroup per CU
 
 // The phases as separate (non-inlined) functions: each gets its own register allocation inside the workgroup's budget
 // of 168 VGPRs (three workgroups per CU) instead of one allocation over the union of all phases.
+// Every phase reports through `done`, a word in the KERNEL's stack frame: a call that is handed a pointer into its caller's frame is
+// not a tail-call candidate, and only for such calls does the compiler drop the callee-saved register convention of these local
+// functions -- with it each phase saved and restored, per call and per lane, every callee-saved vector register it touches (58 for the
+// IK phase), whether the kernel had anything live there or not.
 template <bool BIG>
-__device__ __noinline__ void chain_graph_spatial(ChainArena<BIG>& arena, const ChainArgs& A, int b, int f) {
+__device__ __noinline__ void chain_graph_spatial(ChainArena<BIG>& arena, const ChainArgs& A, int b, int f, int* done) {
     MVMC_ASSUME_LDS(&arena);
     const int C = A.C, P = A.P, N = C * P;
     float* S = A.S_sp + (size_t)b * N * N;
     if ((threadIdx.x >> 6) == 0) affinity_wave(arena.graph, A.kps17, A.counts, A.Fm, C, P, f, nullptr, S);
+    *done = 0;
 }
 template <bool BIG>
-__device__ __noinline__ void chain_graph_temporal(ChainArena<BIG>& arena, const ChainArgs& A, int b, int f, bool pairs_ready) {
+__device__ __noinline__ void chain_graph_temporal(ChainArena<BIG>& arena, const ChainArgs& A, int b, int f, bool pairs_ready, int* done) {
     MVMC_ASSUME_LDS(&arena);
     const int C = A.C, P = A.P, T = A.T, NS = T + C * P;
     double* W = A.W_st + (size_t)b * NS * NS;
     st_affinity_wave<ChainCfg<BIG>::NT>(arena.graph, A.kps17, A.counts, 0, f, A.joints + (size_t)b * T * 54, A.n_tracks + b, A.Pm, A.F2, C, P,
                            T, 0.1, W, nullptr, A.gc + (size_t)b * (C + 1), (!BIG && pairs_ready) ? arena.graph + CH_EOFF : nullptr, C * P);
+    *done = 0;
 }
 // the frame's 2-D / 2-D distances, made while the workgroup waits for its predecessor (they do not depend on the tracklets)
-__device__ __noinline__ void chain_pose_pairs(ChainArena<false>& arena, const ChainArgs& A, int f) {
+__device__ __noinline__ void chain_pose_pairs(ChainArena<false>& arena, const ChainArgs& A, int f, int* done) {
     MVMC_ASSUME_LDS(&arena);
     st_pose_pairs(arena.graph + CH_EOFF, A.kps17, A.counts, f, A.F2, A.C, A.P, 0.1);
+    *done = 0;
 }
 template <bool BIG>
-__device__ __noinline__ void chain_als_spatial(ChainArena<BIG>& arena, const ChainArgs& A, int b, int f) {
+__device__ __noinline__ void chain_als_spatial(ChainArena<BIG>& arena, const ChainArgs& A, int b, int f, int* done) {
     MVMC_ASSUME_LDS(&arena);
     const int C = A.C, N = C * A.P;
     // batch index 0 with pre-offset pointers: the graph, its group counts (the frame's people per view) and outputs
@@ -135,9 +142,10 @@ __device__ __noinline__ void chain_als_spatial(ChainArena<BIG>& arena, const Cha
     else
         als4_graph<float, 24>(arena.als_sp, 0, A.S_sp + (size_t)b * N * N, A.counts + (size_t)f * C, C, N, A.seed, A.seed_len, nullptr,
                               nullptr, A.labels_sp + (size_t)b * N, A.ncl_sp + b, A.iters_sp + b);
+    *done = 0;
 }
 template <bool BIG>
-__device__ __noinline__ void chain_als_temporal(ChainArena<BIG>& arena, const ChainArgs& A, int b) {
+__device__ __noinline__ void chain_als_temporal(ChainArena<BIG>& arena, const ChainArgs& A, int b, int* done) {
     MVMC_ASSUME_LDS(&arena);
     const int C = A.C, NS = A.T + C * A.P;
     if constexpr (BIG)
@@ -146,21 +154,24 @@ __device__ __noinline__ void chain_als_temporal(ChainArena<BIG>& arena, const Ch
     else
         als4_graph<double, 32>(arena.als_st, 0, A.W_st + (size_t)b * NS * NS, A.gc + (size_t)b * (C + 1), C + 1, NS, A.seed, A.seed_len,
                                nullptr, nullptr, A.labels_st + (size_t)b * NS, A.ncl_st + b, A.iters_st + b);
+    *done = 0;
 }
-__device__ __noinline__ void chain_assign(const ChainArgs& A, int b, int f) {
+__device__ __noinline__ void chain_assign(const ChainArgs& A, int b, int f, int* done) {
     assign_chain(threadIdx.x & 63, 64, b, f, A.labels_sp, A.ncl_sp, A.labels_st, A.ncl_st, A.counts, A.n_tracks, A.params, A.C, A.P, A.T, A.K, A.V,
                  A.members, A.cold, A.init, A.status, A.n_new, reinterpret_cast<int32_t*>(A.flags + A.n_chains + 2));
+    *done = 0;
 }
-__device__ __noinline__ void chain_commit(const ChainArgs& A, int b) {
+__device__ __noinline__ void chain_commit(const ChainArgs& A, int b, int* done) {
     commit_chain(threadIdx.x & 63, 64, b, A.status, A.n_new, A.ik_params, A.ik_joints, A.T, A.K, A.n_inits, A.params, A.joints, A.meta, A.n_tracks,
                  A.next_id, A.n_dead, A.slot_src, reinterpret_cast<int32_t*>(A.flags + A.n_chains + 2));
+    *done = 0;
 }
 template <bool BIG>
-__device__ __noinline__ void chain_ik(ChainArena<BIG>& arena, const Ik1Tables& tables, const ChainArgs& A, int b) {
+__device__ __noinline__ void chain_ik(ChainArena<BIG>& arena, const Ik1Tables& tables, const ChainArgs& A, int b, int* done) {
     MVMC_ASSUME_LDS(&arena);
     MVMC_ASSUME_LDS(&tables);
     constexpr int NW = ChainCfg<BIG>::NT / 64;
-    const int wave = threadIdx.x >> 6, NP = A.T + A.K;
+    const int wave = uni((int)(threadIdx.x >> 6)), NP = A.T + A.K;
     // wave w takes the problem slots w, w + NW, ... of this chain
     for (int s = wave; s < NP; s += NW) {
         const int p = b * NP + s;
@@ -168,6 +179,7 @@ __device__ __noinline__ void chain_ik(ChainArena<BIG>& arena, const Ik1Tables& t
                          A.nfev_warm, A.ik_params, A.ik_joints, A.ik_info,
                          A.ik_scratch + (ptrdiff_t)(b * NW + wave - p) * MVMC_IK_SCRATCH_DOUBLES, 3, nullptr);
     }
+    *done = 0;
 }
 
 template <bool BIG>
@@ -188,7 +200,8 @@ chain_kernel(SkelDev skarg, ChainArgs A) {
     // work that does not depend on the chain's state comes before the hand-over: the skeleton tables and, for a workgroup that has a
     // predecessor, the pose-pair block of its first frame's graph
     if (wave == 0) ik1_build_tables(tables, skarg);
-    if constexpr (!BIG) { if (part > 0) chain_pose_pairs(arena, A, b * A.L + t_lo); }
+    int done = 0;   // the phases' report word (see above)
+    if constexpr (!BIG) { if (part > 0) chain_pose_pairs(arena, A, b * A.L + t_lo, &done); }
     if (part > 0) {
         // consumer side of the hand-off (cdna_hip_programming.md Guideline 16): one lane polls the chain's flag relaxed,
         // one agent-scope acquire, then the workgroup's barrier; the chain state is read with plain vector loads after it
@@ -228,18 +241,18 @@ chain_kernel(SkelDev skarg, ChainArgs A) {
         const int f = b * A.L + t;
         if (tid == 0) s_nt = mvmc_ld_i32(A.n_tracks + b);
         __syncthreads();
-        const int nt = s_nt;
+        const int nt = uni(s_nt);
         // ---- graph + association ----
         if (nt <= 0) {   // no live tracklets: match_spatial (motion_capture.py:597-631), f32 affinity
-            chain_graph_spatial<BIG>(arena, A, b, f);
+            chain_graph_spatial<BIG>(arena, A, b, f, &done);
             __syncthreads();
             lap(0);
-            chain_als_spatial<BIG>(arena, A, b, f);
+            chain_als_spatial<BIG>(arena, A, b, f, &done);
         } else {
-            chain_graph_temporal<BIG>(arena, A, b, f, part > 0 && t == t_lo);
+            chain_graph_temporal<BIG>(arena, A, b, f, part > 0 && t == t_lo, &done);
             __syncthreads();
             lap(0);
-            chain_als_temporal<BIG>(arena, A, b);
+            chain_als_temporal<BIG>(arena, A, b, &done);
         }
         __syncthreads();
         lap(1);
@@ -247,13 +260,13 @@ chain_kernel(SkelDev skarg, ChainArgs A) {
         // raise the launch's error word instead of silently tracking nobody
         if (tid == 0 && (nt <= 0 ? A.iters_sp[b] : A.iters_st[b]) < 0)
             __hip_atomic_store(A.flags + A.n_chains + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (wave == 0) chain_assign(A, b, f);   // clusters -> IK problems (bulk copies on the wave, the logic on lane 0)
+        if (wave == 0) chain_assign(A, b, f, &done);   // clusters -> IK problems (bulk copies on the wave, the logic on lane 0)
         __syncthreads();
         lap(2);
-        chain_ik<BIG>(arena, tables, A, b);
+        chain_ik<BIG>(arena, tables, A, b, &done);
         __syncthreads();
         lap(3);
-        if (wave == 0) chain_commit(A, b);      // tracklet table after the frame
+        if (wave == 0) chain_commit(A, b, &done);      // tracklet table after the frame
         __syncthreads();
         lap(4);
         // ---- per-frame outputs ----
@@ -269,6 +282,7 @@ chain_kernel(SkelDev skarg, ChainArgs A) {
         __syncthreads();
         lap(5);
     }
+    if (done != 0) return;   // (never: the phases write 0)
     if (A.out_cycles && tid == 0) {   // accumulated over the chain's parts (they run one after the other)
         double* oc = A.out_cycles + (size_t)b * 8;
         for (int k = 0; k < 6; ++k) oc[k] = (part ? oc[k] : 0.0) + (double)cyc[k];

@@ -86,6 +86,20 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
         t += __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * r), __builtin_amdgcn_readlane(lo, 16 * r));
     return t;
 }
+// A wave-uniform value as a scalar: the compiler keeps it in SGPRs from here on.  A value that VALU code computed (a wave
+// reduction, an LDS read) lives in a vector register per lane even when every lane holds the same number, and around a call to an
+// out-of-line function every live vector register is a 256-byte scratch store + load, where 64 live SGPRs share ONE.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+template <typename Tp>
+__device__ __forceinline__ Tp* uni(Tp* p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return (Tp*)(((unsigned long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ double fast_rcp64(double x) {
     double r = __builtin_amdgcn_rcp(x);
     r = r * (2.0 - x * r);

@@ -62,7 +62,7 @@ struct Ik1Shared {
     double Rg[18 * 9], pos[18 * 3], bvec[18 * 3];
     double hs[18 * 4];      // sin, cos of half the x and y Euler angles of every joint (from the last FK)
     double Wk[NOBS * 6], tk[NOBS * 3];
-    double sc[8];           // {.., beta0, tau0, |J^T J|_1, coupling} at [4..8)
+    double sc[12];          // {|g|^2, |g|_inf, alpha, pred, beta0, tau0, |J^T J|_1, coupling, |step|, |x|, fallback rows}
     int nviews, mode3d;
 #ifdef MVMC_IK_PROFILE
     long long prof[8];
@@ -199,23 +199,61 @@ __device__ __forceinline__ double ik1_eval(Ik1Shared<VM>& S, const Ik1Tables& T,
 }
 
 // ---------------------------------------------------------------------------------------------
+// The solver is a small driver (ik1_trf: wave-uniform control flow, its state in scalar registers) around three
+// out-of-line functions, so that NO vector register is live across a call -- a live one costs a 256-byte scratch store
+// and a load per call, and the model function needs every register the occupancy allows:
+//   ik1_eval_nl         FK + residual (+ blocks) at S.x or S.xn
+//   ik1_model_step      the trust-region model at the last evaluated point AND the first trial step from it
+//   ik1_fallback_trial  a trial step of a model that took the eigenbasis fallback
+//   ik1_retry_trial     a further trial step of a common-path model whose reflectors are in the global scratch
+// Results of a trial: S.xn = the trial point, S.sc[2] = alpha, S.sc[3] = predicted reduction, S.sc[8] = |step|,
+// S.sc[9] = |x|.
+// ---------------------------------------------------------------------------------------------
+template <int VM>
+__device__ __noinline__ double ik1_eval_nl(Ik1Shared<VM>& S, const Ik1Tables& T, int at_trial, int stage, bool want_jac) {
+    MVMC_ASSUME_LDS(&S);
+    MVMC_ASSUME_LDS(&T);
+    return ik1_eval(S, T, at_trial ? S.xn : S.x, stage, want_jac);
+}
+
+// S.xn = S.x + step on the active parameters (stepj: lane j's component), S.sc[9] = |x|
+template <int VM>
+__device__ __forceinline__ void ik1_trial_point(Ik1Shared<VM>& S, const Ik1Tables& T, int stage, int na, double stepj) {
+    const int lane = threadIdx.x & 63;
+    const int nfull = (stage == 0) ? 57 : 57 + T.n_side;
+    double xx = (lane < nfull) ? S.x[lane] * S.x[lane] : 0.0;
+    if (lane + 64 < nfull) xx += S.x[lane + 64] * S.x[lane + 64];
+    const double x_norm = sqrt(wave_sum(xx));
+    if (lane == 0) S.sc[9] = x_norm;
+    if (lane < nfull) S.xn[lane] = S.x[lane];
+    if (lane + 64 < nfull) S.xn[lane + 64] = S.x[lane + 64];
+    MVMC_WAVE_SYNC();
+    if (lane < na) { const int f = T.act[stage][lane]; S.xn[f] = S.x[f] + stepj; }
+    MVMC_WAVE_SYNC();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Trust-region model at the last evaluated point (FK state, Wk, tk, hs in LDS):
 //   g = D^T t (one component per lane),  J^T J = sum_k D_k^T W_k D_k into registers,
 //   then -- unless the gradient test or the evaluation budget stops the iteration (the caller's next step is a
-//   break) -- the Krylov tridiagonalisation and the leading-block checks.
-// Returns kk > 0 (fast path: size of the leading block), -m < 0 (eigenbasis path on m rows of T: lam in the WN slot,
-// suf in the D slot, vectors in the global scratch), 0 (stopped after g).
-// *gg = |g|^2, *ginf = |g|_inf.  S.sc[4..8) = {beta0, tau0, |J^T J|_1, coupling}.
+//   break) -- the Krylov tridiagonalisation, the leading-block checks and, on the common path, the trial step for
+//   (Delta, alpha): the trust-region solve in the tridiagonal basis and Q applied from the reflectors that are
+//   still in the matrix registers.  The first trial a solve rejects is re-made by calling the function again (after
+//   re-evaluating S.x) with the new radius and dump = true: the model is a deterministic function of the LDS state, 17 %
+//   of the warm solves pay that second build once, and the others never send a Householder vector to memory.
+// *mode_out = 0 (stopped after g), 1 (trial made), 2 (eigenbasis path on m = S.sc[10] rows of T: lam in the WN slot, suf in
+// the D slot, vectors and reflectors in the global scratch; the trial is ik1_fallback_trial's).
+// S.sc[0] = |g|^2, S.sc[1] = |g|_inf, S.sc[4..8) = {beta0, tau0, |J^T J|_1, coupling}.
 // ---------------------------------------------------------------------------------------------
 template <int VM, int N>
-__device__ __noinline__ int ik1_model(Ik1Shared<VM>& S, const Ik1Tables& T, int stage, bool budget_left, double gtol, mvmc_gdouble* __restrict__ hh,
-                                      double* gg_out, double* ginf_out) {
+__device__ __noinline__ void ik1_model_step(Ik1Shared<VM>& S, const Ik1Tables& T, int stage, bool budget_left, double gtol,
+                                            mvmc_gdouble* __restrict__ hh, double Delta, double alpha, bool dump, int* mode_out) {
     // S and T arrive as generic pointers (the function is out of line); telling the compiler that they are LDS turns every
     // access below into a ds_ instruction instead of a flat_ one (InferAddressSpaces uses the assumption)
     MVMC_ASSUME_LDS(&S);
     MVMC_ASSUME_LDS(&T);
     const int lane = threadIdx.x & 63;
-    const int na = T.na[stage];
+    const int na = uni(T.na[stage]);
     const bool on = lane < na;
     const int cl = on ? lane : 0;
     const int kind = T.colkind[stage][cl], ja = T.cola[stage][cl], jc = T.colc[stage][cl];
@@ -303,31 +341,110 @@ __device__ __noinline__ int ik1_model(Ik1Shared<VM>& S, const Ik1Tables& T, int 
         }
     }
     MVMC_WAVE_SYNC();
-    const double gg = wave_sum_dpp(gj * gj), ginf = wave_max64(fabs(gj));
-    *gg_out = gg; *ginf_out = ginf;
+    const double gg = uni(wave_sum_dpp(gj * gj)), ginf = uni(wave_max64(fabs(gj)));
+    if (lane == 0) { S.sc[0] = gg; S.sc[1] = ginf; }
     M1STAMP(4)
-    if (ginf < gtol || !budget_left) return 0;
-    const int kk = eightri::tridiag_krylov_w1<N>(a, gj, hh, na, S.sv + SV_D, S.sv + SV_E, S.sv + SV_TAU, S.sv + SV_V0,
-                                                 S.tmp, S.tmp + 64, &S.sc[4]);
+    if (ginf < gtol || !budget_left) { *mode_out = 0; return; }
+    double scv, tauv;
+    int ksteps;
+    const int kk = uni(eightri::tridiag_krylov_w1<N>(a, gj, na, S.sv + SV_D, S.sv + SV_E, S.sv + SV_TAU, S.sv + SV_V0, S.tmp, S.tmp + 64,
+                                                     &S.sc[4], scv, tauv, ksteps));
+    // the reflectors, two rows to a register: the matrix registers die here, before the checks and the trust-region solve
+    double pk[(N - 2) / 2];
+    eightri::pack_reflectors<N>(a, pk);
+    if (dump) eightri::dump_reflectors<N>(pk, scv, ksteps, na, hh);   // a solve that has rejected a trial before: see ik1_trf
     M1STAMP(5)
     bool ok = kk > 0;
     if (ok) ok = eightri::krylov_block_ok(S.sv + SV_D, S.sv + SV_E, kk, na, S.sc[6], S.sc[7], S.tmp, S.tmp + 64, S.tmp + 128,
                                           S.tmp + 192, S.sv + SV_WN);
     MVMC_WAVE_SYNC();
     M1STAMP(6)
-    if (ok) return kk;
+    if (ok) {
+        // ---- the trial step, in the tridiagonal basis ----
+        const double beta0 = S.sc[4], tau0 = S.sc[5], pivmin = 1e-16 * S.sc[6] + 1e-300, coupling = S.sc[7];
+        double* rh = S.tmp;
+        double* cv = S.tmp + 64;
+        rh[lane] = lane == 0 ? beta0 : 0.0;
+        MVMC_WAVE_SYNC();
+        double pred, step_norm;
+        alpha = eightri::tr_solve_tri<false>(S.sv + SV_D, S.sv + SV_E, rh, kk, Delta, alpha, gg, pivmin, nullptr, nullptr, nullptr,
+                                             nullptr, cv, &pred, &step_norm);
+        MVMC_WAVE_SYNC();
+        double c = lane < kk ? cv[lane] : 0.0;
+        if (kk < na) {
+            // component along the first null coordinate: keeps the step orthogonal to the null vector
+            const double eta = coupling * wave_sum_dpp(lane < kk ? S.sv[SV_WN + lane] * c : 0.0);
+            if (lane == kk) c = eta;
+        }
+        const double stepj = eightri::apply_q_packed<N>(pk, scv, tauv, S.sv + SV_V0, tau0, kk, na, c);
+        if (lane == 0) { S.sc[2] = alpha; S.sc[3] = pred; S.sc[8] = step_norm; S.sc[11] = (double)kk; }
+        ik1_trial_point(S, T, stage, na, stepj);
+        M1STAMP(3)
+        *mode_out = 1;
+        return;
+    }
     // No clean split between range and null space (weakly observed directions, missing joints): the step is taken
     // in the eigenbasis of the tridiagonal matrix instead, with the numerically-null cluster removed -- the
     // eigensolver fallback of mvmc_ik.hip in the T basis, where suf = V^T g = beta0 * (first components).
     //   unclean collapse:  T is complete (na rows);   clean collapse: the leading block plus its coupling row.
+    // Its trials outlive this function: the reflectors go to the global scratch.
+    if (!dump) eightri::dump_reflectors<N>(pk, scv, ksteps, na, hh);
     const int m = kk < 0 ? na : (kk < na ? kk + 1 : na);
     mvmc_gdouble* Zg = hh + 64 * NA1;
     eightri::tri_eigh_w1<N>(S.sv + SV_D, S.sv + SV_E, m, S.sv + SV_WN, Zg, S.tmp, S.tmp + 64, S.tmp + 128);
     const double suf = lane < m ? S.sc[4] * Zg[lane] : 0.0;
     MVMC_WAVE_SYNC();
     S.sv[SV_D + lane] = suf;   // d, e are dead: lam lives in the WN slot, suf in the D slot
+    if (lane == 0) S.sc[10] = (double)m;
     MVMC_WAVE_SYNC();
-    return -m;
+    *mode_out = 2;
+}
+
+// A trial step of a model on the eigenbasis path (Delta, alpha -> S.xn and S.sc[2], [3], [8], [9])
+template <int VM>
+__device__ __noinline__ void ik1_fallback_trial(Ik1Shared<VM>& S, const Ik1Tables& T, int stage, const mvmc_gdouble* __restrict__ hh,
+                                                double Delta, double alpha) {
+    MVMC_ASSUME_LDS(&S);
+    MVMC_ASSUME_LDS(&T);
+    const int lane = threadIdx.x & 63;
+    const int na = uni(T.na[stage]), mq = uni((int)S.sc[10]);
+    const double gg = S.sc[0], tau0 = S.sc[5];
+    double* cv = S.tmp + 64;
+    double pred, step_norm;
+    alpha = eightri::tr_solve_eig_w1(S.sv + SV_WN, S.sv + SV_D, mq, Delta, alpha, gg, cv, &pred, &step_norm);
+    MVMC_WAVE_SYNC();
+    const double c = eightri::eig_combine_w1(hh + 64 * NA1, mq, lane < mq ? cv[lane] : 0.0);
+    const double stepj = eightri::apply_q_w1(hh, S.sv + SV_TAU, S.sv + SV_V0, tau0, mq, na, c);
+    if (lane == 0) { S.sc[2] = alpha; S.sc[3] = pred; S.sc[8] = step_norm; }
+    ik1_trial_point(S, T, stage, na, stepj);
+}
+
+// Another trial step (Delta, alpha) of a common-path model whose reflectors were dumped to the global scratch: the trust-region solve on
+// the tridiagonal matrix that is still in LDS, Q from memory.
+template <int VM>
+__device__ __noinline__ void ik1_retry_trial(Ik1Shared<VM>& S, const Ik1Tables& T, int stage, const mvmc_gdouble* __restrict__ hh,
+                                             double Delta, double alpha) {
+    MVMC_ASSUME_LDS(&S);
+    MVMC_ASSUME_LDS(&T);
+    const int lane = threadIdx.x & 63;
+    const int na = uni(T.na[stage]), kk = uni((int)S.sc[11]);
+    const double gg = S.sc[0], beta0 = S.sc[4], tau0 = S.sc[5], pivmin = 1e-16 * S.sc[6] + 1e-300, coupling = S.sc[7];
+    double* rh = S.tmp;
+    double* cv = S.tmp + 64;
+    rh[lane] = lane == 0 ? beta0 : 0.0;
+    MVMC_WAVE_SYNC();
+    double pred, step_norm;
+    alpha = eightri::tr_solve_tri<false>(S.sv + SV_D, S.sv + SV_E, rh, kk, Delta, alpha, gg, pivmin, nullptr, nullptr, nullptr, nullptr,
+                                         cv, &pred, &step_norm);
+    MVMC_WAVE_SYNC();
+    double c = lane < kk ? cv[lane] : 0.0;
+    if (kk < na) {
+        const double eta = coupling * wave_sum_dpp(lane < kk ? S.sv[SV_WN + lane] * c : 0.0);
+        if (lane == kk) c = eta;
+    }
+    const double stepj = eightri::apply_q_w1(hh, S.sv + SV_TAU, S.sv + SV_V0, tau0, kk, na, c);
+    if (lane == 0) { S.sc[2] = alpha; S.sc[3] = pred; S.sc[8] = step_norm; }
+    ik1_trial_point(S, T, stage, na, stepj);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -335,78 +452,66 @@ __device__ __noinline__ int ik1_model(Ik1Shared<VM>& S, const Ik1Tables& T, int 
 // in mvmc_ik.hip on one wave.
 // ---------------------------------------------------------------------------------------------
 template <int VM>
-__device__ void ik1_trf(Ik1Shared<VM>& S, const Ik1Tables& T, int stage, int max_nfev, mvmc_gdouble* __restrict__ hh, double* cost_out, int* nfev_out,
-                        int* njev_out, int* status_out, int* fallbacks_out) {
+__device__ __forceinline__ void ik1_trf(Ik1Shared<VM>& S, const Ik1Tables& T, int stage, int max_nfev, mvmc_gdouble* __restrict__ hh,
+                                        double* cost_out, int* nfev_out, int* njev_out, int* status_out, int* fallbacks_out, bool& dump) {
     const int lane = threadIdx.x & 63;
-    const int nfull = (stage == 0) ? 57 : 57 + T.n_side;
-    const int na = T.na[stage];
+    // wave-uniform state is pinned to scalar registers (uni)
+    const int nfull = uni((stage == 0) ? 57 : 57 + T.n_side);
+    const int na = uni(T.na[stage]);
     const double ftol = 1e-8, xtol = 1e-8, gtol = 1e-8;
-    auto x_norm2 = [&]() {
-        double xx = (lane < nfull) ? S.x[lane] * S.x[lane] : 0.0;
-        if (lane + 64 < nfull) xx += S.x[lane + 64] * S.x[lane + 64];
-        return wave_sum(xx);
+    auto model_step = [&](bool budget_left, double Delta, double alpha, bool dump) {
+        // (the result comes back through the caller's stack on purpose: a call that is handed a pointer into its caller's frame is not
+        // marked as a tail-call candidate, and only then does the compiler drop the callee-saved convention for this local function --
+        // with it, the function's prologue saved and restored 58 vector registers that its caller does not even use)
+        int mode = 0;
+        if (na <= 40) ik1_model_step<VM, 40>(S, T, stage, budget_left, gtol, hh, Delta, alpha, dump, &mode);
+        else ik1_model_step<VM, 50>(S, T, stage, budget_left, gtol, hh, Delta, alpha, dump, &mode);
+        return uni(mode);
     };
     double cost;
-    { P1_T0 cost = ik1_eval(S, T, S.x, stage, true); P1_ADD(0) }
+    { P1_T0 cost = uni(ik1_eval_nl(S, T, 0, stage, true)); P1_ADD(0) }
     int nfev = 1, njev = 0, status = -1;
-    double Delta = sqrt(x_norm2());
+    double Delta;
+    {
+        double xx = (lane < nfull) ? S.x[lane] * S.x[lane] : 0.0;
+        if (lane + 64 < nfull) xx += S.x[lane + 64] * S.x[lane + 64];
+        Delta = uni(sqrt(wave_sum(xx)));
+    }
     if (Delta == 0.0) Delta = 1.0;
-    double alpha = 0.0, gg = 0.0, ginf = 1.0;
-    bool need_model = true;
-    int kk = 0;
+    double alpha = 0.0;
     while (true) {
-        if (need_model) {
-            P1_T0
-            kk = (na <= 40) ? ik1_model<VM, 40>(S, T, stage, nfev < max_nfev, gtol, hh, &gg, &ginf)
-                            : ik1_model<VM, 50>(S, T, stage, nfev < max_nfev, gtol, hh, &gg, &ginf);
-            ++njev;
-            need_model = false;
-            P1_ADD(2)
-        }
-        if (ginf < gtol) status = 1;
+        // the model at x (whose FK state and blocks are in LDS) and, unless it stops the iteration, the first trial from it
+        int mode;
+        { P1_T0 mode = model_step(nfev < max_nfev, Delta, alpha, dump); P1_ADD(2) }
+        bool dumped = dump;   // are this model's reflectors in the global scratch?
+        ++njev;
+        if (uni(S.sc[1]) < gtol) status = 1;
         if (status != -1 || nfev == max_nfev) break;
-        const bool fast = kk > 0;
-        const int mq = fast ? kk : -kk;   // rows of the T basis in use
-        if (!fast) ++*fallbacks_out;
-        const double beta0 = S.sc[4], tau0 = S.sc[5], pivmin = 1e-16 * S.sc[6] + 1e-300, coupling = S.sc[7];
-
+        if (mode == 2) ++*fallbacks_out;
+        bool have_trial = mode == 1;
         double actual = -1.0, cost_new = cost;
         while (actual <= 0.0 && nfev < max_nfev) {
-            double pred, step_norm, stepj;
-            {
-                P1_T0
-                double* rh = S.tmp;
-                double* cv = S.tmp + 64;
-                double c;
-                if (fast) {
-                    rh[lane] = lane == 0 ? beta0 : 0.0;
-                    MVMC_WAVE_SYNC();
-                    alpha = eightri::tr_solve_tri<false>(S.sv + SV_D, S.sv + SV_E, rh, kk, Delta, alpha, gg, pivmin, nullptr,
-                                                         nullptr, nullptr, nullptr, cv, &pred, &step_norm);
-                    MVMC_WAVE_SYNC();
-                    c = lane < kk ? cv[lane] : 0.0;
-                    if (kk < na) {
-                        // component along the first null coordinate: keeps the step orthogonal to the null vector
-                        const double eta = coupling * wave_sum_dpp(lane < kk ? S.sv[SV_WN + lane] * c : 0.0);
-                        if (lane == kk) c = eta;
-                    }
+            if (!have_trial) {
+                if (mode == 2) {
+                    ik1_fallback_trial(S, T, stage, hh, Delta, alpha);
+                } else if (dumped) {
+                    ik1_retry_trial(S, T, stage, hh, Delta, alpha);
                 } else {
-                    alpha = eightri::tr_solve_eig_w1(S.sv + SV_WN, S.sv + SV_D, mq, Delta, alpha, gg, cv, &pred, &step_norm);
-                    MVMC_WAVE_SYNC();
-                    c = eightri::eig_combine_w1(hh + 64 * NA1, mq, lane < mq ? cv[lane] : 0.0);
+                    // the first rejected trial of this solve: the reflectors died with the model's registers -- the state of x back
+                    // into LDS (not an evaluation of the solver's budget: the same numbers again) and the model again, this time
+                    // with its reflectors dumped to the global scratch, like every later model of the solve (solves that reject
+                    // once tend to reject again: the cold ones, which set the length of a chain's first frame)
+                    dump = dumped = true;
+                    ik1_eval_nl(S, T, 0, stage, true);
+                    model_step(true, Delta, alpha, true);
                 }
-                stepj = eightri::apply_q_w1(hh, S.sv + SV_TAU, S.sv + SV_V0, tau0, mq, na, c);
-                P1_ADD(3)
             }
-            const double x_norm = sqrt(x_norm2());
-            if (lane < nfull) S.xn[lane] = S.x[lane];
-            if (lane + 64 < nfull) S.xn[lane + 64] = S.x[lane + 64];
-            MVMC_WAVE_SYNC();
-            if (lane < na) { const int f = T.act[stage][lane]; S.xn[f] = S.x[f] + stepj; }
-            MVMC_WAVE_SYNC();
-            { P1_T0 cost_new = ik1_eval(S, T, S.xn, stage, true); P1_ADD(0) }
+            have_trial = false;
+            alpha = uni(S.sc[2]);
+            const double pred = uni(S.sc[3]), step_norm = uni(S.sc[8]), x_norm = uni(S.sc[9]);
+            { P1_T0 cost_new = uni(ik1_eval_nl(S, T, 1, stage, true)); P1_ADD(0) }
             ++nfev;
-            if (!isfinite(cost_new)) { Delta = 0.25 * step_norm; continue; }
+            if (!isfinite(cost_new)) { Delta = uni(0.25 * step_norm); continue; }
             actual = cost - cost_new;
             // update_tr_radius (common.py:222-245)
             double ratio;
@@ -421,17 +526,16 @@ __device__ void ik1_trf(Ik1Shared<VM>& S, const Ik1Tables& T, int stage, int max
             const bool x_ok = step_norm < xtol * (xtol + x_norm);
             if (f_ok && x_ok) status = 4; else if (f_ok) status = 2; else if (x_ok) status = 3;
             if (status != -1) break;
-            alpha *= Delta / Delta_new;
-            Delta = Delta_new;
+            alpha = uni(alpha * (Delta / Delta_new));
+            Delta = uni(Delta_new);
         }
-        if (actual > 0.0) {
-            if (lane < nfull) S.x[lane] = S.xn[lane];
-            if (lane + 64 < nfull) S.x[lane + 64] = S.xn[lane + 64];
-            MVMC_WAVE_SYNC();
-            cost = cost_new;
-            // the accepted point's FK state and blocks are still in LDS (the last evaluation was at xn)
-            need_model = status == -1 && nfev < max_nfev;
-        }
+        if (!(actual > 0.0)) break;   // budget spent or stopped on a rejected trial
+        if (lane < nfull) S.x[lane] = S.xn[lane];
+        if (lane + 64 < nfull) S.x[lane + 64] = S.xn[lane + 64];
+        MVMC_WAVE_SYNC();
+        cost = cost_new;
+        // the accepted point's FK state and blocks are still in LDS (the last evaluation was at xn)
+        if (!(status == -1 && nfev < max_nfev)) break;
     }
     if (status == -1) status = 0;
     *cost_out = cost; *nfev_out = nfev; *njev_out = njev; *status_out = status;
@@ -521,8 +625,9 @@ __device__ __forceinline__ void ik1_solve(Ik1Shared<VM>& S, const Ik1Tables& T, 
                                           double* __restrict__ joints_out, double* __restrict__ info_out,
                                           double* __restrict__ scratch, int stage_mask, const double* __restrict__ targets3d) {
     const int lane = threadIdx.x & 63;
-    mvmc_gdouble* hh = (mvmc_gdouble*)(scratch + (size_t)b * MVMC_IK_SCRATCH_DOUBLES);   // Householder vectors [0, 3200), eigenvectors [3200, 6400)
-    double* info = info_out ? info_out + (size_t)b * 8 : nullptr;
+    b = uni(b);
+    mvmc_gdouble* hh = uni((mvmc_gdouble*)(scratch + (size_t)b * MVMC_IK_SCRATCH_DOUBLES));   // Householder vectors [0, 3200), eigenvectors [3200, 6400)
+    double* info = uni(info_out ? info_out + (size_t)b * 8 : nullptr);
     // views of this problem (the reference only solves clusters with >= 2 views: motion_capture.py:927,940)
     int q_own = -1;
     if (targets3d == nullptr) {
@@ -546,10 +651,10 @@ __device__ __forceinline__ void ik1_solve(Ik1Shared<VM>& S, const Ik1Tables& T, 
             for (int c = 0; c < 4; ++c) S.pose18[lane * 4 + c] = targets3d[(size_t)b * 72 + kIkObs[lane] * 4 + c];
         if (lane == 0) { S.nviews = 0; S.mode3d = 1; }
     }
-    const int n_side = T.n_side;
+    const int n_side = uni(T.n_side);
     MVMC_WAVE_SYNC();
     // ---- observations: 17 COCO rows + synthetic mid-spine (inverse_kinematics.py:339-348), projection matrices ----
-    const int nv = S.nviews;
+    const int nv = uni(S.nviews);
     if (lane < nv) {
         const double* kp = kps17 + (size_t)q_own * 51;
         double* dst = S.pose18 + lane * 54;
@@ -568,7 +673,7 @@ __device__ __forceinline__ void ik1_solve(Ik1Shared<VM>& S, const Ik1Tables& T, 
     MVMC_WAVE_SYNC();
     // ---- initial parameters ----
     // stage_mask bit 2: every problem starts from init (mvmc_ik_solve_stages); otherwise cold == NULL means all cold
-    const bool is_cold = (stage_mask & 4) ? false : ((cold == nullptr) || cold[b] != 0);
+    const bool is_cold = (stage_mask & 4) ? false : ((cold == nullptr) || uni((int)cold[b]) != 0);
     if (is_cold) {
         // root = midpoint of the triangulated (post-optimised) hips; zero angles; reference lengths
         // (inverse_kinematics.py:390-396 with triangulate(..., 0.01, post_optimize=True))
@@ -588,17 +693,18 @@ __device__ __forceinline__ void ik1_solve(Ik1Shared<VM>& S, const Ik1Tables& T, 
     const long long t_all = clock64();
     MVMC_WAVE_SYNC();
 #endif
-    const int max_nfev = is_cold ? nfev_cold : nfev_warm;
+    const int max_nfev = uni(is_cold ? nfev_cold : nfev_warm);
     double costs[2];
     int nfs[2], njs[2], sts[2], fallbacks = 0;
+    bool dump = false;
 #pragma unroll 1
     for (int stage = 0; stage < 2; ++stage) {
         double c = 0.0; int nf = 0, nj = 0, st = 0;
-        if ((stage_mask >> stage) & 1) ik1_trf(S, T, stage, max_nfev, hh, &c, &nf, &nj, &st, &fallbacks);
+        if ((stage_mask >> stage) & 1) ik1_trf(S, T, stage, max_nfev, hh, &c, &nf, &nj, &st, &fallbacks, dump);
         costs[stage] = c; nfs[stage] = nf; njs[stage] = nj; sts[stage] = st;
         MVMC_WAVE_SYNC();
     }
-    ik1_eval(S, T, S.x, 1, false);  // final FK at the solution
+    ik1_eval_nl(S, T, 0, 1, false);  // final FK at the solution
     for (int i = lane; i < 57 + n_side; i += 64) params_out[(size_t)b * 68 + i] = S.x[i];
     if (lane < 54) joints_out[(size_t)b * 54 + lane] = S.pos[lane];
     if (lane == 0) {

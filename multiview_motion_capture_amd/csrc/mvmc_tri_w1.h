@@ -3,9 +3,13 @@
 // Per step: the reflector of row k (one wave reduction), then p = tau M v and the rank-2 update with the row-side
 // values v_i, w_i read back from LDS as broadcasts (two values per ds_read_b128) -- three FMAs per live row and
 // lane and no cross-lane VALU traffic in the inner loops.  Rows <= k are dead (never read again; their diagonal
-// entry survives because v vanishes there) and are skipped in chunks.  The Householder vectors go to global memory,
-// hh[k * 64 + lane] for lane > k (coalesced rows, read back by apply_q_w1): the matrix registers are needed by the rest
-// of the solver.
+// entry survives because v vanishes there) and are skipped in chunks.  The Householder vectors STAY IN THE MATRIX
+// REGISTERS: row k is dead after step k and is left untouched from then on (w is forced to zero on the lanes <= k, which
+// only ever fed dead entries), so v_k = {1 at lane k+1, a[k] * sc_k beyond} can be re-formed from a[k] and the scalar
+// sc_k, which lane k keeps (scv; tau_k likewise in tauv).  apply_q_packed applies Q from those registers (packed two rows to one) -- the common
+// path makes its trust-region trial inside the same function, before the registers die, and no reflector ever travels
+// to memory; dump_reflectors writes them to the global scratch (hh[k * 64 + lane] for lane > k) for the eigenbasis
+// fallback only, whose trials outlive the registers (apply_q_w1).
 #pragma once
 #include "mvmc_common.h"
 #include "mvmc_eigh_tri.h"
@@ -33,8 +37,8 @@ __device__ __forceinline__ double row_of(const double (&a)[N], int k) {
 // one collapses in front of a block that is not null -- the tridiagonalisation is then complete (all n rows) and
 // meant for tri_eigh_w1.
 template <int N>
-__device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, mvmc_gdouble* __restrict__ hh, int n, double* d,
-                                                 double* e, double* tau, double* v0, double* vb, double* pb, double* out4) {
+__device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, int n, double* d, double* e, double* tau, double* v0,
+                                                 double* vb, double* pb, double* out4, double& scv, double& tauv, int& ksteps) {
     static_assert(N % 2 == 0 && N <= 50, "row count");
     const int lane = threadIdx.x & 63;
     auto wave_max = [](double v) {
@@ -76,7 +80,7 @@ __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, mvmc
             }
         const double p = tk * (p0 + p1);
         const double h = 0.5 * tk * wave_sum_dpp(p * vj);
-        const double wj = p - h * vj;
+        const double wj = lane > k ? p - h * vj : 0.0;   // (lanes <= k: dead columns; zero keeps the dead rows intact)
         pb[lane] = wj;
         MVMC_WAVE_SYNC();
 #pragma unroll
@@ -128,6 +132,7 @@ __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, mvmc
     }
     int kk = n;
     bool unclean = false;
+    scv = 0.0; tauv = 0.0; ksteps = 0;
     for (int k = 0; k < n - 1; ++k) {
         const int j1 = k + 1;
         const double x = row_of<N>(a, k);
@@ -137,7 +142,8 @@ __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, mvmc
         double tk, beta, sc;
         reflector(alpha, sig, tk, beta, sc);
         const double v = lane == j1 ? 1.0 : ((lane > j1 && lane < n) ? x * sc : 0.0);
-        if (lane > k && lane < n) hh[k * 64 + lane] = v;   // v vanishes elsewhere: only the live part travels
+        if (lane == k) { scv = sc; tauv = tk; }
+        ksteps = k + 1;
         if (lane == 0) { e[k] = beta; tau[k] = tk; }
         if (!unclean && fabs(beta) <= tol_c) {
             // the Krylov space is exhausted: everything behind row k must be the null space
@@ -148,6 +154,7 @@ __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, mvmc
             m = wave_max(m);
             if (m <= tol_n) {
                 if (lane == 0) tau[k] = 0.0;
+                if (lane == k) tauv = 0.0;
                 coupling = beta;
                 kk = k + 1;
                 const double xt = row_of<N>(a, j1);   // first diagonal entry of the null block (eigensolver path)
@@ -167,6 +174,67 @@ __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, mvmc
     if (lane == 0) out4[3] = coupling;
     MVMC_WAVE_SYNC();
     return unclean ? -1 : kk;
+}
+
+// The reflectors, packed two rows to a register: row z only matters on the lanes >= z + 2, so the payload of row N - 3 - z (lanes
+// N - 1 - z .. N - 1, z + 1 values) moves into the lanes 0 .. z of row z.  (N - 2) / 2 registers instead of N: what has to stay
+// live through the trust-region solve, whose cyclic reduction needs ~70 registers of its own.
+template <int N>
+__device__ __forceinline__ void pack_reflectors(const double (&a)[N], double (&pk)[(N - 2) / 2]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int z = 0; z < (N - 2) / 2; ++z) {
+        const int zp = N - 3 - z;
+        const double hi = __shfl(a[zp], lane + zp + 2, 64);
+        pk[z] = lane >= z + 2 ? a[z] : hi;
+    }
+}
+
+// Q c from the packed reflectors (pack_reflectors; scv, tauv: tridiag_krylov_w1's per-lane scalars): reflectors kk-2 .. 0, then
+// the first one.  Same operations, in the same order, as apply_q_w1 on the dumped vectors.
+template <int N>
+__device__ __forceinline__ double apply_q_packed(const double (&pk)[(N - 2) / 2], double scv, double tauv, const double* v0, double tau0,
+                                                 int kk, int n, double cj) {
+    constexpr int H = (N - 2) / 2;
+    const int lane = threadIdx.x & 63;
+    auto lane_value = [](double v, int src) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+    };
+#pragma unroll
+    for (int z = N - 2; z >= 0; --z)
+        if (z <= kk - 2) {
+            const double sc = lane_value(scv, z), tk = lane_value(tauv, z);
+            double x = 0.0;
+            if (z < H) x = pk[z];
+            else if (z < N - 2) x = __shfl(pk[N - 3 - z], lane - (z + 2), 64);
+            const double v = lane == z + 1 ? 1.0 : ((lane > z + 1 && lane < n) ? x * sc : 0.0);
+            cj -= tk * wave_sum_dpp(v * cj) * v;
+        }
+    if (tau0 != 0.0) {
+        const double v = lane < n ? v0[lane] : 0.0;
+        cj -= tau0 * wave_sum_dpp(v * cj) * v;
+    }
+    return cj;
+}
+
+// The reflectors of the first `ksteps` steps to global memory, in apply_q_w1's layout (eigenbasis fallback only).
+template <int N>
+__device__ __forceinline__ void dump_reflectors(const double (&pk)[(N - 2) / 2], double scv, int ksteps, int n, mvmc_gdouble* __restrict__ hh) {
+    constexpr int H = (N - 2) / 2;
+    const int lane = threadIdx.x & 63;
+    auto lane_value = [](double v, int src) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+    };
+#pragma unroll
+    for (int z = 0; z < N - 1; ++z)
+        if (z < ksteps) {
+            const double sc = lane_value(scv, z);
+            double x = 0.0;
+            if (z < H) x = pk[z];
+            else if (z < N - 2) x = __shfl(pk[N - 3 - z], lane - (z + 2), 64);
+            const double v = lane == z + 1 ? 1.0 : ((lane > z + 1 && lane < n) ? x * sc : 0.0);
+            if (lane > z && lane < n) hh[z * 64 + lane] = v;
+        }
 }
 
 // Q c for tridiag_krylov_w1 (one wave; lane j holds component j): reflectors kk-2 .. 0 from hh, then the first one.
