@@ -27,7 +27,11 @@ constexpr int NA1 = 50;  // max active parameters
 
 #ifdef MVMC_IK_PROFILE
 #define P1_T0 const long long _t0 = clock64();
+#ifdef MVMC_TRI_PROFILE
+#define P1_ADD(k) if ((threadIdx.x & 63) == 0 && (k) == 2) S.prof[k] += clock64() - _t0;
+#else
 #define P1_ADD(k) if ((threadIdx.x & 63) == 0) S.prof[k] += clock64() - _t0;
+#endif
 #else
 #define P1_T0
 #define P1_ADD(k)
@@ -252,6 +256,7 @@ __device__ __noinline__ void ik1_model_step(Ik1Shared<VM>& S, const Ik1Tables& T
     // access below into a ds_ instruction instead of a flat_ one (InferAddressSpaces uses the assumption)
     MVMC_ASSUME_LDS(&S);
     MVMC_ASSUME_LDS(&T);
+    hh = uni(hh);   // (arrives in vector registers; as a scalar base it costs no register next to the matrix rows)
     const int lane = threadIdx.x & 63;
     const int na = uni(T.na[stage]);
     const bool on = lane < na;
@@ -261,7 +266,11 @@ __device__ __noinline__ void ik1_model_step(Ik1Shared<VM>& S, const Ik1Tables& T
     double ax0 = 0.0, ax1 = 0.0, ax2 = 0.0, pa0 = 0.0, pa1 = 0.0, pa2 = 0.0;
 #ifdef MVMC_IK_PROFILE
     long long _tp = clock64();
+#ifdef MVMC_TRI_PROFILE
+#define M1STAMP(k) { const long long _t = clock64(); if (lane == 0 && (k) == 5) S.prof[k] += _t - _tp; _tp = _t; }
+#else
 #define M1STAMP(k) { const long long _t = clock64(); if (lane == 0) S.prof[k] += _t - _tp; _tp = _t; }
+#endif
 #else
 #define M1STAMP(k)
 #endif
@@ -348,7 +357,11 @@ __device__ __noinline__ void ik1_model_step(Ik1Shared<VM>& S, const Ik1Tables& T
     double scv, tauv;
     int ksteps;
     const int kk = uni(eightri::tridiag_krylov_w1<N>(a, gj, na, S.sv + SV_D, S.sv + SV_E, S.sv + SV_TAU, S.sv + SV_V0, S.tmp, S.tmp + 64,
-                                                     &S.sc[4], scv, tauv, ksteps));
+                                                     &S.sc[4], scv, tauv, ksteps
+#ifdef MVMC_TRI_PROFILE
+                                                     , S.prof
+#endif
+                                                     ));
     // the reflectors, two rows to a register: the matrix registers die here, before the checks and the trust-region solve
     double pk[(N - 2) / 2];
     eightri::pack_reflectors<N>(a, pk);

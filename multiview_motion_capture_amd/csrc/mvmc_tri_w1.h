@@ -38,7 +38,8 @@ __device__ __forceinline__ double row_of(const double (&a)[N], int k) {
 // meant for tri_eigh_w1.
 template <int N>
 __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, int n, double* d, double* e, double* tau, double* v0,
-                                                 double* vb, double* pb, double* out4, double& scv, double& tauv, int& ksteps) {
+                                                 double* vb, double* pb, double* out4, double& scv, double& tauv, int& ksteps,
+                                                 long long* tprof = nullptr) {
     static_assert(N % 2 == 0 && N <= 50, "row count");
     const int lane = threadIdx.x & 63;
     auto wave_max = [](double v) {
@@ -63,34 +64,44 @@ __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, int 
     };
     // M <- H M H with H = I - tk v v^T; rows > k only, in chunks of CH rows behind one wave-uniform test each (a
     // test per row would put a full LDS round trip in front of every FMA; v vanishes on the dead rows of a live chunk)
-    constexpr int CH = 10;
-    static_assert(N % CH == 0, "rows per chunk");
+    constexpr int HB = N <= 40 ? 5 : 3;   // pairs of rows per batch of the rank-2 update
+    constexpr int CH = 10, CHB = N % 20 == 0 ? 20 : 10;
+    static_assert(N % CH == 0 && N % CHB == 0, "rows per chunk");
+#ifdef MVMC_TRI_PROFILE   // diagnostic: cycles of a step's four sections into tprof[0, 3, 4, 6] (tools/tri_step_profile.py)
+    long long _tt = clock64();
+#define TRSTAMP(k) { const long long _t = clock64(); if (lane == 0 && tprof) tprof[k] += _t - _tt; _tt = _t; }
+#else
+#define TRSTAMP(k)
+#endif
     auto two_sided = [&](int k, double tk, double vj) {
+        TRSTAMP(0)   // row, reductions and the reflector's scalars
         vb[lane] = vj;
         MVMC_WAVE_SYNC();
         double p0 = 0.0, p1 = 0.0;
+        // (the product takes CHB rows per LDS round trip: an FMA on a dead row costs 4 cycles, a round trip > 100)
 #pragma unroll
-        for (int c = 0; c < N; c += CH)
-            if (c + CH - 1 > k) {
-                double2 v2[CH / 2];
+        for (int c = 0; c < N; c += CHB)
+            if (c + CHB - 1 > k) {
+                double2 v2[CHB / 2];
 #pragma unroll
-                for (int u = 0; u < CH / 2; ++u) v2[u] = *reinterpret_cast<const double2*>(&vb[c + 2 * u]);
+                for (int u = 0; u < CHB / 2; ++u) v2[u] = *reinterpret_cast<const double2*>(&vb[c + 2 * u]);
 #pragma unroll
-                for (int u = 0; u < CH / 2; ++u) { p0 += a[c + 2 * u] * v2[u].x; p1 += a[c + 2 * u + 1] * v2[u].y; }
+                for (int u = 0; u < CHB / 2; ++u) { p0 += a[c + 2 * u] * v2[u].x; p1 += a[c + 2 * u + 1] * v2[u].y; }
             }
+        TRSTAMP(3)   // v broadcast + matrix-vector product
         const double p = tk * (p0 + p1);
         const double h = 0.5 * tk * wave_sum_dpp(p * vj);
         const double wj = lane > k ? p - h * vj : 0.0;   // (lanes <= k: dead columns; zero keeps the dead rows intact)
         pb[lane] = wj;
         MVMC_WAVE_SYNC();
+        TRSTAMP(4)   // h reduction, w, w broadcast
 #pragma unroll
         for (int c = 0; c < N; c += CH)
             if (c + CH - 1 > k) {
                 // two batches of loads per chunk (6 + 4 rows): ten 16-byte broadcasts in flight at once would push the
                 // N = 50 instance over its register budget
 #pragma unroll
-                for (int h0 = 0; h0 < CH / 2; h0 += 3) {
-                    constexpr int HB = 3;
+                for (int h0 = 0; h0 < CH / 2; h0 += HB) {
                     double2 v2[HB], w2[HB];
 #pragma unroll
                     for (int u = 0; u < HB; ++u)
@@ -109,15 +120,16 @@ __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, int 
                 }
             }
         MVMC_WAVE_SYNC();  // vb / pb are rewritten by the next step
+        TRSTAMP(6)   // rank-2 update
     };
     double anorm;
     {
         double cs = 0.0;
 #pragma unroll
         for (int i = 0; i < N; ++i) cs += fabs(a[i]);
-        anorm = wave_max(cs);
+        anorm = uni(wave_max(cs));
     }
-    const double tol_c = 1e-8 * anorm, tol_n = 1e-13 * anorm;
+    const double tol_c = uni(1e-8 * anorm), tol_n = uni(1e-13 * anorm);   // (long-lived wave-uniform scalars: scalar registers)
     double coupling = 0.0;
     {   // first reflector: H_g g = beta0 e_1
         const double x = lane < n ? gj : 0.0;

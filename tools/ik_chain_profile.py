@@ -22,8 +22,10 @@ for name, sl in (("cold head", info[:, 0]), ("warm", info[:, 1:])):
     inf = sl.reshape(-1, 8)
     inf = inf[~np.isnan(inf[:, 5])]
     tot = inf[:, 5].sum()
-    ev, gram, tri_all, ne, kry, chk, trs = (inf[:, k].sum() for k in (0, 1, 2, 3, 4, 6, 7))
+    ev, gram, model, kry, chk, trs = (inf[:, k].sum() for k in (0, 1, 2, 4, 6, 7))
     print("%s: solves %d, cycles per solve mean %.0f (p50 %.0f p95 %.0f max %.0f)" % (
         name, len(inf), inf[:, 5].mean(), *np.percentile(inf[:, 5], [50, 95, 100])))
-    print("   shares: eval %.3f model(D,g) %.3f krylov-phase %.3f [gram %.3f tridiag %.3f checks %.3f] tr-solve %.3f other %.3f" %
-          (ev / tot, ne / tot, tri_all / tot, gram / tot, kry / tot, chk / tot, trs / tot, 1 - (ev + ne + tri_all + trs) / tot))
+    # the model function (ik1_model_step) = J^T J and g + tridiagonalisation and packing + block checks + the first trial step
+    print("   shares: eval %.3f | model function %.3f = [J^T J, g %.3f | tridiag + pack %.3f | checks %.3f | trial (tr solve, Q) %.3f | rest %.3f]"
+          " | other (driver, retry / fallback trials) %.3f" %
+          (ev / tot, model / tot, gram / tot, kry / tot, chk / tot, trs / tot, (model - gram - kry - chk - trs) / tot, 1 - (ev + model) / tot))
