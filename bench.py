@@ -222,6 +222,9 @@ def main():
     ap.add_argument("--cpu-workers", type=int, default=0,
                     help="worker processes of the CPU baseline on the chain protocol (0 = min(16, host cores))")
     ap.add_argument("--seed", type=int, default=20260103)
+    ap.add_argument("--occlusion", type=float, default=0.0,
+                    help="probability that a view misses a person in a frame (ragged counts, deaths and re-births); 0 = BASELINE workload")
+    ap.add_argument("--spurious", type=float, default=0.0, help="probability that a freed slot holds a false detection")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the one all-gather: nccl = RCCL over xGMI (one rank per GPU); gloo only to "
                          "rehearse several ranks on a box with one GPU (host-staged)")
@@ -259,7 +262,7 @@ def main():
     if F % L:
         raise SystemExit("--frames must be a multiple of --chain-len")
     data = synth.generate(F, C, Pn, args.seed, chain_len=L if args.walk == "chains" else 0, frame_seed=args.seed + 1000 * rank,
-                          shuffle=args.workload != "dlt")
+                          shuffle=args.workload != "dlt", occlusion=args.occlusion, spurious=args.spurious)
     hp = HotPath(data["K"], data["Rt"], device=d)
     kps = torch.from_numpy(data["kps25"]).to(d)
     counts = torch.from_numpy(data["counts"]).to(d)
@@ -412,6 +415,13 @@ def main():
         stage_ms["chain_cycle_shares"] = {n: float(pc[:, k].sum() / tot) for k, n in
                                           enumerate(("graph", "als", "assign", "ik", "commit", "outputs"))}
         stage_ms["chain_mcycles_mean_max"] = [float(pc[:, 6].mean() / 1e6), float(pc[:, 6].max() / 1e6)]
+    tracker_events = None
+    if fused and "next_id" in out:
+        # what the tracker did in one step of this rank (the reference's MvTracker: ids handed out = births, tracklets deleted = deaths)
+        cnt = out["n_tracks"].cpu().numpy().reshape(-1, L)
+        tracker_events = {"births": int(out["next_id"].sum().item()), "deaths": int(out["n_dead"].sum().item()),
+                          "frames_where_the_count_changes": int((np.diff(cnt, axis=1) != 0).sum()),
+                          "mean_live_tracklets": float(cnt.mean())}
     if rank == 0:
         frames_total = F * world * args.steps
         value = frames_total / dt
@@ -470,7 +480,8 @@ def main():
                                      f"warm 5+5 after), {('one launch per step, ' + (str(args.parts or L) + ' workgroup(s) per chain')) if args.path == 'fused' else 'one launch per stage'}" + (f", {args.overlap} steps in flight on alternating streams" if args.overlap > 1 else "") if L > 1 else "+IK, every frame cold-started (chain length 1, max_nfev 50+50)")
                                     if with_ik else ""),
                        "frames_per_gpu": F, "views": C, "people": Pn, "chain_len": L, "seed": args.seed, "parallelism": f"frames x{world}",
-                       "steps_in_flight": args.overlap, **extra},
+                       "steps_in_flight": args.overlap, "occlusion": args.occlusion, "spurious": args.spurious, **extra},
+            "tracker_events_per_step": tracker_events,
             "stages_ms": stage_ms,
             "roofline": {"bound": "hbm", "kernel": dom_kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -64,6 +64,10 @@ __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, int 
     };
     // M <- H M H with H = I - tk v v^T; rows > k only, in chunks of CH rows behind one wave-uniform test each (a
     // test per row would put a full LDS round trip in front of every FMA; v vanishes on the dead rows of a live chunk)
+    // Batch sizes: what a step waits for is the LDS round trip of the row-side broadcasts (> 100 cycles each; the FMAs of a row are 4 - 8),
+    // so the 40-row model takes as many rows per round trip as its registers hold.  Tried and dropped: a software pipeline over 5-row
+    // chunks with two or three chunks of operands in flight (loads of chunk c + 2 in front of the FMAs of chunk c) -- more round trips
+    // and branches than it hides, IK 37.9 -> 40.1 M cycles per chain, and the 50-row model spilled v_j / w_j.
     constexpr int HB = N <= 40 ? 5 : 3;   // pairs of rows per batch of the rank-2 update
     constexpr int CH = 10, CHB = N % 20 == 0 ? 20 : 10;
     static_assert(N % CH == 0 && N % CHB == 0, "rows per chunk");
