@@ -330,8 +330,9 @@ __device__ __noinline__ void ik1_model_step(Ik1Shared<VM>& S, const Ik1Tables& T
         db[lane * 3] = d0; db[lane * 3 + 1] = d1; db[lane * 3 + 2] = d2;
         MVMC_WAVE_SYNC();
         // rows in chunks behind one wave-uniform test each (d_i vanishes on the other rows of a live chunk): the chunk's
-        // broadcast ds_read_b128 are in flight together instead of one LDS round trip per row.  8 rows per chunk in the
-        // 40-row instance; 4 in the 50-row one, whose 100 matrix registers leave no room for 24 more doubles of operands
+        // broadcast ds_read_b128 are in flight together instead of one LDS round trip per row.  Four rows per chunk: the 50-row
+        // instance has no registers for more operands, and in the 40-row one 8 rows per chunk measured slower (fewer chunks are
+        // skipped by the tree sparsity than round trips are saved: IK 37.6 -> 38.6 M cycles per chain)
         constexpr int GR = 4, GL = GR * 3 / 2;
         const unsigned long long m = T.rowmask[stage][k];
         const unsigned mlo = __builtin_amdgcn_readfirstlane((unsigned)m), mhi = __builtin_amdgcn_readfirstlane((unsigned)(m >> 32));

@@ -151,3 +151,46 @@ def test_temporal_graph_n72_t8_vs_oracle(c5):
     assert np.array_equal(out["st"]["x_bin"][0, :n, :n].cpu().numpy().astype(bool), xb_o)
     assert np.array_equal(out["st"]["labels"][0, :n].cpu().numpy(), o.cluster_labels(mm_o, n))
     assert abs(int(out["st"]["iters"][0]) - it_o) <= 2
+
+
+def test_config5_at_full_size_on_the_persistent_kernel():
+    """BASELINE config 5 at one GPU's share of it (200 k frames / 8 GPUs = 25,008 frames of C8 P8 in chains of 16) through
+    mvmc_chain_run's BIG layout: no capacity / hand-over flag, deterministic, shard invariant (two half-shards == the whole: what
+    the multi-GPU split relies on), eight tracklets that keep their identity through their chain, 3-D accuracy against the
+    generator's ground truth.  (Parity with the oracle is the small-size tests' above; the CPU oracle needs minutes per chain here.)"""
+    from multiview_motion_capture_amd import synth
+    from multiview_motion_capture_amd.pipeline import HotPath
+    from multiview_motion_capture_amd.tracker import run_chains_fused, check_chain_flags
+    Ff = 25008
+    data = synth.generate(Ff, C, P, 20260105, chain_len=L)
+    d = torch.device("cuda:0")
+    hp = HotPath(data["K"], data["Rt"], device=d)
+    kps, cnt = torch.from_numpy(data["kps25"]).to(d), torch.from_numpy(data["counts"]).to(d)
+    a = run_chains_fused(hp, kps, cnt, L)
+    b = run_chains_fused(hp, kps, cnt, L)
+    cut = (Ff // L // 2) * L
+    s0 = run_chains_fused(hp, kps[:cut].contiguous(), cnt[:cut].contiguous(), L)
+    s1 = run_chains_fused(hp, kps[cut:].contiguous(), cnt[cut:].contiguous(), L)
+    torch.cuda.synchronize()
+    for r in (a, b, s0, s1):
+        check_chain_flags(r)
+    for k in ("params", "joints", "meta", "n_tracks"):
+        whole = torch.nan_to_num(a[k].double())
+        assert torch.equal(whole, torch.nan_to_num(b[k].double())), f"non-deterministic {k}"
+        assert torch.equal(whole, torch.nan_to_num(torch.cat([s0[k], s1[k]]).double())), f"shard-dependent {k}"
+    n = a["n_tracks"].cpu().numpy()
+    meta = a["meta"].cpu().numpy()
+    joints = a["joints"].cpu().numpy()
+    gt = data["gt_joints"]
+    last = np.arange(Ff) % L == L - 1
+    full_len = (meta[last][:, :P, 2] == L).mean()
+    errs = []
+    for f in range(0, Ff, 23):
+        if n[f] != P:
+            continue
+        dist = np.linalg.norm(joints[f, :P, None] - gt[f][None], axis=-1).mean(axis=-1)
+        errs.append(dist.min(axis=1))
+    errs = np.concatenate(errs)
+    print(f"config 5, {Ff} frames: {100 * (n == P).mean():.2f}% frames with {P} tracks; {100 * full_len:.2f}% of tracklets span their "
+          f"whole chain; mean joint error vs ground truth: median {np.median(errs) * 100:.2f} cm, p95 {np.quantile(errs, 0.95) * 100:.2f} cm")
+    assert (n == P).mean() > 0.95 and full_len > 0.9 and np.median(errs) < 0.05
