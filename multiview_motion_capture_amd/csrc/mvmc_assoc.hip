@@ -1571,69 +1571,75 @@ __device__ __forceinline__ void als5_gram(const double* __restrict__ sF, int n, 
     }
 }
 
-// the solver wave: [G | I] -> [I | inv(G)] by Gauss-Jordan IN REGISTERS (G is symmetric positive definite: no pivoting; the
-// reference forms the explicit inverse too, np.linalg.inv).  Lane (c, h) = (lane & 31, lane >> 5) holds rows 8 h .. 8 h + 7 of column
-// c of the 16 x 32 augmented matrix in cur[8].  Per pivot p (unrolled: every register index is a constant): the pivot row's entry of
-// my column comes from my own registers or from lane ^ 32, the pivot itself by v_readlane, the pivot column's entries of my rows by
-// crossbar broadcasts (ds_bpermute) of lane p of my half -- no LDS memory, no waits on stores.  In three pieces (load, a range of
-// pivots, store) because the sixteen dependent pivots are spread over several phases of the iteration (als5_graph).
+// the solver wave: G -> inv(G) by Gauss-Jordan IN PLACE, IN REGISTERS (G is symmetric positive definite: no pivoting; the reference
+// forms the explicit inverse too, np.linalg.inv).  Lane (c, g) = (lane & 15, lane >> 4) holds rows 4 g .. 4 g + 3 of column c in
+// cur[4]: a row group is one 16-lane DPP row.  Per pivot p (unrolled: every register index is a constant): the pivot row's entry of
+// my column comes from lane (c, p / 4) through the LDS crossbar (one ds_bpermute pair), the pivot itself by v_readlane, and the
+// pivot column's entries of my four rows from lane p of MY OWN DPP row by row_newbcast -- VALU moves, no crossbar round trip.
+// The arithmetic is that of the elimination on the augmented matrix [G | I] (which the first version of this routine carried in
+// eight registers per lane, sixteen crossbar broadcasts per pivot): column 16 + p of the identity part is still e_p when pivot p
+// comes, so its new entries are 1 / piv and 0 - M[i][p] * (1 / piv), and they take the place of column p, which becomes e_p and is
+// never read again.  Same divisions, same FMAs, bit for bit; 16 dependent pivots of ~300 cycles instead of ~600.
 // rho_fix: add rho to the diagonal and put the identity on the unused rank slots while loading (the Gram matrix was stored raw).
-__device__ __forceinline__ double als5_bcast_half(double v, int src_in_half) {
+template <int SRC>
+__device__ __forceinline__ double als5_row_newbcast(double v) {   // lane SRC of the caller's 16-lane row, to the whole row
     int lo = __double2loint(v), hi = __double2hiint(v);
-    const int src = ((threadIdx.x & 32) | src_in_half) << 2;
-    lo = __builtin_amdgcn_ds_bpermute(src, lo);
-    hi = __builtin_amdgcn_ds_bpermute(src, hi);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + SRC, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + SRC, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ void als5_inv_load(double (&cur)[8], const double* __restrict__ sGin, int r, double rho, bool rho_fix) {
+// the pivot column's entries of the caller's four rows (p is a compile-time constant after unrolling: the switch folds)
+__device__ __forceinline__ void als5_pivot_column(const double (&cur)[4], double (&col)[4], int p) {
+#define MVMC_A5C(Z) case Z: _Pragma("unroll") for (int q = 0; q < 4; ++q) col[q] = als5_row_newbcast<Z>(cur[q]); break;
+    switch (p) {
+        MVMC_A5C(0) MVMC_A5C(1) MVMC_A5C(2) MVMC_A5C(3) MVMC_A5C(4) MVMC_A5C(5) MVMC_A5C(6) MVMC_A5C(7)
+        MVMC_A5C(8) MVMC_A5C(9) MVMC_A5C(10) MVMC_A5C(11) MVMC_A5C(12) MVMC_A5C(13) MVMC_A5C(14) MVMC_A5C(15)
+        default: break;
+    }
+#undef MVMC_A5C
+}
+__device__ __forceinline__ void als5_inv_load(double (&cur)[4], const double* __restrict__ sGin, int r, double rho, bool rho_fix) {
     const int lane = threadIdx.x & 63;
-    const int c = lane & 31, h = lane >> 5;
+    const int c = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int row = h * 8 + q;
-        double v;
-        if (c < 16) {
-            v = sGin[row * 16 + c];
-            if (rho_fix) {
-                if (row == c) v += rho;
-                if (row >= r || c >= r) v = row == c ? 1.0 : 0.0;
-            }
-        } else {
-            v = row == c - 16 ? 1.0 : 0.0;
+    for (int q = 0; q < 4; ++q) {
+        const int row = g * 4 + q;
+        double v = sGin[row * 16 + c];
+        if (rho_fix) {
+            if (row == c) v += rho;
+            if (row >= r || c >= r) v = row == c ? 1.0 : 0.0;
         }
         cur[q] = v;
     }
 }
 template <int P0, int P1>
-__device__ __forceinline__ void als5_inv_pivots(double (&cur)[8]) {
+__device__ __forceinline__ void als5_inv_pivots(double (&cur)[4]) {
     const int lane = threadIdx.x & 63;
-    const int h = lane >> 5;
+    const int c = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int p = P0; p < P1; ++p) {
-        const int ph = p >> 3, pq = p & 7;
+        const int pg = p >> 2, pq = p & 3;
         const double mine = cur[pq];
-        const double other = __shfl_xor(mine, 32, 64);
-        const double prow = h == ph ? mine : other;                 // M[p][c]
-        const double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine), p + 32 * ph),
-                                            __builtin_amdgcn_readlane(__double2loint(mine), p + 32 * ph));   // M[p][p]
-        double col[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) col[q] = als5_bcast_half(cur[q], p);   // M[8 h + q][p]
+        double prow = __shfl(mine, pg * 16 + c, 64);                // M[p][c]
+        const double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine), pg * 16 + p),
+                                            __builtin_amdgcn_readlane(__double2loint(mine), pg * 16 + p));   // M[p][p]
+        double col[4];
+        als5_pivot_column(cur, col, p);                             // M[4 g + q][p]
+        if (c == p) prow = 1.0;                                     // (column 16 + p of the augmented matrix: e_p)
         const double f = prow / piv;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int row = h * 8 + q;
-            cur[q] = row == p ? f : cur[q] - col[q] * f;
+        for (int q = 0; q < 4; ++q) {
+            const int row = g * 4 + q;
+            const double old = c == p ? 0.0 : cur[q];
+            cur[q] = row == p ? f : old - col[q] * f;
         }
     }
 }
-__device__ __forceinline__ void als5_inv_store(const double (&cur)[8], double* __restrict__ sG) {
+__device__ __forceinline__ void als5_inv_store(const double (&cur)[4], double* __restrict__ sG) {
     const int lane = threadIdx.x & 63;
-    const int c = lane & 31, h = lane >> 5;
-    if (c >= 16) {
+    const int c = lane & 15, g = lane >> 4;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) sG[(h * 8 + q) * 34 + c] = cur[q];
-    }
+    for (int q = 0; q < 4; ++q) sG[(g * 4 + q) * 34 + 16 + c] = cur[q];
 }
 
 // One graph (index f of the batch) on a 512-thread workgroup; every thread of the workgroup must call it.
@@ -1744,7 +1750,7 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
         // XZY / X1 / H phases -- they crawl beside the tiles' LDS traffic --; the pivot column through v_readlane instead of the LDS
         // crossbar -- 32 scalar moves per pivot cost more than 16 crossbar reads.)
         bool gram_raw = false;      // sGin holds A^T A without rho / identity padding (formed during XZY)
-        double cur[8];
+        double cur[4];
         for (int it = 0; it < 1000; ++it) {
             const double rho = 50.0 / mu;
             als5_inv_load(cur, sGin, r, rho, gram_raw);            // inv(A^T A + rho I) while the workers form H

@@ -1,5 +1,5 @@
 """Bit-level comparison of two builds of the C-ABI library on the bench workload (GPU):
-    python tools/lib_diff.py libA.so libB.so [frames]
+    python tools/lib_diff.py libA.so libB.so [frames] [views] [people]
 Runs run_chains_fused with each library in a child process and compares params / joints / meta / info."""
 import os, subprocess, sys, tempfile
 import numpy as np
@@ -10,8 +10,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     from multiview_motion_capture_amd import synth
     from multiview_motion_capture_amd.pipeline import HotPath
     from multiview_motion_capture_amd.tracker import run_chains_fused, check_chain_flags
-    F = int(sys.argv[3])
-    data = synth.generate(F, 5, 4, 20260103, chain_len=16, frame_seed=20260103)
+    F, Cv, Pp = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    data = synth.generate(F, Cv, Pp, 20260103, chain_len=16, frame_seed=20260103)
     hp = HotPath(data["K"], data["Rt"])
     kps = torch.from_numpy(data["kps25"]).cuda(); cnt = torch.from_numpy(data["counts"]).cuda()
     out = run_chains_fused(hp, kps, cnt, 16, want_info=True)
@@ -22,10 +22,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
 
 a, b = sys.argv[1], sys.argv[2]
 F = sys.argv[3] if len(sys.argv) > 3 else "2048"
+CP = [sys.argv[4] if len(sys.argv) > 4 else "5", sys.argv[5] if len(sys.argv) > 5 else "4"]
 res = []
 for lib in (a, b):
     f = tempfile.mktemp(suffix=".npz")
-    subprocess.run([sys.executable, __file__, "--child", f, F], env=dict(os.environ, MVMC_LIB_PATH=os.path.abspath(lib)), check=True)
+    subprocess.run([sys.executable, __file__, "--child", f, F] + CP, env=dict(os.environ, MVMC_LIB_PATH=os.path.abspath(lib)), check=True)
     res.append(np.load(f))
 for k in ("n_tracks", "meta", "params", "joints", "ik_info"):
     x, y = res[0][k], res[1][k]
