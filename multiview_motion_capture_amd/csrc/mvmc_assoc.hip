@@ -1626,6 +1626,9 @@ __device__ __forceinline__ void als5_inv_pivots(double (&cur)[4]) {
         double col[4];
         als5_pivot_column(cur, col, p);                             // M[4 g + q][p]
         if (c == p) prow = 1.0;                                     // (column 16 + p of the augmented matrix: e_p)
+        // (tried: the reciprocal chain of the wave-uniform pivot taken out of the division -- rcp + two Newton steps while the crossbar
+        // delivers prow, then q = n r, e = fma(-d, q, n), q' = fma(e, r, q), the true division only for out-of-range operands behind a
+        // wave-uniform branch.  Bit-identical, but slower: inversion 8 k -> 10.6 k cycles; the compiler's own expansion stays.)
         const double f = prow / piv;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1719,7 +1722,10 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
         sA[e] = (k < n && a < r) ? seed[k * r + a] : 0.0;
         sB[e] = 0.0;
     }
-    // factor-update roles: threads 0..287 = (rank slot fa, block of four columns fj0..fj0+3); the last wave is the solver
+    // factor-update roles: threads 0..287 = (rank slot fa, block of four columns fj0..fj0+3); the last wave is the solver.
+    // (Tried on these phases, all bit-identical: a 2 x 4 output tile per thread on 144 threads -- 40 % fewer LDS bytes, but the two H
+    // phases went 14.6 k -> 18.2 k cycles and the whole path 67 k -> 58 k frames/s: 2.25 waves cannot cover the LDS latency; eight rows of
+    // X1 per step instead of four -- no change; both together -- 56 k frames/s.)
     const bool worker = tid < NWORK;
     const int fa = tid & 15, fj0 = worker ? (tid >> 4) * 4 : 0;
     __syncthreads();
