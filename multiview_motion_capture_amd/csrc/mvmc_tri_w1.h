@@ -49,21 +49,25 @@ __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, int 
     auto lane_value = [](double v, int src) {  // v of lane src (uniform) as a scalar
         return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
     };
+    // (branch-free: the scalars are selected at the end, so that the chain stays in one basic block with whatever the caller overlaps it with)
     auto reflector = [&](double alpha, double sig, double& tk, double& beta, double& sc) {
-        tk = 0.0; beta = alpha; sc = 0.0;
-        if (sig > 0.0) {
-            const double q2 = alpha * alpha + sig;
-            double rs = __builtin_amdgcn_rsq(q2);
-            rs = rs * (1.5 - 0.5 * q2 * rs * rs);
-            rs = rs * (1.5 - 0.5 * q2 * rs * rs);
-            const double nrm = q2 * rs;
-            beta = alpha >= 0.0 ? -nrm : nrm;
-            tk = 1.0 - alpha * fast_rcp64(beta);
-            sc = fast_rcp64(alpha - beta);
-        }
+        const double q2 = alpha * alpha + sig;
+        double rs = __builtin_amdgcn_rsq(q2);
+        rs = rs * (1.5 - 0.5 * q2 * rs * rs);
+        rs = rs * (1.5 - 0.5 * q2 * rs * rs);
+        const double nrm = q2 * rs;
+        const double b1 = alpha >= 0.0 ? -nrm : nrm;
+        const double t1 = 1.0 - alpha * fast_rcp64(b1);
+        const double s1 = fast_rcp64(alpha - b1);
+        const bool live = sig > 0.0;
+        tk = live ? t1 : 0.0; beta = live ? b1 : alpha; sc = live ? s1 : 0.0;
     };
     // M <- H M H with H = I - tk v v^T; rows > k only, in chunks of CH rows behind one wave-uniform test each (a
     // test per row would put a full LDS round trip in front of every FMA; v vanishes on the dead rows of a live chunk)
+    // Also tried: the product started on the UNSCALED row before the reflector's scalars are known (M v = M e_{k+1} + sc M x~, all rows in
+    // one basic block so that the scheduler can run it inside the latency of the reduction + rsqrt / reciprocal chain): the scheduler
+    // hoists every broadcast load to the top and the matrix rows spill (145 scratch stores / 496 loads in the 50-row model, IK 37 -> 122 M
+    // cycles per chain); it would need a hand-placed schedule (sched_group_barrier per sub-step of the chain).  Not done.
     // Batch sizes: what a step waits for is the LDS round trip of the row-side broadcasts (> 100 cycles each; the FMAs of a row are 4 - 8),
     // so the 40-row model takes as many rows per round trip as its registers hold.  Tried and dropped: a software pipeline over 5-row
     // chunks with two or three chunks of operands in flight (loads of chunk c + 2 in front of the FMAs of chunk c) -- more round trips
@@ -77,28 +81,7 @@ __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, int 
 #else
 #define TRSTAMP(k)
 #endif
-    auto two_sided = [&](int k, double tk, double vj) {
-        TRSTAMP(0)   // row, reductions and the reflector's scalars
-        vb[lane] = vj;
-        MVMC_WAVE_SYNC();
-        double p0 = 0.0, p1 = 0.0;
-        // (the product takes CHB rows per LDS round trip: an FMA on a dead row costs 4 cycles, a round trip > 100)
-#pragma unroll
-        for (int c = 0; c < N; c += CHB)
-            if (c + CHB - 1 > k) {
-                double2 v2[CHB / 2];
-#pragma unroll
-                for (int u = 0; u < CHB / 2; ++u) v2[u] = *reinterpret_cast<const double2*>(&vb[c + 2 * u]);
-#pragma unroll
-                for (int u = 0; u < CHB / 2; ++u) { p0 += a[c + 2 * u] * v2[u].x; p1 += a[c + 2 * u + 1] * v2[u].y; }
-            }
-        TRSTAMP(3)   // v broadcast + matrix-vector product
-        const double p = tk * (p0 + p1);
-        const double h = 0.5 * tk * wave_sum_dpp(p * vj);
-        const double wj = lane > k ? p - h * vj : 0.0;   // (lanes <= k: dead columns; zero keeps the dead rows intact)
-        pb[lane] = wj;
-        MVMC_WAVE_SYNC();
-        TRSTAMP(4)   // h reduction, w, w broadcast
+    auto rank2 = [&](int k, double vj, double wj) {
 #pragma unroll
         for (int c = 0; c < N; c += CH)
             if (c + CH - 1 > k) {
@@ -125,6 +108,30 @@ __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, int 
             }
         MVMC_WAVE_SYNC();  // vb / pb are rewritten by the next step
         TRSTAMP(6)   // rank-2 update
+    };
+    auto two_sided = [&](int k, double tk, double vj) {
+        TRSTAMP(0)   // row, reductions and the reflector's scalars
+        vb[lane] = vj;
+        MVMC_WAVE_SYNC();
+        double p0 = 0.0, p1 = 0.0;
+        // (the product takes CHB rows per LDS round trip: an FMA on a dead row costs 4 cycles, a round trip > 100)
+#pragma unroll
+        for (int c = 0; c < N; c += CHB)
+            if (c + CHB - 1 > k) {
+                double2 v2[CHB / 2];
+#pragma unroll
+                for (int u = 0; u < CHB / 2; ++u) v2[u] = *reinterpret_cast<const double2*>(&vb[c + 2 * u]);
+#pragma unroll
+                for (int u = 0; u < CHB / 2; ++u) { p0 += a[c + 2 * u] * v2[u].x; p1 += a[c + 2 * u + 1] * v2[u].y; }
+            }
+        TRSTAMP(3)   // v broadcast + matrix-vector product
+        const double p = tk * (p0 + p1);
+        const double h = 0.5 * tk * wave_sum_dpp(p * vj);
+        const double wj = lane > k ? p - h * vj : 0.0;   // (lanes <= k: dead columns; zero keeps the dead rows intact)
+        pb[lane] = wj;
+        MVMC_WAVE_SYNC();
+        TRSTAMP(4)   // h reduction, w, w broadcast
+        rank2(k, vj, wj);
     };
     double anorm;
     {
