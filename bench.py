@@ -421,7 +421,10 @@ def main():
         cnt = out["n_tracks"].cpu().numpy().reshape(-1, L)
         tracker_events = {"births": int(out["next_id"].sum().item()), "deaths": int(out["n_dead"].sum().item()),
                           "frames_where_the_count_changes": int((np.diff(cnt, axis=1) != 0).sum()),
-                          "mean_live_tracklets": float(cnt.mean())}
+                          "mean_live_tracklets": float(cnt.mean()),
+                          # bit 0: a cluster with more members than v_max views or more new clusters than k_max in some frame (the
+                          # reference has no such caps); bit 1: tracklet table full
+                          "capacity_word": int(hand_over_flags[-1][-2]) if hand_over_flags and hand_over_flags[-1] is not None else 0}
     if rank == 0:
         frames_total = F * world * args.steps
         value = frames_total / dt
