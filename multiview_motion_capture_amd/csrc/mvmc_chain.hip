@@ -70,6 +70,11 @@ struct MvmcChainArgs {
 namespace {
 
 using ChainArgs = MvmcChainArgs;
+// The launch's arguments as the device functions see them: a reference INTO THE KERNEL-ARGUMENT SEGMENT (constant address space), so
+// every field is a scalar load where it is used.  Handing the phases a reference to the kernel's by-value parameter made the compiler
+// copy the 368-byte struct to the stack of every lane at kernel entry (24 sixteen-byte scratch stores per lane: 98 KB per workgroup,
+// i.e. per frame -- 1 GB per launch) and read every field back from scratch.
+using ChainArgsK = const __attribute__((address_space(4))) MvmcChainArgs;
 
 // Two layouts.  SMALL (configs 1-4: N = C P <= 40 nodes, <= 6 views per person): the rank-8 workgroup ALS variants, 52 KB of LDS,
 // three workgroups per CU.  BIG (config 5, C8 P8: N <= 64, N + T <= 72, <= 8 views per person): the generic workgroup ALS (rank
@@ -109,7 +114,7 @@ static_assert(sizeof(ChainArena<true>) <= 150 * 1024, "BIG: one workgroup per CU
 // functions -- with it each phase saved and restored, per call and per lane, every callee-saved vector register it touches (58 for the
 // IK phase), whether the kernel had anything live there or not.
 template <bool BIG>
-__device__ __noinline__ void chain_graph_spatial(ChainArena<BIG>& arena, const ChainArgs& A, int b, int f, int* done) {
+__device__ __noinline__ void chain_graph_spatial(ChainArena<BIG>& arena, ChainArgsK& A, int b, int f, int* done) {
     MVMC_ASSUME_LDS(&arena);
     const int C = A.C, P = A.P, N = C * P;
     float* S = A.S_sp + (size_t)b * N * N;
@@ -117,7 +122,7 @@ __device__ __noinline__ void chain_graph_spatial(ChainArena<BIG>& arena, const C
     *done = 0;
 }
 template <bool BIG>
-__device__ __noinline__ void chain_graph_temporal(ChainArena<BIG>& arena, const ChainArgs& A, int b, int f, bool pairs_ready, int* done) {
+__device__ __noinline__ void chain_graph_temporal(ChainArena<BIG>& arena, ChainArgsK& A, int b, int f, bool pairs_ready, int* done) {
     MVMC_ASSUME_LDS(&arena);
     const int C = A.C, P = A.P, T = A.T, NS = T + C * P;
     double* W = A.W_st + (size_t)b * NS * NS;
@@ -126,13 +131,13 @@ __device__ __noinline__ void chain_graph_temporal(ChainArena<BIG>& arena, const 
     *done = 0;
 }
 // the frame's 2-D / 2-D distances, made while the workgroup waits for its predecessor (they do not depend on the tracklets)
-__device__ __noinline__ void chain_pose_pairs(ChainArena<false>& arena, const ChainArgs& A, int f, int* done) {
+__device__ __noinline__ void chain_pose_pairs(ChainArena<false>& arena, ChainArgsK& A, int f, int* done) {
     MVMC_ASSUME_LDS(&arena);
     st_pose_pairs(arena.graph + CH_EOFF, A.kps17, A.counts, f, A.F2, A.C, A.P, 0.1);
     *done = 0;
 }
 template <bool BIG>
-__device__ __noinline__ void chain_als_spatial(ChainArena<BIG>& arena, const ChainArgs& A, int b, int f, int* done) {
+__device__ __noinline__ void chain_als_spatial(ChainArena<BIG>& arena, ChainArgsK& A, int b, int f, int* done) {
     MVMC_ASSUME_LDS(&arena);
     const int C = A.C, N = C * A.P;
     // batch index 0 with pre-offset pointers: the graph, its group counts (the frame's people per view) and outputs
@@ -145,7 +150,7 @@ __device__ __noinline__ void chain_als_spatial(ChainArena<BIG>& arena, const Cha
     *done = 0;
 }
 template <bool BIG>
-__device__ __noinline__ void chain_als_temporal(ChainArena<BIG>& arena, const ChainArgs& A, int b, int* done) {
+__device__ __noinline__ void chain_als_temporal(ChainArena<BIG>& arena, ChainArgsK& A, int b, int* done) {
     MVMC_ASSUME_LDS(&arena);
     const int C = A.C, NS = A.T + C * A.P;
     if constexpr (BIG)
@@ -156,18 +161,18 @@ __device__ __noinline__ void chain_als_temporal(ChainArena<BIG>& arena, const Ch
                                nullptr, nullptr, A.labels_st + (size_t)b * NS, A.ncl_st + b, A.iters_st + b);
     *done = 0;
 }
-__device__ __noinline__ void chain_assign(const ChainArgs& A, int b, int f, int* done) {
+__device__ __noinline__ void chain_assign(ChainArgsK& A, int b, int f, int* done) {
     assign_chain(threadIdx.x & 63, 64, b, f, A.labels_sp, A.ncl_sp, A.labels_st, A.ncl_st, A.counts, A.n_tracks, A.params, A.C, A.P, A.T, A.K, A.V,
                  A.members, A.cold, A.init, A.status, A.n_new, reinterpret_cast<int32_t*>(A.flags + A.n_chains + 2));
     *done = 0;
 }
-__device__ __noinline__ void chain_commit(const ChainArgs& A, int b, int* done) {
+__device__ __noinline__ void chain_commit(ChainArgsK& A, int b, int* done) {
     commit_chain(threadIdx.x & 63, 64, b, A.status, A.n_new, A.ik_params, A.ik_joints, A.T, A.K, A.n_inits, A.params, A.joints, A.meta, A.n_tracks,
                  A.next_id, A.n_dead, A.slot_src, reinterpret_cast<int32_t*>(A.flags + A.n_chains + 2));
     *done = 0;
 }
 template <bool BIG>
-__device__ __noinline__ void chain_ik(ChainArena<BIG>& arena, const Ik1Tables& tables, const ChainArgs& A, int b, int* done) {
+__device__ __noinline__ void chain_ik(ChainArena<BIG>& arena, const Ik1Tables& tables, ChainArgsK& A, int b, int* done) {
     MVMC_ASSUME_LDS(&arena);
     MVMC_ASSUME_LDS(&tables);
     constexpr int NW = ChainCfg<BIG>::NT / 64;
@@ -184,7 +189,11 @@ __device__ __noinline__ void chain_ik(ChainArena<BIG>& arena, const Ik1Tables& t
 
 template <bool BIG>
 __global__ void __launch_bounds__(ChainCfg<BIG>::NT, ChainCfg<BIG>::WAVES_PER_SIMD)
-chain_kernel(SkelDev skarg, ChainArgs A) {
+chain_kernel(SkelDev skarg, ChainArgs A_by_value) {
+    // A = the second kernel argument where it lies in the kernel-argument segment (layout: skarg, then A at its natural alignment)
+    constexpr size_t A_OFFSET = (sizeof(SkelDev) + alignof(ChainArgs) - 1) / alignof(ChainArgs) * alignof(ChainArgs);
+    typedef const __attribute__((address_space(4))) char* KernargBytes;
+    ChainArgsK& A = *(ChainArgsK*)((KernargBytes)__builtin_amdgcn_kernarg_segment_ptr() + A_OFFSET);
     extern __shared__ __attribute__((aligned(16))) unsigned char chain_lds[];   // the arena (BIG: 72 KB, beyond the static limit)
     ChainArena<BIG>& arena = *reinterpret_cast<ChainArena<BIG>*>(chain_lds);
     __shared__ Ik1Tables tables;
