@@ -210,6 +210,10 @@ __device__ __forceinline__ double ik1_eval(Ik1Shared<VM>& S, const Ik1Tables& T,
 //   ik1_model_step      the trust-region model at the last evaluated point AND the first trial step from it
 //   ik1_fallback_trial  a trial step of a model that took the eigenbasis fallback
 //   ik1_retry_trial     a further trial step of a common-path model whose reflectors are in the global scratch
+// (Tried again on this structure: everything inlined into one state machine with a single evaluation site and a single model site per
+// row count -- no calls, no per-call save of the register that holds spilled SGPRs.  The allocator then keeps ~40 loop-invariant values
+// of the driver and the evaluation in spill slots and reloads them inside the Householder loop: 192 scratch stores / 1,140 loads in the
+// IK phase.  The out-of-line boundaries are what keeps the model's register allocation to itself.)
 // Results of a trial: S.xn = the trial point, S.sc[2] = alpha, S.sc[3] = predicted reduction, S.sc[8] = |step|,
 // S.sc[9] = |x|.
 // ---------------------------------------------------------------------------------------------
