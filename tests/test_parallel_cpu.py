@@ -1,4 +1,4 @@
-"""N > 1 path on the CPU: a world-size-2 gloo run of parallel.run_sharded end to end -- shard ranges, message packing, the one
+"""N > 1 path on the CPU: world-size-2 and -3 gloo runs of parallel.run_sharded end to end -- shard ranges, message packing, the one
 all-gather, and the stitch of identities across chain and shard boundaries -- with the compute and the device kernels replaced by
 host stand-ins that speak the same message format (oracle/stitch_np.py; there is no GPU here).  The device kernels themselves are
 checked against the same host restatement in tests/test_gpu_parallel.py."""
@@ -6,6 +6,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -119,22 +120,23 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_run_sharded_gloo_world2_end_to_end():
+@pytest.mark.parametrize("world", [2, 3])     # 7 chains: shards of 4 + 3, and of 3 + 2 + 2
+def test_run_sharded_gloo_end_to_end(world):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=180) for _ in procs)
     for p in procs:
         p.join(timeout=60)
-    assert [r[0] for r in res] == [0, 1] and all(r[1] for r in res)
-    assert res[0][5] == res[1][5]                      # both ranks hold the same global identities
-    assert res[0][2] == res[1][2] == 4                  # 3 people + the re-born one
+    assert [r[0] for r in res] == list(range(world)) and all(r[1] for r in res)
+    assert all(r[5] == res[0][5] for r in res)         # every rank holds the same global identities
+    assert all(r[2] == 4 for r in res)                 # 3 people + the re-born one
     seq = fake_sequence()
     assert res[0][4] == int(seq["n_tracks"].sum())
     # the same sequence stitched in one process (world 1) gives the same identities: sharding does not change the result
