@@ -1128,6 +1128,9 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
 // Gauss-Jordan steps P0 .. P1-1 on [G | E]: lane (c, a) = (lane >> 3, lane & 7) holds row a of G in registers (eight replicas) and entry
 // (a, c) of E.  The pivot row of G travels through SGPRs (v_readlane), the pivot row of E through one ds_bpermute.  (Tried: all of E in
 // registers too, rows through v_readlane only -- 16 readlanes per step instead of 9 on average, 13% slower.)
+// (Also tried, round 2: ONE entry of G and of E per lane, the pivot row of both through the LDS crossbar, the row's own pivot-column entry by
+// DPP row_newbcast -- the form that pays for the 16 x 16 inversion of als5.  Bit-identical, but here every pivot then waits for a crossbar
+// round trip beside three worker waves that keep the LDS busy: pivots 3-7 went 0.91 k -> 1.15 k cycles, ALS 22.4 -> 24.2 M cycles per chain.)
 template <int P0, int P1>
 __device__ __forceinline__ void gj_inv_steps(double (&g)[8], double& e, double& dself, int lane) {
     const int a = lane & 7;
