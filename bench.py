@@ -194,8 +194,8 @@ def launch_ranks(n: int) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=10000, help="frames per GPU")
     ap.add_argument("--views", type=int, default=5)
     ap.add_argument("--people", type=int, default=4)
