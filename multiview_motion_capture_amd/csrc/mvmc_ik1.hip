@@ -51,6 +51,7 @@ struct Ik1Tables {
     double dirs[18 * 3], ref_side[18];
     unsigned long long rowmask[2][NOBS];
     int anc[18];
+    int smask[18];   // joints (bit j) whose bone length is side-length slot s
     int maxdepth, na[2], n_side;
     signed char depth[18], parents[18], side_map[18];
     unsigned char act[2][NA1], colkind[2][NA1], cola[2][NA1], colc[2][NA1];
@@ -321,8 +322,14 @@ __device__ __noinline__ void ik1_model_step(Ik1Shared<VM>& S, const Ik1Tables& T
                     d0 = x1 * r2 - x2 * r1; d1 = x2 * r0 - x0 * r2; d2 = x0 * r1 - x1 * r0;
                 }
             } else {
-                for (int j = K; j > 0; j = T.parents[j])
-                    if (T.side_map[j] == ja) { d0 += S.bvec[j * 3]; d1 += S.bvec[j * 3 + 1]; d2 += S.bvec[j * 3 + 2]; }
+                // bones on the path root .. K whose length is slot ja, from K upwards (parents have smaller indices: descending j) -- the
+                // set is a mask intersection, so the lane does not walk the tree through dependent LDS reads
+                unsigned path = ((unsigned)T.anc[K] | (1u << K)) & (unsigned)T.smask[ja] & ~1u;
+                while (path) {
+                    const int j = 31 - __builtin_clz(path);
+                    path &= ~(1u << j);
+                    d0 += S.bvec[j * 3]; d1 += S.bvec[j * 3 + 1]; d2 += S.bvec[j * 3 + 2];
+                }
             }
         }
         const double* W = &S.Wk[k * 6];
@@ -587,6 +594,9 @@ __device__ __forceinline__ void ik1_build_tables(TB& T, const SkelDev& skarg) {
         int d = 0, m = 0;
         for (int a = T.parents[lane]; a >= 0; a = T.parents[a]) { ++d; m |= 1 << a; }
         T.depth[lane] = (signed char)d; T.anc[lane] = m;
+        int sm = 0;
+        for (int j = 0; j < 18; ++j) sm |= (T.side_map[j] == lane) ? (1 << j) : 0;
+        T.smask[lane] = sm;
     }
     MVMC_WAVE_SYNC();
     if (lane == 0) {
