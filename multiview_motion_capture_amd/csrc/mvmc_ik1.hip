@@ -54,6 +54,7 @@ struct Ik1Tables {
     int smask[18];   // joints (bit j) whose bone length is side-length slot s
     int maxdepth, na[2], n_side;
     signed char depth[18], parents[18], side_map[18];
+    signed char lev_list[18], lev_start[20];   // joints ordered by depth; first entry of every level (lev_start[maxdepth + 1] = 18)
     unsigned char act[2][NA1], colkind[2][NA1], cola[2][NA1], colc[2][NA1];
 };
 
@@ -81,13 +82,8 @@ __device__ __forceinline__ double wave_max64(double v) {
 
 // R = Rx Ry Rz through the reference's quaternion product (common.h: euler_to_rot), also returning the half-angle
 // sines / cosines of the first two angles
-__device__ inline void euler_to_rot_hs(const double* e, double* R, double* hs) {
+__device__ inline void rot_from_half_angles(double sx, double cx, double sy, double cy, double sz, double cz, double* R) {
     const double inv = 1.0 / (1.0 + 1e-10);
-    double sx, cx, sy, cy, sz, cz;
-    sincos(e[0] / 2.0, &sx, &cx);
-    sincos(e[1] / 2.0, &sy, &cy);
-    sincos(e[2] / 2.0, &sz, &cz);
-    hs[0] = sx; hs[1] = cx; hs[2] = sy; hs[3] = cy;
     const double q0[4] = {cx, inv * sx, 0.0, 0.0};
     const double q1[4] = {cy, 0.0, inv * sy, 0.0};
     const double q2[4] = {cz, 0.0, 0.0, inv * sz};
@@ -113,8 +109,19 @@ __device__ __forceinline__ double ik1_eval(Ik1Shared<VM>& S, const Ik1Tables& T,
     const int lane = threadIdx.x & 63;
     double* Rl = S.tmp;
     double* off = S.tmp + 162;
+    // the 54 half-angle sincos on 54 lanes (they are the long pole of this phase: three in a row on 18 lanes before), then joint lanes
+    double* szc = S.tmp + 216;   // sin, cos of z / 2 per joint (36 doubles behind Rl and off)
+    if (lane < 54) {
+        const int j = lane / 3, a = lane - 3 * j;
+        double sn, cs;
+        sincos(xs[3 + lane] / 2.0, &sn, &cs);
+        if (a < 2) { S.hs[j * 4 + 2 * a] = sn; S.hs[j * 4 + 2 * a + 1] = cs; }
+        else { szc[j * 2] = sn; szc[j * 2 + 1] = cs; }
+    }
+    MVMC_WAVE_SYNC();
     if (lane < 18) {
-        euler_to_rot_hs(xs + 3 + 3 * lane, &Rl[lane * 9], &S.hs[lane * 4]);
+        const double* h = &S.hs[lane * 4];
+        rot_from_half_angles(h[0], h[1], h[2], h[3], szc[lane * 2], szc[lane * 2 + 1], &Rl[lane * 9]);
         double len = 0.0;
         if (lane > 0) len = (stage == 0) ? S.side[T.side_map[lane]] : xs[57 + T.side_map[lane]];
         for (int k = 0; k < 3; ++k) off[lane * 3 + k] = T.dirs[lane * 3 + k] * len;
@@ -124,9 +131,10 @@ __device__ __forceinline__ double ik1_eval(Ik1Shared<VM>& S, const Ik1Tables& T,
     if (lane < 3) S.pos[lane] = xs[lane];
     MVMC_WAVE_SYNC();
     for (int lev = 1; lev <= T.maxdepth; ++lev) {
-        for (int t = lane; t < 162; t += 64) {
-            const int j = t / 9, e = t - j * 9;
-            if (T.depth[j] == lev) {
+        const int l0 = T.lev_start[lev], l1 = T.lev_start[lev + 1];      // the level's joints: no pass over the other joints' entries
+        for (int t = lane; t < (l1 - l0) * 9; t += 64) {
+            const int j = T.lev_list[l0 + t / 9], e = t - (t / 9) * 9;
+            {
                 const int p = T.parents[j], r = e / 3, c = e - r * 3;
                 const double* Gp = &S.Rg[p * 9];
                 const double* Rj = &Rl[j * 9];
@@ -603,6 +611,13 @@ __device__ __forceinline__ void ik1_build_tables(TB& T, const SkelDev& skarg) {
         int md = 0, moved = 0, lens = 0;  // joints whose rotation moves an observed joint; used length slots
         for (int j = 0; j < 18; ++j) md = T.depth[j] > md ? T.depth[j] : md;
         T.maxdepth = md;
+        int nl = 0;
+        for (int lev = 0; lev <= md; ++lev) {
+            T.lev_start[lev] = (signed char)nl;
+            for (int j = 0; j < 18; ++j)
+                if (T.depth[j] == lev) T.lev_list[nl++] = (signed char)j;
+        }
+        T.lev_start[md + 1] = (signed char)nl;
         T.n_side = n_side;
         for (int k = 0; k < NOBS; ++k) {
             const int K = kIkSkel[k];
