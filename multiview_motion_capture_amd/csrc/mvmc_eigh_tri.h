@@ -498,20 +498,29 @@ __device__ inline bool krylov_block_ok(const double* d, const double* e, int kk,
     if (kk == n) return true;
     // T_kk = L D L^T (positive definite by the count above); w = T_kk^-1 e_{kk-1}: forward substitution leaves
     // only the last component, so w_{kk-1} = 1/D_{kk-1} and w_j = -l_j w_{j+1}
-    double D = d[0];
+    // (the recurrence is serial: its operands travel through v_readlane from per-lane copies -- lane j holds d_j, e_j, then l_j, then
+    // w_j -- instead of one LDS round trip per step in front of the reciprocal chain; same operations in the same order)
+    auto lane_value = [](double v, int src) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+    };
+    const double dl = lane < kk ? d[lane] : 0.0, el = lane < kk - 1 ? e[lane] : 0.0;
+    double lm = 0.0;
+    double D = lane_value(dl, 0);
     for (int j = 0; j < kk - 1; ++j) {
         const double inv = fast_rcp64(D);
-        const double l = e[j] * inv;
-        if (lane == 0) lmul[j] = l;
-        D = d[j + 1] - l * e[j];
+        const double ej = lane_value(el, j);
+        const double l = ej * inv;
+        if (lane == j) lm = l;
+        D = lane_value(dl, j + 1) - l * ej;
     }
     double wj = fast_rcp64(D), ww = wj * wj;
-    if (lane == 0) w[kk - 1] = wj;
+    double wreg = wj;                       // (lane kk - 1 keeps this one)
     for (int j = kk - 2; j >= 0; --j) {
-        wj = -lmul[j] * wj;
+        wj = -lane_value(lm, j) * wj;
         ww += wj * wj;
-        if (lane == 0) w[j] = wj;
+        if (lane == j) wreg = wj;
     }
+    if (lane < kk) w[lane] = wreg;
     if (why && !(ec * ec * ww <= 1e-8)) *why = 3;
     return ec * ec * ww <= 1e-8;
 }
