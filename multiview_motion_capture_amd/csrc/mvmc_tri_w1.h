@@ -68,6 +68,11 @@ __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, int 
     // one basic block so that the scheduler can run it inside the latency of the reduction + rsqrt / reciprocal chain): the scheduler
     // hoists every broadcast load to the top and the matrix rows spill (145 scratch stores / 496 loads in the 50-row model, IK 37 -> 122 M
     // cycles per chain); it would need a hand-placed schedule (sched_group_barrier per sub-step of the chain).  Not done.
+    // And: the loop software-pipelined across the step boundary -- row, reduction and reflector scalars of step k + 1 (they need row k + 1
+    // only) made between the first live chunk of step k's rank-2 update and the rest of it, the next chunk's broadcasts issued in front
+    // of that chain.  Bit-identical, but the preloaded operands (40 registers in the 40-row model) and the second set of step scalars do
+    // not fit: 63 - 73 scratch stores in the model functions, IK 34.5 -> 84 M cycles per chain; without the preload the 50-row model
+    // still spills (36 stores) and nothing is hidden.  Dropped.
     // Batch sizes: what a step waits for is the LDS round trip of the row-side broadcasts (> 100 cycles each; the FMAs of a row are 4 - 8),
     // so the 40-row model takes as many rows per round trip as its registers hold.  Tried and dropped: a software pipeline over 5-row
     // chunks with two or three chunks of operands in flight (loads of chunk c + 2 in front of the FMAs of chunk c) -- more round trips
