@@ -1629,6 +1629,8 @@ __device__ __forceinline__ void als5_inv_pivots(double (&cur)[4]) {
         double col[4];
         als5_pivot_column(cur, col, p);                             // M[4 g + q][p]
         if (c == p) prow = 1.0;                                     // (column 16 + p of the augmented matrix: e_p)
+        // (tried: the pivot row through gfx950's v_permlane32_swap / v_permlane16_swap (both operands the same register: a 16-lane row to all
+        // four) instead of the LDS crossbar -- bit-identical, 77.9 k -> 76.9 k frames/s: the crossbar read is not what the pivot waits for.)
         // (tried: the reciprocal chain of the wave-uniform pivot taken out of the division -- rcp + two Newton steps while the crossbar
         // delivers prow, then q = n r, e = fma(-d, q, n), q' = fma(e, r, q), the true division only for out-of-range operands behind a
         // wave-uniform branch.  Bit-identical, but slower: inversion 8 k -> 10.6 k cycles; the compiler's own expansion stays.)
