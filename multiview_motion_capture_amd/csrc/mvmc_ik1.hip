@@ -486,7 +486,8 @@ __device__ __noinline__ void ik1_retry_trial(Ik1Shared<VM>& S, const Ik1Tables& 
 // ---------------------------------------------------------------------------------------------
 template <int VM>
 __device__ __forceinline__ void ik1_trf(Ik1Shared<VM>& S, const Ik1Tables& T, int stage, int max_nfev, mvmc_gdouble* __restrict__ hh,
-                                        double* cost_out, int* nfev_out, int* njev_out, int* status_out, int* fallbacks_out, bool& dump) {
+                                        double* cost_out, int* nfev_out, int* njev_out, int* status_out, int* fallbacks_out, bool& dump,
+                                        bool& fk_at_x) {
     const int lane = threadIdx.x & 63;
     // wave-uniform state is pinned to scalar registers (uni)
     const int nfull = uni((stage == 0) ? 57 : 57 + T.n_side);
@@ -503,6 +504,7 @@ __device__ __forceinline__ void ik1_trf(Ik1Shared<VM>& S, const Ik1Tables& T, in
     };
     double cost;
     { P1_T0 cost = uni(ik1_eval_nl(S, T, 0, stage, true)); P1_ADD(0) }
+    fk_at_x = true;    // (every other way out of the loop below leaves the FK state of x in LDS: the last evaluation was at the accepted point)
     int nfev = 1, njev = 0, status = -1;
     double Delta;
     {
@@ -562,7 +564,7 @@ __device__ __forceinline__ void ik1_trf(Ik1Shared<VM>& S, const Ik1Tables& T, in
             alpha = uni(alpha * (Delta / Delta_new));
             Delta = uni(Delta_new);
         }
-        if (!(actual > 0.0)) break;   // budget spent or stopped on a rejected trial
+        if (!(actual > 0.0)) { fk_at_x = false; break; }   // budget spent or stopped on a rejected trial: LDS holds the FK state of that trial
         if (lane < nfull) S.x[lane] = S.xn[lane];
         if (lane + 64 < nfull) S.x[lane + 64] = S.xn[lane + 64];
         MVMC_WAVE_SYNC();
@@ -739,15 +741,21 @@ __device__ __forceinline__ void ik1_solve(Ik1Shared<VM>& S, const Ik1Tables& T, 
     const int max_nfev = uni(is_cold ? nfev_cold : nfev_warm);
     double costs[2];
     int nfs[2], njs[2], sts[2], fallbacks = 0;
-    bool dump = false;
+    bool dump = false, fk_final = false;   // fk_final: the FK state in LDS is that of the solution with stage-2 lengths
 #pragma unroll 1
     for (int stage = 0; stage < 2; ++stage) {
         double c = 0.0; int nf = 0, nj = 0, st = 0;
-        if ((stage_mask >> stage) & 1) ik1_trf(S, T, stage, max_nfev, hh, &c, &nf, &nj, &st, &fallbacks, dump);
+        if ((stage_mask >> stage) & 1) {
+            bool at_x = false;
+            ik1_trf(S, T, stage, max_nfev, hh, &c, &nf, &nj, &st, &fallbacks, dump, at_x);
+            fk_final = at_x && stage == 1;
+        }
         costs[stage] = c; nfs[stage] = nf; njs[stage] = nj; sts[stage] = st;
         MVMC_WAVE_SYNC();
     }
-    ik1_eval_nl(S, T, 0, 1, false);  // final FK at the solution
+    // final FK at the solution -- unless the solver's last evaluation was at the accepted point (five of six warm solves): the same
+    // function of the same numbers, already in LDS
+    if (!fk_final) ik1_eval_nl(S, T, 0, 1, false);
     for (int i = lane; i < 57 + n_side; i += 64) params_out[(size_t)b * 68 + i] = S.x[i];
     if (lane < 54) joints_out[(size_t)b * 54 + lane] = S.pos[lane];
     if (lane == 0) {
