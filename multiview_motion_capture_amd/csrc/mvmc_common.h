@@ -100,6 +100,20 @@ __device__ __forceinline__ Tp* uni(Tp* p) {
     return (Tp*)(((unsigned long long)hi << 32) | lo);
 }
 
+// maximum over the wave, same data movement as wave_sum_dpp (rotations inside the rows of 16 lanes, the four row results through
+// SGPRs): no LDS-crossbar butterfly; every lane gets the result
+__device__ __forceinline__ double wave_max_dpp(double v) {
+    v = fmax(v, dpp_mov<0x128>(v));  // row_ror:8
+    v = fmax(v, dpp_mov<0x124>(v));  // row_ror:4
+    v = fmax(v, dpp_mov<0x122>(v));  // row_ror:2
+    v = fmax(v, dpp_mov<0x121>(v));  // row_ror:1
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    double t = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+#pragma unroll
+    for (int r = 1; r < 4; ++r)
+        t = fmax(t, __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * r), __builtin_amdgcn_readlane(lo, 16 * r)));
+    return t;
+}
 __device__ __forceinline__ double fast_rcp64(double x) {
     double r = __builtin_amdgcn_rcp(x);
     r = r * (2.0 - x * r);

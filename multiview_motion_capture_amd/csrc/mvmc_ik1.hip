@@ -75,10 +75,7 @@ struct Ik1Shared {
 #endif
 };
 
-__device__ __forceinline__ double wave_max64(double v) {
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-    return v;
-}
+__device__ __forceinline__ double wave_max64(double v) { return wave_max_dpp(v); }
 
 // R = Rx Ry Rz through the reference's quaternion product (common.h: euler_to_rot), also returning the half-angle
 // sines / cosines of the first two angles

@@ -42,10 +42,7 @@ __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, int 
                                                  long long* tprof = nullptr) {
     static_assert(N % 2 == 0 && N <= 50, "row count");
     const int lane = threadIdx.x & 63;
-    auto wave_max = [](double v) {
-        for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-        return v;
-    };
+    auto wave_max = [](double v) { return wave_max_dpp(v); };
     auto lane_value = [](double v, int src) {  // v of lane src (uniform) as a scalar
         return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
     };
