@@ -194,8 +194,8 @@ __device__ __forceinline__ double ik1_eval(Ik1Shared<VM>& S, const Ik1Tables& T,
     if (want_jac) {
 #pragma unroll
         for (int e = 0; e < 9; ++e) {
-            o[e] += __shfl_xor(o[e], 16, 64);
-            o[e] += __shfl_xor(o[e], 32, 64);
+            o[e] += xor_lane<16>(o[e]);
+            o[e] += xor_lane<32>(o[e]);
         }
         if (lane < NOBS) {
 #pragma unroll
