@@ -1203,13 +1203,16 @@ __device__ __forceinline__ int als7_iterate(const TW* __restrict__ Wf, int ldw, 
     const double tol2 = (1e-4 * n) * (1e-4 * n);
     // ---- solver wave ----
     double g0[R];   // row (lane & 7) of F^T F
-    const int n2 = (n + 1) & ~1;  // rows beyond n are exact zeros
     // (tried: two entries per lane over half of the rows each, fully unrolled: 3% more cycles per iteration in the chain kernel)
     auto form = [&](const double* F) {
         const int a = lane >> 3, b = lane & 7;   // one entry per lane, two accumulators over even / odd rows
         double s0 = 0.0, s1 = 0.0;
-#pragma unroll 4
-        for (int k = 0; k < n2; k += 2) { s0 += F[k * R + a] * F[k * R + b]; s1 += F[(k + 1) * R + a] * F[(k + 1) * R + b]; }
+        // (all 24 rows, fully unrolled: the rows beyond n are exact zeros and add nothing, and with a fixed trip count every load of the
+        // sum is in flight at once -- behind a run-time bound the loop paid an LDS round trip per four rows, and for B^T B the solver
+        // wave's form + inversion is what the workers wait for)
+        static_assert(NMAX >= 24, "rows of the factors");
+#pragma unroll
+        for (int k = 0; k < 24; k += 2) { s0 += F[k * R + a] * F[k * R + b]; s1 += F[(k + 1) * R + a] * F[(k + 1) * R + b]; }
         sG[lane] = s0 + s1;
         MVMC_WAVE_SYNC();
         const double2* gr = reinterpret_cast<const double2*>(&sG[(lane & 7) * R]);
