@@ -31,6 +31,8 @@ sys.path.insert(0, ROOT)
 
 BYTES_PER_FRAME = lambda C, P, J=25: 12 * C * P * J + 4 * C * P + 16 * P * J + 488 * P
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs x 16 fp64 lanes x 2 flop x 2.4 GHz (vector = fp64 MFMA rate on gfx950)
+NOMINAL_CLOCK_HZ = 2.4e9
 FP64_PEAK_TFLOPS = 78.6  # vector fp64
 
 
@@ -463,7 +465,7 @@ def main():
                          mean_njev=float(inf[ok, 6].mean()), eigensolver_fallbacks_per_solve=float(inf[ok, 7].mean()))
         # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; tools/aggregate_profiles.py)
         # of THIS command, recorded with a hash of the kernel sources: a record made from other sources is stale and reported as null
-        traffic, traffic_note = None, "no PMC record for this workload"
+        traffic, traffic_note, fp64 = None, "no PMC record for this workload", None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tp):
             rec = (json.load(open(tp)).get(f"{dom}:{F}x{C}x{Pn}") or {})
@@ -471,6 +473,19 @@ def main():
                 traffic, traffic_note = rec.get("bytes"), f"profiles/{rec.get('source')}"
             elif rec:
                 traffic_note = f"stale: profiles/{rec.get('source')} was measured on other kernel sources"
+            # what bounds the path is the fp64 vector pipe, not HBM: wave instructions of the launch by class (SQ_INSTS_VALU_*_F64,
+            # tools/prof_insts.sh + tools/aggregate_insts.py, same staleness rule) against this run's time per step
+            mix = rec.get("inst_mix") or {}
+            if mix.get("src_sha") == kernel_sources_sha():
+                step_s = dt / args.steps
+                tf = mix["flop_per_launch"] / step_s / 1e12
+                fp64 = {"achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TFLOPS,
+                        "f64_share_of_valu_insts": mix["f64_share_of_valu"], "lanes_active_per_valu_inst": mix["lanes_active_per_valu_inst"],
+                        "valu_pipe_busy": mix["valu_busy_simd_cycles"] / (1024 * NOMINAL_CLOCK_HZ * step_s),
+                        "lds_pipe_busy": mix["lds_busy_cu_cycles"] / (256 * NOMINAL_CLOCK_HZ * step_s),
+                        "source": f"profiles/{mix.get('source')}",
+                        "note": "flop = 64 lanes x (2 FMA + ADD + MUL + TRANS) fp64 wave instructions of one launch (one step) / this run's "
+                                "time per step; pipe shares = busy cycles of the launch's VALU (1024 SIMDs) and LDS (256 CUs) / the step at 2.4 GHz"}
         res = {
             "metric": "frames/s (assoc+triangulate+IK) at C=5,P=4,J=25" if with_ik else
                       ("frames/s (triangulate)" if args.workload == "dlt" else "frames/s (assoc+triangulate)"),
@@ -489,7 +504,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom_kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "launch_ms": launch_ms,
-                         "traffic": traffic, "traffic_source": traffic_note, "bytes_per_frame": bpf,
+                         "traffic": traffic, "traffic_source": traffic_note, "bytes_per_frame": bpf, "fp64": fp64,
                          "note": "latency-bound path (dependent fp64 chains), not HBM bound (SURVEY.md F6); achieved = algorithmic "
                                  "bytes of the frames one launch serves / mean launch duration of the dominant kernel" +
                                  (f" ({args.overlap} launches share the GPU, so a launch lasts longer than ms_per_step)" if args.overlap > 1 else "") +

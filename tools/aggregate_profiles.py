@@ -67,8 +67,11 @@ def main():
             continue
         kf = sum(fe[kern]) / len(fe[kern]) * 1024
         kw = sum(wr[kern]) / len(wr[kern]) * 1024
+        mix = (rec.get(f"{key}:{wkey}") or {}).get("inst_mix")   # tools/aggregate_insts.py's record carries its own source hash
         rec[f"{key}:{wkey}"] = {"kernel": kern, "fetch_bytes": kf, "write_bytes": kw, "bytes": kf + kw,
                                 "source": os.path.basename(out2), "src_sha": kernel_sources_sha(), "unit": unit}
+        if mix:
+            rec[f"{key}:{wkey}"]["inst_mix"] = mix
     json.dump(rec, open(tp, "w"), indent=1)
     print(open(out).read())
     print(open(out2).read())
