@@ -585,76 +585,97 @@ __device__ __noinline__ void ik1_cold_root(Ik1Shared<VM>& S, int nv) {
         for (int c = 0; c < 3; ++c) S.xn[(lane - 11) * 3 + c] = X[c];
 }
 
-// Skeleton-derived tables (depth, ancestor masks, active columns and row masks of both stages); one wave builds them
+// Skeleton-derived tables (depth, ancestor masks, active columns and row masks of both stages).  ONE definition for the device (a wave
+// builds them in LDS: lane = `lane`, a wave sync between the sections) and for the host (mvmc_chain_run builds them once per call and
+// hands them to the chain kernel as a kernel argument -- built by every workgroup they cost 97 k cycles per frame, 2.4 % of a launch).
+template <typename TB>
+__host__ __device__ inline void ik1_tables_section(TB& T, const SkelDev& skarg, int section, int lane) {
+    constexpr int obs_joint[NOBS] = MVMC_IK_SKEL_LIST;   // (= kIkSkel)
+    const int n_side = skarg.n_side;
+    if (section == 0) {
+        if (lane < 18) {
+            for (int k = 0; k < 3; ++k) T.dirs[lane * 3 + k] = skarg.dirs[lane][k];
+            T.parents[lane] = (signed char)skarg.parents[lane];
+            T.side_map[lane] = (signed char)skarg.side_map[lane];
+            T.ref_side[lane] = skarg.ref_side[lane];
+        }
+    } else if (section == 1) {
+        if (lane < 18) {
+            int d = 0, m = 0;
+            for (int a = T.parents[lane]; a >= 0; a = T.parents[a]) { ++d; m |= 1 << a; }
+            T.depth[lane] = (signed char)d; T.anc[lane] = m;
+            int sm = 0;
+            for (int j = 0; j < 18; ++j) sm |= (T.side_map[j] == lane) ? (1 << j) : 0;
+            T.smask[lane] = sm;
+        }
+    } else if (section == 2) {
+        if (lane == 0) {
+            int md = 0, moved = 0, lens = 0;  // joints whose rotation moves an observed joint; used length slots
+            for (int j = 0; j < 18; ++j) md = T.depth[j] > md ? T.depth[j] : md;
+            T.maxdepth = md;
+            int nl = 0;
+            for (int lev = 0; lev <= md; ++lev) {
+                T.lev_start[lev] = (signed char)nl;
+                for (int j = 0; j < 18; ++j)
+                    if (T.depth[j] == lev) T.lev_list[nl++] = (signed char)j;
+            }
+            T.lev_start[md + 1] = (signed char)nl;
+            T.n_side = n_side;
+            for (int k = 0; k < NOBS; ++k) {
+                const int K = obs_joint[k];
+                moved |= T.anc[K];
+                for (int j = K; j > 0; j = T.parents[j]) {
+                    const double* d = &T.dirs[j * 3];
+                    if (d[0] != 0.0 || d[1] != 0.0 || d[2] != 0.0) lens |= 1 << T.side_map[j];
+                }
+            }
+            for (int st = 0; st < 2; ++st) {
+                int n = 0;
+                for (int c = 0; c < 3; ++c) { T.act[st][n] = c; T.colkind[st][n] = 0; T.cola[st][n] = 0; T.colc[st][n] = c; ++n; }
+                for (int a = 0; a < 18; ++a)
+                    if ((moved >> a) & 1)
+                        for (int c = 0; c < 3 && n < NA1; ++c) {
+                            T.act[st][n] = 3 + 3 * a + c; T.colkind[st][n] = 1; T.cola[st][n] = a; T.colc[st][n] = c; ++n;
+                        }
+                if (st == 1)
+                    for (int s = 0; s < n_side && n < NA1; ++s)
+                        if ((lens >> s) & 1) { T.act[st][n] = 57 + s; T.colkind[st][n] = 2; T.cola[st][n] = s; T.colc[st][n] = 0; ++n; }
+                T.na[st] = n;
+            }
+        }
+    } else {
+        if (lane < 2 * NOBS) {
+            const int st = lane >> 4, k = lane & 15, K = obs_joint[k];
+            unsigned long long m = 0;
+            for (int col = 0; col < T.na[st]; ++col) {
+                const int kind = T.colkind[st][col], a = T.cola[st][col];
+                bool nz = kind == 0;
+                if (kind == 1) nz = (T.anc[K] >> a) & 1;
+                if (kind == 2)
+                    for (int j = K; j > 0; j = T.parents[j]) nz |= T.side_map[j] == a;
+                if (nz) m |= 1ull << col;
+            }
+            T.rowmask[st][k] = m;
+        }
+    }
+}
+
 template <typename TB>
 __device__ __forceinline__ void ik1_build_tables(TB& T, const SkelDev& skarg) {
     const int lane = threadIdx.x & 63;
-    const int n_side = skarg.n_side;
-    if (lane < 18) {
-        for (int k = 0; k < 3; ++k) T.dirs[lane * 3 + k] = skarg.dirs[lane][k];
-        T.parents[lane] = (signed char)skarg.parents[lane];
-        T.side_map[lane] = (signed char)skarg.side_map[lane];
-        T.ref_side[lane] = skarg.ref_side[lane];
+#pragma unroll
+    for (int section = 0; section < 4; ++section) {
+        ik1_tables_section(T, skarg, section, lane);
+        MVMC_WAVE_SYNC();
     }
-    MVMC_WAVE_SYNC();
-    if (lane < 18) {
-        int d = 0, m = 0;
-        for (int a = T.parents[lane]; a >= 0; a = T.parents[a]) { ++d; m |= 1 << a; }
-        T.depth[lane] = (signed char)d; T.anc[lane] = m;
-        int sm = 0;
-        for (int j = 0; j < 18; ++j) sm |= (T.side_map[j] == lane) ? (1 << j) : 0;
-        T.smask[lane] = sm;
-    }
-    MVMC_WAVE_SYNC();
-    if (lane == 0) {
-        int md = 0, moved = 0, lens = 0;  // joints whose rotation moves an observed joint; used length slots
-        for (int j = 0; j < 18; ++j) md = T.depth[j] > md ? T.depth[j] : md;
-        T.maxdepth = md;
-        int nl = 0;
-        for (int lev = 0; lev <= md; ++lev) {
-            T.lev_start[lev] = (signed char)nl;
-            for (int j = 0; j < 18; ++j)
-                if (T.depth[j] == lev) T.lev_list[nl++] = (signed char)j;
-        }
-        T.lev_start[md + 1] = (signed char)nl;
-        T.n_side = n_side;
-        for (int k = 0; k < NOBS; ++k) {
-            const int K = kIkSkel[k];
-            moved |= T.anc[K];
-            for (int j = K; j > 0; j = T.parents[j]) {
-                const double* d = &T.dirs[j * 3];
-                if (d[0] != 0.0 || d[1] != 0.0 || d[2] != 0.0) lens |= 1 << T.side_map[j];
-            }
-        }
-        for (int st = 0; st < 2; ++st) {
-            int n = 0;
-            for (int c = 0; c < 3; ++c) { T.act[st][n] = c; T.colkind[st][n] = 0; T.cola[st][n] = 0; T.colc[st][n] = c; ++n; }
-            for (int a = 0; a < 18; ++a)
-                if ((moved >> a) & 1)
-                    for (int c = 0; c < 3 && n < NA1; ++c) {
-                        T.act[st][n] = 3 + 3 * a + c; T.colkind[st][n] = 1; T.cola[st][n] = a; T.colc[st][n] = c; ++n;
-                    }
-            if (st == 1)
-                for (int s = 0; s < n_side && n < NA1; ++s)
-                    if ((lens >> s) & 1) { T.act[st][n] = 57 + s; T.colkind[st][n] = 2; T.cola[st][n] = s; T.colc[st][n] = 0; ++n; }
-            T.na[st] = n;
-        }
-    }
-    MVMC_WAVE_SYNC();
-    if (lane < 2 * NOBS) {
-        const int st = lane >> 4, k = lane & 15, K = kIkSkel[k];
-        unsigned long long m = 0;
-        for (int col = 0; col < T.na[st]; ++col) {
-            const int kind = T.colkind[st][col], a = T.cola[st][col];
-            bool nz = kind == 0;
-            if (kind == 1) nz = (T.anc[K] >> a) & 1;
-            if (kind == 2)
-                for (int j = K; j > 0; j = T.parents[j]) nz |= T.side_map[j] == a;
-            if (nz) m |= 1ull << col;
-        }
-        T.rowmask[st][k] = m;
-    }
-    MVMC_WAVE_SYNC();
+}
+
+// the same tables on the host (every byte defined: the struct travels as a kernel argument)
+inline void ik1_build_tables_host(Ik1Tables& T, const SkelDev& skarg) {
+    unsigned char* bytes = reinterpret_cast<unsigned char*>(&T);
+    for (size_t i = 0; i < sizeof(T); ++i) bytes[i] = 0;
+    for (int section = 0; section < 4; ++section)
+        for (int lane = 0; lane < 64; ++lane) ik1_tables_section(T, skarg, section, lane);
 }
 
 // One solve on the calling wave (problem b); S is this wave's LDS block.  Used by ik1_kernel (one wave per workgroup)

@@ -9,7 +9,8 @@ constexpr int VMAX = 8;    // max views per person
 constexpr int NOBS = 16;   // observed joints per view
 
 // skeleton joint <-> observed keypoint (COCO-17 + synthetic mid-spine at 17); inverse_kinematics.py:366-378
-__device__ __constant__ const int kIkSkel[NOBS] = {1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17};
+#define MVMC_IK_SKEL_LIST {1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17}
+__device__ __constant__ const int kIkSkel[NOBS] = MVMC_IK_SKEL_LIST;
 __device__ __constant__ const int kIkObs[NOBS] = {11, 13, 15, 12, 14, 16, 17, 5, 7, 9, 6, 8, 10, 0, 3, 4};
 
 // 4x4 symmetric Jacobi for the cold-start DLT of one joint (same scheme as mvmc_geom.hip)

@@ -1,11 +1,14 @@
+# throughput against frames per launch, workgroups per chain and steps in flight (one GPU call):
+#   bash tools/parts_sweep.sh [frames:parts:overlap ...]
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/parts
-for cfg in "16 2" "1 2" "1 3" "2 2" "2 3" "16 3" "1 4"; do
-  set -- $cfg
-  python3 bench.py --cpu-frames 0 --parts $1 --overlap $2 > gpurun_out/parts/p$1_o$2.json 2> gpurun_out/parts/p$1_o$2.err
+[ $# -gt 0 ] || set -- 10000:16:2 10000:1:2 10000:2:2 10000:16:3 10000:1:3
+for cfg in "$@"; do
+  IFS=: read F P O <<< "$cfg"
+  python3 bench.py --cpu-frames 0 --frames $F --parts $P --overlap $O > gpurun_out/parts/f${F}_p${P}_o$O.json 2> gpurun_out/parts/f${F}_p${P}_o$O.err
   python3 -c "
-import json,sys
-r=json.load(open('gpurun_out/parts/p$1_o$2.json'))
-print('parts $1 overlap $2', round(r['value']), round(r['ms_per_step'],2), [round(x,1) for x in r['stages_ms']['chain_mcycles_mean_max']])"
+import json
+r=json.load(open('gpurun_out/parts/f${F}_p${P}_o$O.json'))
+print('frames $F parts $P overlap $O', round(r['value']), round(r['ms_per_step'],2), [round(x,1) for x in r['stages_ms']['chain_mcycles_mean_max']])"
 done
