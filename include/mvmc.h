@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVMC_ABI_VERSION 3
+#define MVMC_ABI_VERSION 2
 
 enum {
     MVMC_OK = 0,
@@ -295,15 +295,13 @@ int mvmc_debug_ik_solve_fd(const mvmcSkeleton* skel_host, const double* kps17, c
  * B = n_chains, F = B chain_len).  Two LDS layouts (MVMC_ERR_UNSUPPORTED outside them: use the per-stage entry points), both with
  * p_max <= 8, t_max <= 8:
  *   small  N <= 40, NS <= 48, v_max <= 6 (configs 1-4; three workgroups per CU); every frame's actual graph must have <= 24 nodes
- *          without tracklets and <= 32 with them -- checked on the device: the second of the status words at the end of `flags`
- *          is set after the call when a graph did not fit;
+ *          without tracklets and <= 32 with them -- checked on the device: flags[B + 1] != 0 after the call means a graph did not fit;
  *   big    N <= 64, NS <= 72, v_max <= 8 (config 5, C8 P8; two workgroups per CU); every graph of those sizes fits. */
 typedef struct mvmcChainBuffers {
     int32_t n_chains, chain_len, n_views, p_max, t_max, k_max, v_max, max_nfev_cold, max_nfev_warm, n_inits, seed_len;
     int32_t n_parts;            /* workgroups per chain: 1 = one persistent workgroup per chain; p > 1 (dividing chain_len) =
-                                   p workgroups running consecutive frame ranges of the chain one after the other; a workgroup
-                                   takes the chain that has been ready longest (a ticket and a ready ring in `flags`), so the
-                                   load balances over the CUs whatever order the hardware dispatches the workgroups in */
+                                   p workgroups running consecutive frame ranges of the chain one after the other, so that
+                                   the hardware dispatcher balances the load over the CUs */
     /* inputs */
     const double* kps17;        /* (F,C,P,17,3) after mvmc_ingest */
     const int32_t* counts;      /* (F,C) */
@@ -345,12 +343,11 @@ typedef struct mvmcChainBuffers {
     int32_t* out_n_tracks;      /* (F) */
     double* out_info;           /* (F,NP,8) IK info rows of the frame's problems, or NULL */
     int32_t* out_als_iters;     /* (F) ALS iterations of the frame's graph, or NULL */
-    uint32_t* flags;            /* (B * max(n_parts, 1) + 6) u32, zeroed by the call: [0,B) parts finished per chain, then the
-                                   hand-over queue {ticket, tail, ring of B * (n_parts - 1) entries}, and LAST four status words
-                                   w[0..3]: afterwards w[0] != 0 = a workgroup waited 4 s for a chain to become ready,
-                                   w[1] != 0 = a graph was too large for the kernel's ALS variant, w[2] != 0 = a capacity was
-                                   exceeded (bit 0: more than k_max new clusters or v_max views in a frame, bit 1: more than
-                                   t_max tracklets); in every case the results are void.  (ABI 2 had B + 4 words.) */
+    uint32_t* flags;            /* (B + 4) u32, zeroed by the call: [0,B) hand-over flags of the chains; afterwards flags[B] != 0 =
+                                   a workgroup timed out waiting for its predecessor, flags[B + 1] != 0 = a graph was too large
+                                   for the kernel's ALS variant, flags[B + 2] != 0 = a capacity was exceeded (bit 0: more than
+                                   k_max new clusters or v_max views in a frame, bit 1: more than t_max tracklets); in every
+                                   case the results are void */
     double* out_phase_cycles;   /* (B,8) diagnostic: shader cycles of each chain by phase {graph, ALS, assignment, IK, commit,
                                    outputs, whole chain, 0}, or NULL */
 } mvmcChainBuffers;

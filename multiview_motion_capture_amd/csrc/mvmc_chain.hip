@@ -63,10 +63,8 @@ struct MvmcChainArgs {
     double* out_info;         // (F,NP,8) or NULL
     int32_t* out_iters;       // (F) ALS iterations of the frame's graph, or NULL
     double* out_cycles;       // (B,8) shader cycles by phase {graph, ALS, assign, IK, commit, outputs, total}, or NULL
-    int parts;                // workgroups per chain (consecutive frame ranges, handed over through the ready queue)
-    unsigned* flags;          // [0, B) parts completed per chain.  The whole buffer is zeroed by the launcher
-    unsigned* queue;          // {ticket, tail, ring[B * (parts - 1)]}: the chains whose next part may run, in the order they became ready
-    unsigned* words;          // {time-out, graph too large, capacity bits, -}: the launch's status words
+    int parts;                // workgroups per chain (consecutive frame ranges, handed over through flags)
+    unsigned* flags;          // (B + 1) parts completed per chain; [B] = timeout word.  Zeroed by the launcher
 };
 
 namespace {
@@ -165,12 +163,12 @@ __device__ __noinline__ void chain_als_temporal(ChainArena<BIG>& arena, ChainArg
 }
 __device__ __noinline__ void chain_assign(ChainArgsK& A, int b, int f, int* done) {
     assign_chain(threadIdx.x & 63, 64, b, f, A.labels_sp, A.ncl_sp, A.labels_st, A.ncl_st, A.counts, A.n_tracks, A.params, A.C, A.P, A.T, A.K, A.V,
-                 A.members, A.cold, A.init, A.status, A.n_new, reinterpret_cast<int32_t*>(A.words + 2));
+                 A.members, A.cold, A.init, A.status, A.n_new, reinterpret_cast<int32_t*>(A.flags + A.n_chains + 2));
     *done = 0;
 }
 __device__ __noinline__ void chain_commit(ChainArgsK& A, int b, int* done) {
     commit_chain(threadIdx.x & 63, 64, b, A.status, A.n_new, A.ik_params, A.ik_joints, A.T, A.K, A.n_inits, A.params, A.joints, A.meta, A.n_tracks,
-                 A.next_id, A.n_dead, A.slot_src, reinterpret_cast<int32_t*>(A.words + 2));
+                 A.next_id, A.n_dead, A.slot_src, reinterpret_cast<int32_t*>(A.flags + A.n_chains + 2));
     *done = 0;
 }
 template <bool BIG>
@@ -200,22 +198,22 @@ chain_kernel(Ik1Tables tables_arg, ChainArgs A_by_value) {
     ChainArena<BIG>& arena = *reinterpret_cast<ChainArena<BIG>*>(chain_lds);
     __shared__ Ik1Tables tables;
     __shared__ int s_nt;
-    // Which (chain, part) a workgroup runs is decided when it STARTS, not by its block index: it draws a ticket; the first n_chains
-    // tickets are part 0 of the chains, every later ticket h takes entry h - n_chains of the ready ring, which the workgroups that
-    // finish a part fill in the order they finish (entry = the chain and its next part).  A chain's parts still run one after the other,
-    // but a slot that frees up goes to the chain that has been ready longest instead of to the next block index, whose predecessor may
-    // still be running (with the static part * n_chains + chain mapping 7 % of the resident workgroup time of a launch that shares the
-    // GPU with another was spent waiting, 17 % alone: tools/chain_wait_probe.py), and nothing depends on the dispatch order any more.
-    // No deadlock: a waiting ticket h needs h - n_chains + 1 finished non-final parts; all lower tickets have started, and while some
-    // chain is unfinished they cannot all be final parts.
+    // Workgroup (part, chain): block index = part * n_chains + chain, so every workgroup of part p is dispatched before
+    // any of part p + 1 and a waiting workgroup's predecessor is always resident or finished.  A chain's parts run one
+    // after the other (flag per chain); because later parts start wherever a slot frees up, the CUs that run slower
+    // (three chains instead of two) simply receive fewer of them -- the hardware dispatcher balances the launch.
+    const int b = blockIdx.x % A.n_chains, part = blockIdx.x / A.n_chains;
     const int tid = threadIdx.x, wave = tid >> 6;
 #ifdef MVMC_CHAIN_WAITPROF   // diagnostic build: out_cycles[7] = cycles a chain's workgroups were resident before their frames began
     const long long t_entry = clock64();
 #endif
-    __shared__ int s_task;   // part << 20 | chain, or -1: give up
-    unsigned ticket = 0;
-    if (A.parts > 1 && tid == 0) ticket = __hip_atomic_fetch_add(A.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // the skeleton tables, made on the host by the launcher: from the kernel-argument segment (offset 0) into LDS, a word per lane
+    const int T = A.T, NP = T + A.K;
+    const int t_lo = part * A.L / A.parts, t_hi = (part + 1) * A.L / A.parts;
+    // The skeleton tables (ancestor masks, level lists, active columns, row masks) are made ONCE PER CALL on the host by the launcher
+    // (ik1_build_tables_host: the same source as the device's ik1_build_tables) and arrive as the first kernel argument: a word per
+    // lane from the kernel-argument segment into LDS.  Built here by one wave of every workgroup they cost 97 k cycles per frame --
+    // hidden while a workgroup waits for its predecessor, but 2.4 % of the resident time when two launches share the GPU and the waits
+    // are short (tools/chain_wait_probe.py): 431.7 k -> 437.1 k frames/s on the same box, bit-identical.
     {
         static_assert(sizeof(Ik1Tables) % 4 == 0, "copied by words");
         typedef const __attribute__((address_space(4))) unsigned* KernargWords;
@@ -223,50 +221,41 @@ chain_kernel(Ik1Tables tables_arg, ChainArgs A_by_value) {
         unsigned* dst = reinterpret_cast<unsigned*>(&tables);
         for (int i = tid; i < (int)(sizeof(Ik1Tables) / 4); i += ChainCfg<BIG>::NT) dst[i] = src[i];
     }
-#ifdef MVMC_CHAIN_WAITPROF
-    const long long t_tables = clock64();
-#endif
-    if (A.parts > 1) {
+    // work that does not depend on the chain's state comes before the hand-over: for a workgroup that has a predecessor, the
+    // pose-pair block of its first frame's graph
+    int done = 0;   // the phases' report word (see above)
+    if constexpr (!BIG) { if (part > 0) chain_pose_pairs(arena, A, b * A.L + t_lo, &done); }
+    if (part > 0) {
+        // consumer side of the hand-off (cdna_hip_programming.md Guideline 16): one lane polls the chain's flag relaxed,
+        // one agent-scope acquire, then the workgroup's barrier; the chain state is read with plain vector loads after it
+        __shared__ int s_abort;
         if (tid == 0) {
-            int task = (int)ticket;      // ticket < n_chains: part 0 of chain `ticket`, nothing to wait for
-            if (ticket >= (unsigned)A.n_chains) {
-                // consumer side of the hand-off (cdna_hip_programming.md Guideline 16): one lane polls its ring entry relaxed, one
-                // agent-scope acquire, then the workgroup's barrier; the chain state is read with plain vector loads after it.
-                // Bounded by wall time (~4 s at the 100 MHz constant clock), not by a spin count; a time-out anywhere in the launch
-                // (the error word) also ends this wait, so the waiting workgroups do not pay the time-out one after the other
-                const unsigned* entry = A.queue + 2 + (ticket - (unsigned)A.n_chains);
-                const unsigned long long t0 = wall_clock64();
-                unsigned spins = 0, v;
-                while ((v = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
-                    __builtin_amdgcn_s_sleep(32);
-                    // the launch-wide error word is ONE address for every waiting workgroup of the launch: looked at once in 1024 polls
-                    // (hundreds of pollers on one line cost the whole chip memory bandwidth: measured 370 k -> 331 k frames/s)
-                    if ((++spins & 1023u) != 0u) continue;
-                    if (__hip_atomic_load(A.words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-                    if (wall_clock64() - t0 > 400000000ull) {   // nothing became ready in 4 s; give up loudly
-                        __hip_atomic_store(A.words, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
+            // bounded by wall time (~4 s at the 100 MHz constant clock), not by a spin count; a time-out anywhere in the launch
+            // (the error word) also ends this wait, so a chain of waiting parts does not pay the time-out once per part
+            const unsigned long long t0 = wall_clock64();
+            int abort = 0;
+            unsigned spins = 0;
+            while (__hip_atomic_load(A.flags + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)part) {
+                __builtin_amdgcn_s_sleep(32);
+                // the launch-wide error word is ONE address for every waiting workgroup of the launch: looked at once in 1024 polls
+                // (hundreds of pollers on one line cost the whole chip memory bandwidth: measured 370 k -> 331 k frames/s)
+                if ((++spins & 1023u) != 0u) continue;
+                if (__hip_atomic_load(A.flags + A.n_chains, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { abort = 1; break; }
+                if (wall_clock64() - t0 > 400000000ull) {   // dispatch did not come in block order; give up loudly
+                    __hip_atomic_store(A.flags + A.n_chains, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    abort = 1;
+                    break;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                task = (int)v - 1;       // (v == 0: gave up)
             }
-            s_task = task;               // ONE lane decides; the whole workgroup branches on the same value
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_abort = abort;     // ONE lane decides; the whole workgroup branches on the same value
+            if (abort)           // release the successors: they must not wait for this part's flag
+                __hip_atomic_store(A.flags + b, (unsigned)(part + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        if (s_task < 0) return;
+        if (s_abort) return;
     }
-#ifdef MVMC_CHAIN_WAITPROF
-    const long long t_task = clock64();
-#endif
-    const int task = A.parts > 1 ? uni(s_task) : (int)blockIdx.x;
-    const int b = task & 0xFFFFF, part = task >> 20;
-    const int T = A.T, NP = T + A.K;
-    const int t_lo = part * A.L / A.parts, t_hi = (part + 1) * A.L / A.parts;
-    int done = 0;   // the phases' report word (see above)
-    // the pose-pair block of a later part's first graph does not depend on the chain's state either (it used to be made during the wait)
-    if constexpr (!BIG) { if (part > 0) chain_pose_pairs(arena, A, b * A.L + t_lo, &done); }
     __syncthreads();
     long long cyc[6] = {0, 0, 0, 0, 0, 0}, t_prev = clock64();
     const long long t_start = t_prev;
@@ -293,7 +282,7 @@ chain_kernel(Ik1Tables tables_arg, ChainArgs A_by_value) {
         // a graph with more nodes (or a higher rank) than the workgroup variant of the ALS holds is flagged by it (iters < 0):
         // raise the launch's error word instead of silently tracking nobody
         if (tid == 0 && (nt <= 0 ? A.iters_sp[b] : A.iters_st[b]) < 0)
-            __hip_atomic_store(A.words + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(A.flags + A.n_chains + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (wave == 0) chain_assign(A, b, f, &done);   // clusters -> IK problems (bulk copies on the wave, the logic on lane 0)
         __syncthreads();
         lap(2);
@@ -323,8 +312,6 @@ chain_kernel(Ik1Tables tables_arg, ChainArgs A_by_value) {
         oc[6] = (part ? oc[6] : 0.0) + (double)(clock64() - t_start);
 #ifdef MVMC_CHAIN_WAITPROF
         oc[7] = (part ? oc[7] : 0.0) + (double)(t_start - t_entry);
-        oc[4] = (part ? oc[4] - (double)cyc[4] : 0.0) + (double)(t_tables - t_entry);   // (instead of the commit / output phases)
-        oc[5] = (part ? oc[5] - (double)cyc[5] : 0.0) + (double)(t_task - t_tables);
 #else
         oc[7] = (double)(part + 1);
 #endif
@@ -337,10 +324,6 @@ chain_kernel(Ik1Tables tables_arg, ChainArgs A_by_value) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(A.flags + b, (unsigned)(part + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (part + 1 < A.parts) {   // the chain's next part may run: the next free ring entry (one per finished non-final part)
-                const unsigned at = __hip_atomic_fetch_add(A.queue + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(A.queue + 2 + at, (unsigned)(((part + 1) << 20) | b) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
         }
     }
 }
@@ -406,13 +389,10 @@ extern "C" int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuff
     A.out_info = B.out_info; A.out_iters = B.out_als_iters; A.out_cycles = B.out_phase_cycles;
     A.parts = B.n_parts > 1 ? B.n_parts : 1;
     if (A.parts > 1 && B.chain_len % A.parts != 0) return MVMC_ERR_ARG;
-    // flags: [0, B) progress, {ticket, tail}, ring of B * (parts - 1) entries, the four status words last
-    if (B.n_chains >= (1 << 20) || A.parts >= (1 << 10)) return MVMC_ERR_UNSUPPORTED;   // (a ring entry is part << 20 | chain)
-    const size_t n_flag_words = (size_t)B.n_chains * A.parts + 6;
-    A.flags = B.flags; A.queue = B.flags + B.n_chains; A.words = B.flags + n_flag_words - 4;
-    if (hipMemsetAsync(B.flags, 0, sizeof(unsigned) * n_flag_words, (hipStream_t)stream) != hipSuccess)
+    A.flags = B.flags;
+    if (hipMemsetAsync(B.flags, 0, sizeof(unsigned) * ((size_t)B.n_chains + 4), (hipStream_t)stream) != hipSuccess)
         return MVMC_ERR_LAUNCH;
-    Ik1Tables tables_host;   // the skeleton's tables: once per call, on the host (ik1_build_tables_host), a kernel argument of the launch
+    Ik1Tables tables_host;   // the skeleton's tables: once per call, on the host, a kernel argument of the launch
     ik1_build_tables_host(tables_host, sk);
     if (!small) return mvmc_chain_launch_big(&tables_host, A, B.n_chains * A.parts, (hipStream_t)stream);
     hipLaunchKernelGGL(chain_kernel<false>, dim3(B.n_chains * A.parts), dim3(256), sizeof(ChainArena<false>), (hipStream_t)stream, tables_host, A);

@@ -112,7 +112,7 @@ class ChainTracker:
                 init=e((B, NP, 68), f64), status=e((B, T), i32), n_new=e((B,), i32), ik_params=e((B, NP, 68), f64),
                 ik_joints=e((B, NP, 18, 3), f64), ik_info=e((B, NP, 8), f64), ik_scratch=_chain_scratch(B, d),
                 out_params=e((B, T, 68), f64), out_joints=e((B, T, 18, 3), f64), out_meta=e((B, T, 4), i32),
-                out_n_tracks=e((B,), i32), flags=z((B + 6,), i32))
+                out_n_tracks=e((B,), i32), flags=z((B + 4,), i32))
         w = self._fused
         t = dict(w, kps17=kps17, counts=counts, Pmats=self.hp.P, Fmats=self.hp.F, F2=self.F2, params=self.params,
                  joints=self.joints, meta=self.meta, n_tracks=self.n_tracks, next_id=self.next_id, n_dead=self.n_dead,
@@ -266,7 +266,7 @@ def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tens
         ik_joints=e((B, NP, 18, 3), f64), ik_info=e((B, NP, 8), f64), ik_scratch=_chain_scratch(B, d),
         out_params=e((F, T, 68), f64), out_joints=e((F, T, 18, 3), f64), out_meta=e((F, T, 4), i32), out_n_tracks=e((F,), i32),
         out_info=e((F, NP, 8), f64) if want_info else None, out_als_iters=e((F,), i32) if want_info else None,
-        flags=z((B * max(parts, 1) + 6,), torch.int32),   # progress, hand-over queue, four status words last (mvmc.h)
+        flags=z((B + 4,), torch.int32),
         out_phase_cycles=e((B, 8), f64) if want_info else None)
     if parts > 1 and L % parts:
         raise ValueError("run_chains_fused: parts must divide the chain length")

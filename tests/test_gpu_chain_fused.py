@@ -28,9 +28,7 @@ def test_fused_equals_staged_bit_for_bit(B, L, people, parts):
     """parts = workgroups per chain: None = one per frame (the default), 1 = one persistent workgroup per chain."""
     a, b = _both(B, L, people=people, parts=parts)
     if parts != 1:
-        assert int(b["flags"][-4]) == 0, "a hand-over between the workgroups of a chain timed out"
-        n_ready = B * ((parts or L) - 1)   # every finished non-final part put its chain into the ready ring, every ticket was drawn
-        assert int(b["flags"][B]) == B * (parts or L) and int(b["flags"][B + 1]) == n_ready and (b["flags"][B + 2:B + 2 + n_ready] > 0).all()
+        assert int(b["flags"][B]) == 0, "a hand-over between the workgroups of a chain timed out"
         assert (b["flags"][:B] == (parts or L)).all()
     for k in ("n_tracks", "meta", "n_dead"):
         assert np.array_equal(a[k], b[k]), k

@@ -12,7 +12,7 @@ from bench import kernel_sources_sha  # noqa: E402
 
 def means(d, sub):
     acc = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    for f in [max(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)]:   # newest run
         for r in csv.DictReader(open(f)):
             if sub in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))

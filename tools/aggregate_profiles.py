@@ -23,7 +23,7 @@ def short(name):
 
 
 def pmc(dirname, counter):
-    f = glob.glob(os.path.join(dirname, "*", "*counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(dirname, "*", "*counter_collection.csv")), key=os.path.getmtime)   # newest run (gpurun merges, never deletes)
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
@@ -36,7 +36,7 @@ def main():
     wkey = sys.argv[5] if len(sys.argv) > 5 else "10000x5x4"
     sys.path.insert(0, ROOT)
     from bench import kernel_sources_sha
-    f = glob.glob(os.path.join(stats_dir, "*", "*kernel_stats.csv"))[0]
+    f = max(glob.glob(os.path.join(stats_dir, "*", "*kernel_stats.csv")), key=os.path.getmtime)
     out = os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv")
     rows = list(csv.DictReader(open(f)))
     with open(out, "w") as fo:

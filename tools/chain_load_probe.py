@@ -31,7 +31,7 @@ for B in [int(a) for a in sys.argv[1:]] or [256, 512, 625, 768]:
         j = torch.nan_to_num(out["joints"])
         if ref is None:
             ref = j
-        tmo = None if out["flags"] is None else int(out["flags"][-4])
+        tmo = None if out["flags"] is None else int(out["flags"][B])
         print("B=%4d parts=%d  %.2f ms  %.0f frames/s  chain Mcycles mean %.1f p95 %.1f max %.1f  (ALS mean %.1f IK mean %.1f)  "
               "timeout flag %s, same results as parts=%d: %s" %
               (B, parts, dt * 1e3, B * L / dt, pc[:, 6].mean() / 1e6, np.percentile(pc[:, 6], 95) / 1e6, pc[:, 6].max() / 1e6,

@@ -28,5 +28,4 @@ for overlap in (1, 2):
     pc = np.stack([r["phase_cycles"].cpu().numpy() for r in res[2:]])
     work, wait = pc[..., 6].sum(), pc[..., 7].sum()
     print(f"steps in flight {overlap}: work {pc[..., 6].mean() / 1e6:.1f} M cycles per chain, resident before the frames begin "
-          f"{pc[..., 7].mean() / 1e6:.1f} M = {wait / (work + wait):.3f} of the resident time (skeleton tables {pc[..., 4].mean() / 1e6:.2f} M, "
-          f"waiting for a chain {pc[..., 5].mean() / 1e6:.2f} M, pose pairs + barrier the rest)")
+          f"{pc[..., 7].mean() / 1e6:.1f} M = {wait / (work + wait):.3f} of the resident time")

@@ -1,6 +1,6 @@
 """Per-kernel means of the counters in a rocprofv3 --pmc output directory:  python tools/pmc_kernel.py <dir> [kernel substring]"""
 import collections, csv, glob, os, sys
-f = glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True)[0]
+f = max(glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)   # newest run
 sub = sys.argv[2] if len(sys.argv) > 2 else ""
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):

@@ -1,6 +1,6 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02r; rm -rf $O; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02s; rm -rf $O; mkdir -p $O
 python3 $R/bench.py > $O/bench_c4.json 2> $O/bench_c4.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c4 -- python3 $R/bench.py --cpu-frames 0 > $O/bench_c4_stats.json 2> $O/stats_c4.err
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/fetch_c4 -- python3 $R/bench.py --cpu-frames 0 --steps 2 --warmup 1 > /dev/null 2> $O/fetch_c4.err
