@@ -1161,6 +1161,12 @@ __device__ __forceinline__ int als7_iterate(const TW* __restrict__ Wf, int ldw, 
                                             const double* __restrict__ seed, double* sX, double* sA, double* sB,
                                             double* sG, double* sInvA, double* sInvB, double* sRed) {
     constexpr int R = 8, NS = 3, LDX = NMAX + 1;
+    // Rows of the factors, of the Gram matrix and of the inverses are LDF = 10 doubles apart, not 8: a worker's sixteen-byte reads of row
+    // k = 3 sub + c (eight different rows per quarter-wave) then start 60 banks apart instead of 48 and no two of them share a bank --
+    // with 64-byte rows, rows k and k + 12 (sub and sub + 4) did, and every such read took two passes (a third of the ALS's LDS cycles
+    // were bank conflicts: SQ_LDS_BANK_CONFLICT)
+    constexpr int LDF = 10;
+    static_assert(NMAX * LDF <= NMAX * 16 && 2 * R * LDF <= 4 * NMAX * 16 && R * LDF <= 256, "padded rows fit the arrays of Als4Lds");
     static_assert(NMAX >= 24, "three worker waves of eight rows");
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const bool worker = wv > 0;
@@ -1189,8 +1195,8 @@ __device__ __forceinline__ int als7_iterate(const TW* __restrict__ Wf, int ldw, 
     }
     for (int e = tid; e < NMAX * R; e += 256) {
         const int k = e / R, a = e - k * R;
-        sA[e] = (k < n && a < r) ? seed[k * r + a] : 0.0;
-        sB[e] = 0.0;
+        sA[k * LDF + a] = (k < n && a < r) ? seed[k * r + a] : 0.0;
+        sB[k * LDF + a] = 0.0;
     }
     __syncthreads();
     double mu = 64.0, inv_mu = 1.0 / 64.0;  // mu = 64 * 2^k: the reciprocal is exact
@@ -1212,10 +1218,10 @@ __device__ __forceinline__ int als7_iterate(const TW* __restrict__ Wf, int ldw, 
         // wave's form + inversion is what the workers wait for)
         static_assert(NMAX >= 24, "rows of the factors");
 #pragma unroll
-        for (int k = 0; k < 24; k += 2) { s0 += F[k * R + a] * F[k * R + b]; s1 += F[(k + 1) * R + a] * F[(k + 1) * R + b]; }
-        sG[lane] = s0 + s1;
+        for (int k = 0; k < 24; k += 2) { s0 += F[k * LDF + a] * F[k * LDF + b]; s1 += F[(k + 1) * LDF + a] * F[(k + 1) * LDF + b]; }
+        sG[a * LDF + b] = s0 + s1;
         MVMC_WAVE_SYNC();
-        const double2* gr = reinterpret_cast<const double2*>(&sG[(lane & 7) * R]);
+        const double2* gr = reinterpret_cast<const double2*>(&sG[(lane & 7) * LDF]);
 #pragma unroll
         for (int c = 0; c < R; c += 2) { const double2 v2 = gr[c >> 1]; g0[c] = v2.x; g0[c + 1] = v2.y; }
         MVMC_WAVE_SYNC();
@@ -1228,7 +1234,7 @@ __device__ __forceinline__ int als7_iterate(const TW* __restrict__ Wf, int ldw, 
         ge = (a == c) ? 1.0 : 0.0;
         gd = 0.0;
     };
-    auto inv_store = [&](double* dst) { dst[(lane & 7) * R + (lane >> 3)] = ge * gd; };   // E[a][c] / pivot a
+    auto inv_store = [&](double* dst) { dst[(lane & 7) * LDF + (lane >> 3)] = ge * gd; };   // E[a][c] / pivot a
     // ---- workers ----
     auto rhs = [&](const double* F, bool transposed, double (&hv)[R]) {   // sum_k F[k] xs(k, i) over the group's 24 columns
 #pragma unroll
@@ -1237,7 +1243,7 @@ __device__ __forceinline__ int als7_iterate(const TW* __restrict__ Wf, int ldw, 
         for (int c = 0; c < NS; ++c) {
             const int k = sub * NS + c;
             const double xv = transposed ? sX[k * LDX + i] : x1[c];
-            const double2* fr = reinterpret_cast<const double2*>(&F[k * R]);
+            const double2* fr = reinterpret_cast<const double2*>(&F[k * LDF]);
 #pragma unroll
             for (int a = 0; a < R; a += 2) { const double2 v2 = fr[a >> 1]; hv[a] += v2.x * xv; hv[a + 1] += v2.y * xv; }
         }
@@ -1245,11 +1251,11 @@ __device__ __forceinline__ int als7_iterate(const TW* __restrict__ Wf, int ldw, 
         for (int a = 0; a < R; ++a) hv[a] = oct_sum(hv[a]);
     };
     auto apply = [&](const double* inv, const double (&hv)[R], double* Fout) {   // entry `sub` of inv . hv
-        const double2* gr = reinterpret_cast<const double2*>(&inv[sub * R]);
+        const double2* gr = reinterpret_cast<const double2*>(&inv[sub * LDF]);
         double o0 = 0.0, o1 = 0.0;
 #pragma unroll
         for (int a = 0; a < R; a += 2) { const double2 v2 = gr[a >> 1]; o0 += v2.x * hv[a]; o1 += v2.y * hv[a + 1]; }
-        Fout[i * R + sub] = o0 + o1;
+        Fout[i * LDF + sub] = o0 + o1;
     };
     if (!worker) form(sA);
     for (int it = 0; it < 1000; ++it) {
@@ -1299,7 +1305,7 @@ __device__ __forceinline__ int als7_iterate(const TW* __restrict__ Wf, int ldw, 
         if (worker) {
             double av[R];
             {
-                const double2* ar = reinterpret_cast<const double2*>(&sA[i * R]);
+                const double2* ar = reinterpret_cast<const double2*>(&sA[i * LDF]);
 #pragma unroll
                 for (int a = 0; a < R; a += 2) { const double2 v2 = ar[a >> 1]; av[a] = v2.x; av[a + 1] = v2.y; }
             }
@@ -1307,7 +1313,7 @@ __device__ __forceinline__ int als7_iterate(const TW* __restrict__ Wf, int ldw, 
             for (int c = 0; c < NS; ++c) {
                 const int j = sub * NS + c;
                 double xa = 0.0, xb = 0.0;
-                const double2* br = reinterpret_cast<const double2*>(&sB[j * R]);
+                const double2* br = reinterpret_cast<const double2*>(&sB[j * LDF]);
 #pragma unroll
                 for (int a = 0; a < R; a += 2) { const double2 v2 = br[a >> 1]; xa += av[a] * v2.x; xb += av[a + 1] * v2.y; }
                 const double x = xa + xb;
@@ -1416,7 +1422,7 @@ __device__ __forceinline__ void als4_graph(Als4Lds<NMAX>& L, int f, const TW* __
         return;
     }
     const TW* Wf = W + (size_t)f * ldw * ldw;
-    const int iters = (r <= 8 && n <= 24) ? als7_iterate<TW, NMAX>(Wf, ldw, n, r, sGid, seed, sX, sA, sB, sG, sHp, sHp + 64, sRed)
+    const int iters = (r <= 8 && n <= 24) ? als7_iterate<TW, NMAX>(Wf, ldw, n, r, sGid, seed, sX, sA, sB, sG, sHp, sHp + 80, sRed)
                       : (r <= 8)          ? als4_iterate<TW, NMAX, 8>(Wf, ldw, n, r, sGid, seed, sX, sA, sB, sG, sMul, sDinv, sHp, sRed)
                                           : als4_iterate<TW, NMAX, 16>(Wf, ldw, n, r, sGid, seed, sX, sA, sB, sG, sMul, sDinv, sHp, sRed);
     // ---- tail: X_bin, closure (k = n-1 only), labels -- same rules as als_kernel ----
