@@ -1259,7 +1259,11 @@ __device__ __forceinline__ int als7_iterate(const TW* __restrict__ Wf, int ldw, 
         for (int a = 0; a < R; a += 2) { const double2 v2 = gr[a >> 1]; o0 += v2.x * hv[a]; o1 += v2.y * hv[a + 1]; }
         Fout[i * LDF + sub] = o0 + o1;
     };
-    if (!worker) form(sA);
+    // The first three pivots of (A^T A + ridge I)^-1 are made AHEAD, in the solver wave's idle time at the end of the previous iteration
+    // (it waits ~600 cycles for the workers' X / Z / Y step), with the ridge of that iteration: mu changes in few iterations, and only
+    // then are they made again here -- the workers' X1 step used to wait for them (solver 1.0 k cycles against 0.5 k).
+    double ridge_made = 50.0 * inv_mu;
+    if (!worker) { form(sA); inv_begin(ridge_made); gj_inv_steps<0, 3>(g, ge, gd, lane); }
     for (int it = 0; it < 1000; ++it) {
         const double ridge = 50.0 * inv_mu;  // == 50 / mu exactly
         double hv[R];
@@ -1275,7 +1279,7 @@ __device__ __forceinline__ int als7_iterate(const TW* __restrict__ Wf, int ldw, 
                 x1[c] = v;
                 sX[i * LDX + sub * NS + c] = v;
             }
-        } else {
+        } else if (ridge != ridge_made) {   // (wave-uniform: mu moved at the end of the last iteration)
             inv_begin(ridge);
             gj_inv_steps<0, 3>(g, ge, gd, lane);
         }
@@ -1336,6 +1340,9 @@ __device__ __forceinline__ int als7_iterate(const TW* __restrict__ Wf, int ldw, 
             if (lane == 0) { sRed[wv - 1] = acc_p; sRed[3 + wv - 1] = acc_d; }
         } else {
             form(sA);
+            ridge_made = ridge;   // speculation: mu stays
+            inv_begin(ridge_made);
+            gj_inv_steps<0, 3>(g, ge, gd, lane);
         }
         APROF2(10)
         __syncthreads();
