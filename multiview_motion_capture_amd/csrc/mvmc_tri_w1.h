@@ -75,7 +75,10 @@ __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, int 
     // chunks with two or three chunks of operands in flight (loads of chunk c + 2 in front of the FMAs of chunk c) -- more round trips
     // and branches than it hides, IK 37.9 -> 40.1 M cycles per chain, and the 50-row model spilled v_j / w_j.
     constexpr int HB = N <= 40 ? 5 : 3;   // pairs of rows per batch of the rank-2 update
-    constexpr int CH = 10, CHB = N % 20 == 0 ? 20 : 10;
+    // (CHB: rows per round trip of the product.  Twenty for the 40-row model measured best while a wave's latency was the limit; with the
+    // chip's VALU and LDS pipes as the limit -- two launches in flight, every slot taken -- the ten dead rows a 20-row chunk drags along on
+    // average cost more than the round trip they save: 454.0 k -> 456.1 k frames/s, bit-identical)
+    constexpr int CH = 10, CHB = 10;
     static_assert(N % CH == 0 && N % CHB == 0, "rows per chunk");
 #ifdef MVMC_TRI_PROFILE   // diagnostic: cycles of a step's four sections into tprof[0, 3, 4, 6] (tools/tri_step_profile.py)
     long long _tt = clock64();
@@ -116,7 +119,7 @@ __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, int 
         vb[lane] = vj;
         MVMC_WAVE_SYNC();
         double p0 = 0.0, p1 = 0.0;
-        // (the product takes CHB rows per LDS round trip: an FMA on a dead row costs 4 cycles, a round trip > 100)
+        // (the product takes CHB rows per LDS round trip)
 #pragma unroll
         for (int c = 0; c < N; c += CHB)
             if (c + CHB - 1 > k) {
