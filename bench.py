@@ -226,7 +226,7 @@ def main():
     ap.add_argument("--seed", type=int, default=20260103)
     ap.add_argument("--occlusion", type=float, default=0.0,
                     help="probability that a view misses a person in a frame (ragged counts, deaths and re-births); 0 = BASELINE workload")
-    ap.add_argument("--spurious", type=float, default=0.0, help="probability that a freed slot holds a false detection")
+    ap.add_argument("--spurious", type=float, default=0.0, help="probability that a slot freed by --occlusion holds a false detection instead (conditional)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the one all-gather: nccl = RCCL over xGMI (one rank per GPU); gloo only to "
                          "rehearse several ranks on a box with one GPU (host-staged)")
@@ -234,6 +234,9 @@ def main():
                     help="synthetic scene: 'chains' restarts the people's random walk at every chain head (the workload the round-1 "
                          "numbers were measured on); 'continuous' is one walk over all frames, so the stitch has identities to find")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--sustain", type=int, default=300,
+                    help="after the timed region: this many further consecutive steps of the same command (capped at ~15 s of work), "
+                         "reported as 'sustained' beside 'value'; 0 = skip")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -256,7 +259,7 @@ def main():
     from multiview_motion_capture_amd import synth
     from multiview_motion_capture_amd.pipeline import HotPath
     from multiview_motion_capture_amd import parallel as par
-    from multiview_motion_capture_amd.tracker import run_chains, run_chains_fused
+    from multiview_motion_capture_amd.tracker import check_chain_flags, repair_chains, run_chains, run_chains_fused
 
     F, C, Pn = args.frames, args.views, args.people
     # same cameras on every rank (seed), a different frame shard per rank (frame_seed)
@@ -291,8 +294,6 @@ def main():
                 out = run_chains_fused(hp, kps, counts, L, nfev_cold=args.nfev_cold, nfev_warm=args.nfev_warm, want_info=timed,
                                        parts=args.parts or None, kernel_events=kev)
                 kern_events.append((timed, kev[0][0], kev[0][1]))
-                out.pop("_keepalive", None)
-                hand_over_flags.append(out.pop("flags", None))
             else:
                 out = run_chains(hp, kps, counts, L, nfev_cold=args.nfev_cold, nfev_warm=args.nfev_warm,
                                  events=ik_events if timed else None, want_info=timed, n_groups=args.groups,
@@ -339,14 +340,32 @@ def main():
     comm = torch.cuda.Stream(device=d) if sharded else None
     tail_events, stitched = [], []
 
+    fused_chain = sharded and args.path == "fused"
+    repaired_per_step = []     # chains per step that went through the repair tier (tracker.repair_chains)
+
+    def stream_ctx(i):
+        return torch.cuda.stream(streams[i % len(streams)]) if streams is not None else contextlib.nullcontext()
+
     def issue(i, timed):
-        def compute():
-            return step(timed)
-        ctx = torch.cuda.stream(streams[i % len(streams)]) if streams is not None else contextlib.nullcontext()
-        with ctx:
+        """Launch the compute of step i (asynchronous); finish() completes the step."""
+        with stream_ctx(i):
+            return (i, timed, step(timed))
+
+    def finish(rec):
+        """The end of a step: void words of the chain kernel -> repair tier (reads four words back: the host waits for THIS step's
+        kernel, the next step's is already queued), then pack -> all-gather -> stitch on the communication stream."""
+        i, timed, out = rec
+        with stream_ctx(i):
+            if fused_chain:
+                repaired_per_step.append(repair_chains(hp, kps, counts, out, nfev_cold=args.nfev_cold, nfev_warm=args.nfev_warm))
+                try:
+                    check_chain_flags(out)
+                except (ValueError, RuntimeError) as exc:
+                    raise SystemExit(f"bench.py: step {i} is void: {exc}")
+                out.pop("_keepalive", None)
             if not sharded:
-                return compute()
-            res = par.run_sharded(compute, L, (F // L) * world, rank, world, rows_per_frame=min(Pn + 1, 8), comm_stream=comm,
+                return out
+            res = par.run_sharded(lambda: out, L, (F // L) * world, rank, world, rows_per_frame=min(Pn + 1, 8), comm_stream=comm,
                                   timing=timed)
             if timed:
                 tail_events.append(res["tail_events"])
@@ -357,14 +376,23 @@ def main():
             out["stitch"] = res
             return out
 
-    for i in range(args.warmup):
-        issue(i, False)
+    def run_steps(n, timed):
+        """n steps, args.overlap of them in flight: step i + 1 is launched before step i is finished."""
+        pending, last = [], None
+        for i in range(n):
+            pending.append(issue(i, timed))
+            if len(pending) >= max(1, args.overlap):
+                last = finish(pending.pop(0))
+        while pending:
+            last = finish(pending.pop(0))
+        return last
+
+    run_steps(args.warmup, False)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = issue(i, True)
+    out = run_steps(args.steps, True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -388,9 +416,29 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         serial_ms = e0.elapsed_time(e1)
-    for fl in hand_over_flags:
-        if fl is not None and (int(fl[-4]) != 0 or int(fl[-3]) != 0):
-            raise SystemExit("chain kernel: a hand-over timed out or a graph did not fit; results are void")
+    # the same command, sustained: further consecutive steps (same barrier + synchronize bracket, max over ranks)
+    sustained = None
+    if args.sustain > 0:
+        n_sus = max(args.steps, min(args.sustain, int(15.0 / (dt / args.steps))))
+        if world > 1:
+            t = torch.tensor([n_sus], dtype=torch.int64, device=d if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            n_sus = int(t.item())
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(n_sus, False)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dts = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dts], dtype=torch.float64, device=d if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dts = float(t.item())
+        sustained = {"value": F * world * n_sus / dts, "unit": "frames/s", "steps": n_sus, "ms_per_step": dts / n_sus * 1e3}
+        for res in stitched:
+            par.check_stitch_info(res)
     stage_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items() if v}
     if serial_ms is not None:
         stage_ms["one_step_alone"] = serial_ms
@@ -424,9 +472,11 @@ def main():
         tracker_events = {"births": int(out["next_id"].sum().item()), "deaths": int(out["n_dead"].sum().item()),
                           "frames_where_the_count_changes": int((np.diff(cnt, axis=1) != 0).sum()),
                           "mean_live_tracklets": float(cnt.mean()),
-                          # bit 0: a cluster with more members than v_max views or more new clusters than k_max in some frame (the
-                          # reference has no such caps); bit 1: tracklet table full
-                          "capacity_word": int(hand_over_flags[-1][-2]) if hand_over_flags and hand_over_flags[-1] is not None else 0}
+                          # chains per step whose void word was set (more live tracklets than the chain kernel's table, a graph beyond
+                          # its association variant) and that the repair tier re-ran inside the timed region; after it no word may
+                          # be left (a step with one is void and ends the run, see finish())
+                          "chains_repaired_per_step": float(np.mean(repaired_per_step)) if repaired_per_step else 0.0,
+                          "capacity_word": int(out["void"].max().item()) if "void" in out else 0}
     if rank == 0:
         frames_total = F * world * args.steps
         value = frames_total / dt
@@ -499,6 +549,7 @@ def main():
                                     if with_ik else ""),
                        "frames_per_gpu": F, "views": C, "people": Pn, "chain_len": L, "seed": args.seed, "parallelism": f"frames x{world}",
                        "steps_in_flight": args.overlap, "occlusion": args.occlusion, "spurious": args.spurious, **extra},
+            "sustained": sustained,
             "tracker_events_per_step": tracker_events,
             "stages_ms": stage_ms,
             "roofline": {"bound": "hbm", "kernel": dom_kernel,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVMC_ABI_VERSION 2
+#define MVMC_ABI_VERSION 3
 
 enum {
     MVMC_OK = 0,
@@ -149,7 +149,7 @@ int mvmc_fk(const mvmcSkeleton* skel_host, const double* params, int n_problems,
 /* IK-1..IK-4: PoseSolver.solve (inverse_kinematics.py:351-433) = two trust-region-reflective
  * least-squares stages (solve_pose_reproj :202-238, solve_pose_bone_lens_reproj :241-277; SciPy
  * least_squares defaults, max_nfev evaluations each).
- *   members      (B,V) pose indices into kps17 (-1 padded)
+ *   members      (B,V) pose indices into kps17 (-1 = none; v_max = V <= 64, every member is used)
  *   init_params  (B,68) warm-start parameters, ignored where cold[b] != 0
  *   cold         (B) u8: 1 = cold start (root = midpoint of the post-optimised DLT hips, zero angles,
  *                reference lengths, max_nfev_cold),
@@ -191,7 +191,7 @@ int mvmc_st_affinity(const double* kps17, const int32_t* counts, const int32_t* 
  *   members (B,T+K,V) pose indices; cold (B,T+K) u8; init_params (B,T+K,68);
  *   status (B,T) i32: 0 unmatched (dies), 1 one view (kept, not updated), 2 updated; n_new (B) new tracklets;
  *   overflow (B) i32 in/out or NULL: bit 0 is OR-ed in where a cluster (more than k_max new ones) or a member (more than v_max
- *   views) was dropped for lack of room -- the reference has no such caps */
+ *   views) was dropped for lack of room -- the reference has no such caps; k_max >= C*P / 2 and v_max >= C*P rule both out */
 int mvmc_track_assign(const int32_t* labels_sp, const int32_t* ncl_sp, const int32_t* labels_st,
                       const int32_t* ncl_st, const int32_t* counts, const int32_t* frame_idx,
                       const int32_t* n_tracks, const double* track_params, int n_chains, int n_views, int p_max,
@@ -234,7 +234,9 @@ int mvmc_pack_tracks(const double* out_params, const double* out_joints, const i
  * chain g on the mean joint distance, pairs farther than max_dist (metres) dropped; matched tracklets share a global identity.
  *   gid    (n_chains_total_cap, id_cap) i32 out: global identity of (chain, local id), -1 where the chain has fewer identities
  *   match  (n_chains_total_cap, t_max) i32 out: slot of the previous chain's last frame matched to slot s of this chain's first, -1
- *   info   (4) i32 out: {chains, global identities, error flag (a message overflowed or a chain has more than id_cap ids), pairs}
+ *   info   (4) i32 out: {chains, global identities, error word, pairs}; error word bit 0 = a message overflowed or a chain has more
+ *          than id_cap ids, bit 1 = an assignment did not terminate (cannot happen with finite costs; a tracklet with a non-finite
+ *          joint is given a cost beyond any max_dist, i.e. it matches nobody).  Non-zero = the result is void
  *   work   (2 * n_chains_total_cap * id_cap) i32 device workspace;  n_chains_total_cap >= world * n_chains_cap */
 int mvmc_stitch_chains(const void* messages, long long message_words, int world, int n_chains_cap, int t_max, int row_cap,
                        int id_cap, double max_dist, int n_chains_total_cap, int32_t* gid, int32_t* match, int32_t* info,
@@ -293,15 +295,22 @@ int mvmc_debug_ik_solve_fd(const mvmcSkeleton* skel_host, const double* kps17, c
  * mvmc_track_commit issued frame by frame, and the same results.  Chain b owns frames [b chain_len, (b+1) chain_len).
  * All pointers are device memory owned by the caller (N = n_views p_max, NS = t_max + N, NP = t_max + k_max,
  * B = n_chains, F = B chain_len).  Two LDS layouts (MVMC_ERR_UNSUPPORTED outside them: use the per-stage entry points), both with
- * p_max <= 8, t_max <= 8:
- *   small  N <= 40, NS <= 48, v_max <= 6 (configs 1-4; three workgroups per CU); every frame's actual graph must have <= 24 nodes
- *          without tracklets and <= 32 with them -- checked on the device: flags[B + 1] != 0 after the call means a graph did not fit;
- *   big    N <= 64, NS <= 72, v_max <= 8 (config 5, C8 P8; two workgroups per CU); every graph of those sizes fits. */
+ * p_max <= 8, t_max <= 8, NP <= 64, v_max <= 64:
+ *   small  N <= 40, NS <= 48 (configs 1-4; three workgroups per CU); every frame's actual graph must have <= 24 nodes without
+ *          tracklets and <= 32 with them, and the frame <= 24 poses in clusters (the IK phase's view pool) -- checked on the device;
+ *   big    N <= 64, NS <= 72 (config 5, C8 P8; one 512-thread workgroup per CU); every graph of those sizes fits.
+ * Capacities the reference does not have (motion_capture.py:417-446, :763-808 accept any cluster size and any number of clusters and
+ * tracklets): with k_max >= N / 2 (a new tracklet needs two poses) and v_max >= min(N, 64) (clusters are disjoint sets of the
+ * frame's poses; the view blocks of a frame's IK problems share one pool, so a cluster may be as large as the frame) neither a
+ * cluster nor a member is ever dropped; what remains is t_max (tracklet slots, tied to the rank the association variants hold)
+ * and the graph sizes above.  A chain that exceeds one of them is reported in its void word, flags[B + 4 + b], and its results are
+ * void; tracker.repair_chains re-runs such chains through the per-stage entry points with wider tables. */
 typedef struct mvmcChainBuffers {
     int32_t n_chains, chain_len, n_views, p_max, t_max, k_max, v_max, max_nfev_cold, max_nfev_warm, n_inits, seed_len;
     int32_t n_parts;            /* workgroups per chain: 1 = one persistent workgroup per chain; p > 1 (dividing chain_len) =
                                    p workgroups running consecutive frame ranges of the chain one after the other, so that
                                    the hardware dispatcher balances the load over the CUs */
+    int32_t force_big;          /* != 0: the big layout even where the small one would do (tests) */
     /* inputs */
     const double* kps17;        /* (F,C,P,17,3) after mvmc_ingest */
     const int32_t* counts;      /* (F,C) */
@@ -327,7 +336,8 @@ typedef struct mvmcChainBuffers {
     int32_t* n_clusters_st;     /* (B) */
     int32_t* iters_sp;          /* (B) */
     int32_t* iters_st;          /* (B) */
-    int32_t* members;           /* (B,NP,V) */
+    int32_t* members;           /* (B,NP,V); row s holds n_members[s] entries, the rest of the row is undefined */
+    int32_t* n_members;         /* (B,NP) */
     uint8_t* cold;              /* (B,NP) */
     double* init;               /* (B,NP,68) */
     int32_t* status;            /* (B,T) */
@@ -343,20 +353,16 @@ typedef struct mvmcChainBuffers {
     int32_t* out_n_tracks;      /* (F) */
     double* out_info;           /* (F,NP,8) IK info rows of the frame's problems, or NULL */
     int32_t* out_als_iters;     /* (F) ALS iterations of the frame's graph, or NULL */
-    uint32_t* flags;            /* (B + 4) u32, zeroed by the call: [0,B) hand-over flags of the chains; afterwards flags[B] != 0 =
+    uint32_t* flags;            /* (2 B + 4) u32, zeroed by the call: [0,B) hand-over flags of the chains; afterwards flags[B] != 0 =
                                    a workgroup timed out waiting for its predecessor, flags[B + 1] != 0 = a graph was too large
-                                   for the kernel's ALS variant, flags[B + 2] != 0 = a capacity was exceeded (bit 0: more than
-                                   k_max new clusters or v_max views in a frame, bit 1: more than t_max tracklets); in every
-                                   case the results are void */
+                                   for the kernel's ALS variant, flags[B + 2] != 0 = a capacity was exceeded in some chain (bit 0:
+                                   a cluster, a member or a view block dropped, bit 1: more than t_max tracklets), flags[B + 4 + b] =
+                                   the void word of chain b (bits 0, 1 as before, bit 2 = graph too large): a non-zero word voids
+                                   the chain's results (all chains' after a time-out) */
     double* out_phase_cycles;   /* (B,8) diagnostic: shader cycles of each chain by phase {graph, ALS, assignment, IK, commit,
                                    outputs, whole chain, 0}, or NULL */
 } mvmcChainBuffers;
 int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuffers* buffers, mvmcStream_t stream);
-
-/* Which kernel mvmc_ik_solve launches: 0 = one wave per solve (ik1_kernel, the default); 1 = one 256-thread workgroup
- * per solve (ik_kernel, the first layout, kept as the A/B reference).  Any other value only queries.  Returns the previous mode (-1 =
- * not yet chosen: the first mvmc_ik_solve call takes it from the environment variable MVMC_IK_MODE, default 0). */
-int mvmc_debug_ik_mode(int mode);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,7 @@ SYMBOLS = (
     "mvmc_abi_version", "mvmc_status_string", "mvmc_als_seed_table", "mvmc_ingest", "mvmc_fmats",
     "mvmc_affinity", "mvmc_als_associate", "mvmc_closure_labels", "mvmc_cluster_members", "mvmc_dlt", "mvmc_triangulate_postopt", "mvmc_fk", "mvmc_ik_solve",
     "mvmc_fmats_from_projections", "mvmc_st_affinity", "mvmc_track_assign", "mvmc_track_commit", "mvmc_debug_eigh",
-    "mvmc_debug_trstep", "mvmc_debug_ik_mode", "mvmc_ik_solve_stages", "mvmc_chain_run", "mvmc_svt_associate", "mvmc_debug_ik_solve_fd", "mvmc_pack_message_words", "mvmc_pack_tracks", "mvmc_stitch_chains",
+    "mvmc_debug_trstep", "mvmc_ik_solve_stages", "mvmc_chain_run", "mvmc_svt_associate", "mvmc_debug_ik_solve_fd", "mvmc_pack_message_words", "mvmc_pack_tracks", "mvmc_stitch_chains",
 )
 
 
@@ -39,10 +39,10 @@ class MvmcSkeleton(C.Structure):
 class MvmcChainBuffers(C.Structure):
     """mvmcChainBuffers of include/mvmc.h (field order matters)."""
     _INTS = ("n_chains", "chain_len", "n_views", "p_max", "t_max", "k_max", "v_max", "max_nfev_cold", "max_nfev_warm",
-             "n_inits", "seed_len", "n_parts")
+             "n_inits", "seed_len", "n_parts", "force_big")
     _PTRS = ("kps17", "counts", "Pmats", "Fmats", "F2", "seed_table", "params", "joints", "meta", "n_tracks", "next_id",
              "n_dead", "slot_src", "S_sp", "W_st", "group_counts", "labels_sp", "labels_st", "n_clusters_sp", "n_clusters_st",
-             "iters_sp", "iters_st", "members", "cold", "init", "status", "n_new", "ik_params", "ik_joints", "ik_info",
+             "iters_sp", "iters_st", "members", "n_members", "cold", "init", "status", "n_new", "ik_params", "ik_joints", "ik_info",
              "ik_scratch", "out_params", "out_joints", "out_meta", "out_n_tracks", "out_info", "out_als_iters", "flags", "out_phase_cycles")
     _fields_ = [(n, C.c_int32) for n in _INTS] + [(n, C.c_void_p) for n in _PTRS]
 
@@ -87,7 +87,6 @@ def load():
     lib.mvmc_track_commit.argtypes = [vp] * 4 + [i32] * 4 + [vp] * 9
     lib.mvmc_debug_eigh.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp]
     lib.mvmc_debug_trstep.argtypes = [vp, vp, i32, i32, i32, C.c_double, C.c_double, vp, vp, vp, vp]
-    lib.mvmc_debug_ik_mode.argtypes = [i32]
     lib.mvmc_chain_run.argtypes = [C.POINTER(MvmcSkeleton), C.POINTER(MvmcChainBuffers), vp]
     lib.mvmc_ik_solve_stages.argtypes = [C.POINTER(MvmcSkeleton), vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp]
     lib.mvmc_debug_ik_solve_fd.argtypes = [C.POINTER(MvmcSkeleton), vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]

@@ -2258,8 +2258,9 @@ static int launch_als(const TW* W, const int32_t* gc, int F, int G, int n_max, i
             return MVMC_ERR_LAUNCH;
         hipLaunchKernelGGL((als5_kernel<TW, 72>), dim3(F), dim3(512), lds, s, W, gc, G, n_max, seed, seed_len, xb, mm, lab, nc, it);
     }
-    else if (n_max <= 64) MVMC_ALS(64, 16, 256);
-    else if (n_max <= 80) MVMC_ALS(80, 16, 512);
+    else if (n_max <= 64 && r_max <= 16) MVMC_ALS(64, 16, 256);
+    else if (n_max <= 80 && r_max <= 16) MVMC_ALS(80, 16, 512);
+    else if (n_max <= 80) MVMC_ALS(80, 32, 512);   // up to 16 groups members (the repair tier's 16 tracklet slots): 121 KB of LDS
     else return MVMC_ERR_UNSUPPORTED;
 #undef MVMC_ALS
 #undef MVMC_ALS2

@@ -46,7 +46,8 @@ struct MvmcChainArgs {
     int32_t* ncl_st;          // (B)
     int32_t* iters_sp;        // (B)
     int32_t* iters_st;        // (B)
-    int32_t* members;         // (B,NP,V)         NP = T + K
+    int32_t* members;         // (B,NP,V)         NP = T + K; row s valid in [0, n_members[s])
+    int32_t* n_members;       // (B,NP)
     uint8_t* cold;            // (B,NP)
     double* init;             // (B,NP,68)
     int32_t* status;          // (B,T)
@@ -64,7 +65,9 @@ struct MvmcChainArgs {
     int32_t* out_iters;       // (F) ALS iterations of the frame's graph, or NULL
     double* out_cycles;       // (B,8) shader cycles by phase {graph, ALS, assign, IK, commit, outputs, total}, or NULL
     int parts;                // workgroups per chain (consecutive frame ranges, handed over through flags)
-    unsigned* flags;          // (B + 1) parts completed per chain; [B] = timeout word.  Zeroed by the launcher
+    unsigned* flags;          // (2 B + 4): [0,B) parts completed per chain; [B] time-out, [B+1] graph too large, [B+2] capacity word of
+                              // the launch; [B+4+b] the void word of chain b (bit 0 views / clusters, bit 1 tracklet table, bit 2 graph
+                              // too large for the layout's association variant).  Zeroed by the launcher
 };
 
 namespace {
@@ -81,8 +84,11 @@ using ChainArgsK = const __attribute__((address_space(4))) MvmcChainArgs;
 // <= 16: als5_graph, X1 as a dense n x n matrix in LDS, the element state in registers) on a 512-thread workgroup -- eight waves, so the
 // eight people of a frame are solved side by side -- with 112 KB of LDS in a dynamic allocation, one workgroup per CU.
 template <bool BIG> struct ChainCfg;
-template <> struct ChainCfg<false> { static constexpr int VM = 6, N_MAX = 40, NS_MAX = 48, NT = 256, WG_PER_CU = 3, WAVES_PER_SIMD = 3; };
-template <> struct ChainCfg<true> { static constexpr int VM = 8, N_MAX = 64, NS_MAX = 72, NT = 512, WG_PER_CU = 1, WAVES_PER_SIMD = 2; };
+// POOL = view blocks (pose + projection of one member of a cluster) the IK phase has room for, for ALL problems of a frame together: the
+// clusters of a frame are disjoint, so a frame with at most POOL poses never runs out, whatever the size of a single cluster
+// (SMALL: the association variants hold 24 pose nodes anyway; BIG: N_MAX).
+template <> struct ChainCfg<false> { static constexpr int POOL = 24, N_MAX = 40, NS_MAX = 48, NT = 256, WG_PER_CU = 3, WAVES_PER_SIMD = 3; };
+template <> struct ChainCfg<true> { static constexpr int POOL = 64, N_MAX = 64, NS_MAX = 72, NT = 512, WG_PER_CU = 1, WAVES_PER_SIMD = 2; };
 
 
 constexpr int CH_EOFF = 2368;   // SMALL: doubles of graph scratch in front of the pose-pair block (NS <= 48: 48 * 48 + 6 + 48 = 2358)
@@ -91,7 +97,7 @@ template <bool BIG> union ChainArena;
 template <> union ChainArena<false> {
     Als4Lds<32> als_st;
     Als4Lds<24> als_sp;
-    Ik1Shared<6> ik[4];
+    struct { Ik1Shared ik[4]; double views[24 * MVMC_IK_VIEW_DOUBLES]; } ikp;
     // graph scratch: st_affinity_wave needs (NS*NS + 6) doubles + 2 NS ints (NS <= 48), affinity_wave N*51 doubles + 2 N*N floats
     // + 2 N ints + 4 words (N <= 40)
     // + the pose-pair block made ahead of the hand-over (st_pose_pairs: N * N doubles behind st_affinity_wave's part)
@@ -99,11 +105,12 @@ template <> union ChainArena<false> {
 };
 template <> union ChainArena<true> {
     Als5Lds<72> als;
-    Ik1Shared<8> ik[8];         // eight waves: the eight people of config 5 are solved side by side
+    struct { Ik1Shared ik[8]; double views[64 * MVMC_IK_VIEW_DOUBLES]; } ikp;   // eight waves: the eight people of config 5 are solved side by side
     double graph[64 * 51 + 64 * 64 + 64 + 16];   // affinity_wave at N = 64 (st_affinity_wave at NS = 72 needs 72 * 72 + 6 + 72)
 };
 static_assert(CH_EOFF >= 48 * 48 + 10 + 48 && CH_EOFF + 40 * 40 >= 40 * 51 + 40 * 40 + 40 + 8, "graph scratch covers both graph builders");
-static_assert(sizeof(ChainArena<false>) <= 4 * sizeof(Ik1Shared<6>), "SMALL: the IK blocks set the arena size");
+static_assert(sizeof(ChainArena<false>) <= 4 * sizeof(Ik1Shared) + 24 * MVMC_IK_VIEW_DOUBLES * 8, "SMALL: the IK blocks set the arena size");
+static_assert(sizeof(ChainArena<false>) <= 52 * 1024, "SMALL: three workgroups per CU");
 static_assert(64 * 51 + 64 * 64 + 64 + 16 >= 72 * 72 + 10 + 72, "BIG: graph scratch covers both graph builders");
 static_assert(sizeof(ChainArena<true>) <= 150 * 1024, "BIG: one workgroup per CU");
 
@@ -163,26 +170,36 @@ __device__ __noinline__ void chain_als_temporal(ChainArena<BIG>& arena, ChainArg
 }
 __device__ __noinline__ void chain_assign(ChainArgsK& A, int b, int f, int* done) {
     assign_chain(threadIdx.x & 63, 64, b, f, A.labels_sp, A.ncl_sp, A.labels_st, A.ncl_st, A.counts, A.n_tracks, A.params, A.C, A.P, A.T, A.K, A.V,
-                 A.members, A.cold, A.init, A.status, A.n_new, reinterpret_cast<int32_t*>(A.flags + A.n_chains + 2));
+                 A.members, A.cold, A.init, A.status, A.n_new, reinterpret_cast<int32_t*>(A.flags + A.n_chains + 4 + b), A.n_members);
     *done = 0;
 }
 __device__ __noinline__ void chain_commit(ChainArgsK& A, int b, int* done) {
     commit_chain(threadIdx.x & 63, 64, b, A.status, A.n_new, A.ik_params, A.ik_joints, A.T, A.K, A.n_inits, A.params, A.joints, A.meta, A.n_tracks,
-                 A.next_id, A.n_dead, A.slot_src, reinterpret_cast<int32_t*>(A.flags + A.n_chains + 2));
+                 A.next_id, A.n_dead, A.slot_src, reinterpret_cast<int32_t*>(A.flags + A.n_chains + 4 + b));
     *done = 0;
 }
 template <bool BIG>
 __device__ __noinline__ void chain_ik(ChainArena<BIG>& arena, const Ik1Tables& tables, ChainArgsK& A, int b, int* done) {
     MVMC_ASSUME_LDS(&arena);
     MVMC_ASSUME_LDS(&tables);
-    constexpr int NW = ChainCfg<BIG>::NT / 64;
+    constexpr int NW = ChainCfg<BIG>::NT / 64, POOL = ChainCfg<BIG>::POOL;
+    const int lane = threadIdx.x & 63;
     const int wave = uni((int)(threadIdx.x >> 6)), NP = A.T + A.K;
+    // the view blocks of the frame's problems lie end to end in the pool: block of slot s starts at the members of the slots before it
+    const int cnt = lane < NP ? A.n_members[(size_t)b * NP + lane] : 0;
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+    const int excl = incl - cnt;
     // wave w takes the problem slots w, w + NW, ... of this chain
     for (int s = wave; s < NP; s += NW) {
         const int p = b * NP + s;
-        ik1_solve<ChainCfg<BIG>::VM>(arena.ik[wave], tables, A.kps17, A.Pm, A.members, p, A.V, A.C, A.P, A.init, A.cold, A.nfev_cold,
-                         A.nfev_warm, A.ik_params, A.ik_joints, A.ik_info,
-                         A.ik_scratch + (ptrdiff_t)(b * NW + wave - p) * MVMC_IK_SCRATCH_DOUBLES, 3, nullptr);
+        const int base = uni(__shfl(excl, s, 64)), n_valid = uni(__shfl(cnt, s, 64));
+        const int room = base < POOL ? POOL - base : 0;     // (a frame with more poses than POOL: the problem is cut short and flagged)
+        ik1_solve(arena.ikp.ik[wave], arena.ikp.views + (base < POOL ? base : 0) * MVMC_IK_VIEW_DOUBLES, room, tables, A.kps17, A.Pm, A.members,
+                  p, A.V, A.C, A.P, A.init, A.cold, A.nfev_cold, A.nfev_warm, A.ik_params, A.ik_joints, A.ik_info,
+                  A.ik_scratch + (ptrdiff_t)(b * NW + wave - p) * MVMC_IK_SCRATCH_DOUBLES, 3, nullptr,
+                  reinterpret_cast<int32_t*>(A.flags + A.n_chains + 4 + b), n_valid);
     }
     *done = 0;
 }
@@ -281,8 +298,10 @@ chain_kernel(Ik1Tables tables_arg, ChainArgs A_by_value) {
         lap(1);
         // a graph with more nodes (or a higher rank) than the workgroup variant of the ALS holds is flagged by it (iters < 0):
         // raise the launch's error word instead of silently tracking nobody
-        if (tid == 0 && (nt <= 0 ? A.iters_sp[b] : A.iters_st[b]) < 0)
+        if (tid == 0 && (nt <= 0 ? A.iters_sp[b] : A.iters_st[b]) < 0) {
             __hip_atomic_store(A.flags + A.n_chains + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicOr(A.flags + A.n_chains + 4 + b, 4u);
+        }
         if (wave == 0) chain_assign(A, b, f, &done);   // clusters -> IK problems (bulk copies on the wave, the logic on lane 0)
         __syncthreads();
         lap(2);
@@ -304,6 +323,11 @@ chain_kernel(Ik1Tables tables_arg, ChainArgs A_by_value) {
         }
         __syncthreads();
         lap(5);
+    }
+    // the chain's void word (assignment, IK pool, commit) into the launch's capacity word
+    if (tid == 0) {
+        const unsigned v = __hip_atomic_load(A.flags + A.n_chains + 4 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 3u;
+        if (v) atomicOr(A.flags + A.n_chains + 2, v);
     }
     if (done != 0) return;   // (never: the phases write 0)
     if (A.out_cycles && tid == 0) {   // accumulated over the chain's parts (they run one after the other)
@@ -338,13 +362,11 @@ int mvmc_chain_launch_big(const void* tables_host, const MvmcChainArgs& A, int n
 
 #ifdef MVMC_CHAIN_BIG_TU
 int mvmc_chain_launch_big(const void* tables_host, const MvmcChainArgs& A, int n_blocks, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)chain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)sizeof(ChainArena<true>)) != hipSuccess)
-            return MVMC_ERR_LAUNCH;
-        attr_set = true;
-    }
+    // per call: the attribute belongs to the function ON THE CURRENT DEVICE, and a cached flag would be neither per device nor
+    // thread-safe (it costs ~1 us beside a launch of hundreds of milliseconds)
+    if (hipFuncSetAttribute((const void*)chain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sizeof(ChainArena<true>)) != hipSuccess)
+        return MVMC_ERR_LAUNCH;
     hipLaunchKernelGGL(chain_kernel<true>, dim3(n_blocks), dim3(ChainCfg<true>::NT), sizeof(ChainArena<true>), stream, *static_cast<const Ik1Tables*>(tables_host), A);
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;
@@ -361,12 +383,13 @@ extern "C" int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuff
     // path -- checked on the device, flags[n_chains + 1].  BIG (C8 P8): N <= 64, N + T <= 72: every graph of those sizes fits.
     const int N = B.n_views * B.p_max, NS = B.t_max + N;
     if (B.n_views > 16 || 2 * B.p_max > 16 || 2 * (B.t_max > B.p_max ? B.t_max : B.p_max) > 16) return MVMC_ERR_UNSUPPORTED;
-    const bool small = N <= ChainCfg<false>::N_MAX && NS <= ChainCfg<false>::NS_MAX && B.v_max <= ChainCfg<false>::VM;
-    const bool big = N <= ChainCfg<true>::N_MAX && NS <= ChainCfg<true>::NS_MAX && B.v_max <= ChainCfg<true>::VM;
+    if (B.t_max + B.k_max > 64 || B.v_max > 64) return MVMC_ERR_UNSUPPORTED;   // a lane per problem slot / per member
+    const bool small = N <= ChainCfg<false>::N_MAX && NS <= ChainCfg<false>::NS_MAX && !B.force_big;
+    const bool big = N <= ChainCfg<true>::N_MAX && NS <= ChainCfg<true>::NS_MAX;
     if (!small && !big) return MVMC_ERR_UNSUPPORTED;
     const void* need[] = {B.kps17, B.counts, B.Pmats, B.Fmats, B.F2, B.seed_table, B.params, B.joints, B.meta, B.n_tracks,
                           B.next_id, B.n_dead, B.slot_src, B.S_sp, B.W_st, B.group_counts, B.labels_sp, B.labels_st, B.n_clusters_sp,
-                          B.n_clusters_st, B.iters_sp, B.iters_st, B.members, B.cold, B.init, B.status, B.n_new, B.ik_params, B.ik_joints, B.ik_info, B.ik_scratch,
+                          B.n_clusters_st, B.iters_sp, B.iters_st, B.members, B.n_members, B.cold, B.init, B.status, B.n_new, B.ik_params, B.ik_joints, B.ik_info, B.ik_scratch,
                           B.out_params, B.out_joints, B.out_meta, B.out_n_tracks, B.flags};
     for (const void* q : need)
         if (!q) return MVMC_ERR_ARG;
@@ -383,14 +406,14 @@ extern "C" int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuff
     A.n_dead = B.n_dead; A.slot_src = B.slot_src;
     A.S_sp = B.S_sp; A.W_st = B.W_st; A.gc = B.group_counts; A.labels_sp = B.labels_sp; A.labels_st = B.labels_st;
     A.ncl_sp = B.n_clusters_sp; A.ncl_st = B.n_clusters_st; A.iters_sp = B.iters_sp; A.iters_st = B.iters_st;
-    A.members = B.members; A.cold = B.cold; A.init = B.init; A.status = B.status;
+    A.members = B.members; A.n_members = B.n_members; A.cold = B.cold; A.init = B.init; A.status = B.status;
     A.n_new = B.n_new; A.ik_params = B.ik_params; A.ik_joints = B.ik_joints; A.ik_info = B.ik_info; A.ik_scratch = B.ik_scratch;
     A.out_params = B.out_params; A.out_joints = B.out_joints; A.out_meta = B.out_meta; A.out_n = B.out_n_tracks;
     A.out_info = B.out_info; A.out_iters = B.out_als_iters; A.out_cycles = B.out_phase_cycles;
     A.parts = B.n_parts > 1 ? B.n_parts : 1;
     if (A.parts > 1 && B.chain_len % A.parts != 0) return MVMC_ERR_ARG;
     A.flags = B.flags;
-    if (hipMemsetAsync(B.flags, 0, sizeof(unsigned) * ((size_t)B.n_chains + 4), (hipStream_t)stream) != hipSuccess)
+    if (hipMemsetAsync(B.flags, 0, sizeof(unsigned) * (2 * (size_t)B.n_chains + 4), (hipStream_t)stream) != hipSuccess)
         return MVMC_ERR_LAUNCH;
     Ik1Tables tables_host;   // the skeleton's tables: once per call, on the host, a kernel argument of the launch
     ik1_build_tables_host(tables_host, sk);

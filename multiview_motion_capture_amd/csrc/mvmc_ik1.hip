@@ -58,22 +58,29 @@ struct Ik1Tables {
     unsigned char act[2][NA1], colkind[2][NA1], cola[2][NA1], colc[2][NA1];
 };
 
-// per-solve state (one wave)
-template <int VM>
+// per-solve state (one wave).  The problem's observations are NOT part of it: pose18 (nv x 18 x {x, y, score}: COCO-17 + mid-spine) and
+// the projection matrices (nv x 12) live in a VIEW BLOCK of nv * MVMC_IK_VIEW_DOUBLES doubles that the caller hands to ik1_solve -- the
+// stand-alone kernel a block of v_max views per workgroup, the chain kernel a slice of ONE pool per workgroup: the clusters of a frame
+// are disjoint sets of the frame's poses, so the blocks of all of a frame's problems, laid end to end, never exceed the number of poses
+// in the frame, whatever the size of a single cluster (the reference has no cap on it: motion_capture.py:417-446, :618-626).
 struct Ik1Shared {
     __attribute__((aligned(16))) double tmp[256];
     double sv[SV_COUNT];
     double x[68], xn[68], side[18];
-    double pose18[VM * 54], Pm[VM * 12];   // 3-D-target mode keeps its targets (16 x {x, y, z, weight}) in pose18
     double Rg[18 * 9], pos[18 * 3], bvec[18 * 3];
     double hs[18 * 4];      // sin, cos of half the x and y Euler angles of every joint (from the last FK)
     double Wk[NOBS * 6], tk[NOBS * 3];
     double sc[12];          // {|g|^2, |g|_inf, alpha, pred, beta0, tau0, |J^T J|_1, coupling, |step|, |x|, fallback rows}
     int nviews, mode3d;
+    int view_off, pad_;     // the view block, in doubles from the start of this struct (3-D-target mode keeps 16 x {x, y, z, weight} there)
 #ifdef MVMC_IK_PROFILE
     long long prof[8];
 #endif
 };
+constexpr int MVMC_IK_VIEW_DOUBLES = 54 + 12;
+// (derived from &S, which every out-of-line function declares to be LDS: the accesses stay ds_ instructions)
+__device__ __forceinline__ double* ik1_pose18(Ik1Shared& S) { return reinterpret_cast<double*>(&S) + S.view_off; }
+__device__ __forceinline__ double* ik1_pm(Ik1Shared& S, int nv) { return reinterpret_cast<double*>(&S) + S.view_off + nv * 54; }
 
 __device__ __forceinline__ double wave_max64(double v) { return wave_max_dpp(v); }
 
@@ -101,8 +108,7 @@ __device__ inline void rot_from_half_angles(double sx, double cx, double sy, dou
 // FK + residual; with want_jac also the per-joint normal-equation blocks W_k (S.Wk) and t_k (S.tk).
 // Lane (k, r) = (lane & 15, lane >> 4) handles observed joint k in the views r, r + 4.  Returns 0.5 |f|^2.
 // ---------------------------------------------------------------------------------------------
-template <int VM>
-__device__ __forceinline__ double ik1_eval(Ik1Shared<VM>& S, const Ik1Tables& T, const double* xs, int stage, bool want_jac) {
+__device__ __forceinline__ double ik1_eval(Ik1Shared& S, const Ik1Tables& T, const double* xs, int stage, bool want_jac) {
     const int lane = threadIdx.x & 63;
     double* Rl = S.tmp;
     double* off = S.tmp + 162;
@@ -147,13 +153,16 @@ __device__ __forceinline__ double ik1_eval(Ik1Shared<VM>& S, const Ik1Tables& T,
         MVMC_WAVE_SYNC();
     }
     const int k = lane & 15, r = lane >> 4;
+    const int nviews = uni(S.nviews);
+    const double* pose18 = ik1_pose18(S);
+    const double* Pmv = ik1_pm(S, nviews);
     const double* X = &S.pos[kIkSkel[k] * 3];
     const double X0 = X[0], X1 = X[1], X2 = X[2];
     double f2 = 0.0, o[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (S.mode3d) {
         // residual (pos_k - target_k) * w_k (inverse_kinematics.py:280-336): J_k = w_k D_k, so W_k = w_k^2 I, t_k = w_k f_k
         if (r == 0) {
-            const double* tg = &S.pose18[k * 4];
+            const double* tg = &pose18[k * 4];
             const double w = tg[3], w2 = w * w;
             const double f0 = (X0 - tg[0]) * w, f1 = (X1 - tg[1]) * w, f2c = (X2 - tg[2]) * w;
             f2 = f0 * f0 + f1 * f1 + f2c * f2c;
@@ -161,14 +170,14 @@ __device__ __forceinline__ double ik1_eval(Ik1Shared<VM>& S, const Ik1Tables& T,
             o[6] = w * f0; o[7] = w * f1; o[8] = w * f2c;
         }
     } else
-    for (int v = r; v < S.nviews; v += 4) {
-        const double* P = &S.Pm[v * 12];
+    for (int v = r; v < nviews; v += 4) {
+        const double* P = &Pmv[v * 12];
         const double h0 = P[0] * X0 + P[1] * X1 + P[2] * X2 + P[3];
         const double h1 = P[4] * X0 + P[5] * X1 + P[6] * X2 + P[7];
         const double h2 = P[8] * X0 + P[9] * X1 + P[10] * X2 + P[11];
         const double w = 1e-5 + h2, iw = 1.0 / w;
         const double u = h0 / w, vv = h1 / w;
-        const double* ob = &S.pose18[(v * 18 + kIkObs[k]) * 3];
+        const double* ob = &pose18[(v * 18 + kIkObs[k]) * 3];
         const double s = ob[2];
         const double fu = (u - ob[0]) * s, fv = (vv - ob[1]) * s;
         f2 += fu * fu + fv * fv;
@@ -223,16 +232,14 @@ __device__ __forceinline__ double ik1_eval(Ik1Shared<VM>& S, const Ik1Tables& T,
 // Results of a trial: S.xn = the trial point, S.sc[2] = alpha, S.sc[3] = predicted reduction, S.sc[8] = |step|,
 // S.sc[9] = |x|.
 // ---------------------------------------------------------------------------------------------
-template <int VM>
-__device__ __noinline__ double ik1_eval_nl(Ik1Shared<VM>& S, const Ik1Tables& T, int at_trial, int stage, bool want_jac) {
+__device__ __noinline__ double ik1_eval_nl(Ik1Shared& S, const Ik1Tables& T, int at_trial, int stage, bool want_jac) {
     MVMC_ASSUME_LDS(&S);
     MVMC_ASSUME_LDS(&T);
     return ik1_eval(S, T, at_trial ? S.xn : S.x, stage, want_jac);
 }
 
 // S.xn = S.x + step on the active parameters (stepj: lane j's component), S.sc[9] = |x|
-template <int VM>
-__device__ __forceinline__ void ik1_trial_point(Ik1Shared<VM>& S, const Ik1Tables& T, int stage, int na, double stepj) {
+__device__ __forceinline__ void ik1_trial_point(Ik1Shared& S, const Ik1Tables& T, int stage, int na, double stepj) {
     const int lane = threadIdx.x & 63;
     const int nfull = (stage == 0) ? 57 : 57 + T.n_side;
     double xx = (lane < nfull) ? S.x[lane] * S.x[lane] : 0.0;
@@ -259,8 +266,8 @@ __device__ __forceinline__ void ik1_trial_point(Ik1Shared<VM>& S, const Ik1Table
 // the D slot, vectors and reflectors in the global scratch; the trial is ik1_fallback_trial's).
 // S.sc[0] = |g|^2, S.sc[1] = |g|_inf, S.sc[4..8) = {beta0, tau0, |J^T J|_1, coupling}.
 // ---------------------------------------------------------------------------------------------
-template <int VM, int N>
-__device__ __noinline__ void ik1_model_step(Ik1Shared<VM>& S, const Ik1Tables& T, int stage, bool budget_left, double gtol,
+template <int N>
+__device__ __noinline__ void ik1_model_step(Ik1Shared& S, const Ik1Tables& T, int stage, bool budget_left, double gtol,
                                             mvmc_gdouble* __restrict__ hh, double Delta, double alpha, bool dump, int* mode_out) {
     // S and T arrive as generic pointers (the function is out of line); telling the compiler that they are LDS turns every
     // access below into a ds_ instruction instead of a flat_ one (InferAddressSpaces uses the assumption)
@@ -431,8 +438,7 @@ __device__ __noinline__ void ik1_model_step(Ik1Shared<VM>& S, const Ik1Tables& T
 }
 
 // A trial step of a model on the eigenbasis path (Delta, alpha -> S.xn and S.sc[2], [3], [8], [9])
-template <int VM>
-__device__ __noinline__ void ik1_fallback_trial(Ik1Shared<VM>& S, const Ik1Tables& T, int stage, const mvmc_gdouble* __restrict__ hh,
+__device__ __noinline__ void ik1_fallback_trial(Ik1Shared& S, const Ik1Tables& T, int stage, const mvmc_gdouble* __restrict__ hh,
                                                 double Delta, double alpha) {
     MVMC_ASSUME_LDS(&S);
     MVMC_ASSUME_LDS(&T);
@@ -451,8 +457,7 @@ __device__ __noinline__ void ik1_fallback_trial(Ik1Shared<VM>& S, const Ik1Table
 
 // Another trial step (Delta, alpha) of a common-path model whose reflectors were dumped to the global scratch: the trust-region solve on
 // the tridiagonal matrix that is still in LDS, Q from memory.
-template <int VM>
-__device__ __noinline__ void ik1_retry_trial(Ik1Shared<VM>& S, const Ik1Tables& T, int stage, const mvmc_gdouble* __restrict__ hh,
+__device__ __noinline__ void ik1_retry_trial(Ik1Shared& S, const Ik1Tables& T, int stage, const mvmc_gdouble* __restrict__ hh,
                                              double Delta, double alpha) {
     MVMC_ASSUME_LDS(&S);
     MVMC_ASSUME_LDS(&T);
@@ -481,8 +486,7 @@ __device__ __noinline__ void ik1_retry_trial(Ik1Shared<VM>& S, const Ik1Tables& 
 // trf_no_bounds (trf.py:401-560) with x_scale = 1, linear loss, ftol = xtol = gtol = 1e-8 -- the loop of ik_trf
 // in mvmc_ik.hip on one wave.
 // ---------------------------------------------------------------------------------------------
-template <int VM>
-__device__ __forceinline__ void ik1_trf(Ik1Shared<VM>& S, const Ik1Tables& T, int stage, int max_nfev, mvmc_gdouble* __restrict__ hh,
+__device__ __forceinline__ void ik1_trf(Ik1Shared& S, const Ik1Tables& T, int stage, int max_nfev, mvmc_gdouble* __restrict__ hh,
                                         double* cost_out, int* nfev_out, int* njev_out, int* status_out, int* fallbacks_out, bool& dump,
                                         bool& fk_at_x) {
     const int lane = threadIdx.x & 63;
@@ -495,8 +499,8 @@ __device__ __forceinline__ void ik1_trf(Ik1Shared<VM>& S, const Ik1Tables& T, in
         // marked as a tail-call candidate, and only then does the compiler drop the callee-saved convention for this local function --
         // with it, the function's prologue saved and restored 58 vector registers that its caller does not even use)
         int mode = 0;
-        if (na <= 40) ik1_model_step<VM, 40>(S, T, stage, budget_left, gtol, hh, Delta, alpha, dump, &mode);
-        else ik1_model_step<VM, 50>(S, T, stage, budget_left, gtol, hh, Delta, alpha, dump, &mode);
+        if (na <= 40) ik1_model_step<40>(S, T, stage, budget_left, gtol, hh, Delta, alpha, dump, &mode);
+        else ik1_model_step<50>(S, T, stage, budget_left, gtol, hh, Delta, alpha, dump, &mode);
         return uni(mode);
     };
     double cost;
@@ -574,13 +578,14 @@ __device__ __forceinline__ void ik1_trf(Ik1Shared<VM>& S, const Ik1Tables& T, in
 }
 
 // Cold start: DLT of the 18 keypoints + the reference's one-step post-optimisation; hips -> S.xn[0..6)
-template <int VM>
-__device__ __noinline__ void ik1_cold_root(Ik1Shared<VM>& S, int nv) {
+__device__ __noinline__ void ik1_cold_root(Ik1Shared& S, int nv) {
     MVMC_ASSUME_LDS(&S);
     const int lane = threadIdx.x & 63;
     double X[3] = {0, 0, 0};
-    if (lane < 18) dlt_obs_point(S.pose18, S.Pm, nv, lane, 0.01, X);
-    postopt::post_optimize_wave(X, S.pose18 + (lane < 18 ? lane : 0) * 3, 54, S.Pm, nv, 18);
+    const double* pose18 = ik1_pose18(S);
+    const double* Pmv = ik1_pm(S, nv);
+    if (lane < 18) dlt_obs_point(pose18, Pmv, nv, lane, 0.01, X);
+    postopt::post_optimize_wave(X, pose18 + (lane < 18 ? lane : 0) * 3, 54, Pmv, nv, 18);
     if (lane == 11 || lane == 12)
         for (int c = 0; c < 3; ++c) S.xn[(lane - 11) * 3 + c] = X[c];
 }
@@ -678,28 +683,46 @@ inline void ik1_build_tables_host(Ik1Tables& T, const SkelDev& skarg) {
         for (int lane = 0; lane < 64; ++lane) ik1_tables_section(T, skarg, section, lane);
 }
 
-// One solve on the calling wave (problem b); S is this wave's LDS block.  Used by ik1_kernel (one wave per workgroup)
-// and by the chain kernel (four waves per workgroup, one solve each).
-template <int VM>
-__device__ __forceinline__ void ik1_solve(Ik1Shared<VM>& S, const Ik1Tables& T, const double* __restrict__ kps17,
+// One solve on the calling wave (problem b); S is this wave's LDS block, `views` its view block (LDS, room for vcap views).  Used by
+// ik1_kernel (one wave per workgroup) and by the chain kernel (four or eight waves per workgroup, one solve each).
+// members (.., V): the problem's pose indices, -1 = none (holes allowed).  More members than vcap: the first vcap are used and bit 0 of
+// *ovf is raised (the result is then not the reference's; with the chain kernel's pool and the stand-alone kernel's v_max block it
+// cannot happen unless the caller's v_max is smaller than a cluster).
+__device__ __forceinline__ void ik1_solve(Ik1Shared& S, double* views, int vcap, const Ik1Tables& T, const double* __restrict__ kps17,
                                           const double* __restrict__ Pmats, const int32_t* __restrict__ members, int b, int V,
                                           int C, int Pmax, const double* __restrict__ init, const uint8_t* __restrict__ cold,
                                           int nfev_cold, int nfev_warm, double* __restrict__ params_out,
                                           double* __restrict__ joints_out, double* __restrict__ info_out,
-                                          double* __restrict__ scratch, int stage_mask, const double* __restrict__ targets3d) {
+                                          double* __restrict__ scratch, int stage_mask, const double* __restrict__ targets3d,
+                                          int32_t* ovf = nullptr, int n_valid = -1) {
+    // n_valid >= 0: the row's first n_valid entries are the members (the rest of the row is undefined: the chain kernel's table)
     const int lane = threadIdx.x & 63;
     b = uni(b);
     mvmc_gdouble* hh = uni((mvmc_gdouble*)(scratch + (size_t)b * MVMC_IK_SCRATCH_DOUBLES));   // Householder vectors [0, 3200), eigenvectors [3200, 6400)
     double* info = uni(info_out ? info_out + (size_t)b * 8 : nullptr);
+    if (lane == 0) S.view_off = (int)(views - reinterpret_cast<double*>(&S));
     // views of this problem (the reference only solves clusters with >= 2 views: motion_capture.py:927,940)
     int q_own = -1;
     if (targets3d == nullptr) {
+        // lane v looks at member v (64 per pass); the valid ones are ranked by ballot and parked in LDS at their rank (S.tmp is free here)
+        int* ranked = reinterpret_cast<int*>(S.tmp);
         int nv = 0;
-        for (int v = 0; v < V; ++v) {
-            const int m = members[(size_t)b * V + v];
-            if (m >= 0) { if (nv == lane) q_own = m; ++nv; }
+        if (n_valid >= 0) {
+            nv = n_valid < 64 ? n_valid : 64;
+            if (lane < nv) ranked[lane] = members[(size_t)b * V + lane];
+        } else
+        for (int v0 = 0; v0 < V; v0 += 64) {
+            const int m = (v0 + lane < V) ? members[(size_t)b * V + v0 + lane] : -1;
+            const unsigned long long have = __builtin_amdgcn_ballot_w64(m >= 0);
+            const int rank = nv + __popcll(have & ((1ull << lane) - 1ull));
+            if (m >= 0 && rank < 64) ranked[rank] = m;
+            nv += __popcll(have);
         }
-        if (nv > VM) nv = VM;
+        MVMC_WAVE_SYNC();
+        if (lane < nv) q_own = ranked[lane];
+        MVMC_WAVE_SYNC();
+        nv = uni(nv);
+        if (nv > vcap) { if (ovf && lane == 0) atomicOr(ovf, 1); nv = vcap; }
         if (nv < 2) {
             const double nan = __longlong_as_double(0x7ff8000000000000LL);
             for (int i = lane; i < 68; i += 64) params_out[(size_t)b * 68 + i] = nan;
@@ -711,7 +734,7 @@ __device__ __forceinline__ void ik1_solve(Ik1Shared<VM>& S, const Ik1Tables& T, 
     } else {
         // 3-D-target mode: targets (B,18,4) in the observation row order (COCO-17 + mid-spine)
         if (lane < NOBS)
-            for (int c = 0; c < 4; ++c) S.pose18[lane * 4 + c] = targets3d[(size_t)b * 72 + kIkObs[lane] * 4 + c];
+            for (int c = 0; c < 4; ++c) views[lane * 4 + c] = targets3d[(size_t)b * 72 + kIkObs[lane] * 4 + c];
         if (lane == 0) { S.nviews = 0; S.mode3d = 1; }
     }
     const int n_side = uni(T.n_side);
@@ -720,7 +743,7 @@ __device__ __forceinline__ void ik1_solve(Ik1Shared<VM>& S, const Ik1Tables& T, 
     const int nv = uni(S.nviews);
     if (lane < nv) {
         const double* kp = kps17 + (size_t)q_own * 51;
-        double* dst = S.pose18 + lane * 54;
+        double* dst = views + lane * 54;
         for (int e = 0; e < 51; ++e) dst[e] = kp[e];
         for (int c = 0; c < 2; ++c) {
             const double mid_sh = 0.5 * (kp[5 * 3 + c] + kp[6 * 3 + c]);
@@ -731,7 +754,7 @@ __device__ __forceinline__ void ik1_solve(Ik1Shared<VM>& S, const Ik1Tables& T, 
         sc *= kp[11 * 3 + 2] * kp[12 * 3 + 2];
         dst[53] = sc;
         const double* Pc = Pmats + (size_t)((q_own / Pmax) % C) * 12;
-        for (int e = 0; e < 12; ++e) S.Pm[lane * 12 + e] = Pc[e];
+        for (int e = 0; e < 12; ++e) views[nv * 54 + lane * 12 + e] = Pc[e];
     }
     MVMC_WAVE_SYNC();
     // ---- initial parameters ----
@@ -790,38 +813,70 @@ __device__ __forceinline__ void ik1_solve(Ik1Shared<VM>& S, const Ik1Tables& T, 
     }
 }
 
-template <int VM>
 __global__ void __launch_bounds__(64, 3)
 ik1_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restrict__ Pmats,
-           const int32_t* __restrict__ members, int B, int V, int C, int Pmax, const double* __restrict__ init,
+           const int32_t* __restrict__ members, int B, int V, int vcap, int C, int Pmax, const double* __restrict__ init,
            const uint8_t* __restrict__ cold, int nfev_cold, int nfev_warm, double* __restrict__ params_out,
            double* __restrict__ joints_out, double* __restrict__ info_out, double* __restrict__ scratch, int stage_mask,
-           const double* __restrict__ targets3d) {
-    __shared__ Ik1Shared<VM> S;
+           const double* __restrict__ targets3d, int32_t* __restrict__ overflow) {
+    __shared__ Ik1Shared S;
     __shared__ Ik1Tables T;
+    extern __shared__ __attribute__((aligned(16))) double ik1_views[];   // vcap * MVMC_IK_VIEW_DOUBLES (>= 64: the 3-D targets)
     ik1_build_tables(T, skarg);
-    ik1_solve<VM>(S, T, kps17, Pmats, members, blockIdx.x, V, C, Pmax, init, cold, nfev_cold, nfev_warm, params_out,
-                  joints_out, info_out, scratch, stage_mask, targets3d);
+    ik1_solve(S, ik1_views, vcap, T, kps17, Pmats, members, blockIdx.x, V, C, Pmax, init, cold, nfev_cold, nfev_warm, params_out,
+              joints_out, info_out, scratch, stage_mask, targets3d, overflow ? overflow + blockIdx.x : nullptr);
 }
 
 }  // namespace
 
 #ifndef MVMC_DEVICE_ONLY   // (mvmc_chain.hip includes the device code above)
-// launcher used by mvmc_ik_solve (mvmc_ik.hip)
-int mvmc_ik1_launch(const SkelDev& sk, const double* kps17, const double* Pmats, const int32_t* members, int n_problems,
-                    int v_max, int n_views, int p_max, const double* init_params, const uint8_t* cold, int max_nfev_cold,
-                    int max_nfev_warm, double* params_out, double* joints_out, double* info_out, double* scratch,
-                    int stage_mask, const double* targets3d, hipStream_t stream) {
-    if (v_max <= 6) {
-        hipLaunchKernelGGL(ik1_kernel<6>, dim3(n_problems), dim3(64), 0, stream, sk, kps17, Pmats, members, n_problems, v_max,
-                           n_views, p_max, init_params, cold, max_nfev_cold, max_nfev_warm, params_out, joints_out, info_out,
-                           scratch, stage_mask, targets3d);
-    } else {
-        hipLaunchKernelGGL(ik1_kernel<VMAX>, dim3(n_problems), dim3(64), 0, stream, sk, kps17, Pmats, members, n_problems,
-                           v_max, n_views, p_max, init_params, cold, max_nfev_cold, max_nfev_warm, params_out, joints_out,
-                           info_out, scratch, stage_mask, targets3d);
-    }
+static int mvmc_ik1_launch(const SkelDev& sk, const double* kps17, const double* Pmats, const int32_t* members, int n_problems,
+                           int v_max, int n_views, int p_max, const double* init_params, const uint8_t* cold, int max_nfev_cold,
+                           int max_nfev_warm, double* params_out, double* joints_out, double* info_out, double* scratch,
+                           int stage_mask, const double* targets3d, hipStream_t stream) {
+    // the view block holds every member a problem can have (v_max columns), so no cluster is ever cut short here
+    const int vcap = v_max < 1 ? 1 : v_max;
+    if (vcap > 64) return MVMC_ERR_UNSUPPORTED;   // (a lane per view when the observations are loaded)
+    const size_t lds = sizeof(double) * (size_t)(vcap * MVMC_IK_VIEW_DOUBLES < 64 ? 64 : vcap * MVMC_IK_VIEW_DOUBLES);
+    hipLaunchKernelGGL(ik1_kernel, dim3(n_problems), dim3(64), lds, stream, sk, kps17, Pmats, members, n_problems, v_max, vcap,
+                       n_views, p_max, init_params, cold, max_nfev_cold, max_nfev_warm, params_out, joints_out, info_out,
+                       scratch, stage_mask, targets3d, (int32_t*)nullptr);
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;
+}
+
+extern "C" int mvmc_ik_solve(const mvmcSkeleton* skel_host, const double* kps17, const double* Pmats,
+                             const int32_t* members, int n_problems, int v_max, int n_views, int p_max,
+                             const double* init_params, const uint8_t* cold, int max_nfev_cold, int max_nfev_warm,
+                             double* params_out, double* joints_out, double* info_out, double* scratch,
+                             mvmcStream_t stream) {
+    if (!skel_host || !kps17 || !Pmats || !members || !params_out || !joints_out || !scratch) return MVMC_ERR_ARG;
+    if (v_max <= 0 || n_views <= 0 || p_max <= 0 || max_nfev_cold < 1 || max_nfev_warm < 1) return MVMC_ERR_ARG;
+    if (cold && !init_params) return MVMC_ERR_ARG;
+    if (n_problems <= 0) return n_problems == 0 ? MVMC_OK : MVMC_ERR_ARG;
+    SkelDev sk;
+    if (!skel_to_dev(skel_host, &sk)) return MVMC_ERR_ARG;
+    if (sk.n_side != MVMC_N_SIDE) return MVMC_ERR_UNSUPPORTED;  // the solver is sized for 57 + 11 parameters
+    return mvmc_ik1_launch(sk, kps17, Pmats, members, n_problems, v_max, n_views, p_max, init_params, init_params ? cold : nullptr,
+                           max_nfev_cold, max_nfev_warm, params_out, joints_out, info_out, scratch, 3, nullptr, (hipStream_t)stream);
+}
+
+// Single stages of PoseSolver.solve and the 3-D-target variants; see include/mvmc.h
+extern "C" int mvmc_ik_solve_stages(const mvmcSkeleton* skel_host, const double* kps17, const double* Pmats,
+                                    const int32_t* members, const double* targets3d, int n_problems, int v_max, int n_views,
+                                    int p_max, const double* init_params, int stage_mask, int max_nfev,
+                                    double* params_out, double* joints_out, double* info_out, double* scratch,
+                                    mvmcStream_t stream) {
+    if (!skel_host || !init_params || !params_out || !joints_out || !scratch) return MVMC_ERR_ARG;
+    if (stage_mask < 1 || stage_mask > 3 || max_nfev < 1) return MVMC_ERR_ARG;
+    if (!targets3d && (!kps17 || !Pmats || !members || v_max <= 0 || n_views <= 0 || p_max <= 0)) return MVMC_ERR_ARG;
+    if (n_problems <= 0) return n_problems == 0 ? MVMC_OK : MVMC_ERR_ARG;
+    SkelDev sk;
+    if (!skel_to_dev(skel_host, &sk)) return MVMC_ERR_ARG;
+    if (sk.n_side != MVMC_N_SIDE) return MVMC_ERR_UNSUPPORTED;
+    // every problem is "warm": it starts from init_params with the one evaluation budget
+    return mvmc_ik1_launch(sk, kps17, Pmats, members, n_problems, targets3d ? 1 : v_max, targets3d ? 1 : n_views,
+                           targets3d ? 1 : p_max, init_params, /*cold=*/nullptr, max_nfev, max_nfev, params_out, joints_out,
+                           info_out, scratch, stage_mask | 4, targets3d, (hipStream_t)stream);
 }
 #endif  // MVMC_DEVICE_ONLY

@@ -13,6 +13,7 @@ namespace {
 
 constexpr int ST_T = 16;        // max tracklet slots per frame (t_max <= 16)
 constexpr int ST_HDR = 8;       // header words
+constexpr double MVMC_STITCH_NO_MATCH = 1e30;
 
 struct MsgLayout {
     int b_cap, t_max, row_cap;
@@ -42,6 +43,11 @@ row_offsets_kernel(const int32_t* __restrict__ n_tracks, int F, int T, int32_t* 
     int run = part[tid] - s;
     for (int f = lo; f < hi; ++f) { offsets[f] = run; const int n = n_tracks[f]; run += n < 0 ? 0 : (n > T ? T : n); }
     if (tid == 1023) *total = part[1023];
+}
+
+// an empty shard (world > number of chains): the full header with zero chains, so that the stitch's layout check passes
+__global__ void empty_header_kernel(int L, int T, int row_cap, int32_t* __restrict__ h) {
+    if (threadIdx.x == 0) { h[0] = 0; h[1] = L; h[2] = T; h[3] = 0; h[4] = 0; h[5] = row_cap; h[6] = 0; h[7] = 0; }
 }
 
 // one wave per frame
@@ -85,16 +91,19 @@ pack_kernel(const double* __restrict__ params, const double* __restrict__ joints
     }
 }
 
-// Optimal assignment of n rows to m >= n columns (Kuhn-Munkres with potentials, O(n^2 m)); col_of[i] = column of row i
-__device__ void assign_rows(const double (&a)[ST_T][ST_T], int n, int m, int* col_of) {
+// Optimal assignment of n rows to m >= n columns (Kuhn-Munkres with potentials, O(n^2 m)); col_of[i] = column of row i.
+// Costs must be finite (the caller replaces non-finite entries by a large constant): with a NaN row no column is ever selected and
+// the augmenting loop would never end.  Every loop is bounded regardless (an augmenting path visits a column at most once, and the
+// back-trace has at most m links); false = the bound was hit, col_of is then not a valid assignment.
+__device__ bool assign_rows(const double (&a)[ST_T][ST_T], int n, int m, int* col_of) {
     double u[ST_T + 1], v[ST_T + 1], minv[ST_T + 1];
     int p[ST_T + 1], way[ST_T + 1];
     bool used[ST_T + 1];
-    for (int j = 0; j <= m; ++j) { v[j] = 0.0; p[j] = 0; }
+    for (int j = 0; j <= m; ++j) { v[j] = 0.0; p[j] = 0; way[j] = 0; }
     for (int i = 0; i <= n; ++i) u[i] = 0.0;
     for (int i = 1; i <= n; ++i) {
         p[0] = i;
-        int j0 = 0;
+        int j0 = 0, rounds = 0;
         for (int j = 0; j <= m; ++j) { minv[j] = 1e300; used[j] = false; }
         do {
             used[j0] = true;
@@ -107,14 +116,20 @@ __device__ void assign_rows(const double (&a)[ST_T][ST_T], int n, int m, int* co
                     if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
                     if (minv[j] < delta) { delta = minv[j]; j1 = j; }
                 }
+            if (j1 == 0 || ++rounds > m + 1) return false;
             for (int j = 0; j <= m; ++j)
                 if (used[j]) { u[p[j]] += delta; v[j] -= delta; } else minv[j] -= delta;
             j0 = j1;
         } while (p[j0] != 0);
-        do { const int j1 = way[j0]; p[j0] = p[j1]; j0 = j1; } while (j0);
+        int links = 0;
+        do { const int j1 = way[j0]; p[j0] = p[j1]; j0 = j1; if (++links > m + 1) return false; } while (j0);
     }
+    for (int i = 0; i < n; ++i) col_of[i] = -1;
     for (int j = 1; j <= m; ++j)
         if (p[j] > 0) col_of[p[j] - 1] = j - 1;
+    for (int i = 0; i < n; ++i)
+        if (col_of[i] < 0) return false;
+    return true;
 }
 
 struct StitchArgs {
@@ -193,11 +208,12 @@ stitch_match_kernel(StitchArgs A) {
                 const double dz = (double)__uint_as_float(a[3 * k + 2]) - (double)__uint_as_float(b[3 * k + 2]);
                 sum += sqrt(dx * dx + dy * dy + dz * dz);
             }
-            const double c = sum / 18.0;
+            // a tracklet with a non-finite joint matches nobody: a cost beyond any max_dist, and finite for the assignment
+            const double c = isfinite(sum) ? sum / 18.0 : MVMC_STITCH_NO_MATCH;
             if (swap) cost[j][i] = c; else cost[i][j] = c;
         }
     int col_of[ST_T];
-    assign_rows(cost, nr, nc, col_of);
+    if (!assign_rows(cost, nr, nc, col_of)) { atomicOr(A.info + 2, 2); return; }   // bit 1: an assignment did not terminate
     int pairs = 0;
     for (int r = 0; r < nr; ++r) {
         const int i = swap ? col_of[r] : r, j = swap ? r : col_of[r];
@@ -269,7 +285,8 @@ extern "C" int mvmc_pack_tracks(const double* out_params, const double* out_join
     MsgLayout lay{n_chains_cap, t_max, row_cap};
     hipStream_t s = (hipStream_t)stream;
     if (n_frames == 0) {
-        if (hipMemsetAsync(message, 0, ST_HDR * 4, s) != hipSuccess) return MVMC_ERR_LAUNCH;
+        hipLaunchKernelGGL(empty_header_kernel, dim3(1), dim3(64), 0, s, chain_len, t_max, row_cap, (int32_t*)message);
+        MVMC_CHECK_LAUNCH();
         return MVMC_OK;
     }
     // row_offsets: (n_frames + 1) words, the last one receives the total

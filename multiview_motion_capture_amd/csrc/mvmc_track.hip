@@ -203,15 +203,22 @@ __device__ __forceinline__ void assign_chain(int lane, int nl, int b, int f, con
                                              const int32_t* __restrict__ n_tracks, const double* __restrict__ track_params,
                                              int C, int P, int T, int K, int V, int32_t* __restrict__ members,
                                              uint8_t* __restrict__ cold, double* __restrict__ init,
-                                             int32_t* __restrict__ status, int32_t* __restrict__ n_new, int32_t* ovf = nullptr) {
+                                             int32_t* __restrict__ status, int32_t* __restrict__ n_new, int32_t* ovf = nullptr,
+                                             int32_t* __restrict__ n_members = nullptr) {
     // ovf (one word, may be shared by several chains: atomic OR): bit 0 = a cluster or a member was dropped here for lack of room
-    // (more than K new tracklets, more than V views) -- the reference has no such caps, so the results of the frame are not its own
+    // (more than K new tracklets, more than V views) -- the reference has no such caps, so the results of the frame are not its own.
+    // With K >= (poses of a frame) / 2 and V >= the poses of a frame neither can happen: a new tracklet needs two poses, and the
+    // clusters are disjoint (what the callers pass by default).
+    // n_members (B, T + K) or NULL: with it, the member count of every problem slot is written there and the member table is NOT
+    // padded with -1 (the chain kernel reads the counts; the table's rows are then valid in [0, count) only)
     int nt = mvmc_ld_i32(n_tracks + b);
     nt = nt < 0 ? 0 : (nt > T ? T : nt);
     const int NP = T + K;
     int32_t* mem = members + (size_t)b * NP * V;
     // bulk initialisation, spread over the nl lanes that call (lane = 0 .. nl-1; the cluster logic below is lane 0's)
-    for (int e = lane; e < NP * V; e += nl) mem[e] = -1;
+    int32_t* nmem = n_members ? n_members + (size_t)b * NP : nullptr;
+    if (nmem) { for (int s = lane; s < NP; s += nl) nmem[s] = 0; }
+    else for (int e = lane; e < NP * V; e += nl) mem[e] = -1;
     for (int s = lane; s < NP; s += nl) cold[(size_t)b * NP + s] = s >= T;
     for (int s = lane; s < T; s += nl) status[(size_t)b * T + s] = 0;
     for (int e = lane; e < T * 68; e += nl) {
@@ -294,6 +301,7 @@ __device__ __forceinline__ void assign_chain(int lane, int nl, int b, int f, con
             if (slot >= 0) {
                 if (mem2[0] && rank0 < V) mem[slot * V + rank0] = val2[0];
                 if (mem2[1] && rank1 < V) mem[slot * V + rank1] = val2[1];
+                if (nmem && lane == 0) nmem[slot] = m < V ? m : V;
             }
         }
         if (lane == 0) n_new[b] = created;
@@ -320,6 +328,7 @@ __device__ __forceinline__ void assign_chain(int lane, int nl, int b, int f, con
                 if (ovf && m > V) atomicOr(ovf, 1);
                 if (created < K) {
                     for (int v = 0; v < m && v < V; ++v) mem[(T + created) * V + v] = tmp[v];
+                    if (nmem) nmem[T + created] = m < V ? m : V;
                     ++created;
                 } else if (ovf) atomicOr(ovf, 1);
             }
@@ -343,12 +352,15 @@ __device__ __forceinline__ void assign_chain(int lane, int nl, int b, int f, con
             if (tracklet >= 0) {
                 if (m > 0) {
                     status[(size_t)b * T + tracklet] = m >= 2 ? 2 : 1;
-                    if (m >= 2)
+                    if (m >= 2) {
                         for (int v = 0; v < m && v < V; ++v) mem[tracklet * V + v] = tmp[v];
+                        if (nmem) nmem[tracklet] = m < V ? m : V;
+                    }
                 }
             } else if (m >= 2) {
                 if (created < K) {
                     for (int v = 0; v < m && v < V; ++v) mem[(T + created) * V + v] = tmp[v];
+                    if (nmem) nmem[T + created] = m < V ? m : V;
                     ++created;
                 } else if (ovf) atomicOr(ovf, 1);
             }

@@ -282,12 +282,31 @@ class MvTracker:
             t.time_since_update += 1
         k_d, c_d = torch.as_tensor(kps, device=d), torch.as_tensor(cnt, device=d)
         n_nodes = int(cnt.sum())
+        snap = ch.snapshot()
         # one launch per frame (the chain kernel) when the frame's graph fits its association variants, seven otherwise
-        if ch.fused_ok and n_nodes <= 24 and n_nodes + len(self.tracklets) <= 32:
+        if ch.fused_ok and (C * P > 40 or (n_nodes <= 24 and n_nodes + len(self.tracklets) <= 32)):
             ch.step_fused(k_d, c_d)
         else:
             ch.step(k_d, c_d)
-        ch.check()     # a frame that exceeds p_max / t_max / the cluster capacity raises instead of silently losing people
+        try:
+            ch.check()
+        except ValueError:
+            # The reference has no capacities (motion_capture.py:417-446, :763-808).  The frame is redone from the state saved before
+            # it with the widest tables the kernels hold (tracker.T_WIDE tracklet slots, the per-stage path); only a frame beyond
+            # those raises, and then the tracker is left as it was before the frame.
+            from .tracker import T_WIDE
+            ch.restore(snap)
+            if ch.T >= T_WIDE and not ch.fused_ok:
+                raise
+            wide = ch if ch.T >= T_WIDE else ch.widened(T_WIDE)
+            wsnap = wide.snapshot()
+            wide.step(k_d, c_d)
+            try:
+                wide.check()
+            except ValueError:
+                wide.restore(wsnap)
+                raise
+            self._chain = ch = wide
         n = int(ch.n_tracks[0])
         meta = ch.meta[0, :n].cpu().numpy()
         params = ch.params[0, :n].cpu().numpy()

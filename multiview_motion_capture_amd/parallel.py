@@ -157,7 +157,12 @@ def run_sharded(compute: Callable[[], Dict[str, torch.Tensor]], chain_len: int, 
 
 
 def check_stitch_info(res) -> None:
-    """Raise if the stitched result is void (synchronises)."""
+    """Raise if the stitched result is void.  Synchronises with the tail first: ``info`` is written on the communication stream, and a
+    copy on the current stream is not ordered against it."""
+    if res.get("done") is not None:
+        res["done"].synchronize()
     info = res["info"].cpu().tolist()
-    if info[2]:
+    if info[2] & 1:
         raise RuntimeError("stitch: a message overflowed its row capacity or a chain has more local identities than ID_CAP")
+    if info[2]:
+        raise RuntimeError("stitch: an assignment did not terminate (error word %d)" % info[2])

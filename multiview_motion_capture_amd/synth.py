@@ -74,7 +74,10 @@ def generate(n_frames: int, n_views: int, n_people: int, seed: int, chain_len: i
 
     occlusion: probability that a person is missed entirely by a view in a frame (the view's list gets shorter: ragged counts,
     tracklets seen by one view or none, deaths and re-births); spurious: probability that such a freed slot holds a false
-    detection instead (a random pose of plausible size that matches nobody).  gt_order is -1 for slots that hold no real person.
+    detection instead (a random pose of plausible size that matches nobody) -- CONDITIONAL on the slot being freed, so a view's
+    list is shorter with probability occlusion * (1 - spurious) per person and spurious = 1 turns every occlusion into a ghost
+    (round 2 divided by ``occlusion`` here, which made every freed slot a ghost whenever spurious >= occlusion: no ragged counts).
+    gt_order is -1 for slots that hold no real person.
     Both default to 0, which leaves the output of earlier versions bit for bit unchanged.
 
     chain_len > 0 restarts the random walk every chain_len frames (independent sub-sequences).
@@ -126,7 +129,7 @@ def generate(n_frames: int, n_views: int, n_people: int, seed: int, chain_len: i
     if occlusion > 0.0 or spurious > 0.0:
         rng2 = np.random.default_rng([seed if frame_seed is None else frame_seed, 2])
         gone = rng2.uniform(size=(F, C, Pn)) < occlusion
-        ghost = gone & (rng2.uniform(size=(F, C, Pn)) < (spurious / max(occlusion, 1e-12)))
+        ghost = gone & (rng2.uniform(size=(F, C, Pn)) < spurious)
         centre = rng2.uniform([100.0, 100.0], [900.0, 650.0], size=(F, C, Pn, 1, 2))
         fake = np.concatenate([centre + rng2.normal(0, 60.0, size=(F, C, Pn, 25, 2)), rng2.uniform(0.3, 0.9, size=(F, C, Pn, 25, 1))], axis=-1)
         kps = np.where(ghost[..., None, None], fake, kps)

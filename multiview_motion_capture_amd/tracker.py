@@ -15,6 +15,16 @@ import torch
 from . import device as dev
 from .pipeline import HotPath
 
+T_WIDE = 16   # tracklet slots of the repair tier (include/mvmc.h: the stitch and the widest association variant hold 16)
+
+
+def default_caps(n_views: int, p_max: int):
+    """(k_max, v_max) that a frame's own size rules out ever exceeding: a new tracklet needs two poses, so at most C P / 2 appear in a
+    frame; clusters are disjoint sets of the frame's poses, so one holds at most C P (the reference has neither cap:
+    motion_capture.py:417-446, :618-626, :763-808).  The kernels index members by lane: 64 at most."""
+    n = n_views * p_max
+    return max(1, n // 2), min(n, 64)
+
 
 class ChainTracker:
     def __init__(self, hp: HotPath, n_chains: int, p_max: int, t_max: int = 8, k_max: Optional[int] = None,
@@ -23,12 +33,14 @@ class ChainTracker:
         self.hp, self.B, self.P, self.T = hp, n_chains, p_max, t_max
         C = hp.K.shape[0]
         self.C = C
-        self.K = k_max or p_max + 2
-        self.V = v_max or min(C + 1, 8)
+        k_def, v_def = default_caps(C, p_max)
+        self.K = k_max or k_def
+        self.V = v_max or v_def
         self.nfev_cold, self.nfev_warm = nfev_cold, nfev_warm
-        if 2 * p_max > 16 or C * p_max + t_max > 80:
-            raise ValueError(f"ChainTracker: p_max={p_max}, t_max={t_max}, views={C}: the association kernels hold rank 2 p_max <= 16 "
-                             "and p_max views + t_max <= 80 graph nodes (more than 8 LIVE tracklets in a frame is reported by check())")
+        if 2 * p_max > 16 or t_max > T_WIDE or C * p_max + t_max > 80 or t_max + self.K > 64 or self.V > 64:
+            raise ValueError(f"ChainTracker: p_max={p_max}, t_max={t_max}, views={C}: the association kernels hold rank 2 p_max <= 16, "
+                             f"t_max <= {T_WIDE} and views x p_max + t_max <= 80 graph nodes (more live tracklets than t_max in a frame is "
+                             "reported by check())")
         self.F2 = dev.fmats_from_projections(hp.P)
         B, T = n_chains, t_max
         self.params = torch.zeros((B, T, 68), dtype=torch.float64, device=d)
@@ -108,11 +120,12 @@ class ChainTracker:
                 seed_table=dev.als_seed_table(_cabi.MAX_NODES * _cabi.MAX_NODES, d),
                 S_sp=e((B, N, N), torch.float32), W_st=e((B, NS, NS), f64), group_counts=e((B, Cn + 1), i32),
                 labels_sp=e((B, N), i32), labels_st=e((B, NS), i32), n_clusters_sp=z((B,), i32), n_clusters_st=z((B,), i32),
-                iters_sp=z((B,), i32), iters_st=z((B,), i32), members=e((B, NP, V), i32), cold=e((B, NP), torch.uint8),
+                iters_sp=z((B,), i32), iters_st=z((B,), i32), members=e((B, NP, V), i32), n_members=z((B, NP), i32),
+                cold=e((B, NP), torch.uint8),
                 init=e((B, NP, 68), f64), status=e((B, T), i32), n_new=e((B,), i32), ik_params=e((B, NP, 68), f64),
                 ik_joints=e((B, NP, 18, 3), f64), ik_info=e((B, NP, 8), f64), ik_scratch=_chain_scratch(B, d),
                 out_params=e((B, T, 68), f64), out_joints=e((B, T, 18, 3), f64), out_meta=e((B, T, 4), i32),
-                out_n_tracks=e((B,), i32), flags=z((B + 4,), i32))
+                out_n_tracks=e((B,), i32), flags=z((2 * B + 4,), i32))
         w = self._fused
         t = dict(w, kps17=kps17, counts=counts, Pmats=self.hp.P, Fmats=self.hp.F, F2=self.F2, params=self.params,
                  joints=self.joints, meta=self.meta, n_tracks=self.n_tracks, next_id=self.next_id, n_dead=self.n_dead,
@@ -120,39 +133,64 @@ class ChainTracker:
         buf = _cabi.MvmcChainBuffers()
         for name, val in dict(n_chains=B, chain_len=1, n_views=Cn, p_max=P, t_max=T, k_max=K, v_max=V,
                               max_nfev_cold=self.nfev_cold, max_nfev_warm=self.nfev_warm, n_inits=3,
-                              seed_len=w["seed_table"].numel(), n_parts=1).items():
+                              seed_len=w["seed_table"].numel(), n_parts=1, force_big=0).items():
             setattr(buf, name, int(val))
         for name in _cabi.MvmcChainBuffers._PTRS:
             ten = t[name]
             setattr(buf, name, None if ten is None else ten.data_ptr())
         _cabi.check(_cabi.load().mvmc_chain_run(C.byref(self.hp.skeleton), C.byref(buf),
                                                 C.c_void_p(torch.cuda.current_stream(d).cuda_stream)), "mvmc_chain_run")
-        # the launch zeroes its flag words: fold this frame's error words into the tracker's own (read by check())
-        self.overflow |= (w["flags"][-3].clamp(max=1) * 4 + w["flags"][-2]).to(torch.int32)
-        return dict(members=w["members"], status=w["status"], n_new=w["n_new"], ik_params=w["ik_params"],
-                    ik_joints=w["ik_joints"], ik_info=w["ik_info"], flags=w["flags"])
+        # the launch zeroes its flag words: fold this frame's per-chain void words into the tracker's own (read by check())
+        self.overflow |= w["flags"][B + 4:2 * B + 4]
+        return dict(members=w["members"], n_members=w["n_members"], status=w["status"], n_new=w["n_new"], ik_params=w["ik_params"],
+                    ik_joints=w["ik_joints"], ik_info=w["ik_info"], flags=w["flags"], void=w["flags"][B + 4:2 * B + 4], n_chains=B,
+                    chain_len=1)
 
     def check(self) -> None:
-        """Raise if a capacity was exceeded in any step so far (synchronises): the reference has no such caps, so a frame that
-        hits one is not tracked the way the reference would."""
+        """Raise if a capacity was exceeded since the last call (synchronises), and clear the words: the report is per call, so a
+        caller that restores the state it saved before the frame (snapshot / restore) can go on -- MvTracker.update_4d does, with a
+        wider table.  The reference has no such caps, so a frame that hits one is not tracked the way the reference would."""
         ov = int(self.overflow.max()) if self.overflow.numel() else 0
         if self._fused is not None:
-            fl = self._fused["flags"][-4:].cpu().tolist()
+            B = self.B
+            fl = self._fused["flags"][B:B + 4].cpu().tolist()
+            self._fused["flags"][B:B + 4].zero_()
             if fl[0]:
                 raise RuntimeError("mvmc_chain_run: a hand-over between the workgroups of a chain timed out; results are void")
-            ov |= (4 if fl[1] else 0) | int(fl[2])
+        self.overflow.zero_()
         if ov:
-            what = [m for bit, m in ((1, "more than k_max new clusters or v_max views in a frame"), (2, "more than t_max live tracklets"),
+            what = [m for bit, m in ((1, "a cluster, a member or a view block did not fit (k_max / v_max / the frame's poses)"),
+                                     (2, "more than t_max live tracklets"),
                                      (4, "a graph larger than the association kernel holds")) if ov & bit]
-            raise ValueError("ChainTracker: capacity exceeded (" + "; ".join(what) + "): results are void, use larger p_max / t_max / k_max")
+            raise ValueError("ChainTracker: capacity exceeded (" + "; ".join(what) + "): the frame's results are void")
+
+    _STATE = ("params", "joints", "meta", "n_tracks", "next_id", "n_dead", "slot_src")
+
+    def snapshot(self):
+        """The tracker state (device copies): restore() brings it back, e.g. to redo a frame that exceeded a capacity."""
+        return {k: getattr(self, k).clone() for k in self._STATE}
+
+    def restore(self, snap) -> None:
+        for k in self._STATE:
+            getattr(self, k).copy_(snap[k])
+        self.overflow.zero_()
+
+    def widened(self, t_max: int) -> "ChainTracker":
+        """A tracker with t_max tracklet slots (> the present number) holding this tracker's state."""
+        w = ChainTracker(self.hp, self.B, self.P, t_max, nfev_cold=self.nfev_cold, nfev_warm=self.nfev_warm)
+        T = self.T
+        w.params[:, :T], w.joints[:, :T], w.meta[:, :T], w.slot_src[:, :T] = self.params, self.joints, self.meta, self.slot_src
+        w.n_tracks.copy_(self.n_tracks); w.next_id.copy_(self.next_id); w.n_dead.copy_(self.n_dead)
+        w.frame_idx = self.frame_idx
+        return w
 
     @property
     def fused_ok(self) -> bool:
         """Whether this tracker's padded sizes fit the chain kernel (include/mvmc.h: mvmc_chain_run)."""
         N = self.C * self.P
-        small = N <= 40 and self.T + N <= 48 and self.V <= 6
-        big = N <= 64 and self.T + N <= 72 and self.V <= 8
-        return (small or big) and self.P <= 8 and self.T <= 8 and self.C <= 16
+        small = N <= 40 and self.T + N <= 48
+        big = N <= 64 and self.T + N <= 72
+        return (small or big) and self.P <= 8 and self.T <= 8 and self.C <= 16 and self.T + self.K <= 64
 
 
 def run_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], chain_len: int, t_max=8,
@@ -227,7 +265,7 @@ def run_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], c
 
 def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], chain_len: int, t_max=8,
                      nfev_cold=50, nfev_warm=5, want_info=False, k_max: Optional[int] = None, v_max: Optional[int] = None,
-                     parts: Optional[int] = None, kernel_events: Optional[list] = None):
+                     parts: Optional[int] = None, kernel_events: Optional[list] = None, force_big: bool = False):
     """run_chains in ONE launch (mvmc_chain_run): a persistent workgroup per chain runs graph -> ALS -> assignment ->
     IK -> commit for the chain's frames, so every chain advances at its own pace instead of waiting, stage by stage,
     for the slowest member of every launch.  Same device code and the same results as run_chains.
@@ -245,8 +283,9 @@ def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tens
     if parts is None:
         parts = L   # one workgroup per chain-frame: the finest hand-over, the best balance
     T = t_max
-    K = k_max or P + 2
-    V = v_max or min(Cn + 1, 8)
+    k_def, v_def = default_caps(Cn, P)
+    K = k_max or k_def
+    V = v_max or v_def
     N, NS, NP = Cn * P, T + Cn * P, T + K
     kps17, cnt = dev.ingest(kps, counts)
     d = kps.device
@@ -261,18 +300,19 @@ def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tens
         next_id=z((B,), i32), n_dead=z((B,), i32), slot_src=torch.full((B, T), -1, dtype=i32, device=d),
         S_sp=e((B, N, N), torch.float32), W_st=e((B, NS, NS), f64), group_counts=e((B, Cn + 1), i32),
         labels_sp=e((B, N), i32), labels_st=e((B, NS), i32), n_clusters_sp=z((B,), i32), n_clusters_st=z((B,), i32),
-        iters_sp=z((B,), i32), iters_st=z((B,), i32), members=e((B, NP, V), i32), cold=e((B, NP), torch.uint8),
+        iters_sp=z((B,), i32), iters_st=z((B,), i32), members=e((B, NP, V), i32), n_members=z((B, NP), i32),
+        cold=e((B, NP), torch.uint8),
         init=e((B, NP, 68), f64), status=e((B, T), i32), n_new=e((B,), i32), ik_params=e((B, NP, 68), f64),
         ik_joints=e((B, NP, 18, 3), f64), ik_info=e((B, NP, 8), f64), ik_scratch=_chain_scratch(B, d),
         out_params=e((F, T, 68), f64), out_joints=e((F, T, 18, 3), f64), out_meta=e((F, T, 4), i32), out_n_tracks=e((F,), i32),
         out_info=e((F, NP, 8), f64) if want_info else None, out_als_iters=e((F,), i32) if want_info else None,
-        flags=z((B + 4,), torch.int32),
+        flags=z((2 * B + 4,), torch.int32),
         out_phase_cycles=e((B, 8), f64) if want_info else None)
     if parts > 1 and L % parts:
         raise ValueError("run_chains_fused: parts must divide the chain length")
     buf = _cabi.MvmcChainBuffers()
     for name, val in dict(n_chains=B, chain_len=L, n_views=Cn, p_max=P, t_max=T, k_max=K, v_max=V, max_nfev_cold=nfev_cold,
-                          max_nfev_warm=nfev_warm, n_inits=3, seed_len=seed.numel(), n_parts=parts).items():
+                          max_nfev_warm=nfev_warm, n_inits=3, seed_len=seed.numel(), n_parts=parts, force_big=int(force_big)).items():
         setattr(buf, name, int(val))
     for name, ten in t.items():
         setattr(buf, name, None if ten is None else ten.data_ptr())
@@ -285,7 +325,8 @@ def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tens
         k1.record()
         kernel_events.append((k0, k1))
     res = dict(params=t["out_params"], joints=t["out_joints"], meta=t["out_meta"], n_tracks=t["out_n_tracks"],
-               n_dead=t["n_dead"], next_id=t["next_id"], flags=t["flags"], _keepalive=t)
+               n_dead=t["n_dead"], next_id=t["next_id"], flags=t["flags"], void=t["flags"][B + 4:2 * B + 4], n_chains=B,
+               chain_len=L, _keepalive=t)
     if want_info:
         res["ik_info"] = t["out_info"].view(B, L, NP, 8)
         res["als_iters"] = t["out_als_iters"].view(B, L)
@@ -295,23 +336,72 @@ def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tens
 
 def check_chain_flags(res) -> None:
     """Raise if a run_chains_fused / run_chains result is void (synchronises): a hand-over timed out, a frame's graph was larger
-    than the chain kernel's association variant holds (use run_chains for such data), or a capacity (k_max, v_max, t_max) was
-    exceeded -- the reference has no such caps."""
+    than the chain kernel's association variant holds, or a capacity (t_max; k_max / v_max when the caller passed smaller ones than
+    default_caps) was exceeded -- the reference has no such caps.  repair_chains re-runs the chains concerned with wider tables."""
     if "flags" not in res:      # run_chains: per-chain words {1: clusters / views, 2: tracklet table, 4: graph too large}
         ov = int(res["overflow"].max()) if res["overflow"].numel() else 0
         if ov:
             raise ValueError(f"run_chains: capacity exceeded (word {ov}: 1 = k_max / v_max, 2 = t_max, 4 = graph larger than the "
                              "association kernel holds): results are void")
         return
-    fl = res["flags"][-4:].cpu().tolist()
+    B = res["n_chains"]
+    fl = res["flags"][B:B + 4].cpu().tolist()
     if fl[0]:
         raise RuntimeError("mvmc_chain_run: a hand-over between the workgroups of a chain timed out; results are void")
-    if fl[1]:
+    void = res["flags"][B + 4:2 * B + 4]
+    ov = int(void.max()) if B else 0
+    if ov & 4:
         raise ValueError("mvmc_chain_run: a frame's graph has more nodes than the chain kernel's layout supports (small layout: 24 "
-                         "without, 32 with tracklets); use run_chains")
-    if fl[2]:
-        raise ValueError("mvmc_chain_run: capacity exceeded (" + ("more than k_max new clusters or v_max views in a frame; " if fl[2] & 1 else "")
-                         + ("more than t_max live tracklets" if fl[2] & 2 else "") + "): results are void")
+                         "without, 32 with tracklets); repair_chains / run_chains take such data")
+    if ov:
+        raise ValueError("mvmc_chain_run: capacity exceeded (" + ("a cluster, a member or a view block did not fit; " if ov & 1 else "")
+                         + ("more than t_max live tracklets" if ov & 2 else "") + f") in {int((void != 0).sum())} chain(s): their results are void")
+
+
+def repair_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], res, nfev_cold=50, nfev_warm=5,
+                  t_wide: int = T_WIDE) -> int:
+    """What the reference does where the chain kernel's fixed tables end (it has no caps at all): the chains whose void word is set --
+    more live tracklets than t_max, a graph beyond the layout's association variant -- are run again through the per-stage entry
+    points with t_wide tracklet slots (association on up to 80 nodes, rank 32), and their rows of ``res`` (run_chains_fused's result,
+    same kps / counts) are replaced; the per-frame tables are widened to the slots the repaired chains need.  Synchronises (it reads
+    the void words); returns the number of chains repaired.  Raises if a hand-over timed out or a chain exceeds the repair tier too."""
+    B, L = res["n_chains"], res["chain_len"]
+    fl = res["flags"][B:B + 4].cpu().tolist()
+    if fl[0]:
+        raise RuntimeError("mvmc_chain_run: a hand-over between the workgroups of a chain timed out; results are void")
+    if not (fl[1] or fl[2]):
+        return 0
+    idx = torch.nonzero(res["void"]).flatten()
+    n = int(idx.numel())
+    if n == 0:
+        return 0
+    C, P = kps.shape[1:3]
+    k5 = kps.view(B, L, *kps.shape[1:])[idx].reshape(n * L, *kps.shape[1:]).contiguous()
+    c5 = None if counts is None else counts.view(B, L, C)[idx].reshape(n * L, C).contiguous()
+    sub = run_chains(hp, k5, c5, L, t_max=t_wide, nfev_cold=nfev_cold, nfev_warm=nfev_warm)
+    ov = int(sub["overflow"].max())
+    if ov:
+        raise ValueError(f"repair_chains: a chain exceeds the repair tier as well (word {ov}: 2 = more than {t_wide} live tracklets, "
+                         "4 = a graph of more than 80 nodes)")
+    T = res["params"].shape[1]
+    need = int(sub["n_tracks"].max())
+    if need > T:   # widen the per-frame tables (rare: the repaired chains hold more tracklets than the tables have slots)
+        F = B * L
+        for k, tail in (("params", (68,)), ("joints", (18, 3)), ("meta", (4,))):
+            wide = torch.zeros((F, t_wide) + tail, dtype=res[k].dtype, device=res[k].device)
+            wide[:, :T] = res[k]
+            res[k] = wide
+        T = t_wide
+    for k in ("params", "joints", "meta"):
+        tail = res[k].shape[2:]
+        res[k].view(B, L, T, *tail)[idx] = sub[k].view(n, L, t_wide, *tail)[:, :, :T]
+    res["n_tracks"].view(B, L)[idx] = sub["n_tracks"].view(n, L)
+    res["n_dead"][idx] = sub["n_dead"]
+    res["next_id"][idx] = sub["next_id"]
+    res["void"][idx] = 0
+    res["flags"][B + 1:B + 3] = 0
+    res["repaired"] = idx
+    return n
 
 
 _CHAIN_SCRATCH = {}

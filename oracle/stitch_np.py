@@ -59,6 +59,7 @@ def match_boundary(joints_prev, joints_next, max_dist):
     a = joints_prev.astype(np.float64)[:, None]
     b = joints_next.astype(np.float64)[None]
     cost = np.sqrt(((a - b) ** 2).sum(axis=-1)).sum(axis=-1) / 18.0
+    cost = np.where(np.isfinite(cost), cost, 1e30)      # a tracklet with a non-finite joint matches nobody (SciPy would raise)
     r, c = linear_sum_assignment(cost)
     return [(int(i), int(j)) for i, j in zip(r, c) if cost[i, j] <= max_dist]
 

@@ -22,7 +22,7 @@ def test_header_symbols_exported():
     for name in declared:
         assert hasattr(lib, name), name
     header = open(os.path.join(ROOT, "include", "mvmc.h")).read()
-    assert lib.mvmc_abi_version() == int(re.search(r"#define\s+MVMC_ABI_VERSION\s+(\d+)", header).group(1)) == 2
+    assert lib.mvmc_abi_version() == int(re.search(r"#define\s+MVMC_ABI_VERSION\s+(\d+)", header).group(1)) == 3
 
 
 def test_seed_table_is_numpy_randomstate0():
@@ -62,6 +62,6 @@ def test_chain_buffers_struct_matches_header():
             ints += [n.strip() for n in decl[len("int32_t"):].split(",")]
     assert tuple(ints) == _cabi.MvmcChainBuffers._INTS
     assert tuple(ptrs) == _cabi.MvmcChainBuffers._PTRS
-    # 11 int32 fields: the first pointer starts at the next 8-byte boundary, as in C
-    assert _cabi.MvmcChainBuffers.kps17.offset == 48
-    assert ctypes.sizeof(_cabi.MvmcChainBuffers) == 48 + 8 * len(ptrs)
+    # 13 int32 fields (52 bytes): the first pointer starts at the next 8-byte boundary, as in C
+    assert len(ints) == 13 and _cabi.MvmcChainBuffers.kps17.offset == 56
+    assert ctypes.sizeof(_cabi.MvmcChainBuffers) == 56 + 8 * len(ptrs)
