@@ -41,8 +41,10 @@ class HotPath:
         """TR-1/2 for every cluster: members (F,K,V), n_members (F,K), pts3d (F,K,17,4)."""
         kps17, cnt = assoc["kps17"], assoc["counts"]
         C, P = kps17.shape[1], kps17.shape[2]
-        k_max = self.k_max or P + 2
-        v_max = self.v_max or min(C + 2, 8)
+        # defaults that the frame's size rules out exceeding (the reference has no caps: motion_capture.py:417-446): a cluster needs two
+        # members, so at most C P / 2 of them; one holds at most C P poses
+        k_max = self.k_max or max(1, (C * P) // 2)
+        v_max = self.v_max or min(C * P, 64)
         mem, nm = dev.cluster_members(assoc["labels"], cnt, P, k_max, v_max)
         pts = dev.dlt(kps17, self.P, mem)
         return dict(members=mem, n_members=nm, pts3d=pts)

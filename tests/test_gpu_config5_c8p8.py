@@ -1,5 +1,7 @@
 """Config 5 geometry (C = 8 views, P = 8 people, n = 64 graph nodes, rank 16) at a small frame count:
 the generic kernel variants against the oracle and the generator's ground truth."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -104,6 +106,68 @@ def test_temporal_graph_n72_vs_oracle(c5):
     assert np.array_equal(out["st"]["labels"][0, :n].cpu().numpy(), o.cluster_labels(mm_o, n))
     # every tracklet is matched in >= 2 views and continues (status 2), no new tracklets
     assert out["status"][0, :nt].cpu().tolist() == [2] * nt and int(out["n_new"][0]) == 0
+
+
+def _oracle_als(job):
+    W, dim = job
+    mm, xb, it = o.match_als(W, dim, return_iters=True)
+    return xb, o.cluster_labels(mm, dim[-1]), it
+
+
+def test_als5_vs_oracle_on_many_graphs():
+    """als5_graph (the association of the BIG layout: 61 % of a config-5 chain's cycles) against oracle_np.match_als on the workload's
+    own graphs: 96 float32 spatial graphs of 64 nodes (match_spatial at every frame) and 90 float64 temporal graphs of 72 nodes
+    (match_spatial_time along six chains) of synthetic C8 P8, seed 20260104: X_bin and labels exact, iteration counts +-2
+    (mv_association.py:222-318).  The oracle's 186 graphs run in a process pool on the host."""
+    import multiprocessing as mp
+    from multiview_motion_capture_amd import device as dev, synth
+    from multiview_motion_capture_amd.pipeline import HotPath
+    from multiview_motion_capture_amd.tracker import ChainTracker
+    B, Fn = 6, 96
+    data = synth.generate(Fn, C, P, 20260104, chain_len=L)
+    d = torch.device("cuda:0")
+    hp = HotPath(data["K"], data["Rt"], device=d)
+    kps, cnt = torch.from_numpy(data["kps25"]).to(d), torch.from_numpy(data["counts"]).to(d)
+    jobs, got = [], []
+    # spatial: every frame on its own (mvmc_als_associate dispatches n <= 72, rank <= 16, few graphs to als5_kernel)
+    assoc = hp.associate(kps, cnt, want_mats=True)
+    S, xb, lab, it = (assoc[k].cpu().numpy() for k in ("S", "x_bin", "labels", "iters"))
+    c_np = assoc["counts"].cpu().numpy() if "counts" in assoc else data["counts"]
+    for f in range(Fn):
+        dim = [0] + np.cumsum(c_np[f]).tolist()
+        n = dim[-1]
+        assert n == 64 and S.dtype == np.float32
+        jobs.append((S[f, :n, :n], dim))
+        got.append((xb[f, :n, :n].astype(bool), lab[f, :n], int(it[f])))
+    # temporal: six chains advanced by the per-stage tracker; the graph of every later frame
+    kps17, c17 = dev.ingest(kps, cnt)
+    k4, c4 = kps17.view(B, L, C, P, 17, 3), c17.view(B, L, C)
+    tr = ChainTracker(hp, B, P, t_max=8)
+    for t in range(L):
+        out = tr.step(k4[:, t].contiguous(), c4[:, t].contiguous(), want_debug=True)
+        if t == 0:
+            continue
+        W, gc = out["W"].cpu().numpy(), out["group_counts"].cpu().numpy()
+        lab_t, it_t, xb_t = out["st"]["labels"].cpu().numpy(), out["st"]["iters"].cpu().numpy(), out["st"]["x_bin"].cpu().numpy()
+        for b in range(B):
+            dim = [0] + np.cumsum(gc[b]).tolist()
+            n = dim[-1]
+            assert 64 < n <= 72 and W.dtype == np.float64
+            jobs.append((W[b, :n, :n].copy(), dim))
+            got.append((xb_t[b, :n, :n].astype(bool), lab_t[b, :n], int(it_t[b])))
+    tr.check()
+    with mp.get_context("fork").Pool(min(16, os.cpu_count() or 1)) as pool:
+        exp = pool.map(_oracle_als, jobs, chunksize=2)
+    n_diff, worst = 0, 0
+    for i, ((xb_g, lab_g, it_g), (xb_o, lab_o, it_o)) in enumerate(zip(got, exp)):
+        assert np.array_equal(xb_g, xb_o), i
+        assert np.array_equal(lab_g, lab_o), i
+        n_diff += int(it_g != it_o)
+        worst = max(worst, abs(it_g - it_o))
+    n72 = sum(1 for _, dim in jobs if dim[-1] == 72)
+    print(f"als5 vs oracle: {len(jobs)} graphs ({Fn} spatial f32 n=64, {len(jobs) - Fn} temporal f64 of which {n72} with n=72): "
+          f"{n_diff} iteration counts differ, worst by {worst}")
+    assert len(jobs) >= 2 * 64 and worst <= 2 and n_diff <= len(jobs) // 10
 
 
 def test_chain_kernel_big_layout_is_bit_identical_to_the_staged_path(c5):

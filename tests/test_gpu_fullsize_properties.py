@@ -115,6 +115,11 @@ def test_persistent_chain_kernel_at_full_size(full):
     s0 = run_chains_fused(hp, kps[:cut].contiguous(), cnt[:cut].contiguous(), L)
     s1 = run_chains_fused(hp, kps[cut:].contiguous(), cnt[cut:].contiguous(), L)
     torch.cuda.synchronize()
+    from multiview_motion_capture_amd.tracker import check_chain_flags
+    for r in (f1, f2, s0, s1):
+        check_chain_flags(r)                     # no time-out, no graph-size word
+        assert int(r["void"].max()) == 0         # ... and no chain with a capacity word (the launch's word is their OR)
+    assert not a["overflow"].any()
     for k in ("params", "joints", "meta", "n_tracks"):
         whole = torch.nan_to_num(f1[k].double())
         assert torch.equal(whole, torch.nan_to_num(a[k].double())), f"fused differs from staged: {k}"

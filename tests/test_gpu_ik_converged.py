@@ -112,12 +112,14 @@ def test_joints_and_observable_rotations_within_1e4(conv):
                 drs.append(dr)
                 worst_r = max(worst_r, dr * lever / scale)
                 n_rot += 1
+                assert dr < 3 * tol, (i, jt, dr)     # the rotation itself, no lever / scale (observed max 1.3e-4 over 659 rotations)
                 assert dr * lever / scale < tol, (i, jt, dr)
         if all(k in seen for k in (1, 4, 7)) and abs(abs(xr[4]) - np.pi / 2) > 0.05:
             de = np.abs(np.angle(np.exp(1j * (p[i, 3:6] - xr[3:6])))).max()
             worst_e = max(worst_e, de)
             des.append(de)
             n_euler += 1
+            assert de < 3 * tol, (i, de)             # radians, as they are (observed max 1.1e-4 over 216 cases)
             assert de * 0.15 / scale < tol, (i, de)
     djs = np.array(djs)
     print(f"{len(sel)} cases at the same minimum ({n_short} where the reference stopped short by more than its ftol): joint diff rel. to "

@@ -1,6 +1,7 @@
 """GPU: the persistent chain kernel (mvmc_chain_run, the benchmark's default path) against the REFERENCE tracker on the benchmark's own
-workload: tests/golden/synth_c4_tracker.npz holds MvTracker.update_4d (motion_capture.py:873-963) run by the reference itself over a
-64-frame subset of synthetic config 4 (seed 20260103, C5 P4, chains of 16; oracle/gen_golden_ikconv.py) -- SURVEY.md section 8c."""
+workloads: tests/golden/synth_c4_tracker.npz and synth_c5_tracker.npz hold MvTracker.update_4d (motion_capture.py:873-963) run by the
+reference itself over 64-frame subsets of synthetic config 4 (seed 20260103, C5 P4: the SMALL layout) and config 5 (seed 20260104,
+C8 P8: the BIG layout, als5), chains of 16 (oracle/gen_golden_ikconv.py, oracle/gen_golden_c5.py) -- SURVEY.md section 8c."""
 import numpy as np
 import pytest
 import torch
@@ -10,11 +11,12 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 
-def test_chain_kernel_reproduces_the_reference_tracker_on_the_synthetic_workload():
+@pytest.mark.parametrize("fixture", ["synth_c4_tracker.npz", "synth_c5_tracker.npz"])
+def test_chain_kernel_reproduces_the_reference_tracker_on_the_synthetic_workload(fixture):
     from multiview_motion_capture_amd import synth
     from multiview_motion_capture_amd.pipeline import HotPath
     from multiview_motion_capture_amd.tracker import check_chain_flags, run_chains_fused
-    g = load_golden("synth_c4_tracker.npz")
+    g = load_golden(fixture)
     F, L, C, P = int(g["n_frames"]), int(g["chain_len"]), int(g["n_views"]), int(g["n_people"])
     data = synth.generate(F, C, P, int(g["seed"]), chain_len=L)
     assert float(np.abs(data["kps25"].astype(np.float64)).sum()) == float(g["kps25_checksum"])   # same inputs as the reference saw
@@ -51,6 +53,6 @@ def test_chain_kernel_reproduces_the_reference_tracker_on_the_synthetic_workload
             e_ref.append(pj.min())
             e_dev.append(np.linalg.norm(gt[f, int(pj.argmin())] - joints[f, s], axis=-1).mean())
     print("mean joint error vs ground truth: device %.4f m, reference %.4f m" % (np.mean(e_dev), np.mean(e_ref)))
-    assert np.nanmax(head) < 1e-3
-    assert np.nanmedian(warm) < 5e-3 and np.nanquantile(warm, 0.9) < 2e-2     # the reference's own rounding band (tests/test_gpu_ik.py)
+    assert np.nanmax(head) < 1e-5          # converged solves (observed: 9.5e-7 on config 4)
+    assert np.nanmedian(warm) < 5e-3 and np.nanquantile(warm, 0.9) < 1.6e-2     # the reference's own rounding band (tests/test_gpu_ik.py)
     assert np.mean(e_dev) < 1.1 * np.mean(e_ref) + 1e-3

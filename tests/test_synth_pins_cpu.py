@@ -50,3 +50,28 @@ def test_oracle_tracker_equals_the_reference_on_the_synthetic_workload():
     print("oracle tracker vs the reference's run, first chain: max joint difference", worst)
     assert worst == 0.0   # bit-exact
     assert len(tr.solves) == int(g["n_solves"][:L].sum())
+
+
+def test_oracle_tracker_equals_the_reference_on_config_5_geometry():
+    """The same pin at C8 P8 (tests/golden/synth_c5_tracker.npz, oracle/gen_golden_c5.py: the reference's MvTracker.update_4d on the
+    first chains of synthetic config 5, seed 20260104): 64-node match_spatial graphs, 72-node match_spatial_time graphs, eight solves per
+    frame.  First six frames of chain 0 (the oracle needs ~1.5 s per frame here), bit for bit."""
+    from multiview_motion_capture_amd import synth
+    from threadpoolctl import threadpool_limits
+    g = load_golden("synth_c5_tracker.npz")
+    F, L, C, P = int(g["n_frames"]), int(g["chain_len"]), int(g["n_views"]), int(g["n_people"])
+    assert (C, P, int(g["seed"])) == (8, 8, 20260104)
+    data = synth.generate(F, C, P, int(g["seed"]), chain_len=L)
+    assert float(np.abs(data["kps25"].astype(np.float64)).sum()) == float(g["kps25_checksum"])
+    n = 6
+    k17, cnt = oracle_ingest(data["kps25"][:n].astype(np.float64), data["counts"][:n])
+    tr = tk.OracleTracker(data["K"], data["Rt"], data["P"])
+    with threadpool_limits(limits=1):
+        for f in range(n):
+            tr.update(f + 1, [[k17[f, c, p] for p in range(cnt[f, c])] for c in range(C)])
+            got = [(t.tid, t.state, t.hits, t.length) for t in tr.tracklets]
+            exp = [tuple(int(v) for v in r) for r in g["meta"][f] if r[0] >= 0]
+            assert got == exp, (f, got, exp)
+            for s, t in enumerate(tr.tracklets):
+                assert np.array_equal(t.joints, g["joints"][f, s]), (f, s)
+    assert len(tr.solves) == int(g["n_solves"][:n].sum())
