@@ -310,11 +310,16 @@ def main():
         if args.workload == "dlt":
             # config 2: every person's views are one cluster (no association): ingest + DLT
             from multiview_motion_capture_amd import device as dev
+            # one pass (mvmc_ingest_dlt): the 17-joint tensor stays in LDS; --path stages = the two kernels mvmc_ingest + mvmc_dlt
             e = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if timed else None
             if timed: e[0].record()
-            k17, c17 = dev.ingest(kps, counts)
-            if timed: e[1].record()
-            pts = dev.dlt(k17, hp.P, dlt_members)
+            if args.path == "fused":
+                if timed: e[1].record()
+                pts = dev.ingest_dlt(kps, counts, hp.P, dlt_members.view(F, Pn, C))
+            else:
+                k17, c17 = dev.ingest(kps, counts)
+                if timed: e[1].record()
+                pts = dev.dlt(k17, hp.P, dlt_members)
             if timed:
                 e[2].record()
                 ev["assoc"].append((e[0], e[1])); ev["tri"].append((e[1], e[2]))
@@ -499,7 +504,7 @@ def main():
             achieved = bpf * (F // L) / (launch_ms * 1e-3) / 1e9
         elif args.workload == "dlt":
             # config 2: 12 C P J bytes read + 16 P J written per frame; the DLT kernel dominates
-            dom, dom_kernel = "tri", "dlt_kernel"
+            dom, dom_kernel = "tri", "ingest_dlt_kernel" if args.path == "fused" else "dlt_kernel"
             bpf = 12 * C * Pn * 25 + 16 * Pn * 25
             launch_ms = stage_ms["tri"]
             achieved = bpf * F / (launch_ms * 1e-3) / 1e9

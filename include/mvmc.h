@@ -133,6 +133,16 @@ int mvmc_cluster_members(const int32_t* labels, const int32_t* counts, int n_fra
 int mvmc_dlt(const double* kps, const double* Pmats, const int32_t* members, int n_problems, int v_max,
              int n_views, int p_max, int n_joints, double min_score, double* out, mvmcStream_t stream);
 
+/* IN-1/IN-2 + TR-1/TR-2 in ONE pass over the raw keypoints (BASELINE config 2, triangulation only): mvmc_ingest followed by mvmc_dlt
+ * on the 17 COCO joints, without the 17-joint tensor ever going to memory (a wave per frame keeps it in LDS): 12 C P J bytes in and
+ * 17 x 32 bytes per cluster out per frame instead of the two-kernel form's extra 2 x 408 C P bytes.  Same results bit for bit.
+ *   kps, dtype, n_joints_in, counts_in, ingest_min_score, min_valid, min_bb_size: as mvmc_ingest
+ *   members (F,K,V) i32: the clusters of every frame as pose indices in mvmc_ingest's OUTPUT numbering, (f C + c) P + slot, all of
+ *           frame f (-1 = unused); out (F,K,17,4) f64 as mvmc_dlt; counts_out (F,C) i32 or NULL: people per view after the filter */
+int mvmc_ingest_dlt(const void* kps, int dtype, int n_frames, int n_views, int p_max, int n_joints_in, const int32_t* counts_in,
+                    double ingest_min_score, int min_valid, double min_bb_size, const double* Pmats, const int32_t* members,
+                    int k_max, int v_max, double min_score, double* out, int32_t* counts_out, mvmcStream_t stream);
+
 /* TR-2, post_optimize=True (mv_math_util.py:189-210): scipy least_squares(max_nfev = 2) on the unsigned
  * residual |proj - obs| * score with eps = 1e-6, i.e. one trust-region trial step from the DLT points, kept
  * only if it lowers the cost.  pts (B,J,4) is the output of mvmc_dlt, updated in place (x, y, z only). */

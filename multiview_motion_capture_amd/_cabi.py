@@ -26,7 +26,7 @@ SYMBOLS = (
     "mvmc_abi_version", "mvmc_status_string", "mvmc_als_seed_table", "mvmc_ingest", "mvmc_fmats",
     "mvmc_affinity", "mvmc_als_associate", "mvmc_closure_labels", "mvmc_cluster_members", "mvmc_dlt", "mvmc_triangulate_postopt", "mvmc_fk", "mvmc_ik_solve",
     "mvmc_fmats_from_projections", "mvmc_st_affinity", "mvmc_track_assign", "mvmc_track_commit", "mvmc_debug_eigh",
-    "mvmc_debug_trstep", "mvmc_ik_solve_stages", "mvmc_chain_run", "mvmc_svt_associate", "mvmc_debug_ik_solve_fd", "mvmc_pack_message_words", "mvmc_pack_tracks", "mvmc_stitch_chains",
+    "mvmc_debug_trstep", "mvmc_ik_solve_stages", "mvmc_chain_run", "mvmc_svt_associate", "mvmc_debug_ik_solve_fd", "mvmc_ingest_dlt", "mvmc_pack_message_words", "mvmc_pack_tracks", "mvmc_stitch_chains",
 )
 
 
@@ -77,6 +77,7 @@ def load():
     lib.mvmc_closure_labels.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp]
     lib.mvmc_cluster_members.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.mvmc_dlt.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, f64, vp, vp]
+    lib.mvmc_ingest_dlt.argtypes = [vp, i32, i32, i32, i32, i32, vp, f64, i32, f64, vp, vp, i32, i32, f64, vp, vp, vp]
     lib.mvmc_triangulate_postopt.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
     lib.mvmc_fk.argtypes = [C.POINTER(MvmcSkeleton), vp, i32, vp, vp, vp]
     lib.mvmc_ik_solve.argtypes = [C.POINTER(MvmcSkeleton), vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, i32,

@@ -5,7 +5,8 @@
 // ------------------------------------------------------------------------------------------------
 // DLT: one thread per (problem, joint).  The 2V x 4 system is reduced to its 4x4 normal matrix in
 // fp64 registers and the null vector is the eigenvector of the smallest eigenvalue (== last right
-// singular vector of A, mv_math_util.py:235-236); cyclic Jacobi, fully unrolled -> no scratch.
+// singular vector of A, mv_math_util.py:235-236): inverse iteration on L D L^T, cyclic Jacobi (fully
+// unrolled -> no scratch) where the spectral gap is small or a pivot vanishes.
 // ------------------------------------------------------------------------------------------------
 template <int P, int Q>
 __device__ __forceinline__ void jacobi_rot4(double (&a)[4][4], double (&v)[4][4]) {
@@ -34,75 +35,230 @@ __device__ __forceinline__ void jacobi_rot4(double (&a)[4][4], double (&v)[4][4]
     }
 }
 
-__global__ void __launch_bounds__(256)
-dlt_kernel(const double* __restrict__ kps17, const double* __restrict__ Pm, const int32_t* __restrict__ members,
-           int B, int V, int C, int Pmax, int J, double min_score, double* __restrict__ out) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * J) return;
-    const int b = idx / J, j = idx - b * J;
-    const int ps = J * 3;  // pose stride
-    const int32_t* mem = members + (size_t)b * V;
+// One triangulated point from the views `get(v, kp, Pc)` hands out (v = 0 .. V-1; false = no such member): kp <- {x, y, score},
+// Pc -> the view's 3x4 projection.  out[0..2] = X, out[3] = mean score of the views used; NaN when the cluster is empty.
+// mv_math_util.py:152-187 (triangulate_point_groups_from_multiple_views_linear) + :215-240 (the DLT of one point).
+template <typename Get>
+__device__ __forceinline__ void dlt_point(int V, double min_score, Get get, double* __restrict__ o) {
     int n_all = 0, n_ok = 0;
     for (int v = 0; v < V; ++v) {
-        const int q = mem[v];
-        if (q < 0) continue;
+        double kp[3]; const double* Pc;
+        if (!get(v, kp, Pc)) continue;
         ++n_all;
-        if (kps17[(size_t)q * ps + j * 3 + 2] >= min_score) ++n_ok;
+        if (kp[2] >= min_score) ++n_ok;
     }
-    double* o = out + (size_t)idx * 4;
     if (n_all == 0) {
         const double nan = __longlong_as_double(0x7ff8000000000000LL);
         o[0] = o[1] = o[2] = o[3] = nan;
         return;
     }
     const bool use_all = n_ok < 2;  // "< 2 valid views -> resort to all views" (mv_math_util.py:177-182)
-    double a[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) a[r][c] = 0.0;
+    // upper triangle of the normal matrix A^T A (rows r1 = x P_3 - P_1, r2 = y P_3 - P_2 of every view used)
+    double a00 = 0.0, a01 = 0.0, a02 = 0.0, a03 = 0.0, a11 = 0.0, a12 = 0.0, a13 = 0.0, a22 = 0.0, a23 = 0.0, a33 = 0.0;
     double ssum = 0.0;
     int nused = 0;
     for (int v = 0; v < V; ++v) {
-        const int q = mem[v];
-        if (q < 0) continue;
-        const double* kp = kps17 + (size_t)q * ps + j * 3;
+        double kp[3]; const double* Pc;
+        if (!get(v, kp, Pc)) continue;
         const double x = kp[0], y = kp[1], sc = kp[2];
         if (!use_all && !(sc >= min_score)) continue;
-        const double* Pc = Pm + (size_t)((q / Pmax) % C) * 12;
-        double r1[4], r2[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            r1[k] = x * Pc[8 + k] - Pc[k];
-            r2[k] = y * Pc[8 + k] - Pc[4 + k];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) a[r][c] += r1[r] * r1[c] + r2[r] * r2[c];
+        const double p0 = x * Pc[8] - Pc[0], p1 = x * Pc[9] - Pc[1], p2 = x * Pc[10] - Pc[2], p3 = x * Pc[11] - Pc[3];
+        const double q0 = y * Pc[8] - Pc[4], q1 = y * Pc[9] - Pc[5], q2 = y * Pc[10] - Pc[6], q3 = y * Pc[11] - Pc[7];
+        a00 += p0 * p0 + q0 * q0; a01 += p0 * p1 + q0 * q1; a02 += p0 * p2 + q0 * q2; a03 += p0 * p3 + q0 * q3;
+        a11 += p1 * p1 + q1 * q1; a12 += p1 * p2 + q1 * q2; a13 += p1 * p3 + q1 * q3;
+        a22 += p2 * p2 + q2 * q2; a23 += p2 * p3 + q2 * q3;
+        a33 += p3 * p3 + q3 * q3;
         ssum += sc;
         ++nused;
     }
-    double vv[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) vv[r][c] = (r == c) ? 1.0 : 0.0;
-    const double tr = a[0][0] + a[1][1] + a[2][2] + a[3][3];
-    for (int sweep = 0; sweep < 16; ++sweep) {
-        const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[0][3] * a[0][3] + a[1][2] * a[1][2] +
-                           a[1][3] * a[1][3] + a[2][3] * a[2][3];
-        if (off <= 1e-36 * tr * tr) break;
-        jacobi_rot4<0, 1>(a, vv); jacobi_rot4<0, 2>(a, vv); jacobi_rot4<0, 3>(a, vv);
-        jacobi_rot4<1, 2>(a, vv); jacobi_rot4<1, 3>(a, vv); jacobi_rot4<2, 3>(a, vv);
+    // The right singular vector of the smallest singular value (mv_math_util.py:152-160: SVD of the 2 nv x 4 system, last row of V^T) =
+    // the eigenvector of the smallest eigenvalue of the normal matrix a.  Inverse iteration on a = L D L^T started from e4: the first
+    // iterate is L^-T e4, i.e. the inhomogeneous least-squares point (X, 1); every further solve multiplies the error by
+    // lambda_min / lambda_2 (~1e-5 for pixel noise against a real baseline), so three to five solves reach 1e-13 -- ~300 flops where
+    // the cyclic Jacobi sweeps this replaces took ~3,000 and left the kernel ALU bound at 13 TFLOP/s.  A point
+    // seen by fewer than two views has a rank-deficient matrix (a pivot vanishes): the Jacobi path below keeps handling those.
+    const double tr = a00 + a11 + a22 + a33;
+    double e0, e1, e2, e3;
+    bool done = false;
+    {
+        const double floor_ = 1e-13 * tr;
+        const double d0 = a00, i0 = 1.0 / d0;
+        const double l10 = a01 * i0, l20 = a02 * i0, l30 = a03 * i0;
+        const double d1 = a11 - l10 * a01, i1 = 1.0 / d1;
+        const double l21 = (a12 - l20 * a01) * i1, l31 = (a13 - l30 * a01) * i1;
+        const double d2 = a22 - l20 * a02 - l21 * l21 * d1, i2 = 1.0 / d2;
+        const double l32 = (a23 - l30 * a02 - l31 * l21 * d1) * i2;
+        double d3 = a33 - l30 * a03 - l31 * l31 * d1 - l32 * l32 * d2;
+        if (d0 > floor_ && d1 > floor_ && d2 > floor_) {
+            // (the last pivot is ~lambda_min: rounding may push it to zero or below for consistent observations; its size only scales
+            // the iterates, their direction comes from L)
+            const double tiny = 1e-30 * tr + 1e-300;
+            if (!(d3 > tiny)) d3 = tiny;
+            const double i3 = 1.0 / d3;
+            double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 1.0;
+            bool conv = false;
+            for (int it = 0; it < 8; ++it) {
+                // L y = x;  z = y / D;  L^T w = z
+                const double y0 = x0, y1 = x1 - l10 * y0, y2 = x2 - l20 * y0 - l21 * y1, y3 = x3 - l30 * y0 - l31 * y1 - l32 * y2;
+                const double w3 = y3 * i3;
+                const double w2 = y2 * i2 - l32 * w3;
+                const double w1 = y1 * i1 - l21 * w2 - l31 * w3;
+                const double w0 = y0 * i0 - l10 * w1 - l20 * w2 - l30 * w3;
+                // normalised by the component of largest magnitude (sign included): converged iterates repeat
+                double m = w0;
+                if (fabs(w1) > fabs(m)) m = w1;
+                if (fabs(w2) > fabs(m)) m = w2;
+                if (fabs(w3) > fabs(m)) m = w3;
+                const double inv = 1.0 / m;
+                const double n0 = w0 * inv, n1 = w1 * inv, n2 = w2 * inv, n3 = w3 * inv;
+                const double ch = fmax(fmax(fabs(n0 - x0), fabs(n1 - x1)), fmax(fabs(n2 - x2), fabs(n3 - x3)));
+                x0 = n0; x1 = n1; x2 = n2; x3 = n3;
+                if (it > 0 && ch <= 1e-13) { conv = true; break; }
+            }
+            e0 = x0; e1 = x1; e2 = x2; e3 = x3;
+            // not settled after eight solves = a small spectral gap (clusters of mismatched poses, gross outliers: lambda_min / lambda_2
+            // > ~0.03; 15 % of the points of the Shelf clusters, none of the synthetic ones): the Jacobi path below, as before
+            done = conv;
+        }
     }
-    double lmin = a[0][0];
-    double e0 = vv[0][0], e1 = vv[1][0], e2 = vv[2][0], e3 = vv[3][0];
+    if (!done) {
+        double a[4][4] = {{a00, a01, a02, a03}, {a01, a11, a12, a13}, {a02, a12, a22, a23}, {a03, a13, a23, a33}};
+        double vv[4][4];
 #pragma unroll
-    for (int k = 1; k < 4; ++k)
-        if (a[k][k] < lmin) { lmin = a[k][k]; e0 = vv[0][k]; e1 = vv[1][k]; e2 = vv[2][k]; e3 = vv[3][k]; }
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) vv[r][c] = (r == c) ? 1.0 : 0.0;
+        for (int sweep = 0; sweep < 16; ++sweep) {
+            const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[0][3] * a[0][3] + a[1][2] * a[1][2] +
+                               a[1][3] * a[1][3] + a[2][3] * a[2][3];
+            if (off <= 1e-36 * tr * tr) break;
+            jacobi_rot4<0, 1>(a, vv); jacobi_rot4<0, 2>(a, vv); jacobi_rot4<0, 3>(a, vv);
+            jacobi_rot4<1, 2>(a, vv); jacobi_rot4<1, 3>(a, vv); jacobi_rot4<2, 3>(a, vv);
+        }
+        double lmin = a[0][0];
+        e0 = vv[0][0]; e1 = vv[1][0]; e2 = vv[2][0]; e3 = vv[3][0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+            if (a[k][k] < lmin) { lmin = a[k][k]; e0 = vv[0][k]; e1 = vv[1][k]; e2 = vv[2][k]; e3 = vv[3][k]; }
+    }
     o[0] = e0 / e3; o[1] = e1 / e3; o[2] = e2 / e3;
     o[3] = ssum / (double)nused;
+}
+
+__global__ void __launch_bounds__(256)
+dlt_kernel(const double* __restrict__ kps17, const double* __restrict__ Pm, const int32_t* __restrict__ members,
+           int B, int V, int C, int Pmax, int J, double min_score, double* __restrict__ out) {
+    // the projection matrices through LDS (C <= 16): every thread reads twelve doubles per view, the same for all lanes of a cluster
+    __shared__ double sP[16 * 12];
+    const bool lds_p = C <= 16;
+    if (lds_p) for (int e = threadIdx.x; e < C * 12; e += blockDim.x) sP[e] = Pm[e];
+    __syncthreads();
+    const double* Pv = lds_p ? sP : Pm;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * J) return;
+    const int b = idx / J, j = idx - b * J;
+    const int ps = J * 3;  // pose stride
+    const int32_t* mem = members + (size_t)b * V;
+    dlt_point(V, min_score, [&](int v, double (&kp)[3], const double*& Pc) {
+        const int q = mem[v];
+        if (q < 0) return false;
+        const double* k3 = kps17 + (size_t)q * ps + j * 3;
+        kp[0] = k3[0]; kp[1] = k3[1]; kp[2] = k3[2];
+        Pc = Pv + ((q / Pmax) % C) * 12;
+        return true;
+    }, out + (size_t)idx * 4);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ingest + DLT in one pass (BASELINE config 2: triangulation only).  A 256-thread workgroup takes G frames at a time (G chosen by the
+// launcher so that the G x K x 17 points of the group fill its threads: 15 frames at C5 P1), persistent over the frame groups:
+//   A  the group's raw keypoints (f32 or f64, OpenPose-25 or COCO-17), one (pose, joint) triple per thread and trip, into LDS as the
+//      17-joint f64 poses mvmc_ingest would write;
+//   B  filter_bad_pose per pose, C  per-view compaction (pose_def.py:262-270, motion_capture.py:1023-1043: the rule of mvmc_ingest);
+//   D  one thread per (frame, cluster, joint): the DLT of that point from LDS.
+// The 17-joint tensor (2 KB per view-frame, written and read again by the two-kernel form) never exists in HBM: per frame
+// 12 C P J bytes in, 17 x 32 bytes per cluster out.  (A first version gave every frame its own wave: 17 of 64 lanes at work in D, and
+// fp64 vector instructions cost the same whether 17 or 64 lanes are on -- 9.7 ms for 2 M frames against 6.8 ms for the two kernels.)
+// members (F, K, V): pose indices in mvmc_ingest's output numbering, (f C + c) P + slot, all of frame f; -1 = none.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+ingest_dlt_kernel(const T* __restrict__ kps, int F, int G, int C, int P, int J_in, const int32_t* __restrict__ counts_in,
+                  double min_score_in, int min_valid, double min_bb, const double* __restrict__ Pm,
+                  const int32_t* __restrict__ members, int K, int V, double min_score, double* __restrict__ out,
+                  int32_t* __restrict__ counts_out) {
+    // The poses stay in LDS in the INPUT type (float -> double is exact, so widening at the read gives what mvmc_ingest's f64 tensor
+    // holds): half the LDS bytes for f32 input, twice the workgroups per CU.
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
+    const int tid = threadIdx.x, nq = C * P;
+    T* pose = reinterpret_cast<T*>(sm_raw);                                                  // [G][nq][17][3]
+    int* keep = reinterpret_cast<int*>(sm_raw + (((size_t)G * nq * 51 * sizeof(T) + 7) & ~(size_t)7));   // [G][nq]
+    int* src_of = keep + G * nq;                                    // [G][nq] ingest slot -> source pose of the raw layout, -1 = empty
+    __shared__ double sP[16 * 12];                                  // the projection matrices (C <= 16 checked by the launcher)
+    for (int e = tid; e < C * 12; e += 256) sP[e] = Pm[e];
+    const int n_groups = (F + G - 1) / G;
+    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int f0 = grp * G, g_n = min(G, F - f0);
+        const T* src = kps + (size_t)f0 * nq * J_in * 3;
+        for (int t = tid; t < g_n * nq * 17; t += 256) {            // t = (frame in group, pose, COCO joint)
+            const int gq = t / 17, j = t - gq * 17;
+            const int js = (J_in == 25) ? kOp25ToCoco17[j] : j;
+            const T* s3 = src + ((size_t)gq * J_in + js) * 3;
+            T* d3 = pose + (size_t)t * 3;
+            d3[0] = s3[0]; d3[1] = s3[1]; d3[2] = s3[2];
+        }
+        __syncthreads();
+        for (int t = tid; t < g_n * nq; t += 256) {
+            const int g = t / nq, q = t - g * nq, c = q / P, p = q - c * P;
+            const int cnt = counts_in ? counts_in[(f0 + g) * C + c] : P;
+            int ok = 0;
+            if (p < cnt) {
+                int nv = 0;
+                double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+                const T* ps = pose + (size_t)t * 51;
+                for (int j = 0; j < 17; ++j) {
+                    const double kx = (double)ps[j * 3], ky = (double)ps[j * 3 + 1], ks = (double)ps[j * 3 + 2];
+                    if (ks > min_score_in) {
+                        ++nv;
+                        x0 = fmin(x0, kx); x1 = fmax(x1, kx);
+                        y0 = fmin(y0, ky); y1 = fmax(y1, ky);
+                    }
+                }
+                ok = (nv >= min_valid) && !((x1 - x0) < min_bb || (y1 - y0) < min_bb);
+            }
+            keep[t] = ok;
+        }
+        __syncthreads();
+        for (int t = tid; t < g_n * C; t += 256) {
+            const int g = t / C, c = t - g * C;
+            const int* kp = keep + g * nq + c * P;
+            int* so = src_of + g * nq + c * P;
+            int k = 0;
+            for (int p = 0; p < P; ++p)
+                if (kp[p]) so[k++] = c * P + p;
+            if (counts_out) counts_out[(f0 + g) * C + c] = k;
+            for (; k < P; ++k) so[k] = -1;
+        }
+        __syncthreads();
+        for (int t = tid; t < g_n * K * 17; t += 256) {             // t = (frame in group, cluster, joint)
+            const int gk = t / 17, j = t - gk * 17, g = gk / K;
+            const int32_t* mem = members + ((size_t)f0 * K + gk) * V;
+            const int base = (f0 + g) * nq;
+            const int* so = src_of + g * nq;
+            const T* pg = pose + (size_t)g * nq * 51 + j * 3;
+            dlt_point(V, min_score, [&](int v, double (&kp)[3], const double*& Pc) {
+                const int d = mem[v] - base;
+                if (d < 0 || d >= nq) return false;      // (-1, or a member of another frame: not this kernel's contract)
+                const int q = so[d];
+                if (q < 0) return false;
+                const T* k3 = pg + q * 51;
+                kp[0] = (double)k3[0]; kp[1] = (double)k3[1]; kp[2] = (double)k3[2];
+                Pc = sP + (d / P) * 12;
+                return true;
+            }, out + ((size_t)f0 * K * 17 + t) * 4);
+        }
+        __syncthreads();   // the next group overwrites the LDS block
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -200,6 +356,45 @@ extern "C" int mvmc_dlt(const double* kps17, const double* Pmats, const int32_t*
     const int total = n_problems * n_joints;
     hipLaunchKernelGGL(dlt_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, kps17, Pmats, members,
                        n_problems, v_max, n_views, p_max, n_joints, min_score, out);
+    MVMC_CHECK_LAUNCH();
+    return MVMC_OK;
+}
+
+extern "C" int mvmc_ingest_dlt(const void* kps, int dtype, int n_frames, int n_views, int p_max, int n_joints_in,
+                               const int32_t* counts_in, double ingest_min_score, int min_valid, double min_bb_size,
+                               const double* Pmats, const int32_t* members, int k_max, int v_max, double min_score, double* out,
+                               int32_t* counts_out, mvmcStream_t stream) {
+    if (!kps || !Pmats || !members || !out || n_frames < 0 || n_views <= 0 || p_max <= 0 || k_max <= 0 || v_max <= 0) return MVMC_ERR_ARG;
+    if (n_joints_in != 25 && n_joints_in != 17) return MVMC_ERR_ARG;
+    if (dtype != MVMC_F32 && dtype != MVMC_F64) return MVMC_ERR_ARG;
+    if (n_views > 16) return MVMC_ERR_UNSUPPORTED;
+    if (n_frames == 0) return MVMC_OK;
+    const int nq = n_views * p_max;
+    const size_t per_frame = (size_t)nq * 51 * (dtype == MVMC_F32 ? 4 : 8) + (size_t)2 * nq * sizeof(int);
+    // frames per group: enough points to fill the 256 threads, inside 48 KB of LDS (three workgroups per CU)
+    int G = 256 / (k_max * 17);
+    if (G < 1) G = 1;
+    while (G > 1 && (size_t)G * per_frame > 48 * 1024) --G;
+    if ((size_t)G * per_frame > 64 * 1024) return MVMC_ERR_UNSUPPORTED;
+    if (G > n_frames) G = n_frames;
+    const size_t shm = (((size_t)G * per_frame + 15) & ~(size_t)15) + 16;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    long long blocks = ((long long)n_frames + G - 1) / G;
+    const long long cap = (long long)cus * 16;         // persistent: the workgroups stride over the frame groups
+    if (blocks > cap) blocks = cap;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MVMC_F32)
+        hipLaunchKernelGGL(ingest_dlt_kernel<float>, dim3((unsigned)blocks), dim3(256), shm, s, (const float*)kps, n_frames, G, n_views,
+                           p_max, n_joints_in, counts_in, ingest_min_score, min_valid, min_bb_size, Pmats, members, k_max, v_max,
+                           min_score, out, counts_out);
+    else
+        hipLaunchKernelGGL(ingest_dlt_kernel<double>, dim3((unsigned)blocks), dim3(256), shm, s, (const double*)kps, n_frames, G,
+                           n_views, p_max, n_joints_in, counts_in, ingest_min_score, min_valid, min_bb_size, Pmats, members, k_max,
+                           v_max, min_score, out, counts_out);
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;
 }

@@ -224,6 +224,31 @@ def dlt(kps: torch.Tensor, Pmats: torch.Tensor, members: torch.Tensor, min_score
     return out.reshape(members.shape[:-1] + (J, 4))
 
 
+def ingest_dlt(kps: torch.Tensor, counts: Optional[torch.Tensor], Pmats: torch.Tensor, members: torch.Tensor, min_score=0.01,
+               ingest_min_score=0.01, min_valid=4, min_bb=5.0, want_counts=False):
+    """ingest() + dlt() in one pass (include/mvmc.h: mvmc_ingest_dlt).  kps (F,C,P,25|17,3) f32|f64; members (F,K,V) i32 in ingest()'s
+    output numbering, every cluster inside its own frame -> pts3d (F,K,17,4) f64 [, counts (F,C)]."""
+    if kps.dtype not in (torch.float32, torch.float64):
+        raise ValueError("ingest_dlt: kps must be float32 or float64")
+    _req(kps, kps.dtype, "kps")
+    if kps.dim() != 5 or kps.shape[3] not in (17, 25) or kps.shape[4] != 3:
+        raise ValueError(f"ingest_dlt: expected (F,C,P,25|17,3), got {tuple(kps.shape)}")
+    F, Cn, P, J, _ = kps.shape
+    if counts is not None:
+        _req(counts, torch.int32, "counts", (F, Cn))
+    _req(Pmats, torch.float64, "Pmats", (Cn, 3, 4))
+    if members.dim() != 3 or members.shape[0] != F:
+        raise ValueError("ingest_dlt: members must be (F,K,V)")
+    _req(members, torch.int32, "members")
+    K, V = members.shape[1:]
+    out = torch.empty((F, K, 17, 4), dtype=torch.float64, device=kps.device)
+    cnt = torch.empty((F, Cn), dtype=torch.int32, device=kps.device) if want_counts else None
+    dt = _cabi.MVMC_F32 if kps.dtype == torch.float32 else _cabi.MVMC_F64
+    check(_cabi.load().mvmc_ingest_dlt(_p(kps), dt, F, Cn, P, J, _p(counts), float(ingest_min_score), int(min_valid), float(min_bb),
+                                       _p(Pmats), _p(members), K, V, float(min_score), _p(out), _p(cnt), _stream()), "mvmc_ingest_dlt")
+    return (out, cnt) if want_counts else out
+
+
 def fk(params: torch.Tensor, skeleton: Optional[MvmcSkeleton] = None, want_G=False):
     """FK-1/FK-2.  params (B, 57+n_side) f64 -> joints (B,18,3)[, G (B,18,4,4)]."""
     sk = skeleton if skeleton is not None else make_skeleton()

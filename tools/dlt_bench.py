@@ -29,6 +29,17 @@ for F in (10000, 2000000):
         pts = dev.dlt(k17, Pm, mem)
         e[2].record()
         torch.cuda.synchronize()
+    m3 = mem.view(F, 1, C)
+    for rep in range(3):
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f0.record()
+        fused = dev.ingest_dlt(kps, cnt, Pm, m3)
+        f1.record()
+        torch.cuda.synchronize()
+    assert torch.equal(fused.view(-1), pts.view(-1))
+    t_f = f0.elapsed_time(f1)
+    print("F=%8d  one pass (mvmc_ingest_dlt) %.3f ms -> %.1f M frames/s, algorithmic %.1f GB/s (%.1f %% of 8 TB/s)" %
+          (F, t_f, F / t_f / 1e3, F * (12 * C * P * 25 + 16 * P * 25) / t_f / 1e6, F * (12 * C * P * 25 + 16 * P * 25) / t_f / 1e6 / 80))
     t_in, t_dlt = e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])
     alg = F * (12 * C * P * 25 + 16 * P * 25)
     moved_dlt = F * (C * 17 * 3 * 8 + 17 * 4 * 8 + C * 4)
