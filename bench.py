@@ -234,6 +234,9 @@ def main():
                     help="synthetic scene: 'chains' restarts the people's random walk at every chain head (the workload the round-1 "
                          "numbers were measured on); 'continuous' is one walk over all frames, so the stitch has identities to find")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--hand-over", default="auto", choices=["auto", "static", "queue"],
+                    help="fused path: how a chain's workgroups follow one another: static = by block index (relies on in-order "
+                         "dispatch), queue = ready queue (no such assumption); auto = queue when more than one rank runs")
     ap.add_argument("--sustain", type=int, default=300,
                     help="after the timed region: this many further consecutive steps of the same command (capped at ~15 s of work), "
                          "reported as 'sustained' beside 'value'; 0 = skip")
@@ -292,7 +295,8 @@ def main():
             if args.path == "fused":
                 kev = []
                 out = run_chains_fused(hp, kps, counts, L, nfev_cold=args.nfev_cold, nfev_warm=args.nfev_warm, want_info=timed,
-                                       parts=args.parts or None, kernel_events=kev)
+                                       parts=args.parts or None, kernel_events=kev,
+                                       hand_over=None if args.hand_over == "auto" else args.hand_over)
                 kern_events.append((timed, kev[0][0], kev[0][1]))
             else:
                 out = run_chains(hp, kps, counts, L, nfev_cold=args.nfev_cold, nfev_warm=args.nfev_warm,

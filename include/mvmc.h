@@ -321,6 +321,11 @@ typedef struct mvmcChainBuffers {
                                    p workgroups running consecutive frame ranges of the chain one after the other, so that
                                    the hardware dispatcher balances the load over the CUs */
     int32_t force_big;          /* != 0: the big layout even where the small one would do (tests) */
+    int32_t hand_over;          /* how a chain's workgroups follow one another (n_parts > 1).  0 = by block index (part * n_chains +
+                                   chain; a part waits for its chain's flag: relies on workgroups being dispatched in block order,
+                                   bounded wait, loud time-out); 1 = ready queue (a workgroup draws a ticket when it starts and takes
+                                   the chain that has been ready longest: no assumption about dispatch order; what the multi-GPU
+                                   path uses).  Same results bit for bit */
     /* inputs */
     const double* kps17;        /* (F,C,P,17,3) after mvmc_ingest */
     const int32_t* counts;      /* (F,C) */
@@ -363,12 +368,13 @@ typedef struct mvmcChainBuffers {
     int32_t* out_n_tracks;      /* (F) */
     double* out_info;           /* (F,NP,8) IK info rows of the frame's problems, or NULL */
     int32_t* out_als_iters;     /* (F) ALS iterations of the frame's graph, or NULL */
-    uint32_t* flags;            /* (2 B + 4) u32, zeroed by the call: [0,B) hand-over flags of the chains; afterwards flags[B] != 0 =
-                                   a workgroup timed out waiting for its predecessor, flags[B + 1] != 0 = a graph was too large
-                                   for the kernel's ALS variant, flags[B + 2] != 0 = a capacity was exceeded in some chain (bit 0:
-                                   a cluster, a member or a view block dropped, bit 1: more than t_max tracklets), flags[B + 4 + b] =
-                                   the void word of chain b (bits 0, 1 as before, bit 2 = graph too large): a non-zero word voids
-                                   the chain's results (all chains' after a time-out) */
+    uint32_t* flags;            /* (B (n_parts + 1) + 8) u32, zeroed by the call: [0,B) hand-over flags of the chains; afterwards
+                                   flags[B] != 0 = a workgroup timed out waiting for its predecessor, flags[B + 1] != 0 = a graph was
+                                   too large for the kernel's ALS variant, flags[B + 2] != 0 = a capacity was exceeded in some chain
+                                   (bit 0: a cluster, a member or a view block dropped, bit 1: more than t_max tracklets),
+                                   flags[B + 4 + b] = the void word of chain b (bits 0, 1 as before, bit 2 = graph too large): a
+                                   non-zero word voids the chain's results (all chains' after a time-out); from 2 B + 4 on: the
+                                   ready queue's ticket counter, tail and ring (hand_over == 1) */
     double* out_phase_cycles;   /* (B,8) diagnostic: shader cycles of each chain by phase {graph, ALS, assignment, IK, commit,
                                    outputs, whole chain, 0}, or NULL */
 } mvmcChainBuffers;

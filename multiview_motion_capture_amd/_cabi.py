@@ -39,7 +39,7 @@ class MvmcSkeleton(C.Structure):
 class MvmcChainBuffers(C.Structure):
     """mvmcChainBuffers of include/mvmc.h (field order matters)."""
     _INTS = ("n_chains", "chain_len", "n_views", "p_max", "t_max", "k_max", "v_max", "max_nfev_cold", "max_nfev_warm",
-             "n_inits", "seed_len", "n_parts", "force_big")
+             "n_inits", "seed_len", "n_parts", "force_big", "hand_over")
     _PTRS = ("kps17", "counts", "Pmats", "Fmats", "F2", "seed_table", "params", "joints", "meta", "n_tracks", "next_id",
              "n_dead", "slot_src", "S_sp", "W_st", "group_counts", "labels_sp", "labels_st", "n_clusters_sp", "n_clusters_st",
              "iters_sp", "iters_st", "members", "n_members", "cold", "init", "status", "n_new", "ik_params", "ik_joints", "ik_info",

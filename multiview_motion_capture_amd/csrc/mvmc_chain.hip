@@ -65,9 +65,12 @@ struct MvmcChainArgs {
     int32_t* out_iters;       // (F) ALS iterations of the frame's graph, or NULL
     double* out_cycles;       // (B,8) shader cycles by phase {graph, ALS, assign, IK, commit, outputs, total}, or NULL
     int parts;                // workgroups per chain (consecutive frame ranges, handed over through flags)
+    int queue;                // 0: workgroup (part, chain) = block index (part * n_chains + chain), a part waits for its chain's flag;
+                              // 1: a workgroup draws a ticket when it starts and takes the chain that has been ready longest
     unsigned* flags;          // (2 B + 4): [0,B) parts completed per chain; [B] time-out, [B+1] graph too large, [B+2] capacity word of
                               // the launch; [B+4+b] the void word of chain b (bit 0 views / clusters, bit 1 tracklet table, bit 2 graph
-                              // too large for the layout's association variant).  Zeroed by the launcher
+                              // too large for the layout's association variant); [2B+4] ticket counter, [2B+5] ring tail,
+                              // [2B+6 ...) ready ring of B * (parts - 1) entries (queue mode).  Zeroed by the launcher
 };
 
 namespace {
@@ -215,17 +218,26 @@ chain_kernel(Ik1Tables tables_arg, ChainArgs A_by_value) {
     ChainArena<BIG>& arena = *reinterpret_cast<ChainArena<BIG>*>(chain_lds);
     __shared__ Ik1Tables tables;
     __shared__ int s_nt;
-    // Workgroup (part, chain): block index = part * n_chains + chain, so every workgroup of part p is dispatched before
-    // any of part p + 1 and a waiting workgroup's predecessor is always resident or finished.  A chain's parts run one
-    // after the other (flag per chain); because later parts start wherever a slot frees up, the CUs that run slower
-    // (three chains instead of two) simply receive fewer of them -- the hardware dispatcher balances the launch.
-    const int b = blockIdx.x % A.n_chains, part = blockIdx.x / A.n_chains;
+    // Which (chain, part) a workgroup runs -- two protocols, the results are the same bit for bit:
+    //  * static (A.queue == 0): block index = part * n_chains + chain.  Every workgroup of part p is dispatched before any of part
+    //    p + 1 IF dispatch follows the block index, so a waiting workgroup's predecessor is resident or finished; later parts start
+    //    wherever a slot frees up, and the CUs that run slower simply receive fewer of them.  The wait is bounded (4 s, loud), but the
+    //    order of dispatch is not something the programming model promises.
+    //  * queue (A.queue == 1): the workgroup draws a ticket when it STARTS; the first n_chains tickets are part 0 of the chains, ticket
+    //    h takes entry h - n_chains of a ring that the workgroups finishing a non-final part fill in the order they finish (entry =
+    //    chain and next part).  Nothing depends on the dispatch order.  No deadlock: a waiting ticket h needs h - n_chains + 1
+    //    finished non-final parts; all lower tickets have started (a ticket is drawn by a RUNNING workgroup), and while a chain is
+    //    unfinished they cannot all be final parts.  It costs 0.7 % on one GPU (the pose-pair block below can no longer be made during
+    //    the wait) and is what the multi-GPU path uses, where RCCL's kernels share the CUs with this one.
     const int tid = threadIdx.x, wave = tid >> 6;
 #ifdef MVMC_CHAIN_WAITPROF   // diagnostic build: out_cycles[7] = cycles a chain's workgroups were resident before their frames began
     const long long t_entry = clock64();
 #endif
-    const int T = A.T, NP = T + A.K;
-    const int t_lo = part * A.L / A.parts, t_hi = (part + 1) * A.L / A.parts;
+    __shared__ int s_task;   // part << 20 | chain, or -1: give up
+    unsigned* const qwords = A.flags + 2 * A.n_chains + 4;   // {ticket, tail, ring[]}
+    const bool queue = A.queue != 0 && A.parts > 1;
+    unsigned ticket = 0;
+    if (queue && tid == 0) ticket = __hip_atomic_fetch_add(qwords, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // The skeleton tables (ancestor masks, level lists, active columns, row masks) are made ONCE PER CALL on the host by the launcher
     // (ik1_build_tables_host: the same source as the device's ik1_build_tables) and arrive as the first kernel argument: a word per
     // lane from the kernel-argument segment into LDS.  Built here by one wave of every workgroup they cost 97 k cycles per frame --
@@ -238,41 +250,61 @@ chain_kernel(Ik1Tables tables_arg, ChainArgs A_by_value) {
         unsigned* dst = reinterpret_cast<unsigned*>(&tables);
         for (int i = tid; i < (int)(sizeof(Ik1Tables) / 4); i += ChainCfg<BIG>::NT) dst[i] = src[i];
     }
-    // work that does not depend on the chain's state comes before the hand-over: for a workgroup that has a predecessor, the
-    // pose-pair block of its first frame's graph
+    int b, part;
     int done = 0;   // the phases' report word (see above)
-    if constexpr (!BIG) { if (part > 0) chain_pose_pairs(arena, A, b * A.L + t_lo, &done); }
-    if (part > 0) {
-        // consumer side of the hand-off (cdna_hip_programming.md Guideline 16): one lane polls the chain's flag relaxed,
-        // one agent-scope acquire, then the workgroup's barrier; the chain state is read with plain vector loads after it
-        __shared__ int s_abort;
+    if (!queue) {
+        b = blockIdx.x % A.n_chains; part = blockIdx.x / A.n_chains;
+        // work that does not depend on the chain's state comes before the hand-over: for a workgroup that has a predecessor, the
+        // pose-pair block of its first frame's graph
+        if constexpr (!BIG) { if (part > 0) chain_pose_pairs(arena, A, b * A.L + part * A.L / A.parts, &done); }
+    }
+    if (queue || part > 0) {
+        // consumer side of the hand-off (cdna_hip_programming.md Guideline 16): one lane polls ONE word relaxed (the chain's flag, or
+        // its ticket's ring entry), one agent-scope acquire, then the workgroup's barrier; the chain state is read with plain vector
+        // loads after it
         if (tid == 0) {
-            // bounded by wall time (~4 s at the 100 MHz constant clock), not by a spin count; a time-out anywhere in the launch
-            // (the error word) also ends this wait, so a chain of waiting parts does not pay the time-out once per part
-            const unsigned long long t0 = wall_clock64();
-            int abort = 0;
-            unsigned spins = 0;
-            while (__hip_atomic_load(A.flags + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)part) {
-                __builtin_amdgcn_s_sleep(32);
-                // the launch-wide error word is ONE address for every waiting workgroup of the launch: looked at once in 1024 polls
-                // (hundreds of pollers on one line cost the whole chip memory bandwidth: measured 370 k -> 331 k frames/s)
-                if ((++spins & 1023u) != 0u) continue;
-                if (__hip_atomic_load(A.flags + A.n_chains, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { abort = 1; break; }
-                if (wall_clock64() - t0 > 400000000ull) {   // dispatch did not come in block order; give up loudly
-                    __hip_atomic_store(A.flags + A.n_chains, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    abort = 1;
-                    break;
+            int task = queue ? (int)ticket : ((part << 20) | b);       // queue: ticket < n_chains = part 0 of chain `ticket`
+            const bool must_wait = queue ? ticket >= (unsigned)A.n_chains : true;
+            if (must_wait) {
+                const unsigned* word = queue ? qwords + 2 + (ticket - (unsigned)A.n_chains) : A.flags + b;
+                const unsigned need = queue ? 1u : (unsigned)part;      // ring entries are task + 1 (0 = not yet filled)
+                // bounded by wall time (~4 s at the 100 MHz constant clock), not by a spin count; a time-out anywhere in the launch
+                // (the error word) also ends this wait, so a chain of waiting parts does not pay the time-out once per part
+                const unsigned long long t0 = wall_clock64();
+                bool abort = false;
+                unsigned spins = 0, v;
+                while ((v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+                    __builtin_amdgcn_s_sleep(32);
+                    // the launch-wide error word is ONE address for every waiting workgroup of the launch: looked at once in 1024 polls
+                    // (hundreds of pollers on one line cost the whole chip memory bandwidth: measured 370 k -> 331 k frames/s)
+                    if ((++spins & 1023u) != 0u) continue;
+                    if (__hip_atomic_load(A.flags + A.n_chains, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { abort = true; break; }
+                    if (wall_clock64() - t0 > 400000000ull) {   // static: dispatch did not come in block order; queue: nothing became ready
+                        __hip_atomic_store(A.flags + A.n_chains, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        abort = true;
+                        break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (queue && !abort) task = (int)v - 1;
+                if (abort) {
+                    // release the successors: in the static protocol they must not wait for this part's flag (in the queue protocol every
+                    // waiter sees the error word within 1024 polls)
+                    if (!queue) __hip_atomic_store(A.flags + b, (unsigned)(part + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    task = -1;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            s_abort = abort;     // ONE lane decides; the whole workgroup branches on the same value
-            if (abort)           // release the successors: they must not wait for this part's flag
-                __hip_atomic_store(A.flags + b, (unsigned)(part + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_task = task;     // ONE lane decides; the whole workgroup branches on the same value
         }
         __syncthreads();
-        if (s_abort) return;
+        const int task = uni(s_task);
+        if (task < 0) return;
+        b = task & 0xFFFFF; part = task >> 20;
+        if constexpr (!BIG) { if (queue && part > 0) chain_pose_pairs(arena, A, b * A.L + part * A.L / A.parts, &done); }
     }
+    const int T = A.T, NP = T + A.K;
+    const int t_lo = part * A.L / A.parts, t_hi = (part + 1) * A.L / A.parts;
     __syncthreads();
     long long cyc[6] = {0, 0, 0, 0, 0, 0}, t_prev = clock64();
     const long long t_start = t_prev;
@@ -289,7 +321,7 @@ chain_kernel(Ik1Tables tables_arg, ChainArgs A_by_value) {
             lap(0);
             chain_als_spatial<BIG>(arena, A, b, f, &done);
         } else {
-            chain_graph_temporal<BIG>(arena, A, b, f, part > 0 && t == t_lo, &done);
+            chain_graph_temporal<BIG>(arena, A, b, f, part > 0 && t == t_lo, &done);   // (the pose-pair block of a part's first frame is ready)
             __syncthreads();
             lap(0);
             chain_als_temporal<BIG>(arena, A, b, &done);
@@ -348,6 +380,10 @@ chain_kernel(Ik1Tables tables_arg, ChainArgs A_by_value) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(A.flags + b, (unsigned)(part + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (queue && part + 1 < A.parts) {   // the chain's next part may run: the next free ring entry (one per finished non-final part)
+                const unsigned at = __hip_atomic_fetch_add(qwords + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(qwords + 2 + at, (unsigned)(((part + 1) << 20) | b) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -412,8 +448,10 @@ extern "C" int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuff
     A.out_info = B.out_info; A.out_iters = B.out_als_iters; A.out_cycles = B.out_phase_cycles;
     A.parts = B.n_parts > 1 ? B.n_parts : 1;
     if (A.parts > 1 && B.chain_len % A.parts != 0) return MVMC_ERR_ARG;
+    A.queue = B.hand_over == 1;
+    if (B.n_chains >= (1 << 20) || A.parts >= (1 << 10)) return MVMC_ERR_UNSUPPORTED;   // (a ring entry is part << 20 | chain)
     A.flags = B.flags;
-    if (hipMemsetAsync(B.flags, 0, sizeof(unsigned) * (2 * (size_t)B.n_chains + 4), (hipStream_t)stream) != hipSuccess)
+    if (hipMemsetAsync(B.flags, 0, sizeof(unsigned) * ((size_t)B.n_chains * (A.parts + 1) + 8), (hipStream_t)stream) != hipSuccess)
         return MVMC_ERR_LAUNCH;
     Ik1Tables tables_host;   // the skeleton's tables: once per call, on the host, a kernel argument of the launch
     ik1_build_tables_host(tables_host, sk);

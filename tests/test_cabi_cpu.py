@@ -62,6 +62,6 @@ def test_chain_buffers_struct_matches_header():
             ints += [n.strip() for n in decl[len("int32_t"):].split(",")]
     assert tuple(ints) == _cabi.MvmcChainBuffers._INTS
     assert tuple(ptrs) == _cabi.MvmcChainBuffers._PTRS
-    # 13 int32 fields (52 bytes): the first pointer starts at the next 8-byte boundary, as in C
-    assert len(ints) == 13 and _cabi.MvmcChainBuffers.kps17.offset == 56
+    # 14 int32 fields (56 bytes): the first pointer starts there
+    assert len(ints) == 14 and _cabi.MvmcChainBuffers.kps17.offset == 56
     assert ctypes.sizeof(_cabi.MvmcChainBuffers) == 56 + 8 * len(ptrs)

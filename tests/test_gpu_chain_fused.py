@@ -45,6 +45,38 @@ def test_fused_equals_staged_bit_for_bit(B, L, people, parts):
     assert b["als_iters"].shape == (B, L) and (b["als_iters"] > 0).all()
 
 
+@pytest.mark.parametrize("people,views,force_big", [(4, 5, False), (4, 5, True), (8, 8, False)])
+def test_ready_queue_hand_over_is_bit_identical_to_the_static_mapping(people, views, force_big):
+    """hand_over = "queue": a workgroup draws a ticket when it starts and takes the chain that has been ready longest -- nothing
+    depends on the order in which workgroups are dispatched (what the multi-GPU path uses).  More workgroups than slots (900 chains of 8
+    frames on the SMALL layout: 7,200 workgroups for 768 slots), both layouts: same results as the static mapping bit for bit, every
+    chain's flag at its last part, every ring entry filled, no time-out."""
+    from multiview_motion_capture_amd import synth
+    from multiview_motion_capture_amd.pipeline import HotPath
+    from multiview_motion_capture_amd.tracker import check_chain_flags, run_chains_fused
+    B, L = (900, 8) if views == 5 else (300, 4)
+    data = synth.generate(B * L, views, people, 20260111, chain_len=L)
+    hp = HotPath(data["K"], data["Rt"])
+    kps, cnt = torch.from_numpy(data["kps25"]).cuda(), torch.from_numpy(data["counts"]).cuda()
+    ref = run_chains_fused(hp, kps, cnt, L, hand_over="static", force_big=force_big)
+    for parts in (None, 2):
+        q = run_chains_fused(hp, kps, cnt, L, hand_over="queue", force_big=force_big, parts=parts)
+        torch.cuda.synchronize()
+        check_chain_flags(q)
+        np_ = parts or L
+        fl = q["flags"].cpu().numpy()
+        assert (fl[:B] == np_).all() and fl[B] == 0
+        assert fl[2 * B + 4] == B * np_ and fl[2 * B + 5] == B * (np_ - 1)          # tickets drawn, ring entries written
+        ring = fl[2 * B + 6:2 * B + 6 + B * (np_ - 1)].astype(np.int64) - 1
+        assert (ring >= 0).all() and len(set(ring.tolist())) == B * (np_ - 1)       # every (chain, later part) exactly once
+        for k in ("meta", "n_tracks", "n_dead", "next_id"):
+            assert torch.equal(q[k], ref[k]), k
+        for k in ("params", "joints"):
+            assert torch.equal(torch.nan_to_num(q[k]), torch.nan_to_num(ref[k])), k
+    with pytest.raises(ValueError):
+        run_chains_fused(hp, kps, cnt, L, hand_over="fifo")
+
+
 def test_sizes_outside_the_arena_are_refused():
     from multiview_motion_capture_amd import synth
     from multiview_motion_capture_amd._cabi import MvmcError
