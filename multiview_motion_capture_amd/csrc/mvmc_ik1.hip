@@ -20,6 +20,7 @@
 #include "mvmc_eigh_tri.h"
 #include "mvmc_tri_w1.h"
 #include "mvmc_ik_shared.h"
+#include "mvmc_ik_arrow.h"
 
 namespace {
 
@@ -56,6 +57,30 @@ struct Ik1Tables {
     signed char depth[18], parents[18], side_map[18];
     signed char lev_list[18], lev_start[20];   // joints ordered by depth; first entry of every level (lev_start[maxdepth + 1] = 18)
     unsigned char act[2][NA1], colkind[2][NA1], cola[2][NA1], colc[2][NA1];
+    // reduced coordinates (mvmc_ik_arrow.h).  Reduced column c: rkind 0 = translation along axis rjc; 1 = rotation of joint rja about
+    // its Euler axis rjc; 2 = side-length slot rja; 3 = column rjc of the reduced basis of structure rja (the joint pair s_ja, s_jb)
+    // (kept small: these tables sit in LDS next to the chain kernel's arena, and 272 bytes more cost it its third workgroup per CU)
+    int arrow_ok;                              // the skeleton has the topology the five structures are written for
+    unsigned short lenmask[NOBS];              // per observed joint: the length columns (bit i = reduced column 30 + i) on its path
+    unsigned char rja[40], rjc[40];
+    signed char s_ja[5], s_jb[5], s_tip[5];    // structures: upper joint, lower joint, the lower joint's only child (-1: none)
+    signed char e2r[NA1];                      // Euler column (act order of stage 2; stage 1's are its first 39) -> reduced column, or
+                                               // -(1 + 8 structure + component)
+    // kind of reduced column c: 3 (pair structure) for the limbs and spine + neck, 1 (one joint's rotation) for the head and the root,
+    // 0 translation, 2 length
+    __host__ __device__ static int rkind(int c) { return c < 16 ? 3 : c < 19 ? 1 : c < 22 ? 0 : c < 25 ? 1 : c < 30 ? 3 : 2; }
+    // the reduced columns observed joint k (ancestor mask anc) depends on
+    __host__ __device__ unsigned long long rmask(int stage, int k, int anc) const {
+        unsigned long long m = 0x3Full << 19;                              // translation and root rotation move every joint
+        if ((anc >> 7) & 1 || (anc >> 8) & 1) m |= 0x1Full << 25;          // spine + neck
+        if (stage) m |= (unsigned long long)lenmask[k] << 30;
+        if ((anc >> 1) & 1) m |= 0xFull;                                   // the limb (or the head) below which it hangs
+        if ((anc >> 4) & 1) m |= 0xFull << 4;
+        if ((anc >> 9) & 1) m |= 0xFull << 8;
+        if ((anc >> 12) & 1) m |= 0xFull << 12;
+        if ((anc >> 15) & 1) m |= 0x7ull << 16;
+        return m;
+    }
 };
 
 // per-solve state (one wave).  The problem's observations are NOT part of it: pose18 (nv x 18 x {x, y, score}: COCO-17 + mid-spine) and
@@ -437,13 +462,227 @@ __device__ __noinline__ void ik1_model_step(Ik1Shared& S, const Ik1Tables& T, in
     *mode_out = 2;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same model in REDUCED COORDINATES (mvmc_ik_arrow.h): the nine structural null directions of the Euler-angle Jacobian are
+// projected out by an orthonormal change of basis per limb, so the matrix has 30 / 40 rows and columns instead of 39 / 49 -- every
+// Householder step and every row of the accumulation is a quarter shorter -- and the Krylov space no longer ends in a structural
+// null block.  Everything else (tridiagonalisation from the gradient, block checks, trust-region solve, eigenbasis fallback) is the
+// code of ik1_model_step on the smaller matrix; the step is mapped back to Euler space before the trial point is formed.
+// *mode_out as ik1_model_step, plus 3 = a joint at gimbal lock (the closed-form null vectors need cos(e_y) != 0): not applicable.
+// ---------------------------------------------------------------------------------------------
+template <int N, int STAGE>
+__device__ __noinline__ void ik1_model_step_r(Ik1Shared& S, const Ik1Tables& T, bool budget_left, double gtol,
+                                            mvmc_gdouble* __restrict__ hh, double Delta, double alpha, bool dump, int* mode_out) {
+    // S and T arrive as generic pointers (the function is out of line); telling the compiler that they are LDS turns every
+    // access below into a ds_ instruction instead of a flat_ one (InferAddressSpaces uses the assumption)
+    MVMC_ASSUME_LDS(&S);
+    MVMC_ASSUME_LDS(&T);
+    hh = uni(hh);   // (arrives in vector registers; as a scalar base it costs no register next to the matrix rows)
+    const int lane = threadIdx.x & 63;
+    using namespace arrow;
+    constexpr int stage = STAGE, NR = Dim<STAGE>::NR;
+    static_assert(N == NR, "one matrix row per reduced column");
+    const int na = NR;                        // the model's dimension: reduced columns (mvmc_ik_arrow.h)
+    const int nae = uni(T.na[STAGE]);         // Euler-space columns (the trial point)
+    const bool on = lane < na;
+    const int kind = on ? Ik1Tables::rkind(lane) : 4;
+#ifdef MVMC_IK_PROFILE
+    long long _tp = clock64();
+#ifdef MVMC_TRI_PROFILE
+#define M1STAMP(k) { const long long _t = clock64(); if (lane == 0 && (k) == 5) S.prof[k] += _t - _tp; _tp = _t; }
+#else
+#define M1STAMP(k) { const long long _t = clock64(); if (lane == 0) S.prof[k] += _t - _tp; _tp = _t; }
+#endif
+#else
+#define M1STAMP(k)
+#endif
+    // ---- the reflectors of the five structures (lanes 0 .. 4), from the closed-form null vectors; they wait in S.xn, which nothing
+    // touches until the trial point is formed at the very end ----
+    double* refl = S.xn;
+    bool bad = false;
+    if (lane < 5) bad = structure_reflectors(S.pos, S.hs, S.Rg, T, lane, refl + lane * 11);
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull) { *mode_out = 3; return; }   // gimbal lock: the caller takes the Euler-space model
+    MVMC_WAVE_SYNC();
+    // ---- the lane's column: angular velocities of its (up to two) joints, in the world frame ----
+    int ja = 0, jb = 0;
+    double wa0 = 0.0, wa1 = 0.0, wa2 = 0.0, wb0 = 0.0, wb1 = 0.0, wb2 = 0.0;
+    if (kind == 1) {
+        ja = jb = T.rja[lane];
+        const int jc = T.rjc[lane];
+        const double b[3] = {jc == 0 ? 1.0 : 0.0, jc == 1 ? 1.0 : 0.0, jc == 2 ? 1.0 : 0.0};
+        double w[3];
+        omega_of(&S.hs[ja * 4], &S.Rg[(ja ? T.parents[ja] : 0) * 9], ja == 0, b, w);
+        wa0 = w[0]; wa1 = w[1]; wa2 = w[2];
+    } else if (kind == 3) {
+        const int s = T.rja[lane], bc = T.rjc[lane];
+        ja = T.s_ja[s]; jb = T.s_jb[s];
+        double z[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) z[i] = bc == i ? 1.0 : 0.0;
+        apply_reflectors(refl + s * 11, z);
+        double w[3];
+        omega_of(&S.hs[ja * 4], &S.Rg[T.parents[ja] * 9], false, z, w);
+        wa0 = w[0]; wa1 = w[1]; wa2 = w[2];
+        omega_of(&S.hs[jb * 4], &S.Rg[T.parents[jb] * 9], false, z + 3, w);
+        wb0 = w[0]; wb1 = w[1]; wb2 = w[2];
+    }
+    const int jl = (kind == 2) ? (int)T.rja[lane] : 0;     // length slot
+    const int jcc = (kind == 0) ? (int)T.rjc[lane] : 0;
+    double a[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) a[i] = 0.0;
+    double gj = 0.0;
+    double* db = S.tmp;
+    for (int k = 0; k < NOBS; ++k) {
+        const int K = kIkSkel[k];
+        double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+        if (kind == 0) {
+            d0 = jcc == 0 ? 1.0 : 0.0; d1 = jcc == 1 ? 1.0 : 0.0; d2 = jcc == 2 ? 1.0 : 0.0;
+        } else if (kind == 1 || kind == 3) {
+            const int anc = T.anc[K];
+            if ((anc >> ja) & 1) {
+                const double r0 = S.pos[K * 3] - S.pos[ja * 3], r1 = S.pos[K * 3 + 1] - S.pos[ja * 3 + 1], r2 = S.pos[K * 3 + 2] - S.pos[ja * 3 + 2];
+                d0 = wa1 * r2 - wa2 * r1; d1 = wa2 * r0 - wa0 * r2; d2 = wa0 * r1 - wa1 * r0;
+            }
+            if (kind == 3 && ((anc >> jb) & 1)) {
+                const double r0 = S.pos[K * 3] - S.pos[jb * 3], r1 = S.pos[K * 3 + 1] - S.pos[jb * 3 + 1], r2 = S.pos[K * 3 + 2] - S.pos[jb * 3 + 2];
+                d0 += wb1 * r2 - wb2 * r1; d1 += wb2 * r0 - wb0 * r2; d2 += wb0 * r1 - wb1 * r0;
+            }
+        } else if (kind == 2) {
+            unsigned path = ((unsigned)T.anc[K] | (1u << K)) & (unsigned)T.smask[jl] & ~1u;
+            while (path) {
+                const int j = 31 - __builtin_clz(path);
+                path &= ~(1u << j);
+                d0 += S.bvec[j * 3]; d1 += S.bvec[j * 3 + 1]; d2 += S.bvec[j * 3 + 2];
+            }
+        }
+        const double* W = &S.Wk[k * 6];
+        const double y0 = W[0] * d0 + W[1] * d1 + W[2] * d2;
+        const double y1 = W[1] * d0 + W[3] * d1 + W[4] * d2;
+        const double y2 = W[2] * d0 + W[4] * d1 + W[5] * d2;
+        gj += d0 * S.tk[k * 3] + d1 * S.tk[k * 3 + 1] + d2 * S.tk[k * 3 + 2];
+        MVMC_WAVE_SYNC();  // the previous joint's broadcasts are done
+        db[lane * 3] = d0; db[lane * 3 + 1] = d1; db[lane * 3 + 2] = d2;
+        MVMC_WAVE_SYNC();
+        // rows in chunks behind one wave-uniform test each (d_i vanishes on the other rows of a live chunk): the chunk's
+        // broadcast ds_read_b128 are in flight together instead of one LDS round trip per row.  Four rows per chunk: the 50-row
+        // instance has no registers for more operands, and in the 40-row one 8 rows per chunk measured slower (fewer chunks are
+        // skipped by the tree sparsity than round trips are saved: IK 37.6 -> 38.6 M cycles per chain)
+        constexpr int GR = 4, GL = GR * 3 / 2;
+        const unsigned long long m = T.rmask(STAGE, k, T.anc[K]);
+        const unsigned mlo = __builtin_amdgcn_readfirstlane((unsigned)m), mhi = __builtin_amdgcn_readfirstlane((unsigned)(m >> 32));
+#pragma unroll
+        for (int c = 0; c < N; c += GR) {
+            const unsigned bits = (c < 32 ? (mlo >> (c & 31)) : (mhi >> (c & 31))) & ((1u << GR) - 1u);
+            if (bits) {
+                double2 t[GL];
+#pragma unroll
+                for (int u = 0; u < GL; ++u) t[u] = *reinterpret_cast<const double2*>(&db[c * 3 + 2 * u]);
+                const double* tt = reinterpret_cast<const double*>(t);
+#pragma unroll
+                for (int i = 0; i < GR; ++i)
+                    if (c + i < N) a[c + i] += tt[3 * i] * y0 + tt[3 * i + 1] * y1 + tt[3 * i + 2] * y2;
+            }
+        }
+    }
+    MVMC_WAVE_SYNC();
+    // |g|^2 of the reduced gradient (= the Euler-space one: g is orthogonal to the null vectors), |g|_inf of the Euler-space gradient
+    // B g_r, which is what SciPy tests
+    if (!on) gj = 0.0;
+    db[lane] = gj;
+    MVMC_WAVE_SYNC();
+    const double gg = uni(wave_sum_dpp(gj * gj)), ginf = uni(wave_max64(fabs(expand(T, STAGE, lane, nae, db, refl))));
+    MVMC_WAVE_SYNC();
+    if (lane == 0) { S.sc[0] = gg; S.sc[1] = ginf; }
+    M1STAMP(4)
+    if (ginf < gtol || !budget_left) { *mode_out = 0; return; }
+    double scv, tauv;
+    int ksteps;
+    const int kk = uni(eightri::tridiag_krylov_w1<N>(a, gj, na, S.sv + SV_D, S.sv + SV_E, S.sv + SV_TAU, S.sv + SV_V0, S.tmp, S.tmp + 64,
+                                                     &S.sc[4], scv, tauv, ksteps
+#ifdef MVMC_TRI_PROFILE
+                                                     , S.prof
+#endif
+                                                     ));
+    // the reflectors, two rows to a register: the matrix registers die here, before the checks and the trust-region solve
+    double pk[(N - 2) / 2];
+    eightri::pack_reflectors<N>(a, pk);
+    if (dump) { eightri::dump_reflectors<N>(pk, scv, ksteps, na, hh); if (lane < 55) hh[6400 + lane] = refl[lane]; }   // a solve that has rejected a trial before: see ik1_trf
+    M1STAMP(5)
+    bool ok = kk > 0;
+    if (ok) ok = eightri::krylov_block_ok(S.sv + SV_D, S.sv + SV_E, kk, na, S.sc[6], S.sc[7], S.tmp, S.tmp + 64, S.tmp + 128,
+                                          S.tmp + 192, S.sv + SV_WN);
+    MVMC_WAVE_SYNC();
+    M1STAMP(6)
+    if (ok) {
+        // ---- the trial step, in the tridiagonal basis ----
+        const double beta0 = S.sc[4], tau0 = S.sc[5], pivmin = 1e-16 * S.sc[6] + 1e-300, coupling = S.sc[7];
+        double* rh = S.tmp;
+        double* cv = S.tmp + 64;
+        rh[lane] = lane == 0 ? beta0 : 0.0;
+        MVMC_WAVE_SYNC();
+        double pred, step_norm;
+        alpha = eightri::tr_solve_tri<false>(S.sv + SV_D, S.sv + SV_E, rh, kk, Delta, alpha, gg, pivmin, nullptr, nullptr, nullptr,
+                                             nullptr, cv, &pred, &step_norm);
+        MVMC_WAVE_SYNC();
+        double c = lane < kk ? cv[lane] : 0.0;
+        if (kk < na) {
+            // component along the first null coordinate: keeps the step orthogonal to the null vector
+            const double eta = coupling * wave_sum_dpp(lane < kk ? S.sv[SV_WN + lane] * c : 0.0);
+            if (lane == kk) c = eta;
+        }
+        const double stepr = eightri::apply_q_packed<N>(pk, scv, tauv, S.sv + SV_V0, tau0, kk, na, c);
+        if (lane == 0) { S.sc[2] = alpha; S.sc[3] = pred; S.sc[8] = step_norm; S.sc[11] = (double)kk; }
+        MVMC_WAVE_SYNC();
+        S.tmp[lane] = on ? stepr : 0.0;       // the step in reduced coordinates -> Euler space (the basis is orthonormal: same length)
+        MVMC_WAVE_SYNC();
+        const double stepj = expand(T, STAGE, lane, nae, S.tmp, refl);
+        MVMC_WAVE_SYNC();
+        ik1_trial_point(S, T, stage, nae, stepj);
+        M1STAMP(3)
+        *mode_out = 1;
+        return;
+    }
+    // No clean split between range and null space (weakly observed directions, missing joints): the step is taken
+    // in the eigenbasis of the tridiagonal matrix instead, with the numerically-null cluster removed -- the
+    // eigensolver fallback of mvmc_ik.hip in the T basis, where suf = V^T g = beta0 * (first components).
+    //   unclean collapse:  T is complete (na rows);   clean collapse: the leading block plus its coupling row.
+    // Its trials outlive this function: the reflectors go to the global scratch.
+    if (!dump) { eightri::dump_reflectors<N>(pk, scv, ksteps, na, hh); if (lane < 55) hh[6400 + lane] = refl[lane]; }
+    const int m = kk < 0 ? na : (kk < na ? kk + 1 : na);
+    mvmc_gdouble* Zg = hh + 64 * NA1;
+    eightri::tri_eigh_w1<N>(S.sv + SV_D, S.sv + SV_E, m, S.sv + SV_WN, Zg, S.tmp, S.tmp + 64, S.tmp + 128);
+    const double suf = lane < m ? S.sc[4] * Zg[lane] : 0.0;
+    MVMC_WAVE_SYNC();
+    S.sv[SV_D + lane] = suf;   // d, e are dead: lam lives in the WN slot, suf in the D slot
+    if (lane == 0) S.sc[10] = (double)m;
+    MVMC_WAVE_SYNC();
+    *mode_out = 2;
+}
+
 // A trial step of a model on the eigenbasis path (Delta, alpha -> S.xn and S.sc[2], [3], [8], [9])
+__device__ __forceinline__ void ik1_finish_trial(Ik1Shared& S, const Ik1Tables& T, int stage, bool reduced, int na,
+                                                 const mvmc_gdouble* __restrict__ hh, double stepj) {
+    // stepj: lane j's component of the step in the model's coordinates.  Reduced model: back to Euler space with the reflectors the
+    // model function parked in the global scratch (hh + 6400) next to its Householder vectors
+    const int lane = threadIdx.x & 63;
+    if (!reduced) { ik1_trial_point(S, T, stage, na, stepj); return; }
+    const int nae = uni(T.na[stage]);
+    MVMC_WAVE_SYNC();
+    S.tmp[lane] = lane < na ? stepj : 0.0;
+    if (lane < 55) S.tmp[192 + lane] = hh[6400 + lane];
+    MVMC_WAVE_SYNC();
+    const double se = arrow::expand(T, stage, lane, nae, S.tmp, S.tmp + 192);
+    MVMC_WAVE_SYNC();
+    ik1_trial_point(S, T, stage, nae, se);
+}
+
 __device__ __noinline__ void ik1_fallback_trial(Ik1Shared& S, const Ik1Tables& T, int stage, const mvmc_gdouble* __restrict__ hh,
-                                                double Delta, double alpha) {
+                                                double Delta, double alpha, bool reduced) {
     MVMC_ASSUME_LDS(&S);
     MVMC_ASSUME_LDS(&T);
     const int lane = threadIdx.x & 63;
-    const int na = uni(T.na[stage]), mq = uni((int)S.sc[10]);
+    const int na = uni(reduced ? (stage ? arrow::Dim<1>::NR : arrow::Dim<0>::NR) : T.na[stage]), mq = uni((int)S.sc[10]);
     const double gg = S.sc[0], tau0 = S.sc[5];
     double* cv = S.tmp + 64;
     double pred, step_norm;
@@ -452,17 +691,17 @@ __device__ __noinline__ void ik1_fallback_trial(Ik1Shared& S, const Ik1Tables& T
     const double c = eightri::eig_combine_w1(hh + 64 * NA1, mq, lane < mq ? cv[lane] : 0.0);
     const double stepj = eightri::apply_q_w1(hh, S.sv + SV_TAU, S.sv + SV_V0, tau0, mq, na, c);
     if (lane == 0) { S.sc[2] = alpha; S.sc[3] = pred; S.sc[8] = step_norm; }
-    ik1_trial_point(S, T, stage, na, stepj);
+    ik1_finish_trial(S, T, stage, reduced, na, hh, stepj);
 }
 
 // Another trial step (Delta, alpha) of a common-path model whose reflectors were dumped to the global scratch: the trust-region solve on
 // the tridiagonal matrix that is still in LDS, Q from memory.
 __device__ __noinline__ void ik1_retry_trial(Ik1Shared& S, const Ik1Tables& T, int stage, const mvmc_gdouble* __restrict__ hh,
-                                             double Delta, double alpha) {
+                                             double Delta, double alpha, bool reduced) {
     MVMC_ASSUME_LDS(&S);
     MVMC_ASSUME_LDS(&T);
     const int lane = threadIdx.x & 63;
-    const int na = uni(T.na[stage]), kk = uni((int)S.sc[11]);
+    const int na = uni(reduced ? (stage ? arrow::Dim<1>::NR : arrow::Dim<0>::NR) : T.na[stage]), kk = uni((int)S.sc[11]);
     const double gg = S.sc[0], beta0 = S.sc[4], tau0 = S.sc[5], pivmin = 1e-16 * S.sc[6] + 1e-300, coupling = S.sc[7];
     double* rh = S.tmp;
     double* cv = S.tmp + 64;
@@ -479,7 +718,7 @@ __device__ __noinline__ void ik1_retry_trial(Ik1Shared& S, const Ik1Tables& T, i
     }
     const double stepj = eightri::apply_q_w1(hh, S.sv + SV_TAU, S.sv + SV_V0, tau0, kk, na, c);
     if (lane == 0) { S.sc[2] = alpha; S.sc[3] = pred; S.sc[8] = step_norm; }
-    ik1_trial_point(S, T, stage, na, stepj);
+    ik1_finish_trial(S, T, stage, reduced, na, hh, stepj);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -494,13 +733,24 @@ __device__ __forceinline__ void ik1_trf(Ik1Shared& S, const Ik1Tables& T, int st
     const int nfull = uni((stage == 0) ? 57 : 57 + T.n_side);
     const int na = uni(T.na[stage]);
     const double ftol = 1e-8, xtol = 1e-8, gtol = 1e-8;
+    // The model in reduced coordinates (ik1_model_step_r) unless the skeleton is not the one its structures are written for or a
+    // joint sits at gimbal lock (mode 3, decided before anything is touched): then the Euler-space model.  A solve stays with its
+    // choice while it can: a rebuilt model (first rejected trial) asks again and gets the same answer from the same FK state.
+    bool reduced = false;
     auto model_step = [&](bool budget_left, double Delta, double alpha, bool dump) {
         // (the result comes back through the caller's stack on purpose: a call that is handed a pointer into its caller's frame is not
         // marked as a tail-call candidate, and only then does the compiler drop the callee-saved convention for this local function --
         // with it, the function's prologue saved and restored 58 vector registers that its caller does not even use)
-        int mode = 0;
-        if (na <= 40) ik1_model_step<40>(S, T, stage, budget_left, gtol, hh, Delta, alpha, dump, &mode);
-        else ik1_model_step<50>(S, T, stage, budget_left, gtol, hh, Delta, alpha, dump, &mode);
+        int mode = 3;
+        if (uni(T.arrow_ok)) {
+            if (stage == 0) ik1_model_step_r<30, 0>(S, T, budget_left, gtol, hh, Delta, alpha, dump, &mode);
+            else ik1_model_step_r<40, 1>(S, T, budget_left, gtol, hh, Delta, alpha, dump, &mode);
+        }
+        reduced = uni(mode) != 3;
+        if (!reduced) {
+            if (na <= 40) ik1_model_step<40>(S, T, stage, budget_left, gtol, hh, Delta, alpha, dump, &mode);
+            else ik1_model_step<50>(S, T, stage, budget_left, gtol, hh, Delta, alpha, dump, &mode);
+        }
         return uni(mode);
     };
     double cost;
@@ -529,9 +779,9 @@ __device__ __forceinline__ void ik1_trf(Ik1Shared& S, const Ik1Tables& T, int st
         while (actual <= 0.0 && nfev < max_nfev) {
             if (!have_trial) {
                 if (mode == 2) {
-                    ik1_fallback_trial(S, T, stage, hh, Delta, alpha);
+                    ik1_fallback_trial(S, T, stage, hh, Delta, alpha, reduced);
                 } else if (dumped) {
-                    ik1_retry_trial(S, T, stage, hh, Delta, alpha);
+                    ik1_retry_trial(S, T, stage, hh, Delta, alpha, reduced);
                 } else {
                     // the first rejected trial of this solve: the reflectors died with the model's registers -- the state of x back
                     // into LDS (not an evaluation of the solver's budget: the same numbers again) and the model again, this time
@@ -648,6 +898,59 @@ __host__ __device__ inline void ik1_tables_section(TB& T, const SkelDev& skarg, 
                 T.na[st] = n;
             }
         }
+    } else if (section == 4) {
+        if (lane == 0) {
+            // the structures of the reduced coordinates: legs (hip, knee | ankle), arms (shoulder, elbow | wrist), spine + neck
+            constexpr int want_par[18] = {-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 9, 10, 8, 12, 13, 8, 15, 15};
+            constexpr int sja[5] = {1, 4, 9, 12, 7}, sjb[5] = {2, 5, 10, 13, 8}, stip[5] = {3, 6, 11, 14, -1};
+            bool ok = n_side == 11 && T.na[0] == 39 && T.na[1] == 49;
+            for (int j = 0; j < 18; ++j) ok = ok && T.parents[j] == want_par[j];
+            for (int k = 0; k < NOBS; ++k) ok = ok && obs_joint[k] == (k < 7 ? k + 1 : k + 2);
+            for (int s = 0; s < 5; ++s) { T.s_ja[s] = (signed char)sja[s]; T.s_jb[s] = (signed char)sjb[s]; T.s_tip[s] = (signed char)stip[s]; }
+            int n = 0;
+            for (int s = 0; s < 4; ++s)
+                for (int c = 0; c < 4; ++c) { T.rja[n] = (unsigned char)s; T.rjc[n] = (unsigned char)c; ++n; }
+            for (int c = 0; c < 3; ++c) { T.rja[n] = 15; T.rjc[n] = (unsigned char)c; ++n; }      // head: the nose's angles
+            for (int c = 0; c < 3; ++c) { T.rja[n] = 0; T.rjc[n] = (unsigned char)c; ++n; }       // 19: translation
+            for (int c = 0; c < 3; ++c) { T.rja[n] = 0; T.rjc[n] = (unsigned char)c; ++n; }       // 22: root rotation
+            for (int c = 0; c < 5; ++c) { T.rja[n] = 4; T.rjc[n] = (unsigned char)c; ++n; }       // 25: spine + neck
+            for (int l = 0; l < T.na[1]; ++l)
+                if (T.colkind[1][l] == 2 && n < 40) { T.rja[n] = T.cola[1][l]; T.rjc[n] = 0; ++n; }   // 30: lengths
+            ok = ok && n == 40;
+            for (int l = 0; l < T.na[0]; ++l)      // stage 1's Euler columns are the first of stage 2's
+                ok = ok && T.act[0][l] == T.act[1][l];
+            {
+                int n_len = 0;
+                for (int l = 0; l < T.na[1]; ++l) {
+                    const int kind = T.colkind[1][l], a = T.cola[1][l], c = T.colc[1][l];
+                    int code = 0;
+                    if (kind == 0) code = 19 + c;
+                    else if (kind == 2) code = 30 + n_len++;
+                    else if (a == 0) code = 22 + c;
+                    else if (a == 15) code = 16 + c;
+                    else {
+                        int s_of = -1, comp = 0;
+                        for (int s = 0; s < 5; ++s) {
+                            if (sja[s] == a) { s_of = s; comp = c; }
+                            if (sjb[s] == a) { s_of = s; comp = 3 + c; }
+                        }
+                        ok = ok && s_of >= 0;
+                        code = -(1 + 8 * (s_of < 0 ? 0 : s_of) + comp);
+                    }
+                    T.e2r[l] = (signed char)code;
+                }
+                for (int k = 0; k < NOBS; ++k) {
+                    const int K = obs_joint[k];
+                    unsigned m = 0;
+                    for (int i = 0; i < 10; ++i) {
+                        const unsigned path = ((unsigned)T.anc[K] | (1u << K)) & (unsigned)T.smask[T.rja[30 + i]] & ~1u;
+                        if (path) m |= 1u << i;
+                    }
+                    T.lenmask[k] = (unsigned short)m;
+                }
+            }
+            T.arrow_ok = ok ? 1 : 0;
+        }
     } else {
         if (lane < 2 * NOBS) {
             const int st = lane >> 4, k = lane & 15, K = obs_joint[k];
@@ -669,7 +972,7 @@ template <typename TB>
 __device__ __forceinline__ void ik1_build_tables(TB& T, const SkelDev& skarg) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int section = 0; section < 4; ++section) {
+    for (int section = 0; section < 5; ++section) {
         ik1_tables_section(T, skarg, section, lane);
         MVMC_WAVE_SYNC();
     }
@@ -679,7 +982,7 @@ __device__ __forceinline__ void ik1_build_tables(TB& T, const SkelDev& skarg) {
 inline void ik1_build_tables_host(Ik1Tables& T, const SkelDev& skarg) {
     unsigned char* bytes = reinterpret_cast<unsigned char*>(&T);
     for (size_t i = 0; i < sizeof(T); ++i) bytes[i] = 0;
-    for (int section = 0; section < 4; ++section)
+    for (int section = 0; section < 5; ++section)
         for (int lane = 0; lane < 64; ++lane) ik1_tables_section(T, skarg, section, lane);
 }
 

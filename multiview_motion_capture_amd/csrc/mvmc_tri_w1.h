@@ -27,6 +27,10 @@ __device__ __forceinline__ double row_of(const double (&a)[N], int k) {
 #define MVMC_ROWCASE(Z) case Z: if constexpr (Z < N) x = a[Z]; break;
     switch (k) { MVMC_ROWS50(MVMC_ROWCASE) default: break; }
 #undef MVMC_ROWCASE
+    // The value is pinned here: where its only use sits behind a condition (if (lane == k) d[k] = x), the optimiser sinks the cases'
+    // loads into that block as ONE load through a phi of POINTERS to the rows, before the array has been promoted to registers -- the
+    // whole matrix then lives in scratch memory (seen in the 30-row instance: 118 scratch stores, 262 loads in the model function)
+    asm volatile("" : "+v"(x));
     return x;
 }
 
