@@ -1592,6 +1592,33 @@ __device__ __forceinline__ void als5_gram(const double* __restrict__ sF, int n, 
     }
 }
 
+// The same Gram matrix on the MATRIX CORES, one wave: G = F^T F is a 16 x 16 x n product, eighteen v_mfma_f64_16x16x4_f64 at n = 72.
+// Operand layout (checked on gfx950, tools/mfma_layout_test.hip): lane l gives A[i = l % 16][k = l / 16] and B[k = l / 16][j = l % 16] and
+// receives D[i = l / 16 + 4 v][j = l % 16] in its four accumulator registers -- for F^T F both operands are the SAME register,
+// F[k0 + l / 16][l % 16].  ~0.6 k cycles where the FMA form above took 3 - 6 k on the solver wave; the sums run over k in the matrix
+// core's order, so the result differs from the FMA form's in the last bits (round 3: als5 no longer bit-identical with round 2's; the
+// gates are the oracle's X_bin / labels / iteration counts, tests/test_gpu_config5_c8p8.py).
+typedef double als5_d4 __attribute__((ext_vector_type(4)));
+template <int FSG>
+__device__ __forceinline__ void als5_gram_mfma(const double* __restrict__ sF, int n4, int r, double rho, bool add_rho, double* __restrict__ sGin) {
+    const int li = threadIdx.x & 15, lq = (threadIdx.x & 63) >> 4;
+    als5_d4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < n4; k0 += 4) {
+        const double f = sF[(k0 + lq) * FSG + li];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(f, f, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int a = lq + 4 * v;
+        double g = acc[v];
+        if (add_rho) {
+            if (a == li) g += rho;
+            if (a >= r || li >= r) g = a == li ? 1.0 : 0.0;
+        }
+        sGin[a * 16 + li] = g;
+    }
+}
+
 // the solver wave: G -> inv(G) by Gauss-Jordan IN PLACE, IN REGISTERS (G is symmetric positive definite: no pivoting; the reference
 // forms the explicit inverse too, np.linalg.inv).  Lane (c, g) = (lane & 15, lane >> 4) holds rows 4 g .. 4 g + 3 of column c in
 // cur[4]: a row group is one 16-lane DPP row.  Per pivot p (unrolled: every register index is a constant): the pivot row's entry of
@@ -1752,14 +1779,15 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
     // Output tile per worker thread: 2 rank slots x 2 columns (fa, fa + 1; fj0, fj0 + 1) -- the same four outputs per thread as a 1 x 4
     // tile, but one 16-byte read of each operand per k instead of an 8-byte and two 16-byte ones: these phases run at the LDS's
     // bandwidth, and this form moves 20 % fewer bytes in a third fewer instructions.  Every output's sum is unchanged: bit-identical.
-    const bool worker = tid < NWORK;
-    const int fa = (tid & 7) * 2, fj0 = worker ? (tid >> 3) * 2 : 0;
+    const bool mw = wave < 5;                                       // matrix-core waves of the factor updates: column block `wave`
+    const int li = tid & 15, lq = (tid & 63) >> 4, jb = 16 * wave + li;
     __syncthreads();
     // The solver wave (its 16 dependent pivots are the longest chain of an iteration, so they never stand alone):
     //   phase H   workers: H = A^T X1            | solver: inverts A^T A + rho I (raw Gram matrix from the previous XZY phase + rho)
     //   phase H2  workers: H2 = B^T X1^T         | solver: inverts B^T B + rho I (Gram matrix formed by 256 threads in a short phase)
     //   phase XZY tile owners: X = A B^T, Z, Y   | solver: forms the raw A^T A of the next iteration (rho is added once mu is decided)
-    if (tid < 256) als5_gram<256, FS>(sA, n, r, 50.0 / 64.0, true, sGin, tid);
+    const int n4 = (n + 3) & ~3;      // factor rows beyond n are zero: the products run over whole groups of four rows
+    if (wave == SOLVER) als5_gram_mfma<FS>(sA, n4, r, 50.0 / 64.0, true, sGin);
     __syncthreads();
     // the solver wave shares its SIMD with a worker wave and is the younger of the two: at equal priority it only gets the issue slots
     // the worker leaves (MI355X_MICROARCH.md, two waves per SIMD) -- but it is the critical path, the worker waits for it
@@ -1793,7 +1821,8 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
             A5PROF(3)
             __syncthreads();                                       // (workers: B = inv H)
             A5PROF(4)
-            __syncthreads();                                       // (256 threads: B^T B + rho I)
+            als5_gram_mfma<FS>(sB, n4, r, rho, true, sGin);        // B^T B + rho I on the matrix cores (the workers wait: B is complete only now)
+            __syncthreads();
             als5_inv_load(cur, sGin, r, rho, false);               // inv(B^T B + rho I) while the workers form H2
             als5_inv_pivots<0, 16>(cur);
             als5_inv_store(cur, sG);
@@ -1802,7 +1831,7 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
             A5PROF(3)
             __syncthreads();                                       // (workers: A = inv H2)
             A5PROF(4)
-            als5_gram<64, FS>(sA, n, r, 0.0, false, sGin, tid & 63);   // raw A^T A of the next iteration while the tiles are updated
+            als5_gram_mfma<FS>(sA, n4, r, 0.0, false, sGin);        // raw A^T A of the next iteration while the tiles are updated
             gram_raw = true;
             A5PROF(5)
             if ((tid & 63) == 0) { sRed[wave] = 0.0; sRed[8 + wave] = 0.0; }
@@ -1826,105 +1855,57 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
             const double inv_mu = 1.0 / mu;      // mu = 64 * 2^k: the reciprocal is exact, x * inv_mu == x / mu bit for bit
             const double rho = 50.0 / mu;
             // ================= B = (inv(A^T A + rho I) (A^T X1))^T =================
-            if (worker) {
-                double h[2][2] = {{0, 0}, {0, 0}};
-                for (int k0 = 0; k0 < n; k0 += 4) {
-                    double2 av[4], xv[4];
-    #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        av[u] = *reinterpret_cast<const double2*>(&sA[(k0 + u) * FS + fa]);
-                        xv[u] = *reinterpret_cast<const double2*>(&sX[(k0 + u) * LD + fj0]);
-                    }
-    #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        h[0][0] += av[u].x * xv[u].x; h[0][1] += av[u].x * xv[u].y;
-                        h[1][0] += av[u].y * xv[u].x; h[1][1] += av[u].y * xv[u].y;
-                    }
+            // The products of the factor updates run on the matrix cores (v_mfma_f64_16x16x4_f64, operand layout: als5_gram_mfma): wave
+            // cb < 5 makes the sixteen columns 16 cb .. of the 16 x n results -- H = A^T X1 in n / 4 instructions per wave (eighteen at
+            // n = 72) with two 8-byte LDS reads each, where the FMA form (288 threads, 2 x 2 output tiles) took 6.6 k cycles per product at
+            // the LDS's bandwidth.  Columns beyond n (and beyond the 74 doubles of a row) come out as finite garbage and are not stored.
+            if (mw) {
+                als5_d4 acc = {0.0, 0.0, 0.0, 0.0};
+                for (int k0 = 0; k0 < n4; k0 += 4)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[(k0 + lq) * FS + li], sX[(k0 + lq) * LD + jb], acc, 0, 0, 0);
+                if (jb < LD) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) sH[(lq + 4 * v) * LD + jb] = acc[v];
                 }
-                *reinterpret_cast<double2*>(&sH[fa * LD + fj0]) = make_double2(h[0][0], h[0][1]);
-                *reinterpret_cast<double2*>(&sH[(fa + 1) * LD + fj0]) = make_double2(h[1][0], h[1][1]);
             }
             A5PROF(2)
             __syncthreads();
             A5PROF(3)
-            if (worker) {
-                double gi[2][16];
-    #pragma unroll
-                for (int e = 0; e < 2; ++e)
-    #pragma unroll
-                    for (int b = 0; b < 16; b += 2) {
-                        const double2 g2 = *reinterpret_cast<const double2*>(&sG[(fa + e) * 34 + 16 + b]);
-                        gi[e][b] = g2.x; gi[e][b + 1] = g2.y;
-                    }
-                double o[2][2] = {{0, 0}, {0, 0}};
-    #pragma unroll
-                for (int b0 = 0; b0 < 16; b0 += 4) {
-                    double2 hv[4];
-    #pragma unroll
-                    for (int u = 0; u < 4; ++u) hv[u] = *reinterpret_cast<const double2*>(&sH[(b0 + u) * LD + fj0]);
-    #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        o[0][0] += gi[0][b0 + u] * hv[u].x; o[0][1] += gi[0][b0 + u] * hv[u].y;
-                        o[1][0] += gi[1][b0 + u] * hv[u].x; o[1][1] += gi[1][b0 + u] * hv[u].y;
-                    }
+            if (mw) {      // B^T = inv(G) H: four instructions per wave
+                als5_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int b0 = 0; b0 < 16; b0 += 4)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sG[li * 34 + 16 + b0 + lq], sH[(b0 + lq) * LD + jb], acc, 0, 0, 0);
+                if (jb < n) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) sB[jb * FS + lq + 4 * v] = acc[v];
                 }
-    #pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    if (fj0 + q < n) *reinterpret_cast<double2*>(&sB[(fj0 + q) * FS + fa]) = make_double2(o[0][q], o[1][q]);
             }
             __syncthreads();
             A5PROF(4)
             // ================= A = (inv(B^T B + rho I) (B^T X1^T))^T =================
-            if (tid < 256) als5_gram<256, FS>(sB, n, r, rho, true, sGin, tid);
-            __syncthreads();
-            if (worker) {
-                // H2[a][i] = sum_k B[k][a] X1[i][k] for four rows i = fj0 .. fj0 + 3; four k per step (two 16-byte reads per row)
-                double h[2][2] = {{0, 0}, {0, 0}};
-                for (int k = 0; k < n; k += 4) {      // X1 columns and B rows beyond n are zero
-                    double2 bv[4], xa[2], xb[2];
-    #pragma unroll
-                    for (int u = 0; u < 4; ++u) bv[u] = *reinterpret_cast<const double2*>(&sB[(k + u) * FS + fa]);
-    #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        xa[q] = *reinterpret_cast<const double2*>(&sX[(fj0 + q) * LD + k]);
-                        xb[q] = *reinterpret_cast<const double2*>(&sX[(fj0 + q) * LD + k + 2]);
-                    }
-    #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        h[0][q] += (bv[0].x * xa[q].x + bv[1].x * xa[q].y) + (bv[2].x * xb[q].x + bv[3].x * xb[q].y);
-                        h[1][q] += (bv[0].y * xa[q].x + bv[1].y * xa[q].y) + (bv[2].y * xb[q].x + bv[3].y * xb[q].y);
-                    }
+            __syncthreads();      // (the solver wave: B^T B + rho I)
+            if (mw) {             // H2[a][i] = sum_k B[k][a] X1[i][k]
+                als5_d4 acc = {0.0, 0.0, 0.0, 0.0};
+                for (int k0 = 0; k0 < n4; k0 += 4)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sB[(k0 + lq) * FS + li], sX[jb * LD + k0 + lq], acc, 0, 0, 0);
+                if (jb < LD) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) sH[(lq + 4 * v) * LD + jb] = acc[v];
                 }
-                *reinterpret_cast<double2*>(&sH[fa * LD + fj0]) = make_double2(h[0][0], h[0][1]);
-                *reinterpret_cast<double2*>(&sH[(fa + 1) * LD + fj0]) = make_double2(h[1][0], h[1][1]);
             }
             A5PROF(2)
             __syncthreads();
             A5PROF(3)
-            if (worker) {
-                double gi[2][16];
-    #pragma unroll
-                for (int e = 0; e < 2; ++e)
-    #pragma unroll
-                    for (int b = 0; b < 16; b += 2) {
-                        const double2 g2 = *reinterpret_cast<const double2*>(&sG[(fa + e) * 34 + 16 + b]);
-                        gi[e][b] = g2.x; gi[e][b + 1] = g2.y;
-                    }
-                double o[2][2] = {{0, 0}, {0, 0}};
-    #pragma unroll
-                for (int b0 = 0; b0 < 16; b0 += 4) {
-                    double2 hv[4];
-    #pragma unroll
-                    for (int u = 0; u < 4; ++u) hv[u] = *reinterpret_cast<const double2*>(&sH[(b0 + u) * LD + fj0]);
-    #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        o[0][0] += gi[0][b0 + u] * hv[u].x; o[0][1] += gi[0][b0 + u] * hv[u].y;
-                        o[1][0] += gi[1][b0 + u] * hv[u].x; o[1][1] += gi[1][b0 + u] * hv[u].y;
-                    }
+            if (mw) {
+                als5_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int b0 = 0; b0 < 16; b0 += 4)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sG[li * 34 + 16 + b0 + lq], sH[(b0 + lq) * LD + jb], acc, 0, 0, 0);
+                if (jb < n) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) sA[jb * FS + lq + 4 * v] = acc[v];
                 }
-    #pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    if (fj0 + q < n) *reinterpret_cast<double2*>(&sA[(fj0 + q) * FS + fa]) = make_double2(o[0][q], o[1][q]);
             }
             __syncthreads();
             A5PROF(4)
