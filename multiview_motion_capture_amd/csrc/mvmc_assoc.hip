@@ -1679,7 +1679,11 @@ __device__ __forceinline__ void als5_inv_pivots(double (&cur)[4]) {
         // (tried: the reciprocal chain of the wave-uniform pivot taken out of the division -- rcp + two Newton steps while the crossbar
         // delivers prow, then q = n r, e = fma(-d, q, n), q' = fma(e, r, q), the true division only for out-of-range operands behind a
         // wave-uniform branch.  Bit-identical, but slower: inversion 8 k -> 10.6 k cycles; the compiler's own expansion stays.)
-        const double f = prow / piv;
+        // (round 3: the wave-uniform pivot's reciprocal -- v_rcp_f64 + two Newton steps, ~1 ulp -- instead of an IEEE division per lane: the
+        // division's ~25 dependent instructions were half of a pivot's 380 cycles, and the reciprocal runs while the crossbar delivers prow.
+        // Not bit-identical with the division (round 2 kept that and found the bit-exact reciprocal form slower); the gates are the oracle's
+        // X_bin / labels / iteration counts.)
+        const double f = prow * fast_rcp64(piv);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int row = g * 4 + q;
@@ -1809,12 +1813,19 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
         // (Tried and dropped, each within noise of this form or slower: the pivots of inv(A^T A + rho I) spread speculatively over the
         // XZY / X1 / H phases -- they crawl beside the tiles' LDS traffic --; the pivot column through v_readlane instead of the LDS
         // crossbar -- 32 scalar moves per pivot cost more than 16 crossbar reads.)
-        bool gram_raw = false;      // sGin holds A^T A without rho / identity padding (formed during XZY)
+        // (Tried in round 3: Newton-Schulz on the matrix cores from the previous iteration's inverse, X <- X + X R, R <- R R, eight
+        // v_mfma_f64_16x16x4_f64 per step.  Exact to rounding in four or five steps -- but an fp64 MFMA occupies the pipe for ~64 cycles,
+        // so a step is ~1 k cycles and the inversion ~6 k, what the sixteen Gauss-Jordan pivots take: 91.8 k -> 92.3 k frames/s.  Dropped.)
+        // The inversion for the A update starts as soon as mu is decided -- the solver wave makes the decisions itself right after the
+        // residual sums are in -- and so runs beside the tile owners' X1 phase and the workers' H phase instead of beside H alone: its
+        // first PRE pivots before the barrier that ends the X1 phase, the rest after it.
+        constexpr int PRE = 4;
         double cur[4];
+        als5_inv_load(cur, sGin, r, 50.0 / mu, false);             // (iteration 0: A^T A + rho I was formed before the loop)
+        als5_inv_pivots<0, PRE>(cur);
         for (int it = 0; it < 1000; ++it) {
             const double rho = 50.0 / mu;
-            als5_inv_load(cur, sGin, r, rho, gram_raw);            // inv(A^T A + rho I) while the workers form H
-            als5_inv_pivots<0, 16>(cur);
+            als5_inv_pivots<PRE, 16>(cur);                         // inv(A^T A + rho I), the rest, while the workers form H
             als5_inv_store(cur, sG);
             A5PROF(2)
             __syncthreads();
@@ -1823,6 +1834,7 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
             A5PROF(4)
             als5_gram_mfma<FS>(sB, n4, r, rho, true, sGin);        // B^T B + rho I on the matrix cores (the workers wait: B is complete only now)
             __syncthreads();
+            MVMC_WAVE_SYNC();
             als5_inv_load(cur, sGin, r, rho, false);               // inv(B^T B + rho I) while the workers form H2
             als5_inv_pivots<0, 16>(cur);
             als5_inv_store(cur, sG);
@@ -1832,7 +1844,6 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
             __syncthreads();                                       // (workers: A = inv H2)
             A5PROF(4)
             als5_gram_mfma<FS>(sA, n4, r, 0.0, false, sGin);        // raw A^T A of the next iteration while the tiles are updated
-            gram_raw = true;
             A5PROF(5)
             if ((tid & 63) == 0) { sRed[wave] = 0.0; sRed[8 + wave] = 0.0; }
             __syncthreads();
@@ -1845,6 +1856,9 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
             if (p_res < 1e-4 && d_res < 1e-4) { iters = it + 1; break; }
             if (p_res > 10 * d_res) mu = 2 * mu;
             else if (d_res > 10 * p_res) mu = mu / 2;
+            MVMC_WAVE_SYNC();
+            als5_inv_load(cur, sGin, r, 50.0 / mu, true);          // A^T A + rho I with the NEW rho: the first pivots beside the X1 phase
+            als5_inv_pivots<0, PRE>(cur);
             A5PROF(0)
             __syncthreads();                                       // (tile owners: X1 of the next iteration)
             A5PROF(1)
@@ -1860,9 +1874,14 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
             // n = 72) with two 8-byte LDS reads each, where the FMA form (288 threads, 2 x 2 output tiles) took 6.6 k cycles per product at
             // the LDS's bandwidth.  Columns beyond n (and beyond the 74 doubles of a row) come out as finite garbage and are not stored.
             if (mw) {
+                // (all operands first -- rows beyond n are zero, so the trip count is the constant 18 and the loads are one batch --, then
+                // the chain of matrix instructions: with a load pair in front of every instruction the phase took 4.1 k cycles, not 2.6 k)
                 als5_d4 acc = {0.0, 0.0, 0.0, 0.0};
-                for (int k0 = 0; k0 < n4; k0 += 4)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[(k0 + lq) * FS + li], sX[(k0 + lq) * LD + jb], acc, 0, 0, 0);
+                double fa_[NMAX / 4], xb_[NMAX / 4];
+#pragma unroll
+                for (int u = 0; u < NMAX / 4; ++u) { fa_[u] = sA[(4 * u + lq) * FS + li]; xb_[u] = sX[(4 * u + lq) * LD + jb]; }
+#pragma unroll
+                for (int u = 0; u < NMAX / 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa_[u], xb_[u], acc, 0, 0, 0);
                 if (jb < LD) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) sH[(lq + 4 * v) * LD + jb] = acc[v];
@@ -1887,8 +1906,11 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
             __syncthreads();      // (the solver wave: B^T B + rho I)
             if (mw) {             // H2[a][i] = sum_k B[k][a] X1[i][k]
                 als5_d4 acc = {0.0, 0.0, 0.0, 0.0};
-                for (int k0 = 0; k0 < n4; k0 += 4)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sB[(k0 + lq) * FS + li], sX[jb * LD + k0 + lq], acc, 0, 0, 0);
+                double fb_[NMAX / 4], xb_[NMAX / 4];
+#pragma unroll
+                for (int u = 0; u < NMAX / 4; ++u) { fb_[u] = sB[(4 * u + lq) * FS + li]; xb_[u] = sX[jb * LD + 4 * u + lq]; }
+#pragma unroll
+                for (int u = 0; u < NMAX / 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fb_[u], xb_[u], acc, 0, 0, 0);
                 if (jb < LD) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) sH[(lq + 4 * v) * LD + jb] = acc[v];
