@@ -1514,13 +1514,16 @@ als4_kernel(const TW* __restrict__ W, const int32_t* __restrict__ gcounts, int G
 //     rows 3 ti .., columns 4 tj .. (432 of the 512 threads; eight waves per CU: two per SIMD, so one wave's LDS round trips and
 //     dependent fp64 chains are covered by the other's work);
 //   * X1 = Z - (Y - W + beta) / mu is a dense n x n matrix in LDS (row stride NMAX), read by both factor updates;
-//   * a factor update  B = (inv(A^T A + rho I) (A^T X1))^T : threads 0..287 form H = A^T X1 with a 1 x 4 register tile each
-//     (one factor entry + two 16-byte reads of an X1 row per four FMAs, four rows of loads in flight) while the last wave forms the
-//     16 x 16 normal matrix and inverts it by Gauss-Jordan in LDS (the reference forms explicit inverses too: np.linalg.inv);
-//     then inv(G) H;
+//   * a factor update  B = (inv(A^T A + rho I) (A^T X1))^T : waves 0..4 form the sixteen-column blocks of H = A^T X1 on the MATRIX
+//     CORES (v_mfma_f64_16x16x4_f64: eighteen instructions per block at n = 72, operands read as one batch) while the last wave inverts
+//     the 16 x 16 normal matrix by Gauss-Jordan in registers (the reference forms explicit inverses too: np.linalg.inv); then
+//     inv(G) H, four matrix instructions per block; the Gram matrices A^T A, B^T B are matrix-core products on the solver wave;
 //   * X = A B^T on the 3 x 4 tiles (A rows in registers, one 128-byte B row per column, the next column's row prefetched), the
 //     Z / Y update and the residual sums in the same pass.
-// Seven workgroup barriers per iteration; no state in scratch memory.
+// Seven workgroup barriers per iteration; no state in scratch memory.  Round 3 moved the dense products onto the matrix cores
+// (29 k -> 21.8 k cycles per iteration); an fp64 MFMA keeps the pipe for ~64 cycles, so they pay where whole tiles are full.
+// (Tried: the fifth column block -- half empty at n = 72 -- split over the k range on the waves 4 .. 6 so that no SIMD carries two
+// full chains: 93.0 k -> 90.7 k frames/s; the solver wave's pivots are the critical path, and more matrix work beside them slows them.)
 // ------------------------------------------------------------------------------------------------
 template <int NMAX>
 struct Als5Lds {
@@ -1542,57 +1545,10 @@ struct Als5Lds {
     int s_n, s_r;
 };
 
-// G = F^T F (+ rho on the diagonal; identity on the unused rank slots) over the n rows of the factor F (NMAX x FSG in LDS) into
-// sGin (16 x 16).  NTH = 256: one entry per thread (rows in groups of four so that the LDS round trips overlap).  NTH = 64 (the
-// solver wave): lane (a2, b2) = (lane & 7, lane >> 3) owns the 2 x 2 block rows 2 a2.., columns 2 b2.. -- two 16-byte factor reads
-// per row for four FMAs.  add_rho = false leaves the raw Gram matrix (rho is not known yet).
-template <int NTH, int FSG>
-__device__ __forceinline__ void als5_gram(const double* __restrict__ sF, int n, int r, double rho, bool add_rho, double* __restrict__ sGin, int t) {
-    if constexpr (NTH == 64) {
-        const int a0 = (t & 7) * 2, b0 = (t >> 3) * 2;
-        double g00 = 0.0, g01 = 0.0, g10 = 0.0, g11 = 0.0;
-        for (int k0 = 0; k0 < n; k0 += 4) {
-            double2 fa[4], fb[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                fa[u] = *reinterpret_cast<const double2*>(&sF[(k0 + u) * FSG + a0]);
-                fb[u] = *reinterpret_cast<const double2*>(&sF[(k0 + u) * FSG + b0]);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { g00 += fa[u].x * fb[u].x; g01 += fa[u].x * fb[u].y; g10 += fa[u].y * fb[u].x; g11 += fa[u].y * fb[u].y; }
-        }
-        const double g[2][2] = {{g00, g01}, {g10, g11}};
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int a = a0 + i, bb = b0 + j;
-                double v = g[i][j];
-                if (add_rho) {
-                    if (a == bb) v += rho;
-                    if (a >= r || bb >= r) v = a == bb ? 1.0 : 0.0;
-                }
-                sGin[a * 16 + bb] = v;
-            }
-    } else {
-        const int a = t & 15, bb = t >> 4;
-        double g = 0.0;
-        for (int k0 = 0; k0 < n; k0 += 4) {
-            double fa[4], fb[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { fa[u] = sF[(k0 + u) * FSG + a]; fb[u] = sF[(k0 + u) * FSG + bb]; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) g += fa[u] * fb[u];
-        }
-        if (add_rho) {
-            if (a == bb) g += rho;
-            if (a >= r || bb >= r) g = a == bb ? 1.0 : 0.0;
-        }
-        sGin[a * 16 + bb] = g;
-    }
-}
-
-// The same Gram matrix on the MATRIX CORES, one wave: G = F^T F is a 16 x 16 x n product, eighteen v_mfma_f64_16x16x4_f64 at n = 72.
+// G = F^T F (+ rho on the diagonal; identity on the unused rank slots) over the rows of the factor F (NMAX x FSG in LDS) into sGin
+// (16 x 16), on the MATRIX CORES, one wave: a 16 x 16 x n product, eighteen v_mfma_f64_16x16x4_f64 at n = 72.  add_rho = false leaves
+// the raw Gram matrix (rho is not known yet).  (The FMA forms it replaces -- one entry per thread on 256 threads, 2 x 2 blocks on the
+// solver wave -- took 3 - 6 k cycles on the critical path.)
 // Operand layout (checked on gfx950, tools/mfma_layout_test.hip): lane l gives A[i = l % 16][k = l / 16] and B[k = l / 16][j = l % 16] and
 // receives D[i = l / 16 + 4 v][j = l % 16] in its four accumulator registers -- for F^T F both operands are the SAME register,
 // F[k0 + l / 16][l % 16].  ~0.6 k cycles where the FMA form above took 3 - 6 k on the solver wave; the sums run over k in the matrix
@@ -1707,7 +1663,7 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
                                            uint8_t* __restrict__ match_mat, int32_t* __restrict__ labels,
                                            int32_t* __restrict__ n_clusters, int32_t* __restrict__ iters_out) {
     static_assert(NMAX == 72, "tile grid: 24 x 18 tiles of 3 x 4 elements");
-    constexpr int NT5 = 512, TR = 3, TC = 4, LD = Als5Lds<NMAX>::LD, FS = Als5Lds<NMAX>::FS, NW5 = NT5 / 64, SOLVER = NW5 - 1, NWORK = 16 * (NMAX / 4);
+    constexpr int NT5 = 512, TR = 3, TC = 4, LD = Als5Lds<NMAX>::LD, FS = Als5Lds<NMAX>::FS, NW5 = NT5 / 64, SOLVER = NW5 - 1;
     double *sX = L.sX, *sW = L.sW, *sA = L.sA, *sB = L.sB, *sH = L.sH, *sG = L.sG, *sGin = L.sGin, *sRed = L.sRed;
     int *sGid = L.sGid, *sKeep = L.sKeep;
     uint8_t* sVis = L.sVis;

@@ -1,20 +1,21 @@
 // Temporal inverse kinematics, one WAVE per solve (PoseSolver.solve, inverse_kinematics.py:351-433).
 //
-// Same algorithm as mvmc_ik.hip (analytic-Jacobian TRF, trust-region step in the Krylov tridiagonal basis of
-// (J^T J, g)), re-laid out so that one 64-lane wave owns a person-frame:
+// SciPy's trf_no_bounds / solve_lsq_trust_region restated with an analytic Jacobian and the normal equations:
+// the trust-region step lives in the Krylov tridiagonal basis of (J^T J, g).  A 64-lane wave owns a person-frame:
 //   * no workgroup barriers: every reduction is a DPP wave reduction, every exchange an in-wave LDS broadcast;
-//   * 15 KB of LDS and <= 168 VGPRs per solve: ten solves per CU instead of three, so the ~2,500 solves that one time
-//     step of the chain protocol launches are all resident at once (the old layout needed 3.3 rounds), and the
-//     association kernels of another chain group can share the CU;
-//   * J^T J = sum_k D_k^T W_k D_k is accumulated with lane = column, all rows in registers; a lane forms its own
-//     column of D_k (cross product of its rotation axis with the lever arm) on the fly, the row-side values come back
-//     from LDS as broadcasts, and the tree sparsity of D_k (only ancestors of joint k move it) is a per-joint row mask;
-//   * the tridiagonalisation runs on that register image (mvmc_tri_w1.h), Householder vectors go to a per-solve
-//     global scratch;
-//   * trust-region solve, block checks and the cold start were single-wave code already (mvmc_eigh_tri.h,
-//     mvmc_postopt.h).
-// A model that does not split cleanly into range and null space (1-2 % of the solves) takes the eigensolver
-// fallback in the T basis (tri_eigh_w1): same semantics as the fallback of mvmc_ik.hip, no second launch.
+//   * ~10 KB of LDS (+ the problem's view block) and <= 168 VGPRs per solve: the ~2,500 solves that one time step of the chain
+//     protocol launches are all resident at once, and the association kernels of another chain group can share the CU;
+//   * the model is built in REDUCED COORDINATES (mvmc_ik_arrow.h: the nine structural null directions of the Euler-angle Jacobian
+//     projected out, 30 / 40 columns instead of 39 / 49); J^T J = sum_k D_k^T W_k D_k is accumulated with lane = column, all rows in
+//     registers; a lane forms its own column of D_k (cross products of its joints' angular velocities with the lever arms) on the
+//     fly, the row-side values come back from LDS as broadcasts, and the tree sparsity of D_k (only ancestors of joint k move it)
+//     is a per-joint row mask;
+//   * the tridiagonalisation runs on that register image (mvmc_tri_w1.h); the Householder vectors stay in the matrix registers
+//     through the first trial and go to a per-solve global scratch only for solves that reject a trial;
+//   * trust-region solve, block checks and the cold start are single-wave code (mvmc_eigh_tri.h, mvmc_postopt.h).
+// A model that does not split cleanly into range and null space (weakly observed directions, joints no view sees) takes the
+// eigensolver fallback in the T basis (tri_eigh_w1).  The Euler-space model (ik1_model_step) remains for a joint at gimbal lock and
+// for skeletons the reduced structures are not written for.
 #include "mvmc_common.h"
 #include "mvmc_postopt.h"
 #include "mvmc_eigh_tri.h"
@@ -447,7 +448,7 @@ __device__ __noinline__ void ik1_model_step(Ik1Shared& S, const Ik1Tables& T, in
     }
     // No clean split between range and null space (weakly observed directions, missing joints): the step is taken
     // in the eigenbasis of the tridiagonal matrix instead, with the numerically-null cluster removed -- the
-    // eigensolver fallback of mvmc_ik.hip in the T basis, where suf = V^T g = beta0 * (first components).
+    // eigensolver fallback in the T basis, where suf = V^T g = beta0 * (first components).
     //   unclean collapse:  T is complete (na rows);   clean collapse: the leading block plus its coupling row.
     // Its trials outlive this function: the reflectors go to the global scratch.
     if (!dump) eightri::dump_reflectors<N>(pk, scv, ksteps, na, hh);
@@ -645,7 +646,7 @@ __device__ __noinline__ void ik1_model_step_r(Ik1Shared& S, const Ik1Tables& T, 
     }
     // No clean split between range and null space (weakly observed directions, missing joints): the step is taken
     // in the eigenbasis of the tridiagonal matrix instead, with the numerically-null cluster removed -- the
-    // eigensolver fallback of mvmc_ik.hip in the T basis, where suf = V^T g = beta0 * (first components).
+    // eigensolver fallback in the T basis, where suf = V^T g = beta0 * (first components).
     //   unclean collapse:  T is complete (na rows);   clean collapse: the leading block plus its coupling row.
     // Its trials outlive this function: the reflectors go to the global scratch.
     if (!dump) { eightri::dump_reflectors<N>(pk, scv, ksteps, na, hh); if (lane < 55) hh[6400 + lane] = refl[lane]; }
@@ -723,7 +724,7 @@ __device__ __noinline__ void ik1_retry_trial(Ik1Shared& S, const Ik1Tables& T, i
 
 // ---------------------------------------------------------------------------------------------
 // trf_no_bounds (trf.py:401-560) with x_scale = 1, linear loss, ftol = xtol = gtol = 1e-8 -- the loop of ik_trf
-// in mvmc_ik.hip on one wave.
+// on one wave.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void ik1_trf(Ik1Shared& S, const Ik1Tables& T, int stage, int max_nfev, mvmc_gdouble* __restrict__ hh,
                                         double* cost_out, int* nfev_out, int* njev_out, int* status_out, int* fallbacks_out, bool& dump,
@@ -1107,7 +1108,7 @@ __device__ __forceinline__ void ik1_solve(Ik1Shared& S, double* views, int vcap,
             info[0] = costs[0]; info[1] = nfs[0]; info[2] = sts[0]; info[3] = costs[1]; info[4] = nfs[1]; info[5] = sts[1];
             info[6] = njs[0] + njs[1]; info[7] = fallbacks;
 #ifdef MVMC_IK_PROFILE
-            // diagnostic build only: cycle counts instead of the costs (same slots as ik_kernel's)
+            // diagnostic build only: cycle counts instead of the costs (the slots tools/ik_chain_profile.py reads)
             info[0] = (double)S.prof[0]; info[3] = 0.0; info[2] = (double)S.prof[2];
             info[5] = (double)(clock64() - t_all); info[7] = (double)S.prof[3];
             info[1] = (double)S.prof[4]; info[4] = (double)S.prof[5]; info[6] = (double)S.prof[6];

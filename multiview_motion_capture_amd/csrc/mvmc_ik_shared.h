@@ -1,5 +1,4 @@
-// Pieces shared by the two IK kernels (mvmc_ik.hip: one workgroup per solve, the generic path and the eigensolver
-// fallback; mvmc_ik1.hip: one wave per solve).
+// Pieces shared by the IK kernels (mvmc_ik1.hip: one wave per solve; mvmc_ik_fd.hip: the TRF-faithful diagnostic solver).
 #pragma once
 #include "mvmc_common.h"
 

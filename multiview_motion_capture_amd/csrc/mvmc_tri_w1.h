@@ -476,7 +476,7 @@ __device__ __noinline__ int tri_eigh_w1(const double* d, const double* e, int m,
 }
 
 // solve_lsq_trust_region (common.py:57-168) in the eigenbasis (lam, suf; one lane per eigenpair, m < 64), the
-// rank-deficient branch with the virtual absorber at lane m -- ik_tr_solve of mvmc_ik.hip.  cv <- coefficients.
+// rank-deficient branch with the virtual absorber at lane m (the absorber).  cv <- coefficients.
 __device__ inline double tr_solve_eig_w1(const double* lamv, const double* sufv, int m, double Delta, double alpha0, double gg,
                                          double* cv, double* pred, double* pnorm) {
     const int lane = threadIdx.x & 63;

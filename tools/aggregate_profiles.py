@@ -62,7 +62,7 @@ def main():
             "separate passes, KB x 1024; accesses are 8/12-byte, so the gfx950 x2 correction for 16-B streaming reads does not "
             "apply (ingest_kernel calibrates 1:1 against its known 30 MB input)")
     for key, kern in (("ik", "ik1_kernel<6>"), ("als", "als4_kernel<double, 32>"), ("chain", "chain_kernel<false>"), ("chain", "chain_kernel<true>"),
-                      ("tri", "dlt_kernel")):
+                      ("tri", "dlt_kernel"), ("tri", "ingest_dlt_kernel<float>"), ("tri", "ingest_dlt_kernel<double>")):
         if kern not in fe:
             continue
         kf = sum(fe[kern]) / len(fe[kern]) * 1024
