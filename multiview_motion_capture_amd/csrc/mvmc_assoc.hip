@@ -1538,6 +1538,7 @@ struct Als5Lds {
     __attribute__((aligned(16))) double sH[16 * LD];
     __attribute__((aligned(16))) double sG[16 * 34];   // inverse of the normal matrix in columns 16..31 (rows padded to 34 doubles)
     __attribute__((aligned(16))) double sGin[16 * 16]; // the normal matrix on its way to the solver wave
+    __attribute__((aligned(16))) double sGp[3][16 * 16];   // B^T B in three partial sums over k (waves 0 .. 2), summed by the solver wave's load
     double sRed[16];
     int sGid[NMAX];
     uint8_t sVis[NMAX];
@@ -1555,11 +1556,13 @@ struct Als5Lds {
 // core's order, so the result differs from the FMA form's in the last bits (round 3: als5 no longer bit-identical with round 2's; the
 // gates are the oracle's X_bin / labels / iteration counts, tests/test_gpu_config5_c8p8.py).
 typedef double als5_d4 __attribute__((ext_vector_type(4)));
+// rows [k_lo, k_hi) of F only (raw partial sum: add_rho = false) when several waves share the product
 template <int FSG>
-__device__ __forceinline__ void als5_gram_mfma(const double* __restrict__ sF, int n4, int r, double rho, bool add_rho, double* __restrict__ sGin) {
+__device__ __forceinline__ void als5_gram_mfma(const double* __restrict__ sF, int n4, int r, double rho, bool add_rho, double* __restrict__ sGin,
+                                               int k_lo = 0) {
     const int li = threadIdx.x & 15, lq = (threadIdx.x & 63) >> 4;
     als5_d4 acc = {0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < n4; k0 += 4) {
+    for (int k0 = k_lo; k0 < n4; k0 += 4) {
         const double f = sF[(k0 + lq) * FSG + li];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(f, f, acc, 0, 0, 0);
     }
@@ -1602,13 +1605,15 @@ __device__ __forceinline__ void als5_pivot_column(const double (&cur)[4], double
     }
 #undef MVMC_A5C
 }
-__device__ __forceinline__ void als5_inv_load(double (&cur)[4], const double* __restrict__ sGin, int r, double rho, bool rho_fix) {
+// parts = 3: the matrix arrives as three partial sums 256 doubles apart (sGp)
+__device__ __forceinline__ void als5_inv_load(double (&cur)[4], const double* __restrict__ sGin, int r, double rho, bool rho_fix, int parts = 1) {
     const int lane = threadIdx.x & 63;
     const int c = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int row = g * 4 + q;
         double v = sGin[row * 16 + c];
+        if (parts == 3) v = (v + sGin[256 + row * 16 + c]) + sGin[512 + row * 16 + c];
         if (rho_fix) {
             if (row == c) v += rho;
             if (row >= r || c >= r) v = row == c ? 1.0 : 0.0;
@@ -1739,8 +1744,10 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
     // Output tile per worker thread: 2 rank slots x 2 columns (fa, fa + 1; fj0, fj0 + 1) -- the same four outputs per thread as a 1 x 4
     // tile, but one 16-byte read of each operand per k instead of an 8-byte and two 16-byte ones: these phases run at the LDS's
     // bandwidth, and this form moves 20 % fewer bytes in a third fewer instructions.  Every output's sum is unchanged: bit-identical.
-    const bool mw = wave < 5;                                       // matrix-core waves of the factor updates: column block `wave`
-    const int li = tid & 15, lq = (tid & 63) >> 4, jb = 16 * wave + li;
+    // matrix-core waves of the factor updates: the column blocks 0 .. 4 on the waves 0, 1, 2, 4, 5 -- not on wave 3, which shares its
+    // SIMD with the solver wave: the sixteen dependent pivots are the iteration's critical path and run best with the SIMD to themselves
+    const bool mw = wave < 3 || wave == 4 || wave == 5;
+    const int li = tid & 15, lq = (tid & 63) >> 4, jb = 16 * (wave < 3 ? wave : wave - 1) + li;
     __syncthreads();
     // The solver wave (its 16 dependent pivots are the longest chain of an iteration, so they never stand alone):
     //   phase H   workers: H = A^T X1            | solver: inverts A^T A + rho I (raw Gram matrix from the previous XZY phase + rho)
@@ -1788,10 +1795,8 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
             A5PROF(3)
             __syncthreads();                                       // (workers: B = inv H)
             A5PROF(4)
-            als5_gram_mfma<FS>(sB, n4, r, rho, true, sGin);        // B^T B + rho I on the matrix cores (the workers wait: B is complete only now)
-            __syncthreads();
-            MVMC_WAVE_SYNC();
-            als5_inv_load(cur, sGin, r, rho, false);               // inv(B^T B + rho I) while the workers form H2
+            __syncthreads();                                       // (waves 0 .. 2: B^T B in three partial sums over k)
+            als5_inv_load(cur, L.sGp[0], r, rho, true, 3);         // inv(B^T B + rho I) while the workers form H2
             als5_inv_pivots<0, 16>(cur);
             als5_inv_store(cur, sG);
             A5PROF(2)
@@ -1859,7 +1864,13 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
             __syncthreads();
             A5PROF(4)
             // ================= A = (inv(B^T B + rho I) (B^T X1^T))^T =================
-            __syncthreads();      // (the solver wave: B^T B + rho I)
+            // B^T B: a third of the k range on each of the waves 0 .. 2 (six matrix instructions instead of eighteen on the solver wave, which
+            // everybody waited for); the solver wave adds the three partial sums, rho and the identity padding while loading
+            if (wave < 3) {
+                const int k_lo = wave * (NMAX / 3), k_hi = k_lo + NMAX / 3;
+                als5_gram_mfma<FS>(sB, k_hi < n4 ? k_hi : n4, r, 0.0, false, L.sGp[wave], k_lo);
+            }
+            __syncthreads();
             if (mw) {             // H2[a][i] = sum_k B[k][a] X1[i][k]
                 als5_d4 acc = {0.0, 0.0, 0.0, 0.0};
                 double fb_[NMAX / 4], xb_[NMAX / 4];
