@@ -216,7 +216,7 @@ def main():
                          "0 = one per frame of the chain (default), 1 = one persistent workgroup per chain")
     ap.add_argument("--groups", type=int, default=1,
                     help="chain groups advanced on separate HIP streams (association of one group overlaps IK of another)")
-    ap.add_argument("--overlap", type=int, default=2,
+    ap.add_argument("--overlap", type=int, default=None,
                     help="steps in flight: consecutive steps (independent batches) are issued on N alternating HIP streams, so the "
                          "tail of one launch (its slowest chains, a fifth of the workgroup slots idle) is filled by the head of the "
                          "next; 1 = strictly one step after the other")
@@ -241,6 +241,10 @@ def main():
                     help="after the timed region: this many further consecutive steps of the same command (capped at ~15 s of work), "
                          "reported as 'sustained' beside 'value'; 0 = skip")
     args = ap.parse_args()
+    if args.overlap is None:
+        # two steps in flight fill the tail of the chain kernel's launches; the memory-bound triangulation-only pass (config 2) has no
+        # such tail, and two overlapped launches would only make each of them last twice as long
+        args.overlap = 1 if args.workload == "dlt" else 2
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks as fresh child processes.  Nothing in this process has touched the GPU
