@@ -1621,35 +1621,42 @@ __device__ __forceinline__ void als5_inv_load(double (&cur)[4], const double* __
         cur[q] = v;
     }
 }
+// Pivots come in 2 x 2 BLOCKS (round 3): rows p, p + 1 (p even) live in the same lanes (registers p & 3 and (p & 3) + 1 of row group
+// p / 4), so one crossbar round trip delivers both pivot rows, ONE reciprocal (of the block's determinant) replaces two, and the update
+// is two fused multiply-adds per register -- eight dependent steps per inversion instead of sixteen.  With K = {p, p + 1}, P = M[K][K]:
+//   M'[K][j] = inv(P) M[K][j],  M'[i][j] = M[i][j] - M[i][K] inv(P) M[K][j],  and in the columns of K (the identity part of the
+//   augmented matrix, as in the scalar form): M'[K][K] = inv(P), M'[i][K] = -M[i][K] inv(P).
+// The same elimination as two scalar pivots in exact arithmetic ((a r1 - b' r0) / (a d - b b') is what the second scalar pivot forms
+// from the first one's results); the rounding differs.  G is positive definite, so det P > 0.
 template <int P0, int P1>
 __device__ __forceinline__ void als5_inv_pivots(double (&cur)[4]) {
+    static_assert(P0 % 2 == 0 && P1 % 2 == 0, "pivot blocks are pairs");
     const int lane = threadIdx.x & 63;
     const int c = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int p = P0; p < P1; ++p) {
+    for (int p = P0; p < P1; p += 2) {
         const int pg = p >> 2, pq = p & 3;
-        const double mine = cur[pq];
-        double prow = __shfl(mine, pg * 16 + c, 64);                // M[p][c]
-        const double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine), pg * 16 + p),
-                                            __builtin_amdgcn_readlane(__double2loint(mine), pg * 16 + p));   // M[p][p]
-        double col[4];
-        als5_pivot_column(cur, col, p);                             // M[4 g + q][p]
-        if (c == p) prow = 1.0;                                     // (column 16 + p of the augmented matrix: e_p)
-        // (tried: the pivot row through gfx950's v_permlane32_swap / v_permlane16_swap (both operands the same register: a 16-lane row to all
-        // four) instead of the LDS crossbar -- bit-identical, 77.9 k -> 76.9 k frames/s: the crossbar read is not what the pivot waits for.)
-        // (tried: the reciprocal chain of the wave-uniform pivot taken out of the division -- rcp + two Newton steps while the crossbar
-        // delivers prow, then q = n r, e = fma(-d, q, n), q' = fma(e, r, q), the true division only for out-of-range operands behind a
-        // wave-uniform branch.  Bit-identical, but slower: inversion 8 k -> 10.6 k cycles; the compiler's own expansion stays.)
-        // (round 3: the wave-uniform pivot's reciprocal -- v_rcp_f64 + two Newton steps, ~1 ulp -- instead of an IEEE division per lane: the
-        // division's ~25 dependent instructions were half of a pivot's 380 cycles, and the reciprocal runs while the crossbar delivers prow.
-        // Not bit-identical with the division (round 2 kept that and found the bit-exact reciprocal form slower); the gates are the oracle's
-        // X_bin / labels / iteration counts.)
-        const double f = prow * fast_rcp64(piv);
+        const double m0 = cur[pq], m1 = cur[pq + 1];
+        double r0 = __shfl(m0, pg * 16 + c, 64), r1 = __shfl(m1, pg * 16 + c, 64);      // M[p][c], M[p + 1][c]
+#define MVMC_A5RL(V, L) __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(V), (L)), __builtin_amdgcn_readlane(__double2loint(V), (L)))
+        const double a = MVMC_A5RL(m0, pg * 16 + p), b = MVMC_A5RL(m0, pg * 16 + p + 1);      // M[p][p], M[p][p + 1]
+        const double bt = MVMC_A5RL(m1, pg * 16 + p), d = MVMC_A5RL(m1, pg * 16 + p + 1);     // M[p + 1][p], M[p + 1][p + 1]
+#undef MVMC_A5RL
+        double c0[4], c1[4];
+        als5_pivot_column(cur, c0, p);                              // M[4 g + q][p]
+        als5_pivot_column(cur, c1, p + 1);                          // M[4 g + q][p + 1]
+        const bool in_k = c == p || c == p + 1;
+        if (in_k) { r0 = c == p ? 1.0 : 0.0; r1 = c == p ? 0.0 : 1.0; }   // (columns 16 + p, 16 + p + 1 of the augmented matrix)
+        // (tried on the scalar form: the pivot row through v_permlane swaps instead of the LDS crossbar -- 77.9 k -> 76.9 k frames/s; the
+        // pivot's reciprocal taken out of an IEEE division bit-exactly -- slower; v_rcp_f64 + two Newton steps, ~1 ulp, instead of the
+        // division -- kept: the division's ~25 dependent instructions were half of a pivot's 380 cycles.)
+        const double idet = fast_rcp64(fma(a, d, -(b * bt)));
+        const double f0 = (d * r0 - b * r1) * idet, f1 = (a * r1 - bt * r0) * idet;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int row = g * 4 + q;
-            const double old = c == p ? 0.0 : cur[q];
-            cur[q] = row == p ? f : old - col[q] * f;
+            const double old = in_k ? 0.0 : cur[q];
+            cur[q] = row == p ? f0 : row == p + 1 ? f1 : fma(-c1[q], f1, fma(-c0[q], f0, old));
         }
     }
 }
