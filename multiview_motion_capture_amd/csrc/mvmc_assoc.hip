@@ -1556,6 +1556,9 @@ struct Als5Lds {
 // core's order, so the result differs from the FMA form's in the last bits (round 3: als5 no longer bit-identical with round 2's; the
 // gates are the oracle's X_bin / labels / iteration counts, tests/test_gpu_config5_c8p8.py).
 typedef double als5_d4 __attribute__((ext_vector_type(4)));
+#ifndef MVMC_ALS5_PRE
+#define MVMC_ALS5_PRE 4    // pivots of the A-side inversion made ahead (see the solver wave's loop)
+#endif
 // rows [k_lo, k_hi) of F only (raw partial sum: add_rho = false) when several waves share the product
 template <int FSG>
 __device__ __forceinline__ void als5_gram_mfma(const double* __restrict__ sF, int n4, int r, double rho, bool add_rho, double* __restrict__ sGin,
@@ -1591,8 +1594,9 @@ __device__ __forceinline__ void als5_gram_mfma(const double* __restrict__ sF, in
 template <int SRC>
 __device__ __forceinline__ double als5_row_newbcast(double v) {   // lane SRC of the caller's 16-lane row, to the whole row
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + SRC, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + SRC, 0xF, 0xF, false);
+    // (bound_ctrl: every lane is written, so no "old" value has to be materialised -- a v_mov 0 per DPP move otherwise, a sixth of a pivot's instructions)
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + SRC, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + SRC, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 // the pivot column's entries of the caller's four rows (p is a compile-time constant after unrolling: the switch folds)
@@ -1665,6 +1669,25 @@ __device__ __forceinline__ void als5_inv_store(const double (&cur)[4], double* _
     const int c = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int q = 0; q < 4; ++q) sG[(g * 4 + q) * 34 + 16 + c] = cur[q];
+}
+
+// stop / mu decisions of an iteration (bit 0: stop, bit 1: mu x 2, bit 2: mu / 2), as in als7: p_res = sqrt(sum_p) / n and d_res =
+// mu sqrt(sum_d) / n only feed thresholds, so they are decided on the squared sums (mu is a power of two: mu^2 sum_d is exact) and the IEEE
+// sqrt / divide expressions NumPy rounds through are evaluated only when a comparison is closer than 1e-9 to its threshold -- ~100
+// dependent instructions less on the path between two phases.  Wave-uniform inputs: every wave takes the same decision.
+__device__ __forceinline__ int als5_decide(double sum_p, double sum_d, double mu, int n) {
+    const double tol2 = (1e-4 * n) * (1e-4 * n);
+    const double sP = sum_p, sD = (mu * mu) * sum_d;
+    bool stop = sP < tol2 && sD < tol2, up = sP > 100.0 * sD, down = sD > 100.0 * sP;
+    const double eps = 1e-9;
+    const bool amb = !(sP > 1e-200) || !(sD > 1e-200) || fabs(sP - tol2) <= eps * tol2 || fabs(sD - tol2) <= eps * tol2 ||
+                     fabs(sP - 100.0 * sD) <= eps * sP || fabs(sD - 100.0 * sP) <= eps * sD;
+    if (amb) {
+        asm volatile("" ::: "memory");   // (keeps this a branch: the IEEE sqrt / divide sequences stay off the common path)
+        const double p_res = sqrt(sum_p) / n, d_res = mu * sqrt(sum_d) / n;
+        stop = p_res < 1e-4 && d_res < 1e-4; up = p_res > 10 * d_res; down = d_res > 10 * p_res;
+    }
+    return (stop ? 1 : 0) | (up ? 2 : 0) | (down ? 4 : 0);
 }
 
 // One graph (index f of the batch) on a 512-thread workgroup; every thread of the workgroup must call it.
@@ -1789,7 +1812,12 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
         // The inversion for the A update starts as soon as mu is decided -- the solver wave makes the decisions itself right after the
         // residual sums are in -- and so runs beside the tile owners' X1 phase and the workers' H phase instead of beside H alone: its
         // first PRE pivots before the barrier that ends the X1 phase, the rest after it.
-        constexpr int PRE = 4;
+        // Round 3: and it starts SPECULATIVELY before that, with the current mu, in the time this wave used to wait for the tile owners at
+        // the end of the XZY phase; mu moves in ~40 % of the iterations, and only then the load and the first PRE pivots are redone.
+        // Bit-identical either way: the same operations on the same data.  Same-box A/B on config 5 (frames/s): no speculation 106.1 k,
+        // PRE = 4 107.6 k, PRE = 8 103.8 k -- the stand-alone phase profile liked 8 better (an iteration 18.5 k -> 17.7 k cycles), the
+        // chains do not: the pivots crawl beside the tile waves' LDS traffic and delay the barrier everybody waits at.
+        constexpr int PRE = MVMC_ALS5_PRE;
         double cur[4];
         als5_inv_load(cur, sGin, r, 50.0 / mu, false);             // (iteration 0: A^T A + rho I was formed before the loop)
         als5_inv_pivots<0, PRE>(cur);
@@ -1811,22 +1839,29 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
             A5PROF(3)
             __syncthreads();                                       // (workers: A = inv H2)
             A5PROF(4)
-            als5_gram_mfma<FS>(sA, n4, r, 0.0, false, sGin);        // raw A^T A of the next iteration while the tiles are updated
-            A5PROF(5)
+            // raw A^T A of the next iteration while the tiles are updated -- at the workers' priority: nothing waits for it before the phase
+            // ends, but everybody waits for wave 3, which shares this wave's SIMD and got no issue slots while the product ran at priority 3
+            // (the XZY phase lasted 5.7 k cycles where the other tile waves needed 3.5 k)
+            __builtin_amdgcn_s_setprio(0);
+            als5_gram_mfma<FS>(sA, n4, r, 0.0, false, sGin);
             if ((tid & 63) == 0) { sRed[wave] = 0.0; sRed[8 + wave] = 0.0; }
+            MVMC_WAVE_SYNC();
+            als5_inv_load(cur, sGin, r, 50.0 / mu, true);          // speculation: mu stays
+            als5_inv_pivots<0, PRE>(cur);
+            A5PROF(5)
             __syncthreads();
+            __builtin_amdgcn_s_setprio(3);
             A5PROF(6)
             double sum_p = 0.0, sum_d = 0.0;
 #pragma unroll
             for (int q = 0; q < NW5; ++q) { sum_p += sRed[q]; sum_d += sRed[8 + q]; }
-            const double p_res = sqrt(sum_p) / n;
-            const double d_res = mu * sqrt(sum_d) / n;
-            if (p_res < 1e-4 && d_res < 1e-4) { iters = it + 1; break; }
-            if (p_res > 10 * d_res) mu = 2 * mu;
-            else if (d_res > 10 * p_res) mu = mu / 2;
-            MVMC_WAVE_SYNC();
-            als5_inv_load(cur, sGin, r, 50.0 / mu, true);          // A^T A + rho I with the NEW rho: the first pivots beside the X1 phase
-            als5_inv_pivots<0, PRE>(cur);
+            const int dec = als5_decide(sum_p, sum_d, mu, n);
+            if (dec & 1) { iters = it + 1; break; }
+            if (dec & 6) {
+                mu = (dec & 2) ? 2 * mu : mu / 2;
+                als5_inv_load(cur, sGin, r, 50.0 / mu, true);      // A^T A + rho I with the NEW rho: the first pivots beside the X1 phase
+                als5_inv_pivots<0, PRE>(cur);
+            }
             A5PROF(0)
             __syncthreads();                                       // (tile owners: X1 of the next iteration)
             A5PROF(1)
@@ -1835,7 +1870,6 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
         for (int it = 0; it < 1000; ++it) {
             // (X1 = Z - (Y - W + beta) / mu of this iteration is in sX: written before the loop, then at the end of the previous iteration)
             const double inv_mu = 1.0 / mu;      // mu = 64 * 2^k: the reciprocal is exact, x * inv_mu == x / mu bit for bit
-            const double rho = 50.0 / mu;
             // ================= B = (inv(A^T A + rho I) (A^T X1))^T =================
             // The products of the factor updates run on the matrix cores (v_mfma_f64_16x16x4_f64, operand layout: als5_gram_mfma): wave
             // cb < 5 makes the sixteen columns 16 cb .. of the 16 x n results -- H = A^T X1 in n / 4 instructions per wave (eighteen at
@@ -1933,7 +1967,9 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
                     for (int a = 0; a < TR; ++a)
     #pragma unroll
                         for (int b = 0; b < TC; ++b)
-                            x[a][b] += (ar[a][0].x * bq[b][0].x + ar[a][0].y * bq[b][0].y) + (ar[a][1].x * bq[b][1].x + ar[a][1].y * bq[b][1].y);
+                            // (one chain of fused multiply-adds per element: the phase is bound by instruction issue -- two waves per SIMD,
+                            // twelve independent chains each --, and the pairwise form it replaces cost six instructions per four terms)
+                            x[a][b] = fma(ar[a][1].y, bq[b][1].y, fma(ar[a][1].x, bq[b][1].x, fma(ar[a][0].y, bq[b][0].y, fma(ar[a][0].x, bq[b][0].x, x[a][b]))));
                 }
     #pragma unroll
                 for (int a = 0; a < TR; ++a)
@@ -1942,7 +1978,7 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
                         const unsigned bit = 1u << (a * TC + b);
                         const double xv = x[a][b];
                         double zz = xv + y[a][b] * inv_mu;
-                        zz = zz < 0.0 ? 0.0 : (zz > 1.0 ? 1.0 : zz);
+                        zz = fmin(fmax(zz, 0.0), 1.0);         // (two instructions; the compare / select form of the same clamp took five)
                         zz = (same_grp & bit) ? 0.0 : zz;
                         zz = (on_diag & bit) ? 1.0 : zz;
                         const double dz = xv - zz, dx = xv - xp[a][b];
@@ -1962,11 +1998,10 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
             double sum_p = 0.0, sum_d = 0.0;
     #pragma unroll
             for (int q = 0; q < NW5; ++q) { sum_p += sRed[q]; sum_d += sRed[8 + q]; }
-            const double p_res = sqrt(sum_p) / n;
-            const double d_res = mu * sqrt(sum_d) / n;
-            if (p_res < 1e-4 && d_res < 1e-4) { iters = it + 1; break; }
-            if (p_res > 10 * d_res) mu = 2 * mu;
-            else if (d_res > 10 * p_res) mu = mu / 2;
+            const int dec = als5_decide(sum_p, sum_d, mu, n);
+            if (dec & 1) { iters = it + 1; break; }
+            if (dec & 2) mu = 2 * mu;
+            else if (dec & 4) mu = mu / 2;
             // ---- X1 of the next iteration (sX is free: both factor updates are done) ----
             if (own) {
                 const double inv_next = 1.0 / mu;
