@@ -1943,6 +1943,14 @@ __device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __
             // ================= X = A B^T ; Z ; Y ; residuals =================
             double acc_p = 0.0, acc_d = 0.0;
             if (own) {
+                // (Tried in round 3: X on the matrix cores with the ELEMENT OWNERSHIP in the accumulator layout of v_mfma_f64_16x16x4_f64 --
+                // 5 x 5 tiles of 16 x 16 dealt to the seven worker waves, four matrix instructions per tile, Z / Y / previous X / W of a
+                // lane's sixteen elements in its registers, the update straight on the accumulators, tiles beyond n skipped: 102 KB of
+                // operand reads per iteration instead of 387 KB, exact against the oracle on all 186 graphs.  The stand-alone phase profile
+                // liked it -- an iteration 17.7 k -> 17.3 k cycles at n = 72, 18.8 k -> 16.0 k at n = 64 -- the chains did not: 108.2 k ->
+                // 106.5 k frames/s on the same box.  An fp64 matrix instruction occupies the SIMD's pipe like the sixteen vector FMAs it
+                // stands for (tools/mfma_f64_rate.hip: MFMA waves and vector waves on one SIMD take the SUM of their times), so the tiles'
+                // padding -- 25 x 256 elements for 72 x 72 -- is paid in full.  Dropped.)
                 // X = A B^T on the 3 x 4 tile in four passes over the rank (four slots each): 14 16-byte loads in flight per pass and 28
                 // doubles of operands next to the 48 of state -- more of the rank at once does not fit 256 VGPRs (two waves per SIMD) and
                 // a spilled state costs a global-memory round trip per phase.  Elements beyond n have zero factors, zero state and the
