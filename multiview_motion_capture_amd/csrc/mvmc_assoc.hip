@@ -27,7 +27,7 @@ ingest_kernel(const T* __restrict__ kps, int C, int P, int J_in, const int32_t* 
     const T* src = kps + (size_t)f * nq * J_in * 3;
     for (int e = threadIdx.x; e < nq * 51; e += blockDim.x) {
         int q = e / 51, r = e - q * 51, j = r / 3, k = r - j * 3;
-        int js = (J_in == 25) ? kOp25ToCoco17[j] : j;
+        int js = (J_in == 25) ? op25_to_coco17(j) : j;
         pose[e] = (double)src[(q * J_in + js) * 3 + k];
     }
     __syncthreads();

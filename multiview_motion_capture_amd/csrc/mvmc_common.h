@@ -43,6 +43,10 @@ __device__ __forceinline__ int32_t mvmc_ld_i32(const int32_t* p) {
 
 // OpenPose-25 row of each COCO-17 joint (pose_def.py:72-96 vs :111-137).
 __device__ __constant__ const int kOp25ToCoco17[17] = {0, 16, 15, 18, 17, 5, 2, 6, 3, 7, 4, 12, 9, 13, 10, 14, 11};
+// the same table in registers (five bits per joint): a lookup in the constant above is a dependent global load in front of every keypoint load
+__device__ __forceinline__ int op25_to_coco17(int j) {
+    return j < 12 ? (int)((0x610e3308b193e00ull >> (5 * j)) & 31u) : (int)((0xb729a9u >> (5 * (j - 12))) & 31u);
+}
 
 // Non-contracted double ops: used wherever the reference's NumPy expression rounds
 // after every multiply/add and the result feeds a float32 store (bit-exact D / S).

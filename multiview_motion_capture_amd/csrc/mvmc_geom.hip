@@ -5,34 +5,31 @@
 // ------------------------------------------------------------------------------------------------
 // DLT: one thread per (problem, joint).  The 2V x 4 system is reduced to its 4x4 normal matrix in
 // fp64 registers and the null vector is the eigenvector of the smallest eigenvalue (== last right
-// singular vector of A, mv_math_util.py:235-236): inverse iteration on L D L^T, cyclic Jacobi (fully
-// unrolled -> no scratch) where the spectral gap is small or a pivot vanishes.
+// singular vector of A, mv_math_util.py:235-236): inverse iteration on L D L^T; where the spectral gap is
+// small or a pivot vanishes, the smallest eigenvalue by cyclic Jacobi and the iteration shifted to it.
 // ------------------------------------------------------------------------------------------------
+// Upper triangle of a symmetric 4 x 4 matrix: entry (r, c), r <= c, at index U4(r, c) of ten doubles.
+__host__ __device__ constexpr int U4(int r, int c) { return r <= c ? r * 4 - r * (r - 1) / 2 + (c - r) : c * 4 - c * (c - 1) / 2 + (r - c); }
+// One Jacobi rotation (P, Q) of the cyclic sweep, EIGENVALUES ONLY (no eigenvector accumulation: ten doubles of state where the matrix
+// pair of the first version held thirty-two -- that fallback alone took the kernel from 82 to 164 VGPRs, i.e. from six waves per SIMD
+// to three; the eigenvector now comes from two or three inverse iterations shifted to the eigenvalue found here).
 template <int P, int Q>
-__device__ __forceinline__ void jacobi_rot4(double (&a)[4][4], double (&v)[4][4]) {
-    const double apq = a[P][Q];
+__device__ __forceinline__ void jacobi_rot4_ev(double (&b)[10]) {
+    const double apq = b[U4(P, Q)];
     if (fabs(apq) < 1e-300) return;
-    const double theta = (a[Q][Q] - a[P][P]) / (2.0 * apq);
+    const double theta = (b[U4(Q, Q)] - b[U4(P, P)]) / (2.0 * apq);
     const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
     const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const double akp = a[k][P], akq = a[k][Q];
-        a[k][P] = c * akp - s * akq;
-        a[k][Q] = s * akp + c * akq;
+        if (k == P || k == Q) continue;
+        const double akp = b[U4(k, P)], akq = b[U4(k, Q)];
+        b[U4(k, P)] = c * akp - s * akq;
+        b[U4(k, Q)] = s * akp + c * akq;
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const double apk = a[P][k], aqk = a[Q][k];
-        a[P][k] = c * apk - s * aqk;
-        a[Q][k] = s * apk + c * aqk;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const double vkp = v[k][P], vkq = v[k][Q];
-        v[k][P] = c * vkp - s * vkq;
-        v[k][Q] = s * vkp + c * vkq;
-    }
+    b[U4(P, P)] -= t * apq;
+    b[U4(Q, Q)] += t * apq;
+    b[U4(P, Q)] = 0.0;
 }
 
 // One triangulated point from the views `get(v, kp, Pc)` hands out (v = 0 .. V-1; false = no such member): kp <- {x, y, score},
@@ -54,9 +51,12 @@ __device__ __forceinline__ void dlt_point(int V, double min_score, Get get, doub
     }
     const bool use_all = n_ok < 2;  // "< 2 valid views -> resort to all views" (mv_math_util.py:177-182)
     // upper triangle of the normal matrix A^T A (rows r1 = x P_3 - P_1, r2 = y P_3 - P_2 of every view used)
-    double a00 = 0.0, a01 = 0.0, a02 = 0.0, a03 = 0.0, a11 = 0.0, a12 = 0.0, a13 = 0.0, a22 = 0.0, a23 = 0.0, a33 = 0.0;
+    double a00, a01, a02, a03, a11, a12, a13, a22, a23, a33;
     double ssum = 0.0;
     int nused = 0;
+    auto accumulate = [&]() {
+    a00 = 0.0; a01 = 0.0; a02 = 0.0; a03 = 0.0; a11 = 0.0; a12 = 0.0; a13 = 0.0; a22 = 0.0; a23 = 0.0; a33 = 0.0;
+    ssum = 0.0; nused = 0;
     for (int v = 0; v < V; ++v) {
         double kp[3]; const double* Pc;
         if (!get(v, kp, Pc)) continue;
@@ -71,6 +71,8 @@ __device__ __forceinline__ void dlt_point(int V, double min_score, Get get, doub
         ssum += sc;
         ++nused;
     }
+    };
+    accumulate();
     // The right singular vector of the smallest singular value (mv_math_util.py:152-160: SVD of the 2 nv x 4 system, last row of V^T) =
     // the eigenvector of the smallest eigenvalue of the normal matrix a.  Inverse iteration on a = L D L^T started from e4: the first
     // iterate is L^-T e4, i.e. the inhomogeneous least-squares point (X, 1); every further solve multiplies the error by
@@ -78,70 +80,67 @@ __device__ __forceinline__ void dlt_point(int V, double min_score, Get get, doub
     // the cyclic Jacobi sweeps this replaces took ~3,000 and left the kernel ALU bound at 13 TFLOP/s.  A point
     // seen by fewer than two views has a rank-deficient matrix (a pivot vanishes): the Jacobi path below keeps handling those.
     const double tr = a00 + a11 + a22 + a33;
-    double e0, e1, e2, e3;
-    bool done = false;
-    {
+    double e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 1.0;
+    // inverse iteration on (a - sigma I) = L D L^T from the start vector e; false = a pivot vanished or the iterates did not settle
+    // (reciprocals by v_rcp_f64 + two Newton steps, ~1 ulp: the factors and the normalisation only steer an iteration whose fixed point
+    // does not depend on them, and an IEEE division is ~28 dependent instructions -- a dozen of them were 40 % of a point's instructions)
+    auto inverse_iteration = [&](double sigma, int max_it) -> bool {
         const double floor_ = 1e-13 * tr;
-        const double d0 = a00, i0 = 1.0 / d0;
+        const double d0 = a00 - sigma, i0 = fast_rcp64(d0);
         const double l10 = a01 * i0, l20 = a02 * i0, l30 = a03 * i0;
-        const double d1 = a11 - l10 * a01, i1 = 1.0 / d1;
+        const double d1 = (a11 - sigma) - l10 * a01, i1 = fast_rcp64(d1);
         const double l21 = (a12 - l20 * a01) * i1, l31 = (a13 - l30 * a01) * i1;
-        const double d2 = a22 - l20 * a02 - l21 * l21 * d1, i2 = 1.0 / d2;
+        const double d2 = (a22 - sigma) - l20 * a02 - l21 * l21 * d1, i2 = fast_rcp64(d2);
         const double l32 = (a23 - l30 * a02 - l31 * l21 * d1) * i2;
-        double d3 = a33 - l30 * a03 - l31 * l31 * d1 - l32 * l32 * d2;
-        if (d0 > floor_ && d1 > floor_ && d2 > floor_) {
-            // (the last pivot is ~lambda_min: rounding may push it to zero or below for consistent observations; its size only scales
-            // the iterates, their direction comes from L)
-            const double tiny = 1e-30 * tr + 1e-300;
-            if (!(d3 > tiny)) d3 = tiny;
-            const double i3 = 1.0 / d3;
-            double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 1.0;
-            bool conv = false;
-            for (int it = 0; it < 8; ++it) {
-                // L y = x;  z = y / D;  L^T w = z
-                const double y0 = x0, y1 = x1 - l10 * y0, y2 = x2 - l20 * y0 - l21 * y1, y3 = x3 - l30 * y0 - l31 * y1 - l32 * y2;
-                const double w3 = y3 * i3;
-                const double w2 = y2 * i2 - l32 * w3;
-                const double w1 = y1 * i1 - l21 * w2 - l31 * w3;
-                const double w0 = y0 * i0 - l10 * w1 - l20 * w2 - l30 * w3;
-                // normalised by the component of largest magnitude (sign included): converged iterates repeat
-                double m = w0;
-                if (fabs(w1) > fabs(m)) m = w1;
-                if (fabs(w2) > fabs(m)) m = w2;
-                if (fabs(w3) > fabs(m)) m = w3;
-                const double inv = 1.0 / m;
-                const double n0 = w0 * inv, n1 = w1 * inv, n2 = w2 * inv, n3 = w3 * inv;
-                const double ch = fmax(fmax(fabs(n0 - x0), fabs(n1 - x1)), fmax(fabs(n2 - x2), fabs(n3 - x3)));
-                x0 = n0; x1 = n1; x2 = n2; x3 = n3;
-                if (it > 0 && ch <= 1e-13) { conv = true; break; }
-            }
-            e0 = x0; e1 = x1; e2 = x2; e3 = x3;
-            // not settled after eight solves = a small spectral gap (clusters of mismatched poses, gross outliers: lambda_min / lambda_2
-            // > ~0.03; 15 % of the points of the Shelf clusters, none of the synthetic ones): the Jacobi path below, as before
-            done = conv;
+        double d3 = (a33 - sigma) - l30 * a03 - l31 * l31 * d1 - l32 * l32 * d2;
+        if (!(d0 > floor_ && d1 > floor_ && d2 > floor_)) return false;
+        // (the last pivot is ~lambda_min - sigma: rounding may push it to zero or below for consistent observations; its size only scales
+        // the iterates, their direction comes from L)
+        const double tiny = 1e-30 * tr + 1e-300;
+        if (!(d3 > tiny)) d3 = tiny;
+        const double i3 = fast_rcp64(d3);
+        double x0 = e0, x1 = e1, x2 = e2, x3 = e3;
+        bool conv = false;
+        for (int it = 0; it < max_it; ++it) {
+            // L y = x;  z = y / D;  L^T w = z
+            const double y0 = x0, y1 = x1 - l10 * y0, y2 = x2 - l20 * y0 - l21 * y1, y3 = x3 - l30 * y0 - l31 * y1 - l32 * y2;
+            const double w3 = y3 * i3;
+            const double w2 = y2 * i2 - l32 * w3;
+            const double w1 = y1 * i1 - l21 * w2 - l31 * w3;
+            const double w0 = y0 * i0 - l10 * w1 - l20 * w2 - l30 * w3;
+            // normalised by the component of largest magnitude (sign included): converged iterates repeat
+            double m = w0;
+            if (fabs(w1) > fabs(m)) m = w1;
+            if (fabs(w2) > fabs(m)) m = w2;
+            if (fabs(w3) > fabs(m)) m = w3;
+            const double inv = fast_rcp64(m);
+            const double n0 = w0 * inv, n1 = w1 * inv, n2 = w2 * inv, n3 = w3 * inv;
+            const double ch = fmax(fmax(fabs(n0 - x0), fabs(n1 - x1)), fmax(fabs(n2 - x2), fabs(n3 - x3)));
+            x0 = n0; x1 = n1; x2 = n2; x3 = n3;
+            if (it > 0 && ch <= 1e-13) { conv = true; break; }
         }
-    }
-    if (!done) {
-        double a[4][4] = {{a00, a01, a02, a03}, {a01, a11, a12, a13}, {a02, a12, a22, a23}, {a03, a13, a23, a33}};
-        double vv[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) vv[r][c] = (r == c) ? 1.0 : 0.0;
+        e0 = x0; e1 = x1; e2 = x2; e3 = x3;
+        return conv;
+    };
+    // not settled after eight solves = a small spectral gap (clusters of mismatched poses, gross outliers: lambda_min / lambda_2 > ~0.03;
+    // 15 % of the points of the Shelf clusters, none of the synthetic ones), or a vanished pivot: the smallest eigenvalue by cyclic
+    // Jacobi on the upper triangle, then the same iteration shifted to just below it -- the error then shrinks by
+    // 1e-14 tr / (lambda_2 - lambda_min) per solve, whatever the ratio of the two
+    if (!inverse_iteration(0.0, 8)) {
+        double b[10] = {a00, a01, a02, a03, a11, a12, a13, a22, a23, a33};
         for (int sweep = 0; sweep < 16; ++sweep) {
-            const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[0][3] * a[0][3] + a[1][2] * a[1][2] +
-                               a[1][3] * a[1][3] + a[2][3] * a[2][3];
+            const double off = b[1] * b[1] + b[2] * b[2] + b[3] * b[3] + b[5] * b[5] + b[6] * b[6] + b[8] * b[8];
             if (off <= 1e-36 * tr * tr) break;
-            jacobi_rot4<0, 1>(a, vv); jacobi_rot4<0, 2>(a, vv); jacobi_rot4<0, 3>(a, vv);
-            jacobi_rot4<1, 2>(a, vv); jacobi_rot4<1, 3>(a, vv); jacobi_rot4<2, 3>(a, vv);
+            jacobi_rot4_ev<0, 1>(b); jacobi_rot4_ev<0, 2>(b); jacobi_rot4_ev<0, 3>(b);
+            jacobi_rot4_ev<1, 2>(b); jacobi_rot4_ev<1, 3>(b); jacobi_rot4_ev<2, 3>(b);
         }
-        double lmin = a[0][0];
-        e0 = vv[0][0]; e1 = vv[1][0]; e2 = vv[2][0]; e3 = vv[3][0];
-#pragma unroll
-        for (int k = 1; k < 4; ++k)
-            if (a[k][k] < lmin) { lmin = a[k][k]; e0 = vv[0][k]; e1 = vv[1][k]; e2 = vv[2][k]; e3 = vv[3][k]; }
+        const double lmin = fmin(fmin(b[0], b[4]), fmin(b[7], b[9]));
+        accumulate();      // (the matrix again, from the views: keeping it live across the sweeps would cost twenty registers of the hot path's budget)
+        e0 = 0.0; e1 = 0.0; e2 = 0.0; e3 = 1.0;
+        if (!inverse_iteration(lmin - 1e-14 * tr, 8) && !(e3 == e3)) { e0 = e1 = e2 = 0.0; e3 = 0.0; }   // (NaN guard: 0 / 0 below gives NaN)
     }
-    o[0] = e0 / e3; o[1] = e1 / e3; o[2] = e2 / e3;
+    const double rw = 1.0 / e3;     // (one IEEE division; the three quotients differ from e / e3 by an ulp at most)
+    o[0] = e0 * rw; o[1] = e1 * rw; o[2] = e2 * rw;
     o[3] = ssum / (double)nused;
 }
 
@@ -181,8 +180,11 @@ dlt_kernel(const double* __restrict__ kps17, const double* __restrict__ Pm, cons
 // fp64 vector instructions cost the same whether 17 or 64 lanes are on -- 9.7 ms for 2 M frames against 6.8 ms for the two kernels.)
 // members (F, K, V): pose indices in mvmc_ingest's output numbering, (f C + c) P + slot, all of frame f; -1 = none.
 // ------------------------------------------------------------------------------------------------
+#ifndef MVMC_DLT_WAVES
+#define MVMC_DLT_WAVES 4
+#endif
 template <typename T>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, MVMC_DLT_WAVES)
 ingest_dlt_kernel(const T* __restrict__ kps, int F, int G, int C, int P, int J_in, const int32_t* __restrict__ counts_in,
                   double min_score_in, int min_valid, double min_bb, const double* __restrict__ Pm,
                   const int32_t* __restrict__ members, int K, int V, double min_score, double* __restrict__ out,
@@ -194,23 +196,46 @@ ingest_dlt_kernel(const T* __restrict__ kps, int F, int G, int C, int P, int J_i
     T* pose = reinterpret_cast<T*>(sm_raw);                                                  // [G][nq][17][3]
     int* keep = reinterpret_cast<int*>(sm_raw + (((size_t)G * nq * 51 * sizeof(T) + 7) & ~(size_t)7));   // [G][nq]
     int* src_of = keep + G * nq;                                    // [G][nq] ingest slot -> source pose of the raw layout, -1 = empty
+    int* cnt_l = src_of + G * nq;                                   // [G][C]    the group's view counts
+    int* mem_l = cnt_l + G * C;                                     // [G][K][V] the group's cluster members
     __shared__ double sP[16 * 12];                                  // the projection matrices (C <= 16 checked by the launcher)
     for (int e = tid; e < C * 12; e += 256) sP[e] = Pm[e];
     const int n_groups = (F + G - 1) / G;
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int f0 = grp * G, g_n = min(G, F - f0);
         const T* src = kps + (size_t)f0 * nq * J_in * 3;
-        for (int t = tid; t < g_n * nq * 17; t += 256) {            // t = (frame in group, pose, COCO joint)
-            const int gq = t / 17, j = t - gq * 17;
-            const int js = (J_in == 25) ? kOp25ToCoco17[j] : j;
-            const T* s3 = src + ((size_t)gq * J_in + js) * 3;
-            T* d3 = pose + (size_t)t * 3;
-            d3[0] = s3[0]; d3[1] = s3[1]; d3[2] = s3[2];
+        // Stage A: EVERYTHING the group reads from global memory, issued as one batch of independent loads -- keypoints four trips at a
+        // time, the view counts, the cluster members -- then one wait.  (The first version looked the joint map up in constant memory in
+        // front of every keypoint load, waited for each trip's loads before the next trip's, and read the members and counts from global
+        // memory inside the later stages: ~20 dependent memory round trips per group, which is what the kernel's 2.7 ms were made of.)
+        const int n_tr = g_n * nq * 17;
+        for (int t0 = tid; t0 < n_tr; t0 += 256 * 4) {               // t = (frame in group, pose, COCO joint)
+            T v3[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + 256 * u;
+                if (t < n_tr) {
+                    const int gq = t / 17, j = t - gq * 17;
+                    const int js = (J_in == 25) ? op25_to_coco17(j) : j;
+                    const T* s3 = src + ((size_t)gq * J_in + js) * 3;
+                    v3[u][0] = s3[0]; v3[u][1] = s3[1]; v3[u][2] = s3[2];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + 256 * u;
+                if (t < n_tr) {
+                    T* d3 = pose + (size_t)t * 3;
+                    d3[0] = v3[u][0]; d3[1] = v3[u][1]; d3[2] = v3[u][2];
+                }
+            }
         }
+        for (int t = tid; t < g_n * C; t += 256) cnt_l[t] = counts_in ? counts_in[(size_t)f0 * C + t] : P;
+        for (int t = tid; t < g_n * K * V; t += 256) mem_l[t] = members[(size_t)f0 * K * V + t];
         __syncthreads();
         for (int t = tid; t < g_n * nq; t += 256) {
             const int g = t / nq, q = t - g * nq, c = q / P, p = q - c * P;
-            const int cnt = counts_in ? counts_in[(f0 + g) * C + c] : P;
+            const int cnt = cnt_l[g * C + c];
             int ok = 0;
             if (p < cnt) {
                 int nv = 0;
@@ -242,7 +267,7 @@ ingest_dlt_kernel(const T* __restrict__ kps, int F, int G, int C, int P, int J_i
         __syncthreads();
         for (int t = tid; t < g_n * K * 17; t += 256) {             // t = (frame in group, cluster, joint)
             const int gk = t / 17, j = t - gk * 17, g = gk / K;
-            const int32_t* mem = members + ((size_t)f0 * K + gk) * V;
+            const int* mem = mem_l + gk * V;
             const int base = (f0 + g) * nq;
             const int* so = src_of + g * nq;
             const T* pg = pose + (size_t)g * nq * 51 + j * 3;
@@ -370,11 +395,11 @@ extern "C" int mvmc_ingest_dlt(const void* kps, int dtype, int n_frames, int n_v
     if (n_views > 16) return MVMC_ERR_UNSUPPORTED;
     if (n_frames == 0) return MVMC_OK;
     const int nq = n_views * p_max;
-    const size_t per_frame = (size_t)nq * 51 * (dtype == MVMC_F32 ? 4 : 8) + (size_t)2 * nq * sizeof(int);
-    // frames per group: enough points to fill the 256 threads, inside 48 KB of LDS (three workgroups per CU)
+    const size_t per_frame = (size_t)nq * 51 * (dtype == MVMC_F32 ? 4 : 8) + ((size_t)2 * nq + n_views + (size_t)k_max * v_max) * sizeof(int);
+    // frames per group: enough points to fill the 256 threads, inside 36 KB of LDS (four workgroups per CU: 108 VGPRs)
     int G = 256 / (k_max * 17);
     if (G < 1) G = 1;
-    while (G > 1 && (size_t)G * per_frame > 48 * 1024) --G;
+    while (G > 1 && (size_t)G * per_frame > 36 * 1024) --G;
     if ((size_t)G * per_frame > 64 * 1024) return MVMC_ERR_UNSUPPORTED;
     if (G > n_frames) G = n_frames;
     const size_t shm = (((size_t)G * per_frame + 15) & ~(size_t)15) + 16;
