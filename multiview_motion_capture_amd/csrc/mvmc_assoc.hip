@@ -1131,6 +1131,11 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
 // (Also tried, round 2: ONE entry of G and of E per lane, the pivot row of both through the LDS crossbar, the row's own pivot-column entry by
 // DPP row_newbcast -- the form that pays for the 16 x 16 inversion of als5.  Bit-identical, but here every pivot then waits for a crossbar
 // round trip beside three worker waves that keep the LDS busy: pivots 3-7 went 0.91 k -> 1.15 k cycles, ALS 22.4 -> 24.2 M cycles per chain.)
+// (Round 3: the pivots in 2 x 2 blocks, as in als5 -- one reciprocal and one crossbar round trip per two pivots.  Exact against the
+// oracle's iteration counts, but slower here: a block needs both pivot rows in SGPRs, 4 (8 - p) v_readlane instead of 2 (8 - p) +
+// 2 (7 - p), and the chain it shortens is not what a pivot of this layout waits for: form + inversion 2.27 k -> 2.35 k cycles,
+// 490 k -> 480 k frames/s on the same box.  Also tried: B^T B as three partial sums made by the worker waves over the rows they
+// have just written -- the solver's form 0.77 k -> 0.30 k, the workers' apply phase + 0.35 k: 491 k -> 489 k.)
 template <int P0, int P1>
 __device__ __forceinline__ void gj_inv_steps(double (&g)[8], double& e, double& dself, int lane) {
     const int a = lane & 7;
