@@ -180,15 +180,39 @@ def launch_ranks(n: int) -> int:
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
     sock.close()
+    import tempfile
+    import time
     procs = []
+    out0 = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    # A rank that dies (no such device, a void step, an exception) must not leave the others waiting in a rendezvous or a collective
+    # until their time-outs: the first non-zero exit ends the job -- the remaining ranks (these exact child processes) are terminated.
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    p.terminate()
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    try:
+                        codes[r] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[r] = p.wait()
+            sys.stderr.write(f"bench.py: rank {bad[0]} exited with code {codes[bad[0]]}; the other ranks were stopped\n")
+            break
+        time.sleep(0.2)
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
     return max(abs(c) for c in codes)
 

@@ -67,11 +67,22 @@ def main():
             continue
         kf = sum(fe[kern]) / len(fe[kern]) * 1024
         kw = sum(wr[kern]) / len(wr[kern]) * 1024
+        corr = None
+        if kern.startswith("ingest_dlt_kernel"):
+            # MI355X_MICROARCH.md (HBM / rocprofv3): on gfx950 FETCH_SIZE reports HALF of the bytes of a wide coalesced streaming read.
+            # This kernel streams its input once with 12-byte-per-lane coalesced loads, and the raw counter (1.56 GB at 2 M frames) is
+            # below the 2.1 GB of DISTINCT bytes it must read (17 of 25 joints + members + counts), which no cache can explain; doubled
+            # it is 3.1 GB = the whole 3.0 GB input (the eight unused joints ride along in the 64-byte requests) + tables.
+            corr = {"fetch_counter_bytes": kf, "fetch_correction": 2.0,
+                    "why": "gfx950 FETCH_SIZE counts 64 B per 128-B request of a coalesced streaming read (MI355X_MICROARCH.md); the raw value is below the distinct bytes the kernel reads"}
+            kf *= 2.0
         mix = (rec.get(f"{key}:{wkey}") or {}).get("inst_mix")   # tools/aggregate_insts.py's record carries its own source hash
         rec[f"{key}:{wkey}"] = {"kernel": kern, "fetch_bytes": kf, "write_bytes": kw, "bytes": kf + kw,
                                 "source": os.path.basename(out2), "src_sha": kernel_sources_sha(), "unit": unit}
         if mix:
             rec[f"{key}:{wkey}"]["inst_mix"] = mix
+        if corr:
+            rec[f"{key}:{wkey}"].update(corr)
     json.dump(rec, open(tp, "w"), indent=1)
     print(open(out).read())
     print(open(out2).read())
