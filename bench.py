@@ -258,9 +258,10 @@ def main():
                     help="synthetic scene: 'chains' restarts the people's random walk at every chain head (the workload the round-1 "
                          "numbers were measured on); 'continuous' is one walk over all frames, so the stitch has identities to find")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
-    ap.add_argument("--hand-over", default="auto", choices=["auto", "static", "queue"],
-                    help="fused path: how a chain's workgroups follow one another: static = by block index (relies on in-order "
-                         "dispatch), queue = ready queue (no such assumption); auto = queue when more than one rank runs")
+    ap.add_argument("--hand-over", default="auto", choices=["auto", "ticket", "static", "queue"],
+                    help="fused path: how a chain's workgroups follow one another: ticket = (part, chain) from a ticket drawn at start "
+                         "(no assumption about dispatch order; the default at every N), static = the same mapping by block index "
+                         "(relies on in-order dispatch), queue = ready queue (no assumption, ~3 %% slower); auto = ticket")
     ap.add_argument("--sustain", type=int, default=300,
                     help="after the timed region: this many further consecutive steps of the same command (capped at ~15 s of work), "
                          "reported as 'sustained' beside 'value'; 0 = skip")

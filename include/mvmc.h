@@ -324,8 +324,10 @@ typedef struct mvmcChainBuffers {
     int32_t hand_over;          /* how a chain's workgroups follow one another (n_parts > 1).  0 = by block index (part * n_chains +
                                    chain; a part waits for its chain's flag: relies on workgroups being dispatched in block order,
                                    bounded wait, loud time-out); 1 = ready queue (a workgroup draws a ticket when it starts and takes
-                                   the chain that has been ready longest: no assumption about dispatch order; what the multi-GPU
-                                   path uses).  Same results bit for bit */
+                                   the chain that has been ready longest: no assumption about dispatch order); 2 = the mapping of 0
+                                   indexed by a ticket drawn when the workgroup starts instead of by the block index (a part's
+                                   predecessor holds a lower ticket, so it has started: no assumption about dispatch order, the speed
+                                   of 0; what the Python layer uses).  Same results bit for bit */
     /* inputs */
     const double* kps17;        /* (F,C,P,17,3) after mvmc_ingest */
     const int32_t* counts;      /* (F,C) */
@@ -374,7 +376,7 @@ typedef struct mvmcChainBuffers {
                                    (bit 0: a cluster, a member or a view block dropped, bit 1: more than t_max tracklets),
                                    flags[B + 4 + b] = the void word of chain b (bits 0, 1 as before, bit 2 = graph too large): a
                                    non-zero word voids the chain's results (all chains' after a time-out); from 2 B + 4 on: the
-                                   ready queue's ticket counter, tail and ring (hand_over == 1) */
+                                   ticket counter (hand_over 1, 2), the ready queue's tail and ring (hand_over == 1) */
     double* out_phase_cycles;   /* (B,8) diagnostic: shader cycles of each chain by phase {graph, ALS, assignment, IK, commit,
                                    outputs, whole chain, 0}, or NULL */
 } mvmcChainBuffers;

@@ -180,7 +180,11 @@ __device__ inline double mean17(const double* d) {
 
 // distance of pose b's joints to the epipolar lines of pose a's joints:
 // line = normalise(F^T [x_a, 1]) (computeCorrespondEpilines(pts, 2, F)); mv_math_util.py:307-315
-__device__ __noinline__ double proj_dist(const double* pa, const double* pb, const float* F) {
+// (the result goes through *out, a word in the CALLER's frame: only a call that is handed a pointer into its caller's frame is not a
+// tail-call candidate, and only then does the compiler drop the callee-saved convention of this local function -- with it every call
+// saved and restored the ~50 callee-saved vector registers it touches, 100 scratch stores per call and lane; now 37, and as many in
+// the caller.  mvmc_chain.hip has the story.)
+__device__ __noinline__ void proj_dist(const double* pa, const double* pb, const float* F, double* out) {
     MVMC_ASSUME_LDS(pa); MVMC_ASSUME_LDS(pb);
     double f[9];
     for (int k = 0; k < 9; ++k) f[k] = (double)F[k];
@@ -196,7 +200,7 @@ __device__ __noinline__ double proj_dist(const double* pa, const double* pb, con
         double v = dadd(dadd(dmul(a, pb[j * 3]), dmul(b, pb[j * 3 + 1])), c);
         d[j] = fabs(v);
     }
-    return mean17(d);
+    *out = mean17(d);
 }
 
 // One frame on the calling wave.  sm: N*51 doubles + 2*N*N floats + 2*N ints + 4 words of LDS.
@@ -240,8 +244,9 @@ __device__ __forceinline__ void affinity_wave(double* sm, const double* __restri
         if (j <= i) continue;
         int a = node_v[i], b = node_v[j];
         if (a == b) continue;
-        double d_ab = proj_dist(pts + i * 51, pts + j * 51, Fm + (a * C + b) * 9);
-        double d_ba = proj_dist(pts + j * 51, pts + i * 51, Fm + (b * C + a) * 9);
+        double d_ab, d_ba;
+        proj_dist(pts + i * 51, pts + j * 51, Fm + (a * C + b) * 9, &d_ab);
+        proj_dist(pts + j * 51, pts + i * 51, Fm + (b * C + a) * 9, &d_ba);
         float v = (float)dmul(0.5, dadd(d_ab, d_ba));
         D[i * n + j] = v;
         D[j * n + i] = v;
@@ -1637,6 +1642,10 @@ __device__ __forceinline__ void als5_inv_load(double (&cur)[4], const double* __
 //   augmented matrix, as in the scalar form): M'[K][K] = inv(P), M'[i][K] = -M[i][K] inv(P).
 // The same elimination as two scalar pivots in exact arithmetic ((a r1 - b' r0) / (a d - b b') is what the second scalar pivot forms
 // from the first one's results); the rounding differs.  G is positive definite, so det P > 0.
+// (Tried: LOOK-AHEAD -- every lane carries the current block's pivot rows of its column and applies each block's update to the NEXT
+// block's rows itself (fetched through the crossbar in their state before the block, their pivot-column entries through v_readlane), so
+// that the crossbar round trip leaves the dependent chain.  Exact, bit-identical rows -- and slower: eight more v_readlane and their
+// SGPR hazards per block cost more than the crossbar wait they hide; a block 590 -> 680 cycles, 107.8 k -> 104.7 k frames/s.)
 template <int P0, int P1>
 __device__ __forceinline__ void als5_inv_pivots(double (&cur)[4]) {
     static_assert(P0 % 2 == 0 && P1 % 2 == 0, "pivot blocks are pairs");

@@ -66,7 +66,8 @@ struct MvmcChainArgs {
     double* out_cycles;       // (B,8) shader cycles by phase {graph, ALS, assign, IK, commit, outputs, total}, or NULL
     int parts;                // workgroups per chain (consecutive frame ranges, handed over through flags)
     int queue;                // 0: workgroup (part, chain) = block index (part * n_chains + chain), a part waits for its chain's flag;
-                              // 1: a workgroup draws a ticket when it starts and takes the chain that has been ready longest
+                              // 1: a workgroup draws a ticket when it starts and takes the chain that has been ready longest;
+                              // 2: a workgroup draws a ticket when it starts and (part, chain) = ticket, as in 0
     unsigned* flags;          // (2 B + 4): [0,B) parts completed per chain; [B] time-out, [B+1] graph too large, [B+2] capacity word of
                               // the launch; [B+4+b] the void word of chain b (bit 0 views / clusters, bit 1 tracklet table, bit 2 graph
                               // too large for the layout's association variant); [2B+4] ticket counter, [2B+5] ring tail,
@@ -228,16 +229,27 @@ chain_kernel(Ik1Tables tables_arg, ChainArgs A_by_value) {
     //    chain and next part).  Nothing depends on the dispatch order.  No deadlock: a waiting ticket h needs h - n_chains + 1
     //    finished non-final parts; all lower tickets have started (a ticket is drawn by a RUNNING workgroup), and while a chain is
     //    unfinished they cannot all be final parts.  It costs 0.7 % on one GPU (the pose-pair block below can no longer be made during
-    //    the wait) and is what the multi-GPU path uses, where RCCL's kernels share the CUs with this one.
+    //    the wait).
+    //  * ticket (A.queue == 2, the default): the static mapping, indexed by a TICKET drawn when the workgroup starts instead of by the
+    //    block index: part = ticket / n_chains, chain = ticket % n_chains.  The predecessor of ticket h is ticket h - n_chains: a lower
+    //    ticket, i.e. drawn by a workgroup that has already started -- running or finished, never waiting to be dispatched -- whatever
+    //    order the dispatcher follows; by induction the lowest waiting ticket always has a running predecessor chain, so nothing can
+    //    deadlock.  Chain and part are known at once, so the pose-pair block is made during the wait as in the static mapping, and with
+    //    in-order dispatch the two mappings coincide: the static mapping's speed without its assumption, for one atomic per workgroup.
     const int tid = threadIdx.x, wave = tid >> 6;
 #ifdef MVMC_CHAIN_WAITPROF   // diagnostic build: out_cycles[7] = cycles a chain's workgroups were resident before their frames began
     const long long t_entry = clock64();
 #endif
     __shared__ int s_task;   // part << 20 | chain, or -1: give up
     unsigned* const qwords = A.flags + 2 * A.n_chains + 4;   // {ticket, tail, ring[]}
-    const bool queue = A.queue != 0 && A.parts > 1;
+    const bool queue = A.queue == 1 && A.parts > 1;
+    const bool by_ticket = A.queue == 2 && A.parts > 1;
     unsigned ticket = 0;
-    if (queue && tid == 0) ticket = __hip_atomic_fetch_add(qwords, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((queue || by_ticket) && tid == 0) ticket = __hip_atomic_fetch_add(qwords, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (by_ticket) {                       // every thread needs the index: through s_nt (next written inside the frame loop)
+        if (tid == 0) s_nt = (int)ticket;
+        __syncthreads();
+    }
     // The skeleton tables (ancestor masks, level lists, active columns, row masks) are made ONCE PER CALL on the host by the launcher
     // (ik1_build_tables_host: the same source as the device's ik1_build_tables) and arrive as the first kernel argument: a word per
     // lane from the kernel-argument segment into LDS.  Built here by one wave of every workgroup they cost 97 k cycles per frame --
@@ -253,7 +265,8 @@ chain_kernel(Ik1Tables tables_arg, ChainArgs A_by_value) {
     int b, part;
     int done = 0;   // the phases' report word (see above)
     if (!queue) {
-        b = blockIdx.x % A.n_chains; part = blockIdx.x / A.n_chains;
+        const int idx = by_ticket ? uni(s_nt) : (int)blockIdx.x;
+        b = idx % A.n_chains; part = idx / A.n_chains;
         // work that does not depend on the chain's state comes before the hand-over: for a workgroup that has a predecessor, the
         // pose-pair block of its first frame's graph
         if constexpr (!BIG) { if (part > 0) chain_pose_pairs(arena, A, b * A.L + part * A.L / A.parts, &done); }
@@ -448,7 +461,8 @@ extern "C" int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuff
     A.out_info = B.out_info; A.out_iters = B.out_als_iters; A.out_cycles = B.out_phase_cycles;
     A.parts = B.n_parts > 1 ? B.n_parts : 1;
     if (A.parts > 1 && B.chain_len % A.parts != 0) return MVMC_ERR_ARG;
-    A.queue = B.hand_over == 1;
+    if (B.hand_over < 0 || B.hand_over > 2) return MVMC_ERR_ARG;
+    A.queue = B.hand_over;
     if (B.n_chains >= (1 << 20) || A.parts >= (1 << 10)) return MVMC_ERR_UNSUPPORTED;   // (a ring entry is part << 20 | chain)
     A.flags = B.flags;
     if (hipMemsetAsync(B.flags, 0, sizeof(unsigned) * ((size_t)B.n_chains * (A.parts + 1) + 8), (hipStream_t)stream) != hipSuccess)

@@ -274,9 +274,10 @@ def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tens
     (hand-over through device flags), which lets the hardware dispatcher even out the load when the number of chains is
     not a multiple of the number of workgroup slots.  check_chain_flags(res) tells whether the run is valid.
     kernel_events: a list that receives the (start, end) torch.cuda.Event pair recorded right around the kernel launch.
-    hand_over: "static" (a chain's workgroups are told apart by block index; relies on in-order dispatch, bounded wait) or "queue"
-    (ready queue, no assumption about dispatch order); default: "queue" when torch.distributed runs more than one rank -- RCCL's
-    kernels then share the CUs with this one -- and "static" otherwise (0.7 % faster on one GPU).  Same results bit for bit."""
+    hand_over: "ticket" (default: a workgroup draws a ticket when it starts, ticket = part * n_chains + chain; a part's predecessor
+    holds a lower ticket, so it has started: no assumption about the order of dispatch), "static" (the same mapping by block index:
+    relies on in-order dispatch, bounded wait) or "queue" (ready queue: a freed slot goes to the chain that has been ready longest;
+    no assumption either, ~3 % slower).  Same results bit for bit."""
     import ctypes as C
     from . import _cabi
     F, Cn, P = kps.shape[:3]
@@ -315,14 +316,13 @@ def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tens
     if parts > 1 and L % parts:
         raise ValueError("run_chains_fused: parts must divide the chain length")
     if hand_over is None:
-        import torch.distributed as dist
-        hand_over = "queue" if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 else "static"
-    if hand_over not in ("static", "queue"):
-        raise ValueError("run_chains_fused: hand_over must be 'static' or 'queue'")
+        hand_over = "ticket"
+    if hand_over not in ("static", "queue", "ticket"):
+        raise ValueError("run_chains_fused: hand_over must be 'ticket', 'static' or 'queue'")
     buf = _cabi.MvmcChainBuffers()
     for name, val in dict(n_chains=B, chain_len=L, n_views=Cn, p_max=P, t_max=T, k_max=K, v_max=V, max_nfev_cold=nfev_cold,
                           max_nfev_warm=nfev_warm, n_inits=3, seed_len=seed.numel(), n_parts=parts, force_big=int(force_big),
-                          hand_over=int(hand_over == "queue")).items():
+                          hand_over={"static": 0, "queue": 1, "ticket": 2}[hand_over]).items():
         setattr(buf, name, int(val))
     for name, ten in t.items():
         setattr(buf, name, None if ten is None else ten.data_ptr())

@@ -73,6 +73,19 @@ def test_ready_queue_hand_over_is_bit_identical_to_the_static_mapping(people, vi
             assert torch.equal(q[k], ref[k]), k
         for k in ("params", "joints"):
             assert torch.equal(torch.nan_to_num(q[k]), torch.nan_to_num(ref[k])), k
+        # the ticket protocol (the default): the static mapping indexed by a ticket drawn at start -- same results, every ticket drawn
+        tk = run_chains_fused(hp, kps, cnt, L, hand_over="ticket", force_big=force_big, parts=parts)
+        torch.cuda.synchronize()
+        check_chain_flags(tk)
+        fl = tk["flags"].cpu().numpy()
+        assert (fl[:B] == np_).all() and fl[B] == 0 and fl[2 * B + 4] == B * np_
+        for k in ("meta", "n_tracks", "n_dead", "next_id"):
+            assert torch.equal(tk[k], ref[k]), k
+        for k in ("params", "joints"):
+            assert torch.equal(torch.nan_to_num(tk[k]), torch.nan_to_num(ref[k])), k
+    dflt = run_chains_fused(hp, kps, cnt, L, force_big=force_big)
+    torch.cuda.synchronize()
+    assert int(dflt["flags"][2 * B + 4]) == B * L            # the default protocol draws tickets
     with pytest.raises(ValueError):
         run_chains_fused(hp, kps, cnt, L, hand_over="fifo")
 

@@ -145,8 +145,8 @@ def _rank_main(rank, world, port, q):
     B = F // L
     lo, hi = par.shard_range(B, rank, world)
     comm = torch.cuda.Stream(device=d)
-    # more than one rank: run_chains_fused takes the ready-queue hand-over by itself (no assumption about dispatch order while another
-    # process's kernels and the communication stream's share the GPU); a soak of 100 steps, two in flight, no time-out word allowed
+    # run_chains_fused takes the ticket hand-over by itself (no assumption about dispatch order while another process's kernels and
+    # the communication stream's share the GPU); a soak of 100 steps, two in flight, no time-out word allowed
     from multiview_motion_capture_amd.tracker import check_chain_flags
     k_r, c_r = kps[lo * L:hi * L].contiguous(), counts[lo * L:hi * L].contiguous()
     streams = [torch.cuda.Stream(device=d) for _ in range(2)]
@@ -162,7 +162,7 @@ def _rank_main(rank, world, port, q):
     for old in keep:
         check_chain_flags(old["local"])
         par.check_stitch_info(old)
-    assert int(res["local"]["flags"][2 * (hi - lo) + 4]) == (hi - lo) * L      # tickets were drawn: the queue protocol ran
+    assert int(res["local"]["flags"][2 * (hi - lo) + 4]) == (hi - lo) * L      # tickets were drawn: the order-independent protocol ran
     res["done"].synchronize()
     par.check_stitch_info(res)
     q.put((rank, res["gid"].cpu().numpy()[:B].tobytes(), res["info"].cpu().tolist(), res["match"].cpu().numpy()[:B].tobytes()))
