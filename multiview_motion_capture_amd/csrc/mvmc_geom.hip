@@ -209,10 +209,11 @@ ingest_dlt_kernel(const T* __restrict__ kps, int F, int G, int C, int P, int J_i
         // front of every keypoint load, waited for each trip's loads before the next trip's, and read the members and counts from global
         // memory inside the later stages: ~20 dependent memory round trips per group, which is what the kernel's 2.7 ms were made of.)
         const int n_tr = g_n * nq * 17;
-        for (int t0 = tid; t0 < n_tr; t0 += 256 * 4) {               // t = (frame in group, pose, COCO joint)
-            T v3[4][3];
+        constexpr int NB = 4;                                        // trips per batch (five tie, six spill the staging array)
+        for (int t0 = tid; t0 < n_tr; t0 += 256 * NB) {              // t = (frame in group, pose, COCO joint)
+            T v3[NB][3];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NB; ++u) {
                 const int t = t0 + 256 * u;
                 if (t < n_tr) {
                     const int gq = t / 17, j = t - gq * 17;
@@ -222,7 +223,7 @@ ingest_dlt_kernel(const T* __restrict__ kps, int F, int G, int C, int P, int J_i
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NB; ++u) {
                 const int t = t0 + 256 * u;
                 if (t < n_tr) {
                     T* d3 = pose + (size_t)t * 3;
@@ -396,9 +397,13 @@ extern "C" int mvmc_ingest_dlt(const void* kps, int dtype, int n_frames, int n_v
     if (n_frames == 0) return MVMC_OK;
     const int nq = n_views * p_max;
     const size_t per_frame = (size_t)nq * 51 * (dtype == MVMC_F32 ? 4 : 8) + ((size_t)2 * nq + n_views + (size_t)k_max * v_max) * sizeof(int);
-    // frames per group: enough points to fill the 256 threads, inside 36 KB of LDS (four workgroups per CU: 108 VGPRs)
-    int G = 256 / (k_max * 17);
-    if (G < 1) G = 1;
+    // frames per group: TWO full trips of the 256 threads through the DLT stage (30 frames at C5 P1: the stages' barriers and the
+    // 75-thread filter / compaction stages are per group, and with 15 frames they were a sixth of the time: 1.71 -> 1.49 ms per 2 M
+    // frames; 45 frames need 48 KB of LDS and cost the fourth workgroup per CU: 1.68 ms), inside 36 KB of LDS (four workgroups per CU
+    // at 124 VGPRs)
+    const int g0 = 256 / (k_max * 17) > 0 ? 256 / (k_max * 17) : 1;
+    int G = 2 * g0;
+    if ((size_t)G * per_frame > 36 * 1024) G = g0;
     while (G > 1 && (size_t)G * per_frame > 36 * 1024) --G;
     if ((size_t)G * per_frame > 64 * 1024) return MVMC_ERR_UNSUPPORTED;
     if (G > n_frames) G = n_frames;
