@@ -96,6 +96,8 @@ template <> struct ChainCfg<true> { static constexpr int POOL = 64, N_MAX = 64, 
 
 
 constexpr int CH_EOFF = 2368;   // SMALL: doubles of graph scratch in front of the pose-pair block (NS <= 48: 48 * 48 + 6 + 48 = 2358)
+constexpr int CH_KOFF_BIG = 5280;                  // BIG: the frame's keypoints behind st_affinity_wave's part (72 * 72 + 10 + 72 = 5266)
+constexpr int CH_EOFF_BIG = CH_KOFF_BIG + 64 * 51; // BIG: the pose-pair block (64 x 64) behind the keypoints
 
 template <bool BIG> union ChainArena;
 template <> union ChainArena<false> {
@@ -110,12 +112,14 @@ template <> union ChainArena<false> {
 template <> union ChainArena<true> {
     Als5Lds<72> als;
     struct { Ik1Shared ik[8]; double views[64 * MVMC_IK_VIEW_DOUBLES]; } ikp;   // eight waves: the eight people of config 5 are solved side by side
-    double graph[64 * 51 + 64 * 64 + 64 + 16];   // affinity_wave at N = 64 (st_affinity_wave at NS = 72 needs 72 * 72 + 6 + 72)
+    // affinity_wave at N = 64: 64 * 51 + 64 * 64 + 64 + 16 = 7440; st_affinity_wave at NS = 72: 72 * 72 + 6 + 72, + the frame's keypoints
+    // + the pose-pair block; the line tables of st_pose_pairs_lines (2 * 4 * P * 68 doubles) use st_affinity_wave's part
+    double graph[CH_EOFF_BIG + 64 * 64];
 };
 static_assert(CH_EOFF >= 48 * 48 + 10 + 48 && CH_EOFF + 40 * 40 >= 40 * 51 + 40 * 40 + 40 + 8, "graph scratch covers both graph builders");
 static_assert(sizeof(ChainArena<false>) <= 4 * sizeof(Ik1Shared) + 24 * MVMC_IK_VIEW_DOUBLES * 8, "SMALL: the IK blocks set the arena size");
 static_assert(sizeof(ChainArena<false>) <= 52 * 1024, "SMALL: three workgroups per CU");
-static_assert(64 * 51 + 64 * 64 + 64 + 16 >= 72 * 72 + 10 + 72, "BIG: graph scratch covers both graph builders");
+static_assert(CH_EOFF_BIG + 64 * 64 >= 64 * 51 + 64 * 64 + 64 + 16 && CH_KOFF_BIG >= 72 * 72 + 10 + 72, "BIG: graph scratch covers both graph builders");
 static_assert(sizeof(ChainArena<true>) <= 150 * 1024, "BIG: one workgroup per CU");
 
 // The phases as separate (non-inlined) functions: each gets its own register allocation inside the workgroup's budget
@@ -137,8 +141,21 @@ __device__ __noinline__ void chain_graph_temporal(ChainArena<BIG>& arena, ChainA
     MVMC_ASSUME_LDS(&arena);
     const int C = A.C, P = A.P, T = A.T, NS = T + C * P;
     double* W = A.W_st + (size_t)b * NS * NS;
+    // BIG: the frame's keypoints through LDS (config 5: + 0.7 %).  SMALL keeps reading them from global memory: its pose-pair block is
+    // made while the workgroup waits for its predecessor, where the staging pass is only more work (config 4: - 0.3 %)
+    double* kf = nullptr;
+    const double* Epre = (!BIG && pairs_ready) ? arena.graph + CH_EOFF : nullptr;
+    if constexpr (BIG) {
+        kf = arena.graph + CH_KOFF_BIG;
+        st_stage_keypoints(kf, A.kps17, f, C, P);
+        __syncthreads();
+        if (2 * 4 * P * 68 <= CH_KOFF_BIG && C * P <= 64) {       // the pair errors by line tables (config 5: P = 8)
+            st_pose_pairs_lines<ChainCfg<BIG>::NT>(arena.graph + CH_EOFF_BIG, arena.graph, kf, A.counts, f, A.F2, C, P, 0.1);
+            Epre = arena.graph + CH_EOFF_BIG;
+        }
+    }
     st_affinity_wave<ChainCfg<BIG>::NT>(arena.graph, A.kps17, A.counts, 0, f, A.joints + (size_t)b * T * 54, A.n_tracks + b, A.Pm, A.F2, C, P,
-                           T, 0.1, W, nullptr, A.gc + (size_t)b * (C + 1), (!BIG && pairs_ready) ? arena.graph + CH_EOFF : nullptr, C * P);
+                           T, 0.1, W, nullptr, A.gc + (size_t)b * (C + 1), Epre, C * P, kf);
     *done = 0;
 }
 // the frame's 2-D / 2-D distances, made while the workgroup waits for its predecessor (they do not depend on the tracklets)

@@ -37,7 +37,20 @@ __global__ void fmats_p_kernel(const double* __restrict__ Pm, int C, double* __r
             F2[idx * 9 + i * 3 + j] = det4(P1 + rp[j][0] * 4, P1 + rp[j][1] * 4, P2 + rp[i][0] * 4, P2 + rp[i][1] * 4);
 }
 
-// mean over valid joints of the symmetric point-to-epiline distance; NaN if none is valid
+// The epipolar line of a point under F (transposed = false: l = F x, the line in the other image) or under F^T, scaled as
+// calc_epipolar_error scales it (by 1 / sqrt(a^2 + b^2) unless that is zero), and the norm of the SCALED (a, b) the distance divides by.
+// Shared by epipolar_error and the line tables of st_pose_pairs_lines, so that both form the same expressions.
+__device__ __forceinline__ void epi_line(const double* F, double x, double y, bool transposed, double& a, double& b, double& c, double& nrm) {
+    if (!transposed) { a = F[0] * x + F[1] * y + F[2]; b = F[3] * x + F[4] * y + F[5]; c = F[6] * x + F[7] * y + F[8]; }
+    else             { a = F[0] * x + F[3] * y + F[6]; b = F[1] * x + F[4] * y + F[7]; c = F[2] * x + F[5] * y + F[8]; }
+    const double nu = a * a + b * b, sc = nu != 0.0 ? 1.0 / sqrt(nu) : 1.0;
+    a *= sc; b *= sc; c *= sc;
+    nrm = sqrt(a * a + b * b);
+}
+__device__ __forceinline__ double epi_dist(double a, double b, double c, double nrm, double x, double y) { return fabs(a * x + b * y + c) / nrm; }
+
+// mean over valid joints of the symmetric point-to-epiline distance; NaN if none is valid (epi_line / epi_dist above are these
+// expressions, factored out for the line tables; tests/test_gpu_config5_c8p8.py compares the two forms bit for bit)
 __device__ __noinline__ double epipolar_error(const double* F, const double* k1, const double* k2, double min_score) {
     double total = 0.0;
     int cnt = 0;
@@ -82,10 +95,19 @@ __device__ __noinline__ double reproj_error(const double* joints, const double* 
 // The 2-D / 2-D block of the match_spatial_time graph (calc_epipolar_error per pose pair of different views, motion_capture.py:686-700)
 // depends only on the frame's own detections: a chain-frame workgroup computes it while it waits for its predecessor's tracklets.
 // E[q_i * N + q_j], q = view * P + person, N = C * P; entries of absent poses and same-view pairs are not written (never read).
+// The frame's keypoints (C * P poses x 51 doubles) into LDS, one batch of coalesced loads; every thread of the workgroup calls, the
+// caller synchronises.  epipolar_error / reproj_error walk a pose's 17 joints with a data-dependent `continue` per joint: from global
+// memory that is a chain of dependent memory round trips per pose pair (the pattern that made up the triangulation kernel's 2.7 ms,
+// DESIGN.md section 6); from LDS it is arithmetic.
+__device__ __forceinline__ void st_stage_keypoints(double* dst, const double* __restrict__ kps17, int f, int C, int P) {
+    const double* src = kps17 + (size_t)f * C * P * 51;
+    for (int e = threadIdx.x; e < C * P * 51; e += blockDim.x) dst[e] = src[e];
+}
+// kf_lds: the frame's keypoints staged in LDS by the caller (st_stage_keypoints), or nullptr = read them from kps17
 __device__ __forceinline__ void st_pose_pairs(double* E, const double* __restrict__ kps17, const int32_t* __restrict__ counts, int f,
-                                              const double* __restrict__ F2, int C, int P, double min_score) {
+                                              const double* __restrict__ F2, int C, int P, double min_score, const double* kf_lds = nullptr) {
     const int N = C * P;
-    const double* kf = kps17 + (size_t)f * C * P * 51;
+    const double* kf = kf_lds ? kf_lds : kps17 + (size_t)f * C * P * 51;
     for (int e = threadIdx.x; e < N * N; e += blockDim.x) {
         const int qi = e / N, qj = e - qi * N;
         const int ci = qi / P, cj = qj / P;
@@ -98,13 +120,85 @@ __device__ __forceinline__ void st_pose_pairs(double* E, const double* __restric
     }
 }
 
+// The same block E by LINE TABLES (the BIG layout: 64 poses, 3,584 ordered pairs per frame, where the pair errors were 11 % of a
+// chain's cycles).  A pair's error needs, per joint, the epipolar line of pose i's joint in the other image and that of pose j's joint
+// -- a square root and a division to scale each, another square root for the distance's divisor -- and a line depends on ONE pose and
+// the pair of VIEWS only: the P poses of the other view share it.  Per unordered pair of views {u, v} (two of them per round: the tables
+// fit st_affinity_wave's part of the scratch, which is idle until the block is complete): four tables -- poses of u under F_uv, poses
+// of v under F_uv^T, poses of v under F_vu, poses of u under F_vu^T (the two fundamental matrices are made independently, so (i, j) and
+// (j, i) are different numbers, as in the reference, motion_capture.py:672-700) -- then one thread per ordered pair sums the joints in
+// order with one division per line where epipolar_error does two square roots and two divisions: the same expressions on the same
+// operands (epi_line / epi_dist), bit for bit, in a third of the square roots and divisions.
+// Ls: 2 * 4 * P * 68 doubles of LDS; kf: the frame's keypoints in LDS; every thread of the workgroup calls; ends synchronised.
+template <int NT>
+__device__ __forceinline__ void st_pose_pairs_lines(double* E, double* Ls, const double* kf, const int32_t* __restrict__ counts, int f,
+                                                    const double* __restrict__ F2, int C, int P, double min_score) {
+    const int tid = threadIdx.x, N = C * P, nvp = C * (C - 1) / 2;
+    auto unrank = [&](int vp, int& u, int& v) {        // vp-th pair u < v in lexicographic order
+        u = 0;
+        for (int n = C - 1; vp >= n; --n) { vp -= n; ++u; }
+        v = u + 1 + vp;
+    };
+    for (int r0 = 0; r0 < nvp; r0 += 2) {
+        for (int it = tid; it < 2 * 4 * P * 17; it += NT) {
+            const int joint = it % 17;
+            int t = it / 17;
+            const int p = t % P;
+            t /= P;
+            const int set = t & 3, vl = t >> 2, vp = r0 + vl;
+            if (vp >= nvp) continue;
+            int u, v;
+            unrank(vp, u, v);
+            const int view = (set == 0 || set == 3) ? u : v;
+            const double* Fm = F2 + (set < 2 ? u * C + v : v * C + u) * 9;
+            const double* k = kf + (view * P + p) * 51 + joint * 3;
+            double a, b, c, nrm;
+            epi_line(Fm, k[0], k[1], (set & 1) != 0, a, b, c, nrm);
+            double* L = Ls + (((vl * 4 + set) * P + p) * 17 + joint) * 4;
+            L[0] = a; L[1] = b; L[2] = c; L[3] = nrm;
+        }
+        __syncthreads();
+        for (int it = tid; it < 2 * 2 * P * P; it += NT) {
+            const int pj = it % P;
+            int t = it / P;
+            const int pi = t % P;
+            t /= P;
+            const int dir = t & 1, vl = t >> 1, vp = r0 + vl;
+            if (vp >= nvp) continue;
+            int u, v;
+            unrank(vp, u, v);
+            const int va = dir ? v : u, vb = dir ? u : v;      // the ordered pair: first pose in view va, second in vb; F = F2[va][vb]
+            int na = counts[f * C + va], nb = counts[f * C + vb];
+            na = na < 0 ? 0 : (na > P ? P : na);
+            nb = nb < 0 ? 0 : (nb > P ? P : nb);
+            if (pi >= na || pj >= nb) continue;
+            const int qi = va * P + pi, qj = vb * P + pj;
+            const double* L1 = Ls + ((vl * 4 + (dir ? 2 : 0)) * P + pi) * 68;    // lines of the first pose's joints under F
+            const double* L2 = Ls + ((vl * 4 + (dir ? 3 : 1)) * P + pj) * 68;    // lines of the second pose's joints under F^T
+            const double* k1 = kf + qi * 51, * k2 = kf + qj * 51;
+            double total = 0.0;
+            int cnt = 0;
+            for (int j = 0; j < 17; ++j) {
+                if (!(k1[j * 3 + 2] * k2[j * 3 + 2] > min_score)) continue;
+                const double d1 = epi_dist(L1[j * 4], L1[j * 4 + 1], L1[j * 4 + 2], L1[j * 4 + 3], k2[j * 3], k2[j * 3 + 1]);
+                const double d2 = epi_dist(L2[j * 4], L2[j * 4 + 1], L2[j * 4 + 2], L2[j * 4 + 3], k1[j * 3], k1[j * 3 + 1]);
+                total = total + 0.5 * (d1 + d2);
+                ++cnt;
+            }
+            E[qi * N + qj] = cnt ? total / cnt : __longlong_as_double(0x7ff8000000000000LL);
+        }
+        __syncthreads();
+    }
+}
+
 template <int NT>
 __device__ __forceinline__ void st_affinity_wave(double* sm, const double* __restrict__ kps17, const int32_t* __restrict__ counts,
                                                  int b, int f, const double* __restrict__ track_joints,
                                                  const int32_t* __restrict__ n_tracks, const double* __restrict__ Pm,
                                                  const double* __restrict__ F2, int C, int P, int T, double min_score,
                                                  double* __restrict__ W, double* __restrict__ Dout,
-                                                 int32_t* __restrict__ group_counts, const double* Epre = nullptr, int ldE = 0) {
+                                                 int32_t* __restrict__ group_counts, const double* Epre = nullptr, int ldE = 0,
+                                                 const double* kf_lds = nullptr) {
     // Epre: the pose-pair epipolar errors of this frame made ahead of time (st_pose_pairs; [q_i * ldE + q_j], q = view * P + person)
     constexpr bool WG = NT > 64;
     const int tid = WG ? (int)threadIdx.x : (int)(threadIdx.x & 63);
@@ -133,7 +227,7 @@ __device__ __forceinline__ void st_affinity_wave(double* sm, const double* __res
     }
     sync();
     const int n = s_n;
-    const double* kf = kps17 + (size_t)f * C * P * 51;
+    const double* kf = kf_lds ? kf_lds : kps17 + (size_t)f * C * P * 51;
     const double* tj = track_joints + (size_t)b * T * 54;
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
     for (int e = tid; e < n * n; e += NT) {
