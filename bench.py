@@ -217,6 +217,36 @@ def launch_ranks(n: int) -> int:
     return max(abs(c) for c in codes)
 
 
+OTHER_CONFIGS = (
+    ("config 5: synthetic 25,008 frames/GPU, C=8, P=8 (the per-GPU shard of BASELINE's 200 k frames over 8 GPUs), full path",
+     ["--views", "8", "--people", "8", "--frames", "25008", "--seed", "20260104", "--steps", "3", "--warmup", "1"]),
+    ("config 2: synthetic 2 M frames, C=5, P=1: triangulation only (10 k generated frames tiled on the device)",
+     ["--workload", "dlt", "--people", "1", "--frames", "2000000", "--tile-from", "10000", "--seed", "20260101", "--steps", "20",
+      "--warmup", "3"]),
+)
+
+
+def other_config_lines():
+    """Runs the other BASELINE configurations as child processes of the headline run and returns their lines, trimmed."""
+    import subprocess
+    lines = []
+    for name, argv in OTHER_CONFIGS:
+        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--sustain", "0", "--cpu-frames", "0", "--no-other-configs"]
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            line = json.loads(p.stdout.strip().splitlines()[-1])
+        except Exception as exc:      # never at the cost of the headline line
+            lines.append({"config": name, "error": repr(exc)[:300]})
+            continue
+        keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "tracker_events_per_step",
+                "stages_ms", "accuracy")
+        rec = {"name": name, "command": "python bench.py " + " ".join(argv), **{k: line[k] for k in keep if k in line},
+               "wall_s": time.perf_counter() - t0}
+        lines.append(rec)
+    return lines
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -265,7 +295,18 @@ def main():
     ap.add_argument("--sustain", type=int, default=300,
                     help="after the timed region: this many further consecutive steps of the same command (capped at ~15 s of work), "
                          "reported as 'sustained' beside 'value'; 0 = skip")
+    ap.add_argument("--tile-from", type=int, default=0,
+                    help="generate this many frames on the host and tile them on the device up to --frames (config 2 at 2 M frames: the "
+                         "generator would take minutes; the kernel reads every frame from HBM either way); 0 = generate all frames")
+    ap.add_argument("--other-configs", dest="other_configs", action="store_true", default=None,
+                    help="after the headline region also time BASELINE config 5 (C8 P8, 25,008 frames, 3 steps) and config 2 (C5 P1, "
+                         "triangulation only, 2 M frames, 20 launches) as child runs of this script and report them under "
+                         "'other_configs' (default: on for the default headline command at N = 1)")
+    ap.add_argument("--no-other-configs", dest="other_configs", action="store_false")
     args = ap.parse_args()
+    if args.other_configs is None:
+        args.other_configs = (args.gpus == 1 and args.workload == "full" and (args.frames, args.views, args.people) == (10000, 5, 4)
+                              and args.occlusion == 0.0 and args.path == "fused")
     if args.overlap is None:
         # two steps in flight fill the tail of the chain kernel's launches; the memory-bound triangulation-only pass (config 2) has no
         # such tail, and two overlapped launches would only make each of them last twice as long
@@ -298,11 +339,19 @@ def main():
     L = args.chain_len
     if F % L:
         raise SystemExit("--frames must be a multiple of --chain-len")
-    data = synth.generate(F, C, Pn, args.seed, chain_len=L if args.walk == "chains" else 0, frame_seed=args.seed + 1000 * rank,
+    F_gen = F
+    if args.tile_from:
+        if args.workload != "dlt" or F % args.tile_from or args.tile_from % L:
+            raise SystemExit("--tile-from: only with --workload dlt (independent frames), and it must divide --frames")
+        F_gen = args.tile_from
+    data = synth.generate(F_gen, C, Pn, args.seed, chain_len=L if args.walk == "chains" else 0, frame_seed=args.seed + 1000 * rank,
                           shuffle=args.workload != "dlt", occlusion=args.occlusion, spurious=args.spurious)
     hp = HotPath(data["K"], data["Rt"], device=d)
     kps = torch.from_numpy(data["kps25"]).to(d)
     counts = torch.from_numpy(data["counts"]).to(d)
+    if F_gen != F:
+        kps = kps.repeat(F // F_gen, 1, 1, 1, 1).contiguous()
+        counts = counts.repeat(F // F_gen, 1).contiguous()
     with_ik = args.workload == "full"
     dlt_members = None
     if args.workload == "dlt":      # cluster (f, p) = person slot p of every view (the generator's unshuffled order)
@@ -586,7 +635,8 @@ def main():
                                      f"warm 5+5 after), {('one launch per step, ' + (str(args.parts or L) + ' workgroup(s) per chain')) if args.path == 'fused' else 'one launch per stage'}" + (f", {args.overlap} steps in flight on alternating streams" if args.overlap > 1 else "") if L > 1 else "+IK, every frame cold-started (chain length 1, max_nfev 50+50)")
                                     if with_ik else ""),
                        "frames_per_gpu": F, "views": C, "people": Pn, "chain_len": L, "seed": args.seed, "parallelism": f"frames x{world}",
-                       "steps_in_flight": args.overlap, "occlusion": args.occlusion, "spurious": args.spurious, **extra},
+                       "steps_in_flight": args.overlap, "occlusion": args.occlusion, "spurious": args.spurious,
+                       **({"tiled_from_frames": F_gen} if F_gen != F else {}), **extra},
             "sustained": sustained,
             "tracker_events_per_step": tracker_events,
             "stages_ms": stage_ms,
@@ -633,6 +683,13 @@ def main():
                     res["cpu_baseline"] = numpy_port
             else:
                 res["cpu_baseline"] = cpu_baseline(data, args.cpu_frames, args.nfev_cold)
+        if args.other_configs and world == 1:
+            # BASELINE configs 5 and 2 in the same driver-timed record: child runs of this script (fresh processes: their own inputs, their
+            # own timed regions with the same barrier / synchronize bracket), after this process has given its device memory back
+            del kps, counts, out
+            stitched.clear()
+            torch.cuda.empty_cache()
+            res["other_configs"] = other_config_lines()
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -271,6 +271,24 @@ int mvmc_debug_eigh(const double* A, const double* g, int n_problems, int n, dou
 int mvmc_debug_trstep(const double* B, const double* r, int n_problems, int m, int n, double Delta, double alpha0,
                       double* step, double* out4, double* phase_cycles, mvmcStream_t stream);
 
+/* ONE trust-region model and ONE trial step of the production IK solver from a caller-given iterate -- the unit in which the
+ * reference's recorded iterates are compared (tests/golden/ik_trf_traces.npz: x_k, Delta_k, alpha_k of SciPy's trf_no_bounds,
+ * trf.py:466-500, as called from inverse_kinematics.py:236,274).  The device functions are the solver's own.
+ *   params (B,68): the point x_k (stage 0 optimises the first 57 and keeps params[57:] as lengths; stage 1 all 68)
+ *   Delta, alpha0 (B): trust radius and the Levenberg-Marquardt parameter handed to the sub-problem (solve_lsq_trust_region's
+ *                initial_alpha)
+ *   out (B, MVMC_IK_STEP_OUT_DOUBLES) f64:
+ *     [0] cost at x   [1] |g|_inf   [2] alpha   [3] predicted reduction   [4] |step| as the solver accounts for it (= Delta whenever
+ *     the sub-problem is rank deficient: the share the reference spends on numerically-null directions is modelled, not taken)
+ *     [5] cost at the trial point   [6] path: 0 stopped by the gradient test, 1 Krylov step, 2 eigenbasis fallback; + 4 where the
+ *     Euler-space model was used instead of the reduced coordinates; -1 = fewer than two views   [7] rows of the leading block
+ *     [8, 76) g = J^T f by parameter (0 where the column is structurally zero)   [80, 148) step   [160, 228) trial point
+ *   scratch as mvmc_ik_solve. */
+#define MVMC_IK_STEP_OUT_DOUBLES 240
+int mvmc_debug_ik_model_step(const mvmcSkeleton* skel_host, const double* kps17, const double* Pmats, const int32_t* members,
+                             int n_problems, int v_max, int n_views, int p_max, const double* params, int stage,
+                             const double* Delta, const double* alpha0, double* out, double* scratch, mvmcStream_t stream);
+
 /* The stages of PoseSolver.solve one at a time, and their 3-D-target variants:
  *   stage_mask 1 = solve_pose_reproj (x = root, euler; inverse_kinematics.py:202-238),
  *              2 = solve_pose_bone_lens_reproj (x = root, euler, side lengths; :241-277), 3 = both in sequence;

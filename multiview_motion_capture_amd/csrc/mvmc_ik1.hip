@@ -292,7 +292,9 @@ __device__ __forceinline__ void ik1_trial_point(Ik1Shared& S, const Ik1Tables& T
 // the D slot, vectors and reflectors in the global scratch; the trial is ik1_fallback_trial's).
 // S.sc[0] = |g|^2, S.sc[1] = |g|_inf, S.sc[4..8) = {beta0, tau0, |J^T J|_1, coupling}.
 // ---------------------------------------------------------------------------------------------
-template <int N>
+// DBG (mvmc_debug_ik_model_step only; the solver's instances are DBG = false): the gradient also goes to hh[MVMC_IK_DBG_G + lane].
+constexpr int MVMC_IK_DBG_G = 6500;
+template <int N, bool DBG = false>
 __device__ __noinline__ void ik1_model_step(Ik1Shared& S, const Ik1Tables& T, int stage, bool budget_left, double gtol,
                                             mvmc_gdouble* __restrict__ hh, double Delta, double alpha, bool dump, int* mode_out) {
     // S and T arrive as generic pointers (the function is out of line); telling the compiler that they are LDS turns every
@@ -402,6 +404,7 @@ __device__ __noinline__ void ik1_model_step(Ik1Shared& S, const Ik1Tables& T, in
     MVMC_WAVE_SYNC();
     const double gg = uni(wave_sum_dpp(gj * gj)), ginf = uni(wave_max64(fabs(gj)));
     if (lane == 0) { S.sc[0] = gg; S.sc[1] = ginf; }
+    if (DBG) hh[MVMC_IK_DBG_G + lane] = on ? gj : 0.0;
     M1STAMP(4)
     if (ginf < gtol || !budget_left) { *mode_out = 0; return; }
     double scv, tauv;
@@ -471,7 +474,7 @@ __device__ __noinline__ void ik1_model_step(Ik1Shared& S, const Ik1Tables& T, in
 // code of ik1_model_step on the smaller matrix; the step is mapped back to Euler space before the trial point is formed.
 // *mode_out as ik1_model_step, plus 3 = a joint at gimbal lock (the closed-form null vectors need cos(e_y) != 0): not applicable.
 // ---------------------------------------------------------------------------------------------
-template <int N, int STAGE>
+template <int N, int STAGE, bool DBG = false>
 __device__ __noinline__ void ik1_model_step_r(Ik1Shared& S, const Ik1Tables& T, bool budget_left, double gtol,
                                             mvmc_gdouble* __restrict__ hh, double Delta, double alpha, bool dump, int* mode_out) {
     // S and T arrive as generic pointers (the function is out of line); telling the compiler that they are LDS turns every
@@ -592,7 +595,9 @@ __device__ __noinline__ void ik1_model_step_r(Ik1Shared& S, const Ik1Tables& T, 
     if (!on) gj = 0.0;
     db[lane] = gj;
     MVMC_WAVE_SYNC();
-    const double gg = uni(wave_sum_dpp(gj * gj)), ginf = uni(wave_max64(fabs(expand(T, STAGE, lane, nae, db, refl))));
+    const double ge = expand(T, STAGE, lane, nae, db, refl);
+    const double gg = uni(wave_sum_dpp(gj * gj)), ginf = uni(wave_max64(fabs(ge)));
+    if (DBG) hh[MVMC_IK_DBG_G + lane] = ge;
     MVMC_WAVE_SYNC();
     if (lane == 0) { S.sc[0] = gg; S.sc[1] = ginf; }
     M1STAMP(4)
@@ -987,64 +992,38 @@ inline void ik1_build_tables_host(Ik1Tables& T, const SkelDev& skarg) {
         for (int lane = 0; lane < 64; ++lane) ik1_tables_section(T, skarg, section, lane);
 }
 
-// One solve on the calling wave (problem b); S is this wave's LDS block, `views` its view block (LDS, room for vcap views).  Used by
-// ik1_kernel (one wave per workgroup) and by the chain kernel (four or eight waves per workgroup, one solve each).
-// members (.., V): the problem's pose indices, -1 = none (holes allowed).  More members than vcap: the first vcap are used and bit 0 of
-// *ovf is raised (the result is then not the reference's; with the chain kernel's pool and the stand-alone kernel's v_max block it
-// cannot happen unless the caller's v_max is smaller than a cluster).
-__device__ __forceinline__ void ik1_solve(Ik1Shared& S, double* views, int vcap, const Ik1Tables& T, const double* __restrict__ kps17,
-                                          const double* __restrict__ Pmats, const int32_t* __restrict__ members, int b, int V,
-                                          int C, int Pmax, const double* __restrict__ init, const uint8_t* __restrict__ cold,
-                                          int nfev_cold, int nfev_warm, double* __restrict__ params_out,
-                                          double* __restrict__ joints_out, double* __restrict__ info_out,
-                                          double* __restrict__ scratch, int stage_mask, const double* __restrict__ targets3d,
-                                          int32_t* ovf = nullptr, int n_valid = -1) {
-    // n_valid >= 0: the row's first n_valid entries are the members (the rest of the row is undefined: the chain kernel's table)
+// The members of problem b ranked into the wave: lane v < nv gets its pose index in q_own; returns the number of views used (at most
+// vcap: more raise bit 0 of *ovf).  members (.., V): pose indices, -1 = none (holes allowed); n_valid >= 0: the row's first n_valid
+// entries are the members (the rest of the row is undefined: the chain kernel's table).
+__device__ __forceinline__ int ik1_rank_members(Ik1Shared& S, int vcap, const int32_t* __restrict__ members, int b, int V, int32_t* ovf,
+                                                int n_valid, int& q_own) {
     const int lane = threadIdx.x & 63;
-    b = uni(b);
-    mvmc_gdouble* hh = uni((mvmc_gdouble*)(scratch + (size_t)b * MVMC_IK_SCRATCH_DOUBLES));   // Householder vectors [0, 3200), eigenvectors [3200, 6400)
-    double* info = uni(info_out ? info_out + (size_t)b * 8 : nullptr);
-    if (lane == 0) S.view_off = (int)(views - reinterpret_cast<double*>(&S));
-    // views of this problem (the reference only solves clusters with >= 2 views: motion_capture.py:927,940)
-    int q_own = -1;
-    if (targets3d == nullptr) {
-        // lane v looks at member v (64 per pass); the valid ones are ranked by ballot and parked in LDS at their rank (S.tmp is free here)
-        int* ranked = reinterpret_cast<int*>(S.tmp);
-        int nv = 0;
-        if (n_valid >= 0) {
-            nv = n_valid < 64 ? n_valid : 64;
-            if (lane < nv) ranked[lane] = members[(size_t)b * V + lane];
-        } else
-        for (int v0 = 0; v0 < V; v0 += 64) {
-            const int m = (v0 + lane < V) ? members[(size_t)b * V + v0 + lane] : -1;
-            const unsigned long long have = __builtin_amdgcn_ballot_w64(m >= 0);
-            const int rank = nv + __popcll(have & ((1ull << lane) - 1ull));
-            if (m >= 0 && rank < 64) ranked[rank] = m;
-            nv += __popcll(have);
-        }
-        MVMC_WAVE_SYNC();
-        if (lane < nv) q_own = ranked[lane];
-        MVMC_WAVE_SYNC();
-        nv = uni(nv);
-        if (nv > vcap) { if (ovf && lane == 0) atomicOr(ovf, 1); nv = vcap; }
-        if (nv < 2) {
-            const double nan = __longlong_as_double(0x7ff8000000000000LL);
-            for (int i = lane; i < 68; i += 64) params_out[(size_t)b * 68 + i] = nan;
-            if (lane < 54) joints_out[(size_t)b * 54 + lane] = nan;
-            if (info && lane < 8) info[lane] = nan;
-            return;
-        }
-        if (lane == 0) { S.nviews = nv; S.mode3d = 0; }
-    } else {
-        // 3-D-target mode: targets (B,18,4) in the observation row order (COCO-17 + mid-spine)
-        if (lane < NOBS)
-            for (int c = 0; c < 4; ++c) views[lane * 4 + c] = targets3d[(size_t)b * 72 + kIkObs[lane] * 4 + c];
-        if (lane == 0) { S.nviews = 0; S.mode3d = 1; }
+    // lane v looks at member v (64 per pass); the valid ones are ranked by ballot and parked in LDS at their rank (S.tmp is free here)
+    int* ranked = reinterpret_cast<int*>(S.tmp);
+    int nv = 0;
+    if (n_valid >= 0) {
+        nv = n_valid < 64 ? n_valid : 64;
+        if (lane < nv) ranked[lane] = members[(size_t)b * V + lane];
+    } else
+    for (int v0 = 0; v0 < V; v0 += 64) {
+        const int m = (v0 + lane < V) ? members[(size_t)b * V + v0 + lane] : -1;
+        const unsigned long long have = __builtin_amdgcn_ballot_w64(m >= 0);
+        const int rank = nv + __popcll(have & ((1ull << lane) - 1ull));
+        if (m >= 0 && rank < 64) ranked[rank] = m;
+        nv += __popcll(have);
     }
-    const int n_side = uni(T.n_side);
     MVMC_WAVE_SYNC();
-    // ---- observations: 17 COCO rows + synthetic mid-spine (inverse_kinematics.py:339-348), projection matrices ----
-    const int nv = uni(S.nviews);
+    if (lane < nv) q_own = ranked[lane];
+    MVMC_WAVE_SYNC();
+    nv = uni(nv);
+    if (nv > vcap) { if (ovf && lane == 0) atomicOr(ovf, 1); nv = vcap; }
+    return nv;
+}
+
+// The view block of a problem: 17 COCO rows + synthetic mid-spine (inverse_kinematics.py:339-348) per view, then the projection matrices
+__device__ __forceinline__ void ik1_load_views(double* views, int nv, int q_own, const double* __restrict__ kps17,
+                                               const double* __restrict__ Pmats, int C, int Pmax) {
+    const int lane = threadIdx.x & 63;
     if (lane < nv) {
         const double* kp = kps17 + (size_t)q_own * 51;
         double* dst = views + lane * 54;
@@ -1061,6 +1040,46 @@ __device__ __forceinline__ void ik1_solve(Ik1Shared& S, double* views, int vcap,
         for (int e = 0; e < 12; ++e) views[nv * 54 + lane * 12 + e] = Pc[e];
     }
     MVMC_WAVE_SYNC();
+}
+
+// One solve on the calling wave (problem b); S is this wave's LDS block, `views` its view block (LDS, room for vcap views).  Used by
+// ik1_kernel (one wave per workgroup) and by the chain kernel (four or eight waves per workgroup, one solve each).
+// More members than vcap: the first vcap are used and bit 0 of *ovf is raised (the result is then not the reference's; with the chain
+// kernel's pool and the stand-alone kernel's v_max block it cannot happen unless the caller's v_max is smaller than a cluster).
+__device__ __forceinline__ void ik1_solve(Ik1Shared& S, double* views, int vcap, const Ik1Tables& T, const double* __restrict__ kps17,
+                                          const double* __restrict__ Pmats, const int32_t* __restrict__ members, int b, int V,
+                                          int C, int Pmax, const double* __restrict__ init, const uint8_t* __restrict__ cold,
+                                          int nfev_cold, int nfev_warm, double* __restrict__ params_out,
+                                          double* __restrict__ joints_out, double* __restrict__ info_out,
+                                          double* __restrict__ scratch, int stage_mask, const double* __restrict__ targets3d,
+                                          int32_t* ovf = nullptr, int n_valid = -1) {
+    const int lane = threadIdx.x & 63;
+    b = uni(b);
+    mvmc_gdouble* hh = uni((mvmc_gdouble*)(scratch + (size_t)b * MVMC_IK_SCRATCH_DOUBLES));   // Householder vectors [0, 3200), eigenvectors [3200, 6400)
+    double* info = uni(info_out ? info_out + (size_t)b * 8 : nullptr);
+    if (lane == 0) S.view_off = (int)(views - reinterpret_cast<double*>(&S));
+    // views of this problem (the reference only solves clusters with >= 2 views: motion_capture.py:927,940)
+    int q_own = -1;
+    if (targets3d == nullptr) {
+        const int nv = ik1_rank_members(S, vcap, members, b, V, ovf, n_valid, q_own);
+        if (nv < 2) {
+            const double nan = __longlong_as_double(0x7ff8000000000000LL);
+            for (int i = lane; i < 68; i += 64) params_out[(size_t)b * 68 + i] = nan;
+            if (lane < 54) joints_out[(size_t)b * 54 + lane] = nan;
+            if (info && lane < 8) info[lane] = nan;
+            return;
+        }
+        if (lane == 0) { S.nviews = nv; S.mode3d = 0; }
+    } else {
+        // 3-D-target mode: targets (B,18,4) in the observation row order (COCO-17 + mid-spine)
+        if (lane < NOBS)
+            for (int c = 0; c < 4; ++c) views[lane * 4 + c] = targets3d[(size_t)b * 72 + kIkObs[lane] * 4 + c];
+        if (lane == 0) { S.nviews = 0; S.mode3d = 1; }
+    }
+    const int n_side = uni(T.n_side);
+    MVMC_WAVE_SYNC();
+    const int nv = uni(S.nviews);
+    ik1_load_views(views, nv, q_own, kps17, Pmats, C, Pmax);
     // ---- initial parameters ----
     // stage_mask bit 2: every problem starts from init (mvmc_ik_solve_stages); otherwise cold == NULL means all cold
     const bool is_cold = (stage_mask & 4) ? false : ((cold == nullptr) || uni((int)cold[b]) != 0);
@@ -1131,6 +1150,71 @@ ik1_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __rest
               joints_out, info_out, scratch, stage_mask, targets3d, overflow ? overflow + blockIdx.x : nullptr);
 }
 
+#ifndef MVMC_DEVICE_ONLY
+// ---------------------------------------------------------------------------------------------
+// Diagnostic (mvmc_debug_ik_model_step): ONE trust-region model + ONE trial step of the production solver from a caller-given
+// (x, Delta, alpha) -- the unit in which the reference's recorded iterates are compared (tests/test_gpu_ik_trf_traces.py).  The
+// functions are the solver's own (evaluation, model in reduced coordinates or its Euler-space form, fallback trial); the DBG
+// instances of the model functions differ in one store (the gradient).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64, 3)
+ik1_step_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restrict__ Pmats, const int32_t* __restrict__ members,
+                int V, int vcap, int C, int Pmax, const double* __restrict__ params, int stage, const double* __restrict__ Delta_in,
+                const double* __restrict__ alpha_in, double* __restrict__ out, double* __restrict__ scratch) {
+    __shared__ Ik1Shared S;
+    __shared__ Ik1Tables T;
+    extern __shared__ __attribute__((aligned(16))) double ik1_views[];
+    const int lane = threadIdx.x & 63, b = blockIdx.x;
+    ik1_build_tables(T, skarg);
+    mvmc_gdouble* hh = uni((mvmc_gdouble*)(scratch + (size_t)b * MVMC_IK_SCRATCH_DOUBLES));
+    double* o = out + (size_t)b * MVMC_IK_STEP_OUT_DOUBLES;
+    for (int i = lane; i < MVMC_IK_STEP_OUT_DOUBLES; i += 64) o[i] = 0.0;
+    if (lane == 0) S.view_off = (int)(ik1_views - reinterpret_cast<double*>(&S));
+    int q_own = -1;
+    const int nv = ik1_rank_members(S, vcap, members, b, V, nullptr, -1, q_own);
+    if (nv < 2) { if (lane == 0) o[6] = -1.0; return; }
+    if (lane == 0) { S.nviews = nv; S.mode3d = 0; }
+    const int n_side = uni(T.n_side);
+    MVMC_WAVE_SYNC();
+    ik1_load_views(ik1_views, nv, q_own, kps17, Pmats, C, Pmax);
+    const double* p0 = params + (size_t)b * 68;
+    for (int i = lane; i < 57 + n_side; i += 64) S.x[i] = p0[i];
+    if (lane < n_side) S.side[lane] = p0[57 + lane];
+    MVMC_WAVE_SYNC();
+    const int nfull = (stage == 0) ? 57 : 57 + n_side;
+    const int na = uni(T.na[stage]);
+    const double Delta = Delta_in[b], alpha0 = alpha_in[b], gtol = 1e-8;
+    const double cost = uni(ik1_eval_nl(S, T, 0, stage, true));
+    int mode = 3;
+    bool reduced = false;
+    if (uni(T.arrow_ok)) {
+        if (stage == 0) ik1_model_step_r<30, 0, true>(S, T, true, gtol, hh, Delta, alpha0, false, &mode);
+        else ik1_model_step_r<40, 1, true>(S, T, true, gtol, hh, Delta, alpha0, false, &mode);
+    }
+    reduced = uni(mode) != 3;
+    if (!reduced) {
+        if (na <= 40) ik1_model_step<40, true>(S, T, stage, true, gtol, hh, Delta, alpha0, false, &mode);
+        else ik1_model_step<50, true>(S, T, stage, true, gtol, hh, Delta, alpha0, false, &mode);
+    }
+    mode = uni(mode);
+    if (mode == 2) ik1_fallback_trial(S, T, stage, hh, Delta, alpha0, reduced);
+    MVMC_WAVE_SYNC();
+    if (lane < na) o[8 + T.act[stage][lane]] = hh[MVMC_IK_DBG_G + lane];
+    double cost_new = 0.0;
+    if (mode != 0) {
+        for (int i = lane; i < nfull; i += 64) o[80 + i] = S.xn[i] - S.x[i];
+        for (int i = lane; i < nfull; i += 64) o[160 + i] = S.xn[i];
+        MVMC_WAVE_SYNC();
+        cost_new = uni(ik1_eval_nl(S, T, 1, stage, false));
+    }
+    if (lane == 0) {
+        o[0] = cost; o[1] = S.sc[1];
+        if (mode != 0) { o[2] = S.sc[2]; o[3] = S.sc[3]; o[4] = S.sc[8]; o[5] = cost_new; o[7] = mode == 1 ? S.sc[11] : S.sc[10]; }
+        o[6] = (double)(mode + (reduced ? 0 : 4));
+    }
+}
+#endif
+
 }  // namespace
 
 #ifndef MVMC_DEVICE_ONLY   // (mvmc_chain.hip includes the device code above)
@@ -1182,5 +1266,22 @@ extern "C" int mvmc_ik_solve_stages(const mvmcSkeleton* skel_host, const double*
     return mvmc_ik1_launch(sk, kps17, Pmats, members, n_problems, targets3d ? 1 : v_max, targets3d ? 1 : n_views,
                            targets3d ? 1 : p_max, init_params, /*cold=*/nullptr, max_nfev, max_nfev, params_out, joints_out,
                            info_out, scratch, stage_mask | 4, targets3d, (hipStream_t)stream);
+}
+
+extern "C" int mvmc_debug_ik_model_step(const mvmcSkeleton* skel_host, const double* kps17, const double* Pmats, const int32_t* members,
+                                        int n_problems, int v_max, int n_views, int p_max, const double* params, int stage,
+                                        const double* Delta, const double* alpha0, double* out, double* scratch, mvmcStream_t stream) {
+    if (!skel_host || !kps17 || !Pmats || !members || !params || !Delta || !alpha0 || !out || !scratch) return MVMC_ERR_ARG;
+    if (v_max <= 0 || n_views <= 0 || p_max <= 0 || stage < 0 || stage > 1) return MVMC_ERR_ARG;
+    if (n_problems <= 0) return n_problems == 0 ? MVMC_OK : MVMC_ERR_ARG;
+    SkelDev sk;
+    if (!skel_to_dev(skel_host, &sk)) return MVMC_ERR_ARG;
+    if (sk.n_side != MVMC_N_SIDE) return MVMC_ERR_UNSUPPORTED;
+    if (v_max > 64) return MVMC_ERR_UNSUPPORTED;
+    const size_t lds = sizeof(double) * (size_t)(v_max * MVMC_IK_VIEW_DOUBLES < 64 ? 64 : v_max * MVMC_IK_VIEW_DOUBLES);
+    hipLaunchKernelGGL(ik1_step_kernel, dim3(n_problems), dim3(64), lds, (hipStream_t)stream, sk, kps17, Pmats, members, v_max, v_max,
+                       n_views, p_max, params, stage, Delta, alpha0, out, scratch);
+    MVMC_CHECK_LAUNCH();
+    return MVMC_OK;
 }
 #endif  // MVMC_DEVICE_ONLY

@@ -360,6 +360,27 @@ def ik_solve_fd(kps17: torch.Tensor, Pmats: torch.Tensor, members: torch.Tensor,
     return params, joints, info
 
 
+def ik_model_step(kps17: torch.Tensor, Pmats: torch.Tensor, members: torch.Tensor, params: torch.Tensor, stage: int,
+                  Delta: torch.Tensor, alpha0: torch.Tensor, skeleton: Optional[MvmcSkeleton] = None) -> torch.Tensor:
+    """Diagnostic: one trust-region model + one trial step of the production IK from (params, Delta, alpha0) per problem
+    (mvmc_debug_ik_model_step; layout of the (B, 240) result in include/mvmc.h)."""
+    sk = skeleton if skeleton is not None else make_skeleton()
+    F, Cn, P = kps17.shape[:3]
+    _req(kps17, torch.float64, "kps17", (F, Cn, P, 17, 3))
+    _req(Pmats, torch.float64, "Pmats", (Cn, 3, 4))
+    _req(members, torch.int32, "members")
+    B, V = members.shape
+    _req(params, torch.float64, "params", (B, 68))
+    _req(Delta, torch.float64, "Delta", (B,))
+    _req(alpha0, torch.float64, "alpha0", (B,))
+    dev = kps17.device
+    out = torch.empty((B, _cabi.IK_STEP_OUT_DOUBLES), dtype=torch.float64, device=dev)
+    check(_cabi.load().mvmc_debug_ik_model_step(C.byref(sk), _p(kps17), _p(Pmats), _p(members), B, V, Cn, P, _p(params), int(stage),
+                                                _p(Delta), _p(alpha0), _p(out), _p(_ik_scratch(B, dev)), _stream()),
+          "mvmc_debug_ik_model_step")
+    return out
+
+
 # ----------------------------------------------------------------------------
 # temporal layer (match_spatial_time + tracker), batched over chains
 # ----------------------------------------------------------------------------
