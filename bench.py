@@ -438,40 +438,70 @@ def main():
         with stream_ctx(i):
             return (i, timed, step(timed))
 
+    check_stream = torch.cuda.Stream(device=d) if sharded else None
+
     def finish(rec):
-        """The end of a step: void words of the chain kernel -> repair tier (reads four words back: the host waits for THIS step's
-        kernel, the next step's is already queued), then pack -> all-gather -> stitch on the communication stream."""
+        """The end of a step's compute: pack (+ the shard's own stitch) -> all-gather -> stitch on the communication stream, behind an
+        event -- no device word is read here.  The chain kernel's validity words (hand-over time-out, capacities) travel in the message,
+        so every rank learns of a void step from the gathered messages; settle() looks at them a few steps later."""
         i, timed, out = rec
         with stream_ctx(i):
-            if fused_chain:
-                repaired_per_step.append(repair_chains(hp, kps, counts, out, nfev_cold=args.nfev_cold, nfev_warm=args.nfev_warm))
-                try:
-                    check_chain_flags(out)
-                except (ValueError, RuntimeError) as exc:
-                    raise SystemExit(f"bench.py: step {i} is void: {exc}")
-                out.pop("_keepalive", None)
             if not sharded:
                 return out
             res = par.run_sharded(lambda: out, L, (F // L) * world, rank, world, rows_per_frame=min(Pn + 1, 8), comm_stream=comm,
-                                  timing=timed)
-            if timed:
-                tail_events.append(res["tail_events"])
-            stitched.append(res)
-            if len(stitched) > 3:
-                stitched.pop(0)
-            out = res["local"]
-            out["stitch"] = res
-            return out
+                                  timing=timed, t_msg=par.T_MSG)
+            res["step"], res["timed"] = i, timed
+            return res
+
+    def settle(res):
+        """A finished step's verdict, read once its tail is done (the host is `overlap` steps ahead by then: one small read on an
+        idle stream).  Void on some rank -> every rank has seen it: the rank concerned runs its repair tier (tracker.repair_chains: the
+        chains that outgrew the chain kernel's tables again through the per-stage entry points), then all ranks repeat the step's tail.
+        A step that stays void ends the run."""
+        if not sharded:
+            return res
+        out = res["local"]
+        with torch.cuda.stream(check_stream):
+            try:
+                par.check_stitch_info(res)
+                if fused_chain:
+                    repaired_per_step.append(0)
+            except RuntimeError as exc:
+                if not (fused_chain and "void" in str(exc)):
+                    raise SystemExit(f"bench.py: step {res['step']} is void: {exc}")
+                try:
+                    repaired_per_step.append(repair_chains(hp, kps, counts, out, nfev_cold=args.nfev_cold, nfev_warm=args.nfev_warm))
+                    check_chain_flags(out)
+                    timed = res["timed"]
+                    res = par.run_sharded(lambda: out, L, (F // L) * world, rank, world, rows_per_frame=min(Pn + 1, 8), comm_stream=comm,
+                                          timing=timed, t_msg=par.T_MSG)
+                    res["timed"] = timed
+                    par.check_stitch_info(res)
+                except (ValueError, RuntimeError) as exc2:
+                    raise SystemExit(f"bench.py: step {res.get('step')} is void: {exc2}")
+        out.pop("_keepalive", None)
+        if res["timed"] and res.get("tail_events"):
+            tail_events.append(res["tail_events"])
+        stitched.append(res)
+        if len(stitched) > 3:
+            stitched.pop(0)
+        out["stitch"] = res
+        return out
 
     def run_steps(n, timed):
-        """n steps, args.overlap of them in flight: step i + 1 is launched before step i is finished."""
-        pending, last = [], None
+        """n steps, args.overlap of them in flight: step i + 1 is launched before step i's tail is queued, and a step is settled
+        (its validity read) `overlap` steps after its tail was queued -- the only place the host waits for the device."""
+        pending, tails, last = [], [], None
         for i in range(n):
             pending.append(issue(i, timed))
             if len(pending) >= max(1, args.overlap):
-                last = finish(pending.pop(0))
+                tails.append(finish(pending.pop(0)))
+            while len(tails) > max(1, args.overlap):
+                last = settle(tails.pop(0))
         while pending:
-            last = finish(pending.pop(0))
+            tails.append(finish(pending.pop(0)))
+        while tails:
+            last = settle(tails.pop(0))
         return last
 
     run_steps(args.warmup, False)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVMC_ABI_VERSION 3
+#define MVMC_ABI_VERSION 4
 
 enum {
     MVMC_OK = 0,
@@ -228,26 +228,47 @@ int mvmc_track_commit(const int32_t* status, const int32_t* n_new, const double*
  *   bounds  (n_chains_cap, 2, t_max, MVMC_BOUND_WORDS): tracklet table of the chain's first / last frame:
  *           {local id i32 or -1, 18 x 3 joints f32 (NaN when empty), pad}
  *   rows    (row_cap, MVMC_ROW_WORDS): one row per LIVE tracklet and frame, in frame order:
- *           {frame, slot, id, state, hits, length} i32, 54 joints f32, 68 parameters f32 */
+ *           {frame, slot, id, state, hits, length} i32, 54 joints f32, 68 parameters f32
+ *   local   the shard's OWN stitch, made before the gather so that no rank repeats another's work:
+ *           [0,8) i32 {identities that start in this shard, pairs matched at its inner chain boundaries, error word (bit 0: a chain
+ *                 with more than id_cap ids, bit 1: an assignment did not terminate), void word (bit i = void_words[i] != 0), 0 ...}
+ *           lmatch (n_chains_cap, t_max) i32: slot of the previous chain's last frame matched to slot s of this chain's first (-1;
+ *                 the shard's first chain: -1, its boundary belongs to the gathered pass)
+ *           lgid   (n_chains_cap, id_cap) i32: shard-local identity of (chain, local id), numbered in chain order; -1 = no such id */
 #define MVMC_BOUND_WORDS 56
 #define MVMC_ROW_WORDS 128
-long long mvmc_pack_message_words(int n_chains_cap, int t_max, int row_cap);   /* -1 on bad arguments */
+long long mvmc_pack_message_words(int n_chains_cap, int t_max, int row_cap, int id_cap);   /* -1 on bad arguments */
+long long mvmc_pack_work_words(int n_frames, int chain_len, int id_cap);                  /* words of mvmc_pack_tracks' workspace */
 
-/* Packs mvmc_chain_run's per-frame outputs (out_params (F,T,68), out_joints (F,T,18,3), out_meta (F,T,4), out_n_tracks (F)) and
- * next_id (n_chains) into `message` (mvmc_pack_message_words words).  row_offsets: (n_frames + 1) i32 device workspace.  t_max <= 16. */
+/* Packs mvmc_chain_run's per-frame outputs (out_params (F,t_tables,68), out_joints (F,t_tables,18,3), out_meta (F,t_tables,4),
+ * out_n_tracks (F)) and next_id (n_chains) into `message` (mvmc_pack_message_words words), then stitches the shard's own chain
+ * boundaries (chain b-1 | b: optimal assignment -- Kuhn-Munkres -- of the last frame's tracklets to the first frame's on the mean
+ * joint distance, pairs farther than max_dist metres dropped) and numbers its identities locally (the `local` section).
+ *   t_tables  slots per frame of the tables; t_max <= 16 slots of the message: the SAME on every rank (a rank whose repair tier
+ *             widened its tables still packs t_max slots; every frame's live tracklets must fit: more are cut and show as an
+ *             overflow of rows wanted in no header -- callers pass t_max >= the widest table any rank can have)
+ *   void_words (n_void_words <= 32) u32 device words or NULL: non-zero words (mvmc_chain_run's flags[B .. B + 3): hand-over time-out,
+ *             graph too large, capacity exceeded) are recorded in the message, and every rank's stitch reports them (info[2] bit 2):
+ *             a void step is seen by all ranks without any of them reading device memory before the collective
+ *   work      mvmc_pack_work_words i32 device workspace */
 int mvmc_pack_tracks(const double* out_params, const double* out_joints, const int32_t* out_meta, const int32_t* out_n_tracks,
-                     const int32_t* next_id, int n_frames, int chain_len, int t_max, int n_chains_cap, int row_cap,
-                     int32_t* row_offsets, void* message, mvmcStream_t stream);
+                     const int32_t* next_id, int n_frames, int chain_len, int t_tables, int t_max, int n_chains_cap, int row_cap,
+                     int id_cap, double max_dist, const uint32_t* void_words, int n_void_words, int32_t* work, void* message,
+                     mvmcStream_t stream);
 
 /* Stitches the chains of `world` gathered messages (rank order = sequence order; message r at messages + r * message_words words).
- * Chain boundary g-1 | g: optimal assignment (Kuhn-Munkres) of the last frame's tracklets of chain g-1 to the first frame's of
- * chain g on the mean joint distance, pairs farther than max_dist (metres) dropped; matched tracklets share a global identity.
+ * The inner boundaries of every shard arrive stitched (the `local` sections); here only the world - 1 boundaries between shards are
+ * matched (same rule), local identities become global ones (roots numbered in chain order), and the tables are written -- the result
+ * of one pass over all chain boundaries, at a cost per rank that does not grow with the number of chains of the OTHER ranks beyond
+ * writing their rows of the tables.
  *   gid    (n_chains_total_cap, id_cap) i32 out: global identity of (chain, local id), -1 where the chain has fewer identities
  *   match  (n_chains_total_cap, t_max) i32 out: slot of the previous chain's last frame matched to slot s of this chain's first, -1
  *   info   (4) i32 out: {chains, global identities, error word, pairs}; error word bit 0 = a message overflowed or a chain has more
  *          than id_cap ids, bit 1 = an assignment did not terminate (cannot happen with finite costs; a tracklet with a non-finite
- *          joint is given a cost beyond any max_dist, i.e. it matches nobody).  Non-zero = the result is void
- *   work   (2 * n_chains_total_cap * id_cap) i32 device workspace;  n_chains_total_cap >= world * n_chains_cap */
+ *          joint is given a cost beyond any max_dist, i.e. it matches nobody), bit 2 = some shard's void word is set (its compute
+ *          step was void).  Non-zero = the result is void
+ *   work   mvmc_stitch_work_words i32 device workspace;  n_chains_total_cap >= world * n_chains_cap; id_cap as packed */
+long long mvmc_stitch_work_words(int world, int t_max, int id_cap);
 int mvmc_stitch_chains(const void* messages, long long message_words, int world, int n_chains_cap, int t_max, int row_cap,
                        int id_cap, double max_dist, int n_chains_total_cap, int32_t* gid, int32_t* match, int32_t* info,
                        int32_t* work, mvmcStream_t stream);

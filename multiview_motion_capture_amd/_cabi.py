@@ -27,7 +27,7 @@ SYMBOLS = (
     "mvmc_abi_version", "mvmc_status_string", "mvmc_als_seed_table", "mvmc_ingest", "mvmc_fmats",
     "mvmc_affinity", "mvmc_als_associate", "mvmc_closure_labels", "mvmc_cluster_members", "mvmc_dlt", "mvmc_triangulate_postopt", "mvmc_fk", "mvmc_ik_solve",
     "mvmc_fmats_from_projections", "mvmc_st_affinity", "mvmc_track_assign", "mvmc_track_commit", "mvmc_debug_eigh",
-    "mvmc_debug_trstep", "mvmc_ik_solve_stages", "mvmc_chain_run", "mvmc_svt_associate", "mvmc_debug_ik_solve_fd", "mvmc_debug_ik_model_step", "mvmc_ingest_dlt", "mvmc_pack_message_words", "mvmc_pack_tracks", "mvmc_stitch_chains",
+    "mvmc_debug_trstep", "mvmc_ik_solve_stages", "mvmc_chain_run", "mvmc_svt_associate", "mvmc_debug_ik_solve_fd", "mvmc_debug_ik_model_step", "mvmc_ingest_dlt", "mvmc_pack_message_words", "mvmc_pack_work_words", "mvmc_stitch_work_words", "mvmc_pack_tracks", "mvmc_stitch_chains",
 )
 
 
@@ -94,17 +94,20 @@ def load():
     lib.mvmc_debug_ik_solve_fd.argtypes = [C.POINTER(MvmcSkeleton), vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
     if hasattr(lib, "mvmc_debug_ik_model_step"):   # (absent from older builds loaded through MVMC_LIB_PATH for A/B comparisons)
         lib.mvmc_debug_ik_model_step.argtypes = [C.POINTER(MvmcSkeleton), vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp]
-    lib.mvmc_pack_message_words.argtypes = [i32, i32, i32]
-    lib.mvmc_pack_tracks.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
+    lib.mvmc_pack_message_words.argtypes = [i32, i32, i32, i32]
+    lib.mvmc_pack_work_words.argtypes = [i32, i32, i32]
+    lib.mvmc_stitch_work_words.argtypes = [i32, i32, i32]
+    lib.mvmc_pack_tracks.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f64, vp, i32, vp, vp, vp]
     lib.mvmc_stitch_chains.argtypes = [vp, C.c_longlong, i32, i32, i32, i32, i32, f64, i32, vp, vp, vp, vp, vp]
     ab = bool(os.environ.get("MVMC_LIB_PATH"))   # an older build loaded for an A/B comparison may lack the newest diagnostics
     for name in SYMBOLS:
         if ab and name.startswith("mvmc_debug_") and not hasattr(lib, name):
             continue
         getattr(lib, name)  # AttributeError if the library does not export it
-        if name not in ("mvmc_status_string", "mvmc_pack_message_words"):
+        if name not in ("mvmc_status_string", "mvmc_pack_message_words", "mvmc_pack_work_words", "mvmc_stitch_work_words"):
             getattr(lib, name).restype = C.c_int
-    lib.mvmc_pack_message_words.restype = C.c_longlong
+    for name in ("mvmc_pack_message_words", "mvmc_pack_work_words", "mvmc_stitch_work_words"):
+        getattr(lib, name).restype = C.c_longlong
     _lib = lib
     return lib
 

@@ -334,9 +334,12 @@ def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tens
     if kernel_events is not None:
         k1.record()
         kernel_events.append((k0, k1))
+    # void_words: {a hand-over timed out, a graph too large for the layout's association, a capacity exceeded} -- non-zero = the step is
+    # void unless repair_chains clears it; parallel.run_sharded sends them along, so every rank learns of a void step from the gathered
+    # messages instead of each rank reading its own words back before the collective
     res = dict(params=t["out_params"], joints=t["out_joints"], meta=t["out_meta"], n_tracks=t["out_n_tracks"],
-               n_dead=t["n_dead"], next_id=t["next_id"], flags=t["flags"], void=t["flags"][B + 4:2 * B + 4], n_chains=B,
-               chain_len=L, _keepalive=t)
+               n_dead=t["n_dead"], next_id=t["next_id"], flags=t["flags"], void=t["flags"][B + 4:2 * B + 4],
+               void_words=t["flags"][B:B + 3], n_chains=B, chain_len=L, _keepalive=t)
     if want_info:
         res["ik_info"] = t["out_info"].view(B, L, NP, 8)
         res["als_iters"] = t["out_als_iters"].view(B, L)

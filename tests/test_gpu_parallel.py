@@ -60,6 +60,30 @@ def test_pack_kernel_is_bit_identical_to_host_restatement(run):
         gb, eb = got[o_b:o_r].reshape(b_cap, 2, T, 56)[:B], exp[o_b:o_r].reshape(b_cap, 2, T, 56)[:B]
         assert np.array_equal(gb[..., :55], eb[..., :55])            # ids + joints (NaN bit patterns included)
         assert np.array_equal(got[o_r:o_r + n_written * 128], exp[o_r:o_r + n_written * 128])
+        # the shard's own stitch (made while packing): inner boundaries matched, identities numbered locally
+        e = par.unpack_message(exp, b_cap, T, row_cap)
+        assert (u["local_roots"], u["local_pairs"], u["local_error"], u["void_word"]) == \
+               (e["local_roots"], e["local_pairs"], e["local_error"], e["void_word"]) and u["local_error"] == 0
+        assert np.array_equal(u["lmatch"], e["lmatch"]) and np.array_equal(u["lgid"], e["lgid"])
+        assert u["local_pairs"] > 0 and u["local_roots"] >= P
+    # a message with more slots per frame than the tables (what every rank sends when another rank's tables may be wider), and the
+    # step's validity words travelling with it
+    vw = torch.tensor([0, 5, 0], dtype=torch.int32, device=run["d"])
+    msg = par.pack_tracks(out, out["next_id"], L, B, F * P, t_msg=16, void_words=vw)
+    torch.cuda.synchronize()
+    exp = sn.pack_np(h["params"], h["joints"], h["meta"], h["n_tracks"], h["next_id"], L, B, F * P, t_msg=16, void_words=[0, 5, 0])
+    got = msg.cpu().numpy()
+    assert got.shape == exp.shape
+    u, e = par.unpack_message(got, B, 16, F * P), par.unpack_message(exp, B, 16, F * P)
+    assert u["t_max"] == 16 and u["void_word"] == 2 == e["void_word"]
+    for k in ("ids", "bound_ids", "row_meta", "lmatch", "lgid"):
+        assert np.array_equal(u[k], e[k]), k
+    assert np.array_equal(u["row_joints"], e["row_joints"]) and np.array_equal(u["bound_joints"], e["bound_joints"], equal_nan=True)
+    st = par.stitch_chains(msg.view(1, -1), B, 16, F * P)
+    torch.cuda.synchronize()
+    assert int(st["info"][2]) == 4
+    with pytest.raises(RuntimeError, match="void"):
+        par.check_stitch_info(st)
     # 2 KB per frame at P = 4: 512 B per live tracklet-frame instead of the (T = 8)-padded float64 tables
     assert par.message_words(B, T, F * P) * 4 / F < 2.6e3
 
@@ -94,6 +118,54 @@ def test_stitch_kernel_equals_host_restatement(run, world):
         one_msgs, bc1, rc1 = _split_messages(run, 1)
         one = sn.stitch_np(one_msgs.cpu().numpy(), bc1, T, rc1)
         assert np.array_equal(one["gid"][:B], exp["gid"][:B])
+
+
+def test_stitch_cost_does_not_grow_with_the_number_of_ranks():
+    """The tail at the size of BASELINE config 5's per-GPU shard (1,563 chains of 16 frames, 8 tracklets): pack + the shard's own
+    stitch before the gather, and after it the stitch of `world` such messages -- which matches only world - 1 boundaries and writes the
+    tables.  Synthetic tables (the kernels do not care where the joints come from): 8 people walking, chain-local slot orders."""
+    from multiview_motion_capture_amd import parallel as par
+    d = torch.device("cuda:0")
+    Lc, Bc, Pc, Tc = 16, 1563, 8, 8
+    Fc = Lc * Bc
+    rng = np.random.default_rng(5)
+    base = rng.uniform(-2, 2, size=(Pc, 1, 3)) + rng.normal(size=(Pc, 18, 3)) * 0.2
+    walk = np.cumsum(rng.normal(scale=0.002, size=(Fc, 1, 1, 3)), axis=0)
+    joints = np.zeros((Fc, Tc, 18, 3))
+    meta = np.zeros((Fc, Tc, 4), dtype=np.int32)
+    for b in range(Bc):
+        order = rng.permutation(Pc)
+        joints[b * Lc:(b + 1) * Lc] = (base[None] + walk[b * Lc:(b + 1) * Lc])[:, order]
+        meta[b * Lc:(b + 1) * Lc, :, 0] = np.arange(Pc)[None]
+    out = dict(params=torch.zeros((Fc, Tc, 68), dtype=torch.float64, device=d), joints=torch.from_numpy(joints).to(d),
+               meta=torch.from_numpy(meta).to(d), n_tracks=torch.full((Fc,), Pc, dtype=torch.int32, device=d))
+    nid = torch.full((Bc,), Pc, dtype=torch.int32, device=d)
+    row_cap = Fc * Pc
+
+    def timed(fn, n=5):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            r = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n, r
+
+    t_pack, msg = timed(lambda: par.pack_tracks(out, nid, Lc, Bc, row_cap, t_msg=par.T_MSG))
+    times = {}
+    for world in (1, 2, 5, 8):
+        msgs = msg.view(1, -1).repeat(world, 1).contiguous()
+        times[world], st = timed(lambda: par.stitch_chains(msgs, Bc, par.T_MSG, row_cap))
+        info = st["info"].cpu().tolist()
+        # every shard is the same walk: all 8 people are matched at every boundary, shard boundaries included (the walk's step is tiny)
+        assert info == [world * Bc, Pc, 0, (world * Bc - 1) * Pc], info
+        gid = st["gid"].cpu().numpy()[:world * Bc, :Pc]
+        assert (np.sort(gid, axis=1) == np.arange(Pc)[None]).all()
+    print(f"config-5 shard (1,563 chains, 8 tracklets): pack + own stitch {t_pack:.3f} ms; gathered stitch at world 1 / 2 / 5 / 8: "
+          + " / ".join(f"{times[w]:.3f}" for w in (1, 2, 5, 8)) + " ms")
+    assert times[1] < 0.5 and times[8] < 0.5 + 0.1 * 8        # (round 3: 5.08 ms at world 1, growing with the world)
 
 
 def test_global_identities_follow_the_ground_truth_people(run):
@@ -193,3 +265,66 @@ def test_run_sharded_two_processes_one_gpu(run):
     B = F // L
     assert np.array_equal(np.frombuffer(res[0][1], dtype=np.int32).reshape(B, -1), one["gid"].cpu().numpy()[:B])
     assert res[0][2] == one["info"].cpu().tolist()
+
+
+def _nccl_main(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    import torch.distributed as dist
+    from multiview_motion_capture_amd import parallel as par
+    from multiview_motion_capture_amd.tracker import check_chain_flags, run_chains_fused
+    d = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=d)
+    par.FORCE_COLLECTIVE = True        # no world == 1 short-cut: the all-gather is issued through RCCL
+    from multiview_motion_capture_amd import synth
+    from multiview_motion_capture_amd.pipeline import HotPath
+    Fb, Lb = 10000, 16                 # the benchmark's launch: 625 chains x 16 workgroups, every workgroup slot of the chip taken
+    data = synth.generate(Fb, C, P, 20260103, chain_len=Lb, frame_seed=20260103)
+    hp = HotPath(data["K"], data["Rt"], device=d)
+    kps, counts = torch.from_numpy(data["kps25"]).to(d), torch.from_numpy(data["counts"]).to(d)
+    comm = torch.cuda.Stream(device=d)
+    streams = [torch.cuda.Stream(device=d) for _ in range(2)]
+    torch.cuda.synchronize()
+    keep, n_coll = [], 0
+    import time
+    t0 = time.perf_counter()
+    for i in range(100):
+        with torch.cuda.stream(streams[i % 2]):
+            res = par.run_sharded(lambda: run_chains_fused(hp, kps, counts, Lb), Lb, Fb // Lb, 0, 1, rows_per_frame=P + 1, comm_stream=comm,
+                                  t_msg=par.T_MSG)
+        n_coll += 1
+        keep.append(res)
+        if len(keep) > 2:
+            old = keep.pop(0)
+            check_chain_flags(old["local"])       # no hand-over time-out word
+            par.check_stitch_info(old)
+    for old in keep:
+        check_chain_flags(old["local"])
+        par.check_stitch_info(old)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    info = res["info"].cpu().tolist()
+    ok = res["messages"].shape[0] == 1 and torch.equal(res["messages"][0], res["message"]) and info[0] == Fb // Lb and info[2] == 0
+    q.put((bool(ok), n_coll, Fb * 100 / dt, dist.get_backend()))
+    dist.destroy_process_group()
+
+
+def test_rccl_collective_beside_two_chain_launches_in_flight():
+    """The `nccl` backend (RCCL) initialised at world size 1 in a fresh process, the all-gather forced (no world == 1 short-cut), 100
+    steps of the benchmark's size with two chain-kernel launches in flight: RCCL's work has to find room beside 768 resident workgroups,
+    and no hand-over may time out.  (More than one GPU is not available to the tests; this is the same call path as N > 1.)"""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_main, args=(port, q))
+    p.start()
+    ok, n_coll, fps, backend = q.get(timeout=600)
+    p.join(timeout=120)
+    print(f"RCCL at world size 1: {n_coll} forced all-gathers beside the chain kernel, {fps / 1e3:.0f} k frames/s, backend {backend}")
+    assert ok and n_coll == 100 and backend == "nccl" and p.exitcode == 0

@@ -58,9 +58,10 @@ def fake_sequence(seed=0):
     return dict(params=params, joints=joints, meta=meta, n_tracks=n_tracks, next_id=next_id, who=who)
 
 
-def _pack(out, next_id, chain_len, b_cap, row_cap):
+def _pack(out, next_id, chain_len, b_cap, row_cap, t_msg=None, void_words=None):
     return torch.from_numpy(sn.pack_np(out["params"].numpy(), out["joints"].numpy(), out["meta"].numpy(), out["n_tracks"].numpy(),
-                                       next_id.numpy(), chain_len, b_cap, row_cap))
+                                       next_id.numpy(), chain_len, b_cap, row_cap, t_msg=t_msg,
+                                       void_words=None if void_words is None else void_words.numpy()))
 
 
 def _stitch(msgs, b_cap, t_max, row_cap, max_dist):
@@ -88,27 +89,52 @@ def _check_identities(gid, seq, b_cap, world):
     return len(all_ids)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode="plain"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     seq = fake_sequence()
     lo, hi = shard_range(N_CHAINS, rank, world)
+    # mode "one_rank_widened": rank 1's tables have 16 slots per frame (what tracker.repair_chains leaves behind when a repaired chain
+    # needs more than 8), rank 0's have 8 -- both must send messages of the same size and layout (t_msg)
+    widen = mode == "one_rank_widened" and rank == 1
+    t_msg = 16 if mode == "one_rank_widened" else None
+    t_view = t_msg or T
 
     def compute():
         sl = slice(lo * L, hi * L)
-        return dict(params=torch.from_numpy(seq["params"][sl]), joints=torch.from_numpy(seq["joints"][sl]),
-                    meta=torch.from_numpy(seq["meta"][sl]), n_tracks=torch.from_numpy(seq["n_tracks"][sl]),
-                    next_id=torch.from_numpy(seq["next_id"][lo:hi]))
+        tabs = {k: seq[k][sl] for k in ("params", "joints", "meta")}
+        if widen:
+            for k, v in tabs.items():
+                w = np.zeros((v.shape[0], 16) + v.shape[2:], dtype=v.dtype)
+                w[:, :T] = v
+                tabs[k] = w
+        out = {k: torch.from_numpy(v) for k, v in tabs.items()}
+        out.update(n_tracks=torch.from_numpy(seq["n_tracks"][sl]), next_id=torch.from_numpy(seq["next_id"][lo:hi]))
+        if mode == "void_rank_1":
+            out["void_words"] = torch.tensor([0, 0, 1 if rank == 1 else 0], dtype=torch.int32)
+        return out
 
-    res = run_sharded(compute, L, N_CHAINS, rank, world, rows_per_frame=P, pack=_pack, stitch=_stitch)
+    res = run_sharded(compute, L, N_CHAINS, rank, world, rows_per_frame=P, pack=_pack, stitch=_stitch, t_msg=t_msg)
     info = res["info"].numpy()
+    if mode == "void_rank_1":
+        # every rank sees rank 1's void word in the gathered messages: the step is void everywhere, nobody read a device word
+        from multiview_motion_capture_amd.parallel import check_stitch_info
+        try:
+            check_stitch_info(res)
+            raised = False
+        except RuntimeError as exc:
+            raised = "void" in str(exc)
+        q.put((rank, bool(raised and info[2] & 4), 0, 0, 0, b""))
+        dist.destroy_process_group()
+        return
     ok = info[0] == N_CHAINS and info[2] == 0
     n_ids = _check_identities(res["gid"].numpy(), seq, res["b_cap"], world)
+    ok = ok and all(res["messages"][r].numel() == res["messages"][0].numel() for r in range(world))
     # every shard's rows arrived: frames, slots and joints of rank r are in message r
     got = 0
     for r in range(world):
-        u = unpack_message(res["messages"][r].numpy(), res["b_cap"], T, res["row_cap"])
+        u = unpack_message(res["messages"][r].numpy(), res["b_cap"], t_view, res["row_cap"])
         l2, h2 = shard_range(N_CHAINS, r, world)
         sl = slice(l2 * L, h2 * L)
         ok = ok and u["n_chains"] == h2 - l2 and u["n_rows"] == int(seq["n_tracks"][sl].sum()) == u["rows_wanted"]
@@ -120,20 +146,30 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])     # 7 chains: shards of 4 + 3, and of 3 + 2 + 2
-def test_run_sharded_gloo_end_to_end(world):
+def _run_world(world, mode):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=180) for _ in procs)
     for p in procs:
         p.join(timeout=60)
+    return res
+
+
+def test_a_void_step_of_one_rank_is_seen_by_every_rank():
+    res = _run_world(2, "void_rank_1")
+    assert [r[0] for r in res] == [0, 1] and all(r[1] for r in res)
+
+
+@pytest.mark.parametrize("world,mode", [(2, "plain"), (3, "plain"), (2, "one_rank_widened")])  # 7 chains: shards of 4 + 3, of 3 + 2 + 2
+def test_run_sharded_gloo_end_to_end(world, mode):
+    res = _run_world(world, mode)
     assert [r[0] for r in res] == list(range(world)) and all(r[1] for r in res)
     assert all(r[5] == res[0][5] for r in res)         # every rank holds the same global identities
     assert all(r[2] == 4 for r in res)                 # 3 people + the re-born one
@@ -143,6 +179,7 @@ def test_run_sharded_gloo_end_to_end(world):
     one = sn.stitch_np(sn.pack_np(seq["params"], seq["joints"], seq["meta"], seq["n_tracks"], seq["next_id"], L, N_CHAINS,
                                   N_CHAINS * L * P)[None], N_CHAINS, T, N_CHAINS * L * P)
     two = np.frombuffer(res[0][5], dtype=np.int32).reshape(-1, 16)
+    # (with one rank's tables widened to 16 slots the identities are the same again: the message's slot count is fixed, not the tables')
     # (gid rows are global chain indices, whatever the sharding)
     assert np.array_equal(one["gid"][:N_CHAINS], two[:N_CHAINS])
     assert one["info"][3] == res[0][3]
