@@ -1,4 +1,5 @@
 // Geometry kernels for gfx950: batched multi-view DLT (TR-1/TR-2) and forward kinematics (FK-1/FK-2).
+#include <cstdlib>
 #include "mvmc_common.h"
 #include "mvmc_postopt.h"
 
@@ -37,42 +38,43 @@ __device__ __forceinline__ void jacobi_rot4_ev(double (&b)[10]) {
 // mv_math_util.py:152-187 (triangulate_point_groups_from_multiple_views_linear) + :215-240 (the DLT of one point).
 template <typename Get>
 __device__ __forceinline__ void dlt_point(int V, double min_score, Get get, double* __restrict__ o) {
-    int n_all = 0, n_ok = 0;
+    // upper triangle of the normal matrix A^T A (rows r1 = x P_3 - P_1, r2 = y P_3 - P_2 of every view used).  ONE pass over the views in
+    // the common case: the views with score >= min_score are accumulated while all views are counted; only a point that fewer than
+    // two such views see ("< 2 valid views -> resort to all views", mv_math_util.py:177-182) is accumulated again over all of them.
+    // (The first version counted in a pass of its own: the members, slots and keypoints of every view were read twice.)
+    double a00, a01, a02, a03, a11, a12, a13, a22, a23, a33;
+    double ssum = 0.0;
+    int nused = 0, n_all = 0, n_ok = 0;
+    auto accumulate = [&](bool use_all) {
+    a00 = 0.0; a01 = 0.0; a02 = 0.0; a03 = 0.0; a11 = 0.0; a12 = 0.0; a13 = 0.0; a22 = 0.0; a23 = 0.0; a33 = 0.0;
+    ssum = 0.0; nused = 0; n_all = 0; n_ok = 0;
     for (int v = 0; v < V; ++v) {
         double kp[3]; const double* Pc;
         if (!get(v, kp, Pc)) continue;
+        const double x = kp[0], y = kp[1], sc = kp[2];
         ++n_all;
-        if (kp[2] >= min_score) ++n_ok;
+        const bool ok = sc >= min_score;
+        n_ok += ok ? 1 : 0;
+        if (!use_all && !ok) continue;
+        const double p0 = x * Pc[8] - Pc[0], p1 = x * Pc[9] - Pc[1], p2 = x * Pc[10] - Pc[2], p3 = x * Pc[11] - Pc[3];
+        const double q0 = y * Pc[8] - Pc[4], q1 = y * Pc[9] - Pc[5], q2 = y * Pc[10] - Pc[6], q3 = y * Pc[11] - Pc[7];
+        // two fused multiply-adds per entry (the sum p p + q q + a in one chain: a third fewer instructions than product, fma, add)
+        a00 = fma(p0, p0, fma(q0, q0, a00)); a01 = fma(p0, p1, fma(q0, q1, a01)); a02 = fma(p0, p2, fma(q0, q2, a02));
+        a03 = fma(p0, p3, fma(q0, q3, a03)); a11 = fma(p1, p1, fma(q1, q1, a11)); a12 = fma(p1, p2, fma(q1, q2, a12));
+        a13 = fma(p1, p3, fma(q1, q3, a13)); a22 = fma(p2, p2, fma(q2, q2, a22)); a23 = fma(p2, p3, fma(q2, q3, a23));
+        a33 = fma(p3, p3, fma(q3, q3, a33));
+        ssum += sc;
+        ++nused;
     }
+    };
+    accumulate(false);
     if (n_all == 0) {
         const double nan = __longlong_as_double(0x7ff8000000000000LL);
         o[0] = o[1] = o[2] = o[3] = nan;
         return;
     }
-    const bool use_all = n_ok < 2;  // "< 2 valid views -> resort to all views" (mv_math_util.py:177-182)
-    // upper triangle of the normal matrix A^T A (rows r1 = x P_3 - P_1, r2 = y P_3 - P_2 of every view used)
-    double a00, a01, a02, a03, a11, a12, a13, a22, a23, a33;
-    double ssum = 0.0;
-    int nused = 0;
-    auto accumulate = [&]() {
-    a00 = 0.0; a01 = 0.0; a02 = 0.0; a03 = 0.0; a11 = 0.0; a12 = 0.0; a13 = 0.0; a22 = 0.0; a23 = 0.0; a33 = 0.0;
-    ssum = 0.0; nused = 0;
-    for (int v = 0; v < V; ++v) {
-        double kp[3]; const double* Pc;
-        if (!get(v, kp, Pc)) continue;
-        const double x = kp[0], y = kp[1], sc = kp[2];
-        if (!use_all && !(sc >= min_score)) continue;
-        const double p0 = x * Pc[8] - Pc[0], p1 = x * Pc[9] - Pc[1], p2 = x * Pc[10] - Pc[2], p3 = x * Pc[11] - Pc[3];
-        const double q0 = y * Pc[8] - Pc[4], q1 = y * Pc[9] - Pc[5], q2 = y * Pc[10] - Pc[6], q3 = y * Pc[11] - Pc[7];
-        a00 += p0 * p0 + q0 * q0; a01 += p0 * p1 + q0 * q1; a02 += p0 * p2 + q0 * q2; a03 += p0 * p3 + q0 * q3;
-        a11 += p1 * p1 + q1 * q1; a12 += p1 * p2 + q1 * q2; a13 += p1 * p3 + q1 * q3;
-        a22 += p2 * p2 + q2 * q2; a23 += p2 * p3 + q2 * q3;
-        a33 += p3 * p3 + q3 * q3;
-        ssum += sc;
-        ++nused;
-    }
-    };
-    accumulate();
+    const bool use_all = n_ok < 2;
+    if (use_all) accumulate(true);
     // The right singular vector of the smallest singular value (mv_math_util.py:152-160: SVD of the 2 nv x 4 system, last row of V^T) =
     // the eigenvector of the smallest eigenvalue of the normal matrix a.  Inverse iteration on a = L D L^T started from e4: the first
     // iterate is L^-T e4, i.e. the inhomogeneous least-squares point (X, 1); every further solve multiplies the error by
@@ -135,7 +137,7 @@ __device__ __forceinline__ void dlt_point(int V, double min_score, Get get, doub
             jacobi_rot4_ev<1, 2>(b); jacobi_rot4_ev<1, 3>(b); jacobi_rot4_ev<2, 3>(b);
         }
         const double lmin = fmin(fmin(b[0], b[4]), fmin(b[7], b[9]));
-        accumulate();      // (the matrix again, from the views: keeping it live across the sweeps would cost twenty registers of the hot path's budget)
+        accumulate(use_all);   // (the matrix again, from the views: keeping it live across the sweeps would cost twenty registers of the hot path's budget)
         e0 = 0.0; e1 = 0.0; e2 = 0.0; e3 = 1.0;
         if (!inverse_iteration(lmin - 1e-14 * tr, 8) && !(e3 == e3)) { e0 = e1 = e2 = 0.0; e3 = 0.0; }   // (NaN guard: 0 / 0 below gives NaN)
     }
@@ -288,6 +290,198 @@ ingest_dlt_kernel(const T* __restrict__ kps, int F, int G, int C, int P, int J_i
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same pass for float32 input, software-pipelined (round 4; what BASELINE config 2 runs).  Two LDS buffers; while the workgroup
+// triangulates group g out of one, group g + 1 lands in the other by LDS-DMA:
+//   * global_load_lds_dwordx3 -- a lane hands the hardware the address of ONE (x, y, score) triple and the wave's 64 triples land
+//     side by side in LDS: the OpenPose-25 -> COCO-17 gather is the lanes' source addresses, no staging registers, no ds_write, and
+//     nothing for the wave to wait for until the top of the next iteration;
+//   * the barriers inside an iteration are raw s_barrier behind s_waitcnt lgkmcnt(0) -- a __syncthreads() would drain the DMA in
+//     flight (its fence waits for vmcnt(0)); the two buffers are separate __shared__ objects and the loop body is instantiated once
+//     per buffer order, so that the compiler can tell the buffer being read from the one being filled (a ds_read that may alias a
+//     pending LDS-DMA gets a vmcnt(0) in front of it);
+//   * filter_bad_pose and the per-view compaction are ONE stage (a thread per (frame, view) walks the view's poses): two barriers per
+//     group where the first version had four.
+// Results are those of ingest_dlt_kernel<float> and of mvmc_ingest + mvmc_dlt, bit for bit (same dlt_point on the same numbers).
+// ------------------------------------------------------------------------------------------------
+constexpr int ID2_TRIPLES = 1280;        // per buffer: G frames x nq poses x 17 joints (15 frames at C5 P1), FOUR floats each: the
+                                         // hardware writes a lane's 12 bytes at 16-byte lane stride (tools/glds12_test.hip)
+constexpr int ID2_MISC_INTS = 256;       // view counts [G][C], then cluster members [G][K][V]: a word of each per thread
+constexpr int ID2_SLOT_INTS = 128;       // ingest slot -> source pose [G][nq]
+struct Id2Buf {
+    __attribute__((aligned(16))) float pose[ID2_TRIPLES * 4];
+    int small[ID2_MISC_INTS];            // the group's view counts [G][C], then its cluster members [G][K][V]
+};
+
+// One LDS-DMA of 12 bytes per lane: lane l's triple at base + off lands at LDS byte address lds_wave + 16 l (a 4-byte hole behind each).
+// Inline asm on purpose: hipcc counts a __builtin_amdgcn_global_load_lds and, unable to tell which LDS bytes it writes, puts
+// s_waitcnt vmcnt(0) in front of the next LDS read of ANY object (seen in the ISA of the first version: the DMA was drained right after
+// it was issued).  An asm statement is outside its bookkeeping: the kernel counts these itself (s_waitcnt vmcnt at the top of every
+// iteration, then the barrier, then the reads).  M0 is written in the statement that reads it and restored (the compiler reserves it).
+// The address is a scalar base (the group's first byte) + a 32-bit lane offset that is the SAME for every group: no address arithmetic
+// per group at all.
+__device__ __forceinline__ void id2_glds12(const float* base, unsigned off, unsigned lds_wave) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(base), "s"(__builtin_amdgcn_readfirstlane(lds_wave)) : "memory");
+}
+// a pointer the compiler must hold in scalar registers (the "s" operand of the statements here: a value it cannot prove uniform it
+// would otherwise hand over in vector registers, which is not an encoding of these instructions)
+template <typename T>
+__device__ __forceinline__ const T* id2_uniform(const T* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const T*>(((unsigned long long)hi << 32) | lo);
+}
+// one word per lane (lane stride 4 bytes): the small per-group tables
+__device__ __forceinline__ void id2_glds4(const int32_t* base, unsigned off, unsigned lds_wave) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(base), "s"(__builtin_amdgcn_readfirstlane(lds_wave)) : "memory");
+}
+__device__ __forceinline__ unsigned id2_lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+
+struct Id2Args {
+    const float* kps; const double* Pm; int F, G, C, P, J_in; const int32_t* counts_in; double min_score_in; int min_valid; double min_bb;
+    const int32_t* members; int K, V; double min_score; double* out; int32_t* counts_out;
+};
+
+constexpr int ID2_TRIPS = ID2_TRIPLES / 256;
+// byte offset, from a group's first keypoint, of the triple that element t = tid + 256 u of the group's LDS image comes from:
+// (frame in group, pose, COCO joint) -> the joint's row of the raw pose (the OpenPose-25 -> COCO-17 gather)
+struct Id2Offsets { unsigned o[ID2_TRIPS]; };
+__device__ __forceinline__ Id2Offsets id2_offsets(const Id2Args& A) {
+    Id2Offsets r;
+#pragma unroll
+    for (int u = 0; u < ID2_TRIPS; ++u) {
+        const int t = threadIdx.x + 256 * u;
+        const int gq = t / 17, j = t - gq * 17;
+        const int js = (A.J_in == 25) ? op25_to_coco17(j) : j;
+        r.o[u] = (unsigned)((gq * A.J_in + js) * 12);
+    }
+    return r;
+}
+
+// group grp -> buffer b, asynchronously (every wave issues its own share; nothing is waited for here)
+__device__ __forceinline__ void id2_issue(const Id2Args& A, Id2Buf& b, int grp, const Id2Offsets& off) {
+    const int tid = threadIdx.x;
+    const unsigned w0 = __builtin_amdgcn_readfirstlane(tid & ~63);     // the wave's first element: uniform
+    const int nq = A.C * A.P, f0 = grp * A.G, g_n = min(A.G, A.F - f0);
+    const float* src = id2_uniform(A.kps + (size_t)f0 * nq * A.J_in * 3);
+    const int n_tr = g_n * nq * 17;                                     // elements = (frame in group, pose, COCO joint) triples
+    const unsigned pose0 = id2_lds_addr(b.pose) + w0 * 16;
+#pragma unroll
+    for (int u = 0; u < ID2_TRIPS; ++u)
+        if (tid + 256 * u < n_tr) id2_glds12(src, off.o[u], pose0 + 256 * 16 * u);
+    // the group's view counts and cluster members, a word of each per thread (also by DMA, also outside the compiler's count: an
+    // ordinary load here would have the compiler wait -- for everything, the DMA included -- where the loop comes round)
+    const int n_c = g_n * A.C, n_m = g_n * A.K * A.V;
+    const unsigned small0 = id2_lds_addr(b.small) + w0 * 4;
+    if (A.counts_in) { if (tid < n_c) id2_glds4(id2_uniform(A.counts_in + (size_t)f0 * A.C), tid * 4u, small0); }
+    else if (tid < n_c) b.small[tid] = A.P;
+    if (tid < n_m) id2_glds4(id2_uniform(A.members + (size_t)f0 * A.K * A.V), tid * 4u, small0 + A.G * A.C * 4);
+}
+
+// group grp out of buffer `cur` (its loads were issued an iteration ago) while the next one lands in `nxt`
+__device__ __forceinline__ void id2_step(const Id2Args& A, Id2Buf& cur, Id2Buf& nxt, int* __restrict__ src_of,
+                                         const double* __restrict__ sP, int grp, int grp_next, int n_groups,
+                                         const Id2Offsets& off, float score_thr, int& prev_pts) {
+    const int tid = threadIdx.x, nq = A.C * A.P, P = A.P, C = A.C, K = A.K, V = A.V;
+    const unsigned p_magic = (65536u + (unsigned)P - 1u) / (unsigned)P;   // d / P = d * p_magic >> 16 for d < 128, P <= 16
+    // what this wave issued an iteration ago (the current group's DMA) has landed; its last two operations -- the previous group's
+    // result stores -- may still be on their way (memory operations complete in order: at most two outstanding = they).  As the
+    // builtin, so that the compiler's own count of its stores stays right (the DMA it does not see is OLDER than anything it can think
+    // is still pending here) ...
+    // -- unless this wave had no point in the previous group (the first iteration; a short last group): then nothing younger than the
+    // DMA is outstanding, and "at most two" would let the DMA's own last two operations through
+    if ((int)__builtin_amdgcn_readfirstlane(tid & ~63) < prev_pts) __builtin_amdgcn_s_waitcnt(0x0F72);     // vmcnt(2)
+    else __builtin_amdgcn_s_waitcnt(0x0F70);                                                                // vmcnt(0)
+    // ... then the whole workgroup's
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef ID2_NO_DMA      // (timing experiment: the buffers are filled once; every later group re-uses them)
+    if (grp_next < n_groups && grp_next < 2 * (int)gridDim.x) id2_issue(A, nxt, grp_next, off);
+#else
+    if (grp_next < n_groups) id2_issue(A, nxt, grp_next, off);
+#endif
+    const int* cnt_l = cur.small;
+    const int* mem_l = cur.small + A.G * C;
+    const int f0 = grp * A.G, g_n = min(A.G, A.F - f0);
+    const float* pose = cur.pose;
+    // filter_bad_pose + per-view compaction (motion_capture.py:1023-1043; pose_def.py:262-270: the rule of mvmc_ingest)
+    for (int t = tid; t < g_n * C; t += 256) {
+        const int g = t / C, c = t - g * C;
+        const int cnt = cnt_l[t];
+        int* so = src_of + g * nq + c * P;
+        int k = 0;
+        for (int p = 0; p < P; ++p) {
+            if (p >= cnt) break;
+            // in float32, exactly: score_thr is the smallest float above the double threshold, minima / maxima of floats are floats,
+            // and the box sides are differenced in double as before
+            int nv = 0;
+            float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+            const float4* ps = reinterpret_cast<const float4*>(pose) + (size_t)(g * nq + c * P + p) * 17;
+#pragma unroll
+            for (int j = 0; j < 17; ++j) {
+                const float4 k4 = ps[j];
+                const bool on = k4.z >= score_thr;
+                nv += on ? 1 : 0;
+                x0 = fminf(x0, on ? k4.x : INFINITY); x1 = fmaxf(x1, on ? k4.x : -INFINITY);
+                y0 = fminf(y0, on ? k4.y : INFINITY); y1 = fmaxf(y1, on ? k4.y : -INFINITY);
+            }
+            const double wx = (double)x1 - (double)x0, wy = (double)y1 - (double)y0;
+            if ((nv >= A.min_valid) && !(wx < A.min_bb || wy < A.min_bb)) so[k++] = c * P + p;
+        }
+        if (A.counts_out) A.counts_out[(f0 + g) * C + c] = k;
+        for (; k < P; ++k) so[k] = -1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int t = tid; t < g_n * K * 17; t += 256) {             // t = (frame in group, cluster, joint)
+        const int gk = t / 17, j = t - gk * 17, g = gk / K;
+        const int* mem = mem_l + gk * V;
+        const int base = (f0 + g) * nq;
+        const int* so = src_of + g * nq;
+        const float4* pg = reinterpret_cast<const float4*>(pose) + (size_t)g * nq * 17 + j;
+#ifdef ID2_NO_DLT      // (timing experiment: the stage's LDS reads and stores without its arithmetic)
+        { const int d0 = mem[0] - base; const float4 k4 = pg[(d0 >= 0 && d0 < nq ? so[d0] : 0) * 17];
+          double* o = A.out + ((size_t)f0 * K * 17 + t) * 4; o[0] = k4.x; o[1] = k4.y; o[2] = k4.z; o[3] = sP[j]; continue; }
+#endif
+        dlt_point(V, A.min_score, [&](int v, double (&kp)[3], const double*& Pc) {
+            const int d = mem[v] - base;
+            if (d < 0 || d >= nq) return false;      // (-1, or a member of another frame: not this kernel's contract)
+            const int q = so[d];
+            if (q < 0) return false;
+            const float4 k4 = pg[q * 17];
+            kp[0] = (double)k4.x; kp[1] = (double)k4.y; kp[2] = (double)k4.z;
+            Pc = sP + ((unsigned)d * p_magic >> 16) * 12;        // d / P (d < C P <= 128: exact)
+            return true;
+        }, A.out + ((size_t)f0 * K * 17 + t) * 4);
+    }
+    prev_pts = g_n * K * 17;      // (the waves whose first thread is below this issued their two result stores last)
+}
+
+__global__ void __launch_bounds__(256, 3)      // (45 KB of LDS: three workgroups per CU, so 168 registers may be used)
+ingest_dlt2_kernel(Id2Args A) {
+    __shared__ Id2Buf bufA;
+    __shared__ Id2Buf bufB;
+    __shared__ int src_of[ID2_SLOT_INTS];
+    __shared__ double sP[16 * 12];                                  // the projection matrices (C <= 16 checked by the launcher)
+    for (int e = threadIdx.x; e < A.C * 12; e += 256) sP[e] = A.Pm[e];
+    const int n_groups = (A.F + A.G - 1) / A.G, stride = gridDim.x;
+    int grp = blockIdx.x;
+    const Id2Offsets off = id2_offsets(A);
+    float score_thr = (float)A.min_score_in;                       // k.z > min_score_in (double)  <=>  k.z >= score_thr (float)
+    if ((double)score_thr <= A.min_score_in) score_thr = nextafterf(score_thr, INFINITY);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                            // (the matrices' loads: nothing of the compiler's is pending from here on)
+    if (grp < n_groups) id2_issue(A, bufA, grp, off);
+    int prev_pts = 0;
+    for (; grp < n_groups; grp += 2 * stride) {
+        id2_step(A, bufA, bufB, src_of, sP, grp, grp + stride, n_groups, off, score_thr, prev_pts);
+        if (grp + stride < n_groups) id2_step(A, bufB, bufA, src_of, sP, grp + stride, grp + 2 * stride, n_groups, off, score_thr, prev_pts);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // post-optimise of triangulated points (mv_math_util.py:189-210): one wave per problem
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
@@ -396,6 +590,32 @@ extern "C" int mvmc_ingest_dlt(const void* kps, int dtype, int n_frames, int n_v
     if (n_views > 16) return MVMC_ERR_UNSUPPORTED;
     if (n_frames == 0) return MVMC_OK;
     const int nq = n_views * p_max;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MVMC_F32 && !getenv("MVMC_INGEST_DLT_V1")) {
+        // the pipelined kernel: frames per group = what one LDS buffer holds, preferring a whole number of 256-thread trips through the
+        // DLT stage (15 frames at C5 P1: 255 points)
+        int G2 = ID2_TRIPLES / (nq * 17);
+        while (G2 > 0 && ((long long)G2 * (n_views + (long long)k_max * v_max) > ID2_MISC_INTS || G2 * nq > ID2_SLOT_INTS)) --G2;   // (a word
+        // of the counts and of the members per thread: both fit 256 threads when their sum fits ID2_MISC_INTS)
+        const int trip = 256 / (k_max * 17);
+        if (trip > 0 && G2 > trip) G2 = (G2 / trip) * trip;
+        if (G2 > n_frames) G2 = n_frames;
+        if (G2 > 0) {
+            Id2Args A{(const float*)kps, Pmats, n_frames, G2, n_views, p_max, n_joints_in, counts_in, ingest_min_score, min_valid, min_bb_size,
+                      members, k_max, v_max, min_score, out, counts_out};
+            long long blocks = ((long long)n_frames + G2 - 1) / G2;
+            const long long cap = (long long)cus * 3;      // persistent and resident (44 KB of LDS each): the workgroups stride over the groups
+            if (blocks > cap) blocks = cap;
+            hipLaunchKernelGGL(ingest_dlt2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, A);
+            MVMC_CHECK_LAUNCH();
+            return MVMC_OK;
+        }
+    }
     const size_t per_frame = (size_t)nq * 51 * (dtype == MVMC_F32 ? 4 : 8) + ((size_t)2 * nq + n_views + (size_t)k_max * v_max) * sizeof(int);
     // frames per group: TWO full trips of the 256 threads through the DLT stage (30 frames at C5 P1: the stages' barriers and the
     // 75-thread filter / compaction stages are per group, and with 15 frames they were a sixth of the time: 1.71 -> 1.49 ms per 2 M
@@ -408,15 +628,9 @@ extern "C" int mvmc_ingest_dlt(const void* kps, int dtype, int n_frames, int n_v
     if ((size_t)G * per_frame > 64 * 1024) return MVMC_ERR_UNSUPPORTED;
     if (G > n_frames) G = n_frames;
     const size_t shm = (((size_t)G * per_frame + 15) & ~(size_t)15) + 16;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    }
     long long blocks = ((long long)n_frames + G - 1) / G;
     const long long cap = (long long)cus * 16;         // persistent: the workgroups stride over the frame groups
     if (blocks > cap) blocks = cap;
-    hipStream_t s = (hipStream_t)stream;
     if (dtype == MVMC_F32)
         hipLaunchKernelGGL(ingest_dlt_kernel<float>, dim3((unsigned)blocks), dim3(256), shm, s, (const float*)kps, n_frames, G, n_views,
                            p_max, n_joints_in, counts_in, ingest_min_score, min_valid, min_bb_size, Pmats, members, k_max, v_max,
