@@ -36,7 +36,8 @@ __device__ __forceinline__ void jacobi_rot4_ev(double (&b)[10]) {
 // One triangulated point from the views `get(v, kp, Pc)` hands out (v = 0 .. V-1; false = no such member): kp <- {x, y, score},
 // Pc -> the view's 3x4 projection.  out[0..2] = X, out[3] = mean score of the views used; NaN when the cluster is empty.
 // mv_math_util.py:152-187 (triangulate_point_groups_from_multiple_views_linear) + :215-240 (the DLT of one point).
-template <typename Get>
+// VU > 0: the view loops are unrolled VU times behind `v < V` tests (V <= VU), for callers whose `get` serves view v out of registers.
+template <int VU = 0, typename Get>
 __device__ __forceinline__ void dlt_point(int V, double min_score, Get get, double* __restrict__ o) {
     // upper triangle of the normal matrix A^T A (rows r1 = x P_3 - P_1, r2 = y P_3 - P_2 of every view used).  ONE pass over the views in
     // the common case: the views with score >= min_score are accumulated while all views are counted; only a point that fewer than
@@ -48,14 +49,14 @@ __device__ __forceinline__ void dlt_point(int V, double min_score, Get get, doub
     auto accumulate = [&](bool use_all) {
     a00 = 0.0; a01 = 0.0; a02 = 0.0; a03 = 0.0; a11 = 0.0; a12 = 0.0; a13 = 0.0; a22 = 0.0; a23 = 0.0; a33 = 0.0;
     ssum = 0.0; nused = 0; n_all = 0; n_ok = 0;
-    for (int v = 0; v < V; ++v) {
+    auto view = [&](int v) {
         double kp[3]; const double* Pc;
-        if (!get(v, kp, Pc)) continue;
+        if (!get(v, kp, Pc)) return;
         const double x = kp[0], y = kp[1], sc = kp[2];
         ++n_all;
         const bool ok = sc >= min_score;
         n_ok += ok ? 1 : 0;
-        if (!use_all && !ok) continue;
+        if (!use_all && !ok) return;
         const double p0 = x * Pc[8] - Pc[0], p1 = x * Pc[9] - Pc[1], p2 = x * Pc[10] - Pc[2], p3 = x * Pc[11] - Pc[3];
         const double q0 = y * Pc[8] - Pc[4], q1 = y * Pc[9] - Pc[5], q2 = y * Pc[10] - Pc[6], q3 = y * Pc[11] - Pc[7];
         // two fused multiply-adds per entry (the sum p p + q q + a in one chain: a third fewer instructions than product, fma, add)
@@ -65,6 +66,13 @@ __device__ __forceinline__ void dlt_point(int V, double min_score, Get get, doub
         a33 = fma(p3, p3, fma(q3, q3, a33));
         ssum += sc;
         ++nused;
+    };
+    if constexpr (VU > 0) {
+#pragma unroll
+        for (int v = 0; v < VU; ++v)
+            if (v < V) view(v);
+    } else {
+        for (int v = 0; v < V; ++v) view(v);
     }
     };
     accumulate(false);
@@ -290,137 +298,105 @@ ingest_dlt_kernel(const T* __restrict__ kps, int F, int G, int C, int P, int J_i
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same pass for float32 input, software-pipelined (round 4; what BASELINE config 2 runs).  Two LDS buffers; while the workgroup
-// triangulates group g out of one, group g + 1 lands in the other by LDS-DMA:
-//   * global_load_lds_dwordx3 -- a lane hands the hardware the address of ONE (x, y, score) triple and the wave's 64 triples land
-//     side by side in LDS: the OpenPose-25 -> COCO-17 gather is the lanes' source addresses, no staging registers, no ds_write, and
-//     nothing for the wave to wait for until the top of the next iteration;
-//   * the barriers inside an iteration are raw s_barrier behind s_waitcnt lgkmcnt(0) -- a __syncthreads() would drain the DMA in
-//     flight (its fence waits for vmcnt(0)); the two buffers are separate __shared__ objects and the loop body is instantiated once
-//     per buffer order, so that the compiler can tell the buffer being read from the one being filled (a ds_read that may alias a
-//     pending LDS-DMA gets a vmcnt(0) in front of it);
-//   * filter_bad_pose and the per-view compaction are ONE stage (a thread per (frame, view) walks the view's poses): two barriers per
-//     group where the first version had four.
+// The same pass for float32 input as a producer / consumer pipeline inside the workgroup (round 4; what BASELINE config 2 runs).
+// Two LDS buffers.  Of a workgroup's four waves ONE is the loader and three triangulate:
+//   loader   issues the NEXT group's keypoints as LDS-DMA (global_load_lds_dwordx3: a lane hands the hardware the address of one
+//            (x, y, score) triple and the wave's 64 triples land side by side in LDS, 16 bytes apart -- the OpenPose-25 -> COCO-17
+//            gather is the lanes' source addresses; no staging registers, no ds_write), waits for them, runs filter_bad_pose and the
+//            per-view compaction on them (a lane per (frame, view)) and writes the frame's view counts;
+//   the others  one thread per (frame, cluster, joint) of the CURRENT group: the DLT of that point out of LDS, two 16-byte stores.
+// ONE barrier per group (raw s_barrier behind s_waitcnt lgkmcnt(0): a __syncthreads() fences vmcnt(0) and would make the triangulating
+// waves wait for their result stores): the triangulating waves never execute a load, a filter or a wait for memory.  Which wave loads
+// rotates with the workgroup's index, so that the (light) loaders of the workgroups sharing a CU sit on different SIMDs.
+// The DMA is inline asm on purpose: hipcc counts a __builtin_amdgcn_global_load_lds and, unable to tell which LDS bytes it writes,
+// puts s_waitcnt vmcnt(0) in front of the next LDS read of ANY object (seen in the ISA of the first version).
 // Results are those of ingest_dlt_kernel<float> and of mvmc_ingest + mvmc_dlt, bit for bit (same dlt_point on the same numbers).
+// History of the round (2 M frames, C5 P1): first version (four stages behind barriers, register staging) 1.52 ms; LDS-DMA double
+// buffering with every wave doing everything 1.25 ms; this form: see DESIGN.md section 6.
 // ------------------------------------------------------------------------------------------------
-constexpr int ID2_TRIPLES = 1280;        // per buffer: G frames x nq poses x 17 joints (15 frames at C5 P1), FOUR floats each: the
+constexpr int ID3_DLT_THREADS = 192;     // three triangulating waves
+constexpr int ID3_TRIPLES = 960;         // per buffer: G frames x nq poses x 17 joints (11 frames at C5 P1), FOUR floats each: the
                                          // hardware writes a lane's 12 bytes at 16-byte lane stride (tools/glds12_test.hip)
-constexpr int ID2_MISC_INTS = 256;       // view counts [G][C], then cluster members [G][K][V]: a word of each per thread
-constexpr int ID2_SLOT_INTS = 128;       // ingest slot -> source pose [G][nq]
-struct Id2Buf {
-    __attribute__((aligned(16))) float pose[ID2_TRIPLES * 4];
-    int small[ID2_MISC_INTS];            // the group's view counts [G][C], then its cluster members [G][K][V]
+constexpr int ID3_MISC_INTS = 256;       // view counts [G][C], then cluster members [G][K][V]
+constexpr int ID3_SLOT_INTS = 128;       // ingest slot -> source pose [G][nq]
+struct Id3Buf {
+    __attribute__((aligned(16))) float pose[ID3_TRIPLES * 4];
+    int small[ID3_MISC_INTS];
+    int src_of[ID3_SLOT_INTS];
 };
 
-// One LDS-DMA of 12 bytes per lane: lane l's triple at base + off lands at LDS byte address lds_wave + 16 l (a 4-byte hole behind each).
-// Inline asm on purpose: hipcc counts a __builtin_amdgcn_global_load_lds and, unable to tell which LDS bytes it writes, puts
-// s_waitcnt vmcnt(0) in front of the next LDS read of ANY object (seen in the ISA of the first version: the DMA was drained right after
-// it was issued).  An asm statement is outside its bookkeeping: the kernel counts these itself (s_waitcnt vmcnt at the top of every
-// iteration, then the barrier, then the reads).  M0 is written in the statement that reads it and restored (the compiler reserves it).
-// The address is a scalar base (the group's first byte) + a 32-bit lane offset that is the SAME for every group: no address arithmetic
-// per group at all.
-__device__ __forceinline__ void id2_glds12(const float* base, unsigned off, unsigned lds_wave) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(off), "s"(base), "s"(__builtin_amdgcn_readfirstlane(lds_wave)) : "memory");
-}
-// a pointer the compiler must hold in scalar registers (the "s" operand of the statements here: a value it cannot prove uniform it
+// a pointer the compiler must hold in scalar registers (the "s" operand of the statements below: a value it cannot prove uniform it
 // would otherwise hand over in vector registers, which is not an encoding of these instructions)
 template <typename T>
-__device__ __forceinline__ const T* id2_uniform(const T* p) {
+__device__ __forceinline__ const T* id3_uniform(const T* p) {
     const unsigned long long v = (unsigned long long)p;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return reinterpret_cast<const T*>(((unsigned long long)hi << 32) | lo);
 }
+// One LDS-DMA of 12 bytes per lane: lane l's triple at base + off lands at LDS byte address lds_wave + 16 l (a 4-byte hole behind each).
+// M0 is written in the statement that reads it and restored (the compiler reserves it).
+__device__ __forceinline__ void id3_glds12(const float* base, unsigned off, unsigned lds_wave) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(base), "s"(__builtin_amdgcn_readfirstlane(lds_wave)) : "memory");
+}
 // one word per lane (lane stride 4 bytes): the small per-group tables
-__device__ __forceinline__ void id2_glds4(const int32_t* base, unsigned off, unsigned lds_wave) {
+__device__ __forceinline__ void id3_glds4(const int32_t* base, unsigned off, unsigned lds_wave) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(off), "s"(base), "s"(__builtin_amdgcn_readfirstlane(lds_wave)) : "memory");
 }
-__device__ __forceinline__ unsigned id2_lds_addr(const void* p) {
+__device__ __forceinline__ unsigned id3_lds_addr(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
 }
 
-struct Id2Args {
+struct Id3Args {
     const float* kps; const double* Pm; int F, G, C, P, J_in; const int32_t* counts_in; double min_score_in; int min_valid; double min_bb;
     const int32_t* members; int K, V; double min_score; double* out; int32_t* counts_out;
 };
 
-constexpr int ID2_TRIPS = ID2_TRIPLES / 256;
-// byte offset, from a group's first keypoint, of the triple that element t = tid + 256 u of the group's LDS image comes from:
-// (frame in group, pose, COCO joint) -> the joint's row of the raw pose (the OpenPose-25 -> COCO-17 gather)
-struct Id2Offsets { unsigned o[ID2_TRIPS]; };
-__device__ __forceinline__ Id2Offsets id2_offsets(const Id2Args& A) {
-    Id2Offsets r;
-#pragma unroll
-    for (int u = 0; u < ID2_TRIPS; ++u) {
-        const int t = threadIdx.x + 256 * u;
-        const int gq = t / 17, j = t - gq * 17;
-        const int js = (A.J_in == 25) ? op25_to_coco17(j) : j;
-        r.o[u] = (unsigned)((gq * A.J_in + js) * 12);
-    }
-    return r;
-}
-
-// group grp -> buffer b, asynchronously (every wave issues its own share; nothing is waited for here)
-__device__ __forceinline__ void id2_issue(const Id2Args& A, Id2Buf& b, int grp, const Id2Offsets& off) {
-    const int tid = threadIdx.x;
-    const unsigned w0 = __builtin_amdgcn_readfirstlane(tid & ~63);     // the wave's first element: uniform
-    const int nq = A.C * A.P, f0 = grp * A.G, g_n = min(A.G, A.F - f0);
-    const float* src = id2_uniform(A.kps + (size_t)f0 * nq * A.J_in * 3);
+// the loader wave: group grp -> buffer b (DMA, wait, filter + compaction)
+__device__ __forceinline__ void id3_load_group(const Id3Args& A, Id3Buf& b, int grp, float score_thr) {
+    const int lane = threadIdx.x & 63;
+    const int nq = A.C * A.P, C = A.C, P = A.P, f0 = grp * A.G, g_n = min(A.G, A.F - f0);
+    const float* src = id3_uniform(A.kps + (size_t)f0 * nq * A.J_in * 3);
     const int n_tr = g_n * nq * 17;                                     // elements = (frame in group, pose, COCO joint) triples
-    const unsigned pose0 = id2_lds_addr(b.pose) + w0 * 16;
-#pragma unroll
-    for (int u = 0; u < ID2_TRIPS; ++u)
-        if (tid + 256 * u < n_tr) id2_glds12(src, off.o[u], pose0 + 256 * 16 * u);
-    // the group's view counts and cluster members, a word of each per thread (also by DMA, also outside the compiler's count: an
-    // ordinary load here would have the compiler wait -- for everything, the DMA included -- where the loop comes round)
-    const int n_c = g_n * A.C, n_m = g_n * A.K * A.V;
-    const unsigned small0 = id2_lds_addr(b.small) + w0 * 4;
-    if (A.counts_in) { if (tid < n_c) id2_glds4(id2_uniform(A.counts_in + (size_t)f0 * A.C), tid * 4u, small0); }
-    else if (tid < n_c) b.small[tid] = A.P;
-    if (tid < n_m) id2_glds4(id2_uniform(A.members + (size_t)f0 * A.K * A.V), tid * 4u, small0 + A.G * A.C * 4);
-}
-
-// group grp out of buffer `cur` (its loads were issued an iteration ago) while the next one lands in `nxt`
-__device__ __forceinline__ void id2_step(const Id2Args& A, Id2Buf& cur, Id2Buf& nxt, int* __restrict__ src_of,
-                                         const double* __restrict__ sP, int grp, int grp_next, int n_groups,
-                                         const Id2Offsets& off, float score_thr, int& prev_pts) {
-    const int tid = threadIdx.x, nq = A.C * A.P, P = A.P, C = A.C, K = A.K, V = A.V;
-    const unsigned p_magic = (65536u + (unsigned)P - 1u) / (unsigned)P;   // d / P = d * p_magic >> 16 for d < 128, P <= 16
-    // what this wave issued an iteration ago (the current group's DMA) has landed; its last two operations -- the previous group's
-    // result stores -- may still be on their way (memory operations complete in order: at most two outstanding = they).  As the
-    // builtin, so that the compiler's own count of its stores stays right (the DMA it does not see is OLDER than anything it can think
-    // is still pending here) ...
-    // -- unless this wave had no point in the previous group (the first iteration; a short last group): then nothing younger than the
-    // DMA is outstanding, and "at most two" would let the DMA's own last two operations through
-    if ((int)__builtin_amdgcn_readfirstlane(tid & ~63) < prev_pts) __builtin_amdgcn_s_waitcnt(0x0F72);     // vmcnt(2)
-    else __builtin_amdgcn_s_waitcnt(0x0F70);                                                                // vmcnt(0)
-    // ... then the whole workgroup's
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#ifdef ID2_NO_DMA      // (timing experiment: the buffers are filled once; every later group re-uses them)
-    if (grp_next < n_groups && grp_next < 2 * (int)gridDim.x) id2_issue(A, nxt, grp_next, off);
-#else
-    if (grp_next < n_groups) id2_issue(A, nxt, grp_next, off);
-#endif
-    const int* cnt_l = cur.small;
-    const int* mem_l = cur.small + A.G * C;
-    const int f0 = grp * A.G, g_n = min(A.G, A.F - f0);
-    const float* pose = cur.pose;
-    // filter_bad_pose + per-view compaction (motion_capture.py:1023-1043; pose_def.py:262-270: the rule of mvmc_ingest)
-    for (int t = tid; t < g_n * C; t += 256) {
+    const unsigned pose0 = id3_lds_addr(b.pose);
+    for (int t0 = 0; t0 < n_tr; t0 += 64) {
+        const int t = t0 + lane;
+        if (t < n_tr) {
+            const int gq = t / 17, j = t - gq * 17;
+            const int js = (A.J_in == 25) ? op25_to_coco17(j) : j;
+            id3_glds12(src, (unsigned)((gq * A.J_in + js) * 12), pose0 + t0 * 16);
+        }
+    }
+    const int n_c = g_n * C, n_m = g_n * A.K * A.V;
+    const unsigned small0 = id3_lds_addr(b.small);
+    for (int t0 = 0; t0 < n_c; t0 += 64) {
+        const int t = t0 + lane;
+        if (t < n_c) {
+            if (A.counts_in) id3_glds4(id3_uniform(A.counts_in + (size_t)f0 * C), t * 4u, small0 + t0 * 4);
+            else b.small[t] = P;
+        }
+    }
+    for (int t0 = 0; t0 < n_m; t0 += 64) {
+        const int t = t0 + lane;
+        if (t < n_m) id3_glds4(id3_uniform(A.members + (size_t)f0 * A.K * A.V), t * 4u, small0 + (A.G * C + t0) * 4);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // this wave's DMA has landed (and its earlier count stores are out)
+    // filter_bad_pose + per-view compaction (motion_capture.py:1023-1043; pose_def.py:262-270: the rule of mvmc_ingest), in float32,
+    // exactly: score_thr is the smallest float above the double threshold, minima / maxima of floats are floats, and the box sides are
+    // differenced in double
+    for (int t = lane; t < n_c; t += 64) {
         const int g = t / C, c = t - g * C;
-        const int cnt = cnt_l[t];
-        int* so = src_of + g * nq + c * P;
+        const int cnt = b.small[t];
+        int* so = b.src_of + g * nq + c * P;
         int k = 0;
         for (int p = 0; p < P; ++p) {
             if (p >= cnt) break;
-            // in float32, exactly: score_thr is the smallest float above the double threshold, minima / maxima of floats are floats,
-            // and the box sides are differenced in double as before
             int nv = 0;
             float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
-            const float4* ps = reinterpret_cast<const float4*>(pose) + (size_t)(g * nq + c * P + p) * 17;
+            const float4* ps = reinterpret_cast<const float4*>(b.pose) + (size_t)(g * nq + c * P + p) * 17;
 #pragma unroll
             for (int j = 0; j < 17; ++j) {
                 const float4 k4 = ps[j];
@@ -435,49 +411,81 @@ __device__ __forceinline__ void id2_step(const Id2Args& A, Id2Buf& cur, Id2Buf& 
         if (A.counts_out) A.counts_out[(f0 + g) * C + c] = k;
         for (; k < P; ++k) so[k] = -1;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    for (int t = tid; t < g_n * K * 17; t += 256) {             // t = (frame in group, cluster, joint)
-        const int gk = t / 17, j = t - gk * 17, g = gk / K;
-        const int* mem = mem_l + gk * V;
-        const int base = (f0 + g) * nq;
-        const int* so = src_of + g * nq;
-        const float4* pg = reinterpret_cast<const float4*>(pose) + (size_t)g * nq * 17 + j;
-#ifdef ID2_NO_DLT      // (timing experiment: the stage's LDS reads and stores without its arithmetic)
-        { const int d0 = mem[0] - base; const float4 k4 = pg[(d0 >= 0 && d0 < nq ? so[d0] : 0) * 17];
-          double* o = A.out + ((size_t)f0 * K * 17 + t) * 4; o[0] = k4.x; o[1] = k4.y; o[2] = k4.z; o[3] = sP[j]; continue; }
-#endif
+}
+
+// a triangulating thread: point dt = (frame in group, cluster, joint) of group grp out of buffer b
+template <int VU>
+__device__ __forceinline__ void id3_point(const Id3Args& A, const Id3Buf& b, const double* __restrict__ sP, int grp, int dt,
+                                          unsigned p_magic) {
+    const int nq = A.C * A.P, K = A.K, V = A.V, f0 = grp * A.G, g_n = min(A.G, A.F - f0);
+    if (dt >= g_n * K * 17) return;
+    const int gk = dt / 17, j = dt - gk * 17, g = gk / K;
+    const int* mem = b.small + A.G * A.C + gk * V;
+    const int base = (f0 + g) * nq;
+    const int* so = b.src_of + g * nq;
+    const float4* pg = reinterpret_cast<const float4*>(b.pose) + (size_t)g * nq * 17 + j;
+    double* o = A.out + ((size_t)f0 * K * 17 + dt) * 4;
+    if constexpr (VU > 0) {
+        // member -> slot -> keypoint of ALL views first: three rounds of independent LDS reads instead of three dependent reads per view
+        int dd[VU], qq[VU];
+        float kx[VU], ky[VU], ks[VU];
+#pragma unroll
+        for (int v = 0; v < VU; ++v) dd[v] = v < V ? mem[v] - base : -1;
+#pragma unroll
+        for (int v = 0; v < VU; ++v) qq[v] = (dd[v] >= 0 && dd[v] < nq) ? so[dd[v]] : -1;      // (-1, or a member of another frame: not this kernel's contract)
+#pragma unroll
+        for (int v = 0; v < VU; ++v) {
+            const float4 k4 = pg[(qq[v] < 0 ? 0 : qq[v]) * 17];
+            kx[v] = k4.x; ky[v] = k4.y; ks[v] = k4.z;
+        }
+        dlt_point<VU>(V, A.min_score, [&](int v, double (&kp)[3], const double*& Pc) {
+            if (qq[v] < 0) return false;
+            kp[0] = (double)kx[v]; kp[1] = (double)ky[v]; kp[2] = (double)ks[v];
+            Pc = sP + ((unsigned)dd[v] * p_magic >> 16) * 12;        // d / P (d < C P <= 128: exact)
+            return true;
+        }, o);
+    } else {
         dlt_point(V, A.min_score, [&](int v, double (&kp)[3], const double*& Pc) {
             const int d = mem[v] - base;
-            if (d < 0 || d >= nq) return false;      // (-1, or a member of another frame: not this kernel's contract)
+            if (d < 0 || d >= nq) return false;
             const int q = so[d];
             if (q < 0) return false;
             const float4 k4 = pg[q * 17];
             kp[0] = (double)k4.x; kp[1] = (double)k4.y; kp[2] = (double)k4.z;
-            Pc = sP + ((unsigned)d * p_magic >> 16) * 12;        // d / P (d < C P <= 128: exact)
+            Pc = sP + ((unsigned)d * p_magic >> 16) * 12;
             return true;
-        }, A.out + ((size_t)f0 * K * 17 + t) * 4);
+        }, o);
     }
-    prev_pts = g_n * K * 17;      // (the waves whose first thread is below this issued their two result stores last)
 }
 
-__global__ void __launch_bounds__(256, 3)      // (45 KB of LDS: three workgroups per CU, so 168 registers may be used)
-ingest_dlt2_kernel(Id2Args A) {
-    __shared__ Id2Buf bufA;
-    __shared__ Id2Buf bufB;
-    __shared__ int src_of[ID2_SLOT_INTS];
+template <int VU>
+__global__ void __launch_bounds__(256, 4)
+ingest_dlt3_kernel(Id3Args A) {
+    __shared__ Id3Buf bufA;
+    __shared__ Id3Buf bufB;
     __shared__ double sP[16 * 12];                                  // the projection matrices (C <= 16 checked by the launcher)
-    for (int e = threadIdx.x; e < A.C * 12; e += 256) sP[e] = A.Pm[e];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int e = tid; e < A.C * 12; e += 256) sP[e] = A.Pm[e];
     const int n_groups = (A.F + A.G - 1) / A.G, stride = gridDim.x;
-    int grp = blockIdx.x;
-    const Id2Offsets off = id2_offsets(A);
+    const int load_wave = (int)(blockIdx.x & 3u);                   // rotates: the loaders of a CU's workgroups sit on different SIMDs
+    const bool loader = wave == load_wave;
+    const int dt = (((wave - load_wave - 1) & 3) << 6) | (tid & 63);   // thread index among the 192 triangulating threads
+    const unsigned p_magic = (65536u + (unsigned)A.P - 1u) / (unsigned)A.P;   // d / P = d * p_magic >> 16 for d < 128, P <= 16
     float score_thr = (float)A.min_score_in;                       // k.z > min_score_in (double)  <=>  k.z >= score_thr (float)
     if ((double)score_thr <= A.min_score_in) score_thr = nextafterf(score_thr, INFINITY);
+    int grp = blockIdx.x;
     __builtin_amdgcn_s_waitcnt(0x0F70);                            // (the matrices' loads: nothing of the compiler's is pending from here on)
-    if (grp < n_groups) id2_issue(A, bufA, grp, off);
-    int prev_pts = 0;
+    if (loader && grp < n_groups) id3_load_group(A, bufA, grp, score_thr);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     for (; grp < n_groups; grp += 2 * stride) {
-        id2_step(A, bufA, bufB, src_of, sP, grp, grp + stride, n_groups, off, score_thr, prev_pts);
-        if (grp + stride < n_groups) id2_step(A, bufB, bufA, src_of, sP, grp + stride, grp + 2 * stride, n_groups, off, score_thr, prev_pts);
+        // group grp out of bufA while grp + stride is prepared in bufB, then the other way round
+        if (loader) { if (grp + stride < n_groups) id3_load_group(A, bufB, grp + stride, score_thr); }
+        else id3_point<VU>(A, bufA, sP, grp, dt, p_magic);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (grp + stride >= n_groups) break;
+        if (loader) { if (grp + 2 * stride < n_groups) id3_load_group(A, bufA, grp + 2 * stride, score_thr); }
+        else id3_point<VU>(A, bufB, sP, grp + stride, dt, p_magic);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 }
 
@@ -596,22 +604,21 @@ extern "C" int mvmc_ingest_dlt(const void* kps, int dtype, int n_frames, int n_v
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == MVMC_F32 && !getenv("MVMC_INGEST_DLT_V1")) {
-        // the pipelined kernel: frames per group = what one LDS buffer holds, preferring a whole number of 256-thread trips through the
-        // DLT stage (15 frames at C5 P1: 255 points)
-        int G2 = ID2_TRIPLES / (nq * 17);
-        while (G2 > 0 && ((long long)G2 * (n_views + (long long)k_max * v_max) > ID2_MISC_INTS || G2 * nq > ID2_SLOT_INTS)) --G2;   // (a word
-        // of the counts and of the members per thread: both fit 256 threads when their sum fits ID2_MISC_INTS)
-        const int trip = 256 / (k_max * 17);
-        if (trip > 0 && G2 > trip) G2 = (G2 / trip) * trip;
-        if (G2 > n_frames) G2 = n_frames;
-        if (G2 > 0) {
-            Id2Args A{(const float*)kps, Pmats, n_frames, G2, n_views, p_max, n_joints_in, counts_in, ingest_min_score, min_valid, min_bb_size,
+    if (dtype == MVMC_F32 && !getenv("MVMC_INGEST_DLT_V1") && k_max * 17 <= ID3_DLT_THREADS) {
+        // the pipelined kernel: frames per group = what the three triangulating waves take in one trip (11 frames at C5 P1: 187 points)
+        // and one LDS buffer holds
+        int G3 = ID3_DLT_THREADS / (k_max * 17);
+        while (G3 > 0 && ((long long)G3 * nq * 17 > ID3_TRIPLES || (long long)G3 * (n_views + (long long)k_max * v_max) > ID3_MISC_INTS ||
+                          G3 * nq > ID3_SLOT_INTS)) --G3;
+        if (G3 > n_frames) G3 = n_frames;
+        if (G3 > 0 && nq <= 128 && p_max <= 16) {
+            Id3Args A{(const float*)kps, Pmats, n_frames, G3, n_views, p_max, n_joints_in, counts_in, ingest_min_score, min_valid, min_bb_size,
                       members, k_max, v_max, min_score, out, counts_out};
-            long long blocks = ((long long)n_frames + G2 - 1) / G2;
-            const long long cap = (long long)cus * 3;      // persistent and resident (44 KB of LDS each): the workgroups stride over the groups
+            long long blocks = ((long long)n_frames + G3 - 1) / G3;
+            const long long cap = (long long)cus * 4;      // persistent and resident (35 KB of LDS each): the workgroups stride over the groups
             if (blocks > cap) blocks = cap;
-            hipLaunchKernelGGL(ingest_dlt2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, A);
+            if (v_max <= 5) hipLaunchKernelGGL(ingest_dlt3_kernel<5>, dim3((unsigned)blocks), dim3(256), 0, s, A);
+            else hipLaunchKernelGGL(ingest_dlt3_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, A);
             MVMC_CHECK_LAUNCH();
             return MVMC_OK;
         }
