@@ -111,6 +111,7 @@ __device__ __forceinline__ void dlt_point(int V, double min_score, Get get, doub
         const double i3 = fast_rcp64(d3);
         double x0 = e0, x1 = e1, x2 = e2, x3 = e3;
         bool conv = false;
+        double ch_prev = 1.0;
         for (int it = 0; it < max_it; ++it) {
             // L y = x;  z = y / D;  L^T w = z
             const double y0 = x0, y1 = x1 - l10 * y0, y2 = x2 - l20 * y0 - l21 * y1, y3 = x3 - l30 * y0 - l31 * y1 - l32 * y2;
@@ -123,11 +124,18 @@ __device__ __forceinline__ void dlt_point(int V, double min_score, Get get, doub
             if (fabs(w1) > fabs(m)) m = w1;
             if (fabs(w2) > fabs(m)) m = w2;
             if (fabs(w3) > fabs(m)) m = w3;
-            const double inv = fast_rcp64(m);
+            const double inv = fast_rcp64(m);   // (the bare v_rcp_f64 will not do although the factor only scales the iterate: its error,
+                                                // ~1e-8 and not a smooth function of m, keeps consecutive iterates 1e-9 apart for ever:
+                                                // every point then fell through to the Jacobi path, 6.3 ms instead of 1.2)
             const double n0 = w0 * inv, n1 = w1 * inv, n2 = w2 * inv, n3 = w3 * inv;
             const double ch = fmax(fmax(fabs(n0 - x0), fabs(n1 - x1)), fmax(fabs(n2 - x2), fabs(n3 - x3)));
             x0 = n0; x1 = n1; x2 = n2; x3 = n3;
-            if (it > 0 && ch <= 1e-13) { conv = true; break; }
+            // settled: the iterate repeats to 1e-13 -- or, the changes shrinking geometrically (by lambda_min / lambda_2 per solve), the
+            // NEXT change would: ch (ch / ch_prev) <= 1e-13 with the ratio itself below 1e-3.  The second test saves the solve that
+            // only confirms (three solves instead of four at the usual gap of ~1e-5); the iterate it stops at is within that product of
+            // the fixed point.
+            if (it > 0 && (ch <= 1e-13 || (it > 1 && ch <= 1e-3 * ch_prev && ch * ch <= 1e-13 * ch_prev))) { conv = true; break; }
+            ch_prev = ch;
         }
         e0 = x0; e1 = x1; e2 = x2; e3 = x3;
         return conv;
@@ -362,6 +370,12 @@ __device__ __forceinline__ void id3_load_group(const Id3Args& A, Id3Buf& b, int 
     const float* src = id3_uniform(A.kps + (size_t)f0 * nq * A.J_in * 3);
     const int n_tr = g_n * nq * 17;                                     // elements = (frame in group, pose, COCO joint) triples
     const unsigned pose0 = id3_lds_addr(b.pose);
+#ifdef ID3_NO_LOAD      // (timing experiment: the keypoints and slots of a workgroup's first two groups are re-used)
+    const bool stale = grp >= 2 * (int)gridDim.x;
+#else
+    const bool stale = false;
+#endif
+    if (!stale)
     for (int t0 = 0; t0 < n_tr; t0 += 64) {
         const int t = t0 + lane;
         if (t < n_tr) {
@@ -384,6 +398,7 @@ __device__ __forceinline__ void id3_load_group(const Id3Args& A, Id3Buf& b, int 
         if (t < n_m) id3_glds4(id3_uniform(A.members + (size_t)f0 * A.K * A.V), t * 4u, small0 + (A.G * C + t0) * 4);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // this wave's DMA has landed (and its earlier count stores are out)
+    if (stale) return;
     // filter_bad_pose + per-view compaction (motion_capture.py:1023-1043; pose_def.py:262-270: the rule of mvmc_ingest), in float32,
     // exactly: score_thr is the smallest float above the double threshold, minima / maxima of floats are floats, and the box sides are
     // differenced in double
@@ -419,6 +434,9 @@ __device__ __forceinline__ void id3_point(const Id3Args& A, const Id3Buf& b, con
                                           unsigned p_magic) {
     const int nq = A.C * A.P, K = A.K, V = A.V, f0 = grp * A.G, g_n = min(A.G, A.F - f0);
     if (dt >= g_n * K * 17) return;
+#ifdef ID3_NO_DLT       // (timing experiment)
+    return;
+#endif
     const int gk = dt / 17, j = dt - gk * 17, g = gk / K;
     const int* mem = b.small + A.G * A.C + gk * V;
     const int base = (f0 + g) * nq;
@@ -467,7 +485,12 @@ ingest_dlt3_kernel(Id3Args A) {
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int e = tid; e < A.C * 12; e += 256) sP[e] = A.Pm[e];
     const int n_groups = (A.F + A.G - 1) / A.G, stride = gridDim.x;
-    const int load_wave = (int)(blockIdx.x & 3u);                   // rotates: the loaders of a CU's workgroups sit on different SIMDs
+#ifndef ID3_ROT_SHIFT
+#define ID3_ROT_SHIFT 8
+#endif
+    // rotates with the workgroup's index so that the loaders of the workgroups sharing a CU sit on different SIMDs: with 256 CUs the
+    // workgroups b, b + 256, b + 512, b + 768 of the resident grid share one (measured against rotating by b itself: DESIGN.md)
+    const int load_wave = (int)((blockIdx.x >> ID3_ROT_SHIFT) & 3u);
     const bool loader = wave == load_wave;
     const int dt = (((wave - load_wave - 1) & 3) << 6) | (tid & 63);   // thread index among the 192 triangulating threads
     const unsigned p_magic = (65536u + (unsigned)A.P - 1u) / (unsigned)A.P;   // d / P = d * p_magic >> 16 for d < 128, P <= 16
