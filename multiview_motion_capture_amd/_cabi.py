@@ -67,47 +67,49 @@ def load():
             "run __graft_entry__.build() (or make -C multiview_motion_capture_amd/csrc).")
     lib = C.CDLL(_LIB_PATH)
     vp, i32, f64 = C.c_void_p, C.c_int, C.c_double
-    lib.mvmc_abi_version.restype = C.c_int
-    lib.mvmc_status_string.restype = C.c_char_p
-    lib.mvmc_status_string.argtypes = [C.c_int]
-    lib.mvmc_als_seed_table.argtypes = [vp, i32]
-    lib.mvmc_ingest.argtypes = [vp, i32, i32, i32, i32, i32, vp, f64, i32, f64, vp, vp, vp]
-    lib.mvmc_fmats.argtypes = [vp, vp, i32, vp, vp]
-    lib.mvmc_affinity.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
-    lib.mvmc_als_associate.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp]
-    lib.mvmc_closure_labels.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp]
-    lib.mvmc_cluster_members.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
-    lib.mvmc_dlt.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, f64, vp, vp]
-    lib.mvmc_ingest_dlt.argtypes = [vp, i32, i32, i32, i32, i32, vp, f64, i32, f64, vp, vp, i32, i32, f64, vp, vp, vp]
-    lib.mvmc_triangulate_postopt.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
-    lib.mvmc_fk.argtypes = [C.POINTER(MvmcSkeleton), vp, i32, vp, vp, vp]
-    lib.mvmc_ik_solve.argtypes = [C.POINTER(MvmcSkeleton), vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, i32,
-                                  vp, vp, vp, vp, vp]
-    lib.mvmc_fmats_from_projections.argtypes = [vp, i32, vp, vp]
-    lib.mvmc_st_affinity.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f64, vp, vp, vp, vp]
-    lib.mvmc_track_assign.argtypes = [vp] * 8 + [i32] * 6 + [vp] * 7
-    lib.mvmc_track_commit.argtypes = [vp] * 4 + [i32] * 4 + [vp] * 9
-    lib.mvmc_debug_eigh.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp]
-    lib.mvmc_debug_trstep.argtypes = [vp, vp, i32, i32, i32, C.c_double, C.c_double, vp, vp, vp, vp]
-    lib.mvmc_chain_run.argtypes = [C.POINTER(MvmcSkeleton), C.POINTER(MvmcChainBuffers), vp]
-    lib.mvmc_ik_solve_stages.argtypes = [C.POINTER(MvmcSkeleton), vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp]
-    lib.mvmc_debug_ik_solve_fd.argtypes = [C.POINTER(MvmcSkeleton), vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
-    if hasattr(lib, "mvmc_debug_ik_model_step"):   # (absent from older builds loaded through MVMC_LIB_PATH for A/B comparisons)
-        lib.mvmc_debug_ik_model_step.argtypes = [C.POINTER(MvmcSkeleton), vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp]
-    lib.mvmc_pack_message_words.argtypes = [i32, i32, i32, i32]
-    lib.mvmc_pack_work_words.argtypes = [i32, i32, i32]
-    lib.mvmc_stitch_work_words.argtypes = [i32, i32, i32]
-    lib.mvmc_pack_tracks.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f64, vp, i32, vp, vp, vp]
-    lib.mvmc_stitch_chains.argtypes = [vp, C.c_longlong, i32, i32, i32, i32, i32, f64, i32, vp, vp, vp, vp, vp]
-    ab = bool(os.environ.get("MVMC_LIB_PATH"))   # an older build loaded for an A/B comparison may lack the newest diagnostics
+    SK = C.POINTER(MvmcSkeleton)
+    argtypes = {
+        "mvmc_status_string": [C.c_int],
+        "mvmc_als_seed_table": [vp, i32],
+        "mvmc_ingest": [vp, i32, i32, i32, i32, i32, vp, f64, i32, f64, vp, vp, vp],
+        "mvmc_fmats": [vp, vp, i32, vp, vp],
+        "mvmc_affinity": [vp, vp, vp, i32, i32, i32, vp, vp, vp],
+        "mvmc_als_associate": [vp, i32, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp],
+        "mvmc_closure_labels": [vp, vp, i32, i32, vp, vp, vp, vp],
+        "mvmc_cluster_members": [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp],
+        "mvmc_dlt": [vp, vp, vp, i32, i32, i32, i32, i32, f64, vp, vp],
+        "mvmc_ingest_dlt": [vp, i32, i32, i32, i32, i32, vp, f64, i32, f64, vp, vp, i32, i32, f64, vp, vp, vp],
+        "mvmc_triangulate_postopt": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp],
+        "mvmc_fk": [SK, vp, i32, vp, vp, vp],
+        "mvmc_ik_solve": [SK, vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp],
+        "mvmc_fmats_from_projections": [vp, i32, vp, vp],
+        "mvmc_st_affinity": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f64, vp, vp, vp, vp],
+        "mvmc_track_assign": [vp] * 8 + [i32] * 6 + [vp] * 7,
+        "mvmc_track_commit": [vp] * 4 + [i32] * 4 + [vp] * 9,
+        "mvmc_debug_eigh": [vp, vp, i32, i32, vp, vp, vp, vp, vp],
+        "mvmc_debug_trstep": [vp, vp, i32, i32, i32, f64, f64, vp, vp, vp, vp],
+        "mvmc_chain_run": [SK, C.POINTER(MvmcChainBuffers), vp],
+        "mvmc_ik_solve_stages": [SK, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp],
+        "mvmc_debug_ik_solve_fd": [SK, vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp],
+        "mvmc_debug_ik_model_step": [SK, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp],
+        "mvmc_pack_message_words": [i32, i32, i32, i32],
+        "mvmc_pack_work_words": [i32, i32, i32],
+        "mvmc_stitch_work_words": [i32, i32, i32],
+        "mvmc_pack_tracks": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f64, vp, i32, vp, vp, vp],
+        "mvmc_stitch_chains": [vp, C.c_longlong, i32, i32, i32, i32, i32, f64, i32, vp, vp, vp, vp, vp],
+    }
+    restypes = {"mvmc_status_string": C.c_char_p, "mvmc_pack_message_words": C.c_longlong, "mvmc_pack_work_words": C.c_longlong,
+                "mvmc_stitch_work_words": C.c_longlong}
+    # A build of another revision loaded through MVMC_LIB_PATH for a same-box A/B comparison (tools/lib_diff.py, tools/*_ab.sh) may
+    # lack entry points that were added since; only then is a missing symbol skipped -- the shipped library must export every one.
+    ab = bool(os.environ.get("MVMC_LIB_PATH"))
     for name in SYMBOLS:
-        if ab and name.startswith("mvmc_debug_") and not hasattr(lib, name):
+        if ab and not hasattr(lib, name):
             continue
-        getattr(lib, name)  # AttributeError if the library does not export it
-        if name not in ("mvmc_status_string", "mvmc_pack_message_words", "mvmc_pack_work_words", "mvmc_stitch_work_words"):
-            getattr(lib, name).restype = C.c_int
-    for name in ("mvmc_pack_message_words", "mvmc_pack_work_words", "mvmc_stitch_work_words"):
-        getattr(lib, name).restype = C.c_longlong
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        if name in argtypes:
+            fn.argtypes = argtypes[name]
+        fn.restype = restypes.get(name, C.c_int)
     _lib = lib
     return lib
 

@@ -2277,6 +2277,16 @@ static int launch_als(const TW* W, const int32_t* gc, int F, int G, int n_max, i
 #define MVMC_ALS4(NM)                                                                                     \
     hipLaunchKernelGGL((als4_kernel<TW, NM>), dim3(F), dim3(256), 0, s, W, gc, G, n_max, seed, seed_len, xb, mm, \
                        lab, nc, it)
+    // WHICH VARIANT A CALL REACHES (n = n_max nodes, r = r_max = min(n, 2 g_max), F graphs in the launch) -- every one is reached:
+    //   n <= 32, r <= 16, F <= 4096   als4_kernel<., 24 | 32>   one 256-thread workgroup per graph; inside it rank <= 8 and n <= 24 (every
+    //                                 graph of configs 1-4) run als7_iterate (solver wave + three worker waves), the rest als4_iterate.
+    //                                 The temporal path (625 graphs per launch), the chain kernel's SMALL layout (same device functions)
+    //   n <= 32, r <= 16, F >  4096   als2_kernel<., 24 | 32>   one wave per graph: the all-frames-cold protocol, config 3 (10 k graphs)
+    //   n <= 32, r >  16              als_kernel<., 24 | 32, r = n>   (a view with more than 8 people)
+    //   n <= 72, r <= 16, F <= 4096   als5_kernel<., 72>        512 threads per graph, products on the matrix cores: config 5's temporal
+    //                                 graphs (64 poses + 8 tracklets); the chain kernel's BIG layout runs the same als5_graph
+    //   n <= 64 | 80, r <= 16         als_kernel<., 64 | 80, 16>   config 5 in the many-graphs form (match_spatial of 25 k frames)
+    //   n <= 80, r <= 32              als_kernel<., 80, 32>     the repair tier (tracker.T_WIDE = 16 tracklet slots)
     // Variants are sized by (max nodes, max rank).  r_max is only the caller's bound (2 x largest group
     // capacity); the kernels check the frame's actual rank and flag iters = -1 if it does not fit.
     // Few graphs per launch (the temporal path: one frame of every chain): the launch lasts as long as its

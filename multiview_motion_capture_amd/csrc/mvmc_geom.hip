@@ -94,7 +94,8 @@ __device__ __forceinline__ void dlt_point(int V, double min_score, Get get, doub
     // inverse iteration on (a - sigma I) = L D L^T from the start vector e; false = a pivot vanished or the iterates did not settle
     // (reciprocals by v_rcp_f64 + two Newton steps, ~1 ulp: the factors and the normalisation only steer an iteration whose fixed point
     // does not depend on them, and an IEEE division is ~28 dependent instructions -- a dozen of them were 40 % of a point's instructions)
-    auto inverse_iteration = [&](double sigma, int max_it) -> bool {
+    // -> 0 settled, 1 not settled after max_it solves, 2 a pivot vanished (no solve was made: e is untouched)
+    auto inverse_iteration = [&](double sigma, int max_it) -> int {
         const double floor_ = 1e-13 * tr;
         const double d0 = a00 - sigma, i0 = fast_rcp64(d0);
         const double l10 = a01 * i0, l20 = a02 * i0, l30 = a03 * i0;
@@ -103,7 +104,7 @@ __device__ __forceinline__ void dlt_point(int V, double min_score, Get get, doub
         const double d2 = (a22 - sigma) - l20 * a02 - l21 * l21 * d1, i2 = fast_rcp64(d2);
         const double l32 = (a23 - l30 * a02 - l31 * l21 * d1) * i2;
         double d3 = (a33 - sigma) - l30 * a03 - l31 * l31 * d1 - l32 * l32 * d2;
-        if (!(d0 > floor_ && d1 > floor_ && d2 > floor_)) return false;
+        if (!(d0 > floor_ && d1 > floor_ && d2 > floor_)) return 2;
         // (the last pivot is ~lambda_min - sigma: rounding may push it to zero or below for consistent observations; its size only scales
         // the iterates, their direction comes from L)
         const double tiny = 1e-30 * tr + 1e-300;
@@ -138,13 +139,13 @@ __device__ __forceinline__ void dlt_point(int V, double min_score, Get get, doub
             ch_prev = ch;
         }
         e0 = x0; e1 = x1; e2 = x2; e3 = x3;
-        return conv;
+        return conv ? 0 : 1;
     };
     // not settled after eight solves = a small spectral gap (clusters of mismatched poses, gross outliers: lambda_min / lambda_2 > ~0.03;
     // 15 % of the points of the Shelf clusters, none of the synthetic ones), or a vanished pivot: the smallest eigenvalue by cyclic
     // Jacobi on the upper triangle, then the same iteration shifted to just below it -- the error then shrinks by
     // 1e-14 tr / (lambda_2 - lambda_min) per solve, whatever the ratio of the two
-    if (!inverse_iteration(0.0, 8)) {
+    if (inverse_iteration(0.0, 8) != 0) {
         double b[10] = {a00, a01, a02, a03, a11, a12, a13, a22, a23, a33};
         for (int sweep = 0; sweep < 16; ++sweep) {
             const double off = b[1] * b[1] + b[2] * b[2] + b[3] * b[3] + b[5] * b[5] + b[6] * b[6] + b[8] * b[8];
@@ -155,7 +156,11 @@ __device__ __forceinline__ void dlt_point(int V, double min_score, Get get, doub
         const double lmin = fmin(fmin(b[0], b[4]), fmin(b[7], b[9]));
         accumulate(use_all);   // (the matrix again, from the views: keeping it live across the sweeps would cost twenty registers of the hot path's budget)
         e0 = 0.0; e1 = 0.0; e2 = 0.0; e3 = 1.0;
-        if (!inverse_iteration(lmin - 1e-14 * tr, 8) && !(e3 == e3)) { e0 = e1 = e2 = 0.0; e3 = 0.0; }   // (NaN guard: 0 / 0 below gives NaN)
+        // A pivot that vanishes even in the shifted matrix = the null space has more than one dimension (a point one view sees, two
+        // views on one line of sight): the reference returns whichever null vector LAPACK happens to produce, there is no point to
+        // agree on -- NaN, never the start vector (0, 0, 0, 1) dressed up as the point (0, 0, 0)
+        const int st = inverse_iteration(lmin - 1e-14 * tr, 8);
+        if (st == 2 || !(e3 == e3)) { e0 = e1 = e2 = 0.0; e3 = 0.0; }   // (0 / 0 below gives NaN)
     }
     const double rw = 1.0 / e3;     // (one IEEE division; the three quotients differ from e / e3 by an ulp at most)
     o[0] = e0 * rw; o[1] = e1 * rw; o[2] = e2 * rw;

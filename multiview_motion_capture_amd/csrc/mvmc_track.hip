@@ -366,7 +366,7 @@ __device__ __forceinline__ void assign_chain(int lane, int nl, int b, int f, con
             }
             const unsigned long long m_lo = __builtin_amdgcn_ballot_w64(mem2[0]), m_hi = __builtin_amdgcn_ballot_w64(mem2[1]);
             int m = __popcll(m_lo) + __popcll(m_hi);
-            if (nt == 0 && m > 64) m = 64;
+            if (nt == 0 && m > 64) { if (ovf && lane == 0) atomicOr(ovf, 1); m = 64; }   // (a cluster of more than 64 poses: cut, and SAID so)
             const int rank0 = __popcll(m_lo & lower_lo), rank1 = __popcll(m_lo) + __popcll(m_hi & lower_lo);
             int tracklet = -1;
             if (nt != 0) {

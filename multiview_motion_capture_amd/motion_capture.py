@@ -278,8 +278,6 @@ class MvTracker:
                 kps[0, c, k, :, 2] = np.asarray(pose.keypoints_score).ravel()
             cnt[0, c] = len(frm.poses)
         d = ch.hp.device
-        for t in self.tracklets:
-            t.time_since_update += 1
         k_d, c_d = torch.as_tensor(kps, device=d), torch.as_tensor(cnt, device=d)
         n_nodes = int(cnt.sum())
         snap = ch.snapshot()
@@ -307,7 +305,13 @@ class MvTracker:
                 wide.restore(wsnap)
                 raise
             self._chain = ch = wide
+        # (only now, the frame having gone through: a frame that raises leaves the tracker -- host side included -- as it was)
+        for t in self.tracklets:
+            t.time_since_update += 1
         n = int(ch.n_tracks[0])
+        if ch.T > self._t_max and n <= self._t_max:
+            # the crowd has thinned out: back to the tables the one-launch path runs on (a wide tracker takes seven launches per frame)
+            self._chain = ch = ch.narrowed(self._t_max)
         meta = ch.meta[0, :n].cpu().numpy()
         params = ch.params[0, :n].cpu().numpy()
         joints = ch.joints[0, :n].cpu().numpy()

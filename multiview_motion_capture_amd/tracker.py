@@ -184,6 +184,16 @@ class ChainTracker:
         w.frame_idx = self.frame_idx
         return w
 
+    def narrowed(self, t_max: int) -> "ChainTracker":
+        """The inverse of widened(): a tracker with t_max slots holding this one's first t_max (the caller has checked that no chain
+        has more live tracklets than that) -- back on the tables the chain kernel runs on once a crowded scene has thinned out."""
+        n = ChainTracker(self.hp, self.B, self.P, t_max, nfev_cold=self.nfev_cold, nfev_warm=self.nfev_warm)
+        n.params.copy_(self.params[:, :t_max]); n.joints.copy_(self.joints[:, :t_max]); n.meta.copy_(self.meta[:, :t_max])
+        n.slot_src.copy_(self.slot_src[:, :t_max])
+        n.n_tracks.copy_(self.n_tracks); n.next_id.copy_(self.next_id); n.n_dead.copy_(self.n_dead)
+        n.frame_idx = self.frame_idx
+        return n
+
     @property
     def fused_ok(self) -> bool:
         """Whether this tracker's padded sizes fit the chain kernel (include/mvmc.h: mvmc_chain_run)."""

@@ -58,3 +58,22 @@ def test_null_vector_reaches_the_smallest_singular_value(baseline, noise):
             # ||A x|| >= s_min for every unit x; the returned one must reach it (relative to the system's scale s_max)
             worst = max(worst, (res - s[-1]) / s[0])
     assert worst < 1e-9, worst
+
+
+def test_a_point_without_a_unique_null_vector_is_nan_not_the_origin():
+    """A cluster of ONE view (HotPath.triangulate runs the DLT on every cluster) and two views on the same line of sight: the 2V x 4
+    system has a null space of more than one dimension, the reference returns whichever vector LAPACK produces.  The device says so
+    (NaN) instead of dressing the iteration's start vector up as the point (0, 0, 0); the mean score is still the reference's."""
+    from multiview_motion_capture_amd import device as dev
+    rng = np.random.default_rng(7)
+    C = 3
+    P = _cams(rng, C, 1.0)
+    P[2] = P[1]                                               # views 1 and 2: the same camera
+    kps = np.zeros((2, C, 1, 17, 3))
+    kps[..., :2] = rng.uniform(100, 800, (2, C, 1, 17, 2))
+    kps[:, 2] = kps[:, 1]                                     # ... seeing the same pixels
+    kps[..., 2] = 0.8
+    members = np.array([[0, -1, -1], [4, 5, -1]], dtype=np.int32)    # frame 0: view 0 alone; frame 1: the two coincident views
+    out = dev.dlt(torch.from_numpy(kps).cuda(), torch.from_numpy(P).cuda(), torch.from_numpy(members).cuda()).cpu().numpy().reshape(2, 17, 4)
+    assert np.isnan(out[..., :3]).all(), out[:, :2]
+    assert np.allclose(out[..., 3], 0.8)
