@@ -616,7 +616,7 @@ def main():
             achieved = bpf * (F // L) / (launch_ms * 1e-3) / 1e9
         elif args.workload == "dlt":
             # config 2: 12 C P J bytes read + 16 P J written per frame; the DLT kernel dominates
-            dom, dom_kernel = "tri", "ingest_dlt_kernel" if args.path == "fused" else "dlt_kernel"
+            dom, dom_kernel = "tri", "ingest_dlt3_kernel" if args.path == "fused" else "dlt_kernel"
             bpf = 12 * C * Pn * 25 + 16 * Pn * 25
             launch_ms = stage_ms["tri"]
             achieved = bpf * F / (launch_ms * 1e-3) / 1e9

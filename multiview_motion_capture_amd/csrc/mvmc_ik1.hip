@@ -793,6 +793,10 @@ __device__ __forceinline__ void ik1_trf(Ik1Shared& S, const Ik1Tables& T, int st
                     // into LDS (not an evaluation of the solver's budget: the same numbers again) and the model again, this time
                     // with its reflectors dumped to the global scratch, like every later model of the solve (solves that reject
                     // once tend to reject again: the cold ones, which set the length of a chain's first frame)
+                    // (measured in round 4, bit-identical results: dumping only on demand -- every rejected first trial pays the rebuild,
+                    // no model dumps pre-emptively -- takes 6.5 % off the launch's write traffic, 2.26 -> 2.11 GB, and costs 0.7 % of
+                    // throughput; only the warm solves on demand: -1.6 % of the writes, no change in speed.  The dumps are not where
+                    // the launch's 2.3 GB of writes come from; left as it was)
                     dump = dumped = true;
                     ik1_eval_nl(S, T, 0, stage, true);
                     model_step(true, Delta, alpha, true);

@@ -58,31 +58,46 @@ def main():
             w.writerow([k, len(fe[k]), "%.3f" % (sum(fe[k]) / len(fe[k])), "%.3f" % (sum(wr[k]) / max(1, len(wr[k])))])
     tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     rec = json.load(open(tp)) if os.path.exists(tp) else {}
-    unit = ("bytes per launch (chain_kernel: one launch = the whole step of 10,000 frames; ik1 / als4: one time step of all 625 chains); rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in "
-            "separate passes, KB x 1024; accesses are 8/12-byte, so the gfx950 x2 correction for 16-B streaming reads does not "
-            "apply (ingest_kernel calibrates 1:1 against its known 30 MB input)")
+    unit = ("bytes per launch (chain_kernel: one launch = the whole step of 10,000 frames; ik1 / als4: one time step of all 625 chains); rocprofv3 --pmc "
+            "FETCH_SIZE and WRITE_SIZE in separate passes, KB x 1024.  fetch_counter_bytes is the counter as read; fetch_bytes = that x "
+            "fetch_correction, the factor MEASURED on a calibration kernel with the same access pattern and a known byte count "
+            "(tools/fetch_calib.hip: on gfx950 the counter tallies a 128-byte request of a streaming read at 64 bytes); 1.0 for the chain "
+            "kernels, whose accesses are 8 / 12-byte pieces of small per-frame tables (ingest_kernel calibrates 1:1 against its known 30 MB input)")
+    # calibration factors of this session, if the session ran tools/fetch_calib.hip (prof_r04.sh): known bytes / counter
+    calib = {}
+    cdir = os.path.join(os.path.dirname(os.path.normpath(fdir)), "calib")
+    if os.path.isdir(cdir):
+        cal = pmc(cdir, "FETCH_SIZE")
+        known = 4000000 * 300.0
+        for k, v in cal.items():
+            if k.startswith("calib_"):
+                calib[k] = known / (sum(v) / len(v) * 1024)
+        print("FETCH_SIZE calibration (known bytes / counter):", {k: round(v, 3) for k, v in calib.items()})
     for key, kern in (("ik", "ik1_kernel<6>"), ("als", "als4_kernel<double, 32>"), ("chain", "chain_kernel<false>"), ("chain", "chain_kernel<true>"),
-                      ("tri", "dlt_kernel"), ("tri", "ingest_dlt_kernel<float>"), ("tri", "ingest_dlt_kernel<double>")):
+                      ("tri", "dlt_kernel"), ("tri", "ingest_dlt_kernel<float>"), ("tri", "ingest_dlt_kernel<double>"), ("tri", "ingest_dlt3_kernel<5>"),
+                      ("tri", "ingest_dlt3_kernel<0>")):
         if kern not in fe:
             continue
         kf = sum(fe[kern]) / len(fe[kern]) * 1024
         kw = sum(wr[kern]) / len(wr[kern]) * 1024
-        corr = None
-        if kern.startswith("ingest_dlt_kernel"):
-            # MI355X_MICROARCH.md (HBM / rocprofv3): on gfx950 FETCH_SIZE reports HALF of the bytes of a wide coalesced streaming read.
-            # This kernel streams its input once with 12-byte-per-lane coalesced loads, and the raw counter (1.56 GB at 2 M frames) is
-            # below the 2.1 GB of DISTINCT bytes it must read (17 of 25 joints + members + counts), which no cache can explain; doubled
-            # it is 3.1 GB = the whole 3.0 GB input (the eight unused joints ride along in the 64-byte requests) + tables.
-            corr = {"fetch_counter_bytes": kf, "fetch_correction": 2.0,
-                    "why": "gfx950 FETCH_SIZE counts 64 B per 128-B request of a coalesced streaming read (MI355X_MICROARCH.md); the raw value is below the distinct bytes the kernel reads"}
-            kf *= 2.0
+        corr = {"fetch_counter_bytes": kf, "fetch_correction": 1.0}
+        pattern = "calib_gather_dma" if kern.startswith("ingest_dlt3") else ("calib_copy12" if kern.startswith("ingest_dlt_kernel") else None)
+        if pattern:
+            if pattern in calib:
+                corr = {"fetch_counter_bytes": kf, "fetch_correction": calib[pattern],
+                        "why": f"measured in the same session on tools/fetch_calib.hip's {pattern} (same access pattern, known byte count)"}
+            else:
+                # no calibration in this session: MI355X_MICROARCH.md (HBM / rocprofv3) -- gfx950 FETCH_SIZE reports HALF of the bytes of a
+                # wide coalesced streaming read
+                corr = {"fetch_counter_bytes": kf, "fetch_correction": 2.0,
+                        "why": "gfx950 FETCH_SIZE counts 64 B per 128-B request of a coalesced streaming read (MI355X_MICROARCH.md); not calibrated in this session"}
+            kf *= corr["fetch_correction"]
         mix = (rec.get(f"{key}:{wkey}") or {}).get("inst_mix")   # tools/aggregate_insts.py's record carries its own source hash
         rec[f"{key}:{wkey}"] = {"kernel": kern, "fetch_bytes": kf, "write_bytes": kw, "bytes": kf + kw,
                                 "source": os.path.basename(out2), "src_sha": kernel_sources_sha(), "unit": unit}
         if mix:
             rec[f"{key}:{wkey}"]["inst_mix"] = mix
-        if corr:
-            rec[f"{key}:{wkey}"].update(corr)
+        rec[f"{key}:{wkey}"].update(corr)
     json.dump(rec, open(tp, "w"), indent=1)
     print(open(out).read())
     print(open(out2).read())

@@ -2,7 +2,7 @@
 # Same-box A/B of library variants: tools/lib_ab.sh name1 name2 ...  (multiview_motion_capture_amd/lib/libmvmc_<name>.so), two rounds each
 for round in 1 2; do
   for n in "$@"; do
-    MVMC_LIB_PATH=$PWD/multiview_motion_capture_amd/lib/libmvmc_$n.so timeout -k 10 200 python bench.py --cpu-frames 0 2>/dev/null > gpurun_out/ab_$n.json || exit 1
+    MVMC_LIB_PATH=$PWD/multiview_motion_capture_amd/lib/libmvmc_$n.so timeout -k 10 200 python bench.py --cpu-frames 0 --no-other-configs --sustain 0 2>/dev/null > gpurun_out/ab_$n.json || exit 1
     python - "$n" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/ab_%s.json" % sys.argv[1]))
