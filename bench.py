@@ -220,6 +220,8 @@ def launch_ranks(n: int) -> int:
 OTHER_CONFIGS = (
     ("config 5: synthetic 25,008 frames/GPU, C=8, P=8 (the per-GPU shard of BASELINE's 200 k frames over 8 GPUs), full path",
      ["--views", "8", "--people", "8", "--frames", "25008", "--seed", "20260104", "--steps", "3", "--warmup", "1"]),
+    ("config 3: synthetic 10 k frames, C=5, P=4: epipolar affinity + association + triangulation, every frame independent",
+     ["--workload", "assoc_dlt", "--seed", "20260102", "--steps", "10", "--warmup", "2"]),
     ("config 2: synthetic 2 M frames, C=5, P=1: triangulation only (10 k generated frames tiled on the device)",
      ["--workload", "dlt", "--people", "1", "--frames", "2000000", "--tile-from", "10000", "--seed", "20260101", "--steps", "20",
       "--warmup", "3"]),
@@ -299,8 +301,8 @@ def main():
                     help="generate this many frames on the host and tile them on the device up to --frames (config 2 at 2 M frames: the "
                          "generator would take minutes; the kernel reads every frame from HBM either way); 0 = generate all frames")
     ap.add_argument("--other-configs", dest="other_configs", action="store_true", default=None,
-                    help="after the headline region also time BASELINE config 5 (C8 P8, 25,008 frames, 3 steps) and config 2 (C5 P1, "
-                         "triangulation only, 2 M frames, 20 launches) as child runs of this script and report them under "
+                    help="after the headline region also time BASELINE config 5 (C8 P8, 25,008 frames, 3 steps), config 3 (C5 P4, association "
+                         "+ triangulation, 10 steps) and config 2 (C5 P1, triangulation only, 2 M frames, 20 launches) as child runs of this script and report them under "
                          "'other_configs' (default: on for the default headline command at N = 1)")
     ap.add_argument("--no-other-configs", dest="other_configs", action="store_false")
     args = ap.parse_args()
@@ -599,7 +601,7 @@ def main():
         value = frames_total / dt
         bpf = BYTES_PER_FRAME(C, Pn)
         dom = "ik" if with_ik else "assoc"
-        dom_kernel = "ik1_kernel" if with_ik else "als_kernel"
+        dom_kernel = "ik1_kernel" if with_ik else "als4_kernel<float, 24>"
         if fused:
             # the whole step is ONE launch of chain_kernel over the rank's F frames
             dom, dom_kernel = "chain", "chain_kernel"

@@ -2279,9 +2279,12 @@ static int launch_als(const TW* W, const int32_t* gc, int F, int G, int n_max, i
                        lab, nc, it)
     // WHICH VARIANT A CALL REACHES (n = n_max nodes, r = r_max = min(n, 2 g_max), F graphs in the launch) -- every one is reached:
     //   n <= 32, r <= 16, F <= 4096   als4_kernel<., 24 | 32>   one 256-thread workgroup per graph; inside it rank <= 8 and n <= 24 (every
-    //                                 graph of configs 1-4) run als7_iterate (solver wave + three worker waves), the rest als4_iterate.
-    //                                 The temporal path (625 graphs per launch), the chain kernel's SMALL layout (same device functions)
-    //   n <= 32, r <= 16, F >  4096   als2_kernel<., 24 | 32>   one wave per graph: the all-frames-cold protocol, config 3 (10 k graphs)
+    //     or n <= 24, r <= 8, any F    graph of configs 1-4) run als7_iterate (solver wave + three worker waves), the rest als4_iterate.
+    //                                 The temporal path (625 graphs per launch), the chain kernel's SMALL layout (same device functions),
+    //                                 config 3 and the all-frames-cold protocol (10 k graphs of n = 20, rank 8)
+    //   n <= 32, r <= 16, F >  4096   als2_kernel<., 24 | 32>   one wave per graph: many graphs with more than four people per view or
+    //     (and n > 24 or r > 8)        more than 24 nodes (als4_iterate's 14 k cycles per iteration on 512 resident graphs lose against
+    //                                 1,024 resident waves there)
     //   n <= 32, r >  16              als_kernel<., 24 | 32, r = n>   (a view with more than 8 people)
     //   n <= 72, r <= 16, F <= 4096   als5_kernel<., 72>        512 threads per graph, products on the matrix cores: config 5's temporal
     //                                 graphs (64 poses + 8 tracklets); the chain kernel's BIG layout runs the same als5_graph
@@ -2291,7 +2294,9 @@ static int launch_als(const TW* W, const int32_t* gc, int F, int G, int n_max, i
     // capacity); the kernels check the frame's actual rank and flag iters = -1 if it does not fit.
     // Few graphs per launch (the temporal path: one frame of every chain): the launch lasts as long as its
     // slowest graph, so a whole workgroup works on each; many graphs: one wave per graph fills the machine.
-    const bool few = F <= 4096;
+    // (round 4: graphs the solver-wave form als7_iterate holds -- n <= 24, rank <= 8 -- take the workgroup kernel at ANY batch size: 512
+    // graphs resident at 7.4 k cycles per iteration beat als2's 1,024 at ~20 k; config 3, 10 k graphs: 484 k -> 642 k frames/s)
+    const bool few = F <= 4096 || (n_max <= 24 && r_max <= 8);
     if (n_max <= 24 && r_max <= 16) { if (few) MVMC_ALS4(24); else MVMC_ALS2(24); }
     else if (n_max <= 32 && r_max <= 16) { if (few) MVMC_ALS4(32); else MVMC_ALS2(32); }
     else if (n_max <= 24) MVMC_ALS(24, 24, 64);
