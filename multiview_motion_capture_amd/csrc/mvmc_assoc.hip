@@ -1507,8 +1507,11 @@ __device__ __forceinline__ void als4_graph(Als4Lds<NMAX>& L, int f, const TW* __
     }
 }
 
+#ifndef ALS4_WG_PER_CU
+#define ALS4_WG_PER_CU 3   // (168 registers, as in the chain kernel: 768 graphs resident instead of 512 at the 198 the compiler takes when left alone)
+#endif
 template <typename TW, int NMAX>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, ALS4_WG_PER_CU)
 als4_kernel(const TW* __restrict__ W, const int32_t* __restrict__ gcounts, int G, int ldw,
             const double* __restrict__ seed, int seed_len, uint8_t* __restrict__ x_bin,
             uint8_t* __restrict__ match_mat, int32_t* __restrict__ labels, int32_t* __restrict__ n_clusters,
