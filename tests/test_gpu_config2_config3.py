@@ -116,3 +116,43 @@ def test_config3_association_and_triangulation_10k_c5p4():
     print("config 3 at 10 k frames: %d / %d sampled frames with every pose in its person's cluster; hip error median %.2f cm" %
           (good, len(range(0, F, 5)), np.median(err) * 100))
     assert good >= 0.97 * len(range(0, F, 5)) and np.median(err) < 0.02
+
+
+@pytest.mark.parametrize("C,P,K,V,J,F", [(5, 1, 1, 5, 25, 1003), (8, 2, 3, 8, 25, 517), (3, 4, 5, 3, 17, 260), (6, 3, 11, 4, 25, 97),
+                                         (4, 2, 12, 4, 25, 64)])
+def test_one_pass_triangulation_equals_the_two_kernels_on_ragged_shapes(C, P, K, V, J, F):
+    """mvmc_ingest_dlt's float32 pipeline (loader wave + triangulating waves, LDS-DMA gathers, groups that do not divide the frame
+    count) against mvmc_ingest + mvmc_dlt, bit for bit, where the shapes are NOT the benchmark's: several people per view with ragged
+    counts and poses the filter drops, several clusters per frame with holes (-1) and fewer or more than five views, COCO-17 input,
+    the unrolled (V <= 5) and the generic view loop, more clusters than the pipeline holds (K = 12: the first one-pass kernel)."""
+    from multiview_motion_capture_amd import device as dev
+    rng = np.random.default_rng(1000 * C + 10 * P + K)
+    d = torch.device("cuda:0")
+    kps = rng.uniform(50, 900, (F, C, P, J, 3)).astype(np.float32)
+    kps[..., 2] = rng.uniform(0, 1, (F, C, P, J)).astype(np.float32)
+    kps[rng.uniform(size=(F, C, P, J)) < 0.1] = 0.0                               # dropped joints, OpenPose style
+    kps[rng.uniform(size=(F, C, P)) < 0.1] *= np.float32(0.001)                   # a pose the filter rejects (tiny box)
+    cnt = rng.integers(0, P + 1, (F, C)).astype(np.int32)
+    Pm = rng.normal(size=(C, 3, 4)) * np.array([1000.0, 1000.0, 1.0])[None, :, None]
+    Pm[:, 2, 3] += 4.0
+    kd, cd, Pd = torch.from_numpy(kps).to(d), torch.from_numpy(cnt).to(d), torch.from_numpy(Pm).to(d)
+    k17, c17 = dev.ingest(kd, cd)
+    c17h = c17.cpu().numpy()
+    # clusters: random subsets of the frame's kept poses (ingest numbering (f C + c) P + slot), padded with -1, some empty
+    mem = -np.ones((F, K, V), dtype=np.int32)
+    for f in range(F):
+        pool = [(f * C + c) * P + s for c in range(C) for s in range(c17h[f, c])]
+        for k in range(K):
+            n = int(rng.integers(0, V + 1))
+            if pool and n:
+                pick = rng.choice(len(pool), size=min(n, len(pool)), replace=False)
+                where = np.sort(rng.choice(V, size=len(pick), replace=False))
+                mem[f, k, where] = np.array(pool)[pick]
+    md = torch.from_numpy(mem).to(d)
+    two = dev.dlt(k17, Pd, md.view(F * K, V)).view(F, K, 17, 4)
+    one, c_one = dev.ingest_dlt(kd, cd, Pd, md, want_counts=True)
+    torch.cuda.synchronize()
+    assert torch.equal(c_one, c17)
+    a, b = one.cpu().numpy(), two.cpu().numpy()
+    assert np.array_equal(a, b, equal_nan=True), (np.argwhere(~((a == b) | (np.isnan(a) & np.isnan(b))))[:5])
+    assert np.isfinite(a[..., 3]).sum() > 0
