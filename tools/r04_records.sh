@@ -7,6 +7,7 @@ python bench.py --no-other-configs --cpu-frames 0 --views 8 --people 8 --frames 
 python bench.py --no-other-configs --cpu-frames 0 --workload dlt --people 1 --frames 2000000 --tile-from 10000 --seed 20260101 > $O/r04_bench_dlt_2M_C5P1.json 2> $O/dlt.err
 python bench.py --no-other-configs --workload dlt --people 1 --seed 20260101 > $O/r04_bench_dlt_10k_C5P1.json 2> $O/dlt10k.err
 python bench.py --no-other-configs --cpu-frames 0 --occlusion 0.05 --spurious 0.2 > $O/r04_bench_fused_10k_C5P4_occluded.json 2> $O/occ.err
+python bench.py --no-other-configs --cpu-frames 0 --workload assoc_dlt --seed 20260102 > $O/r04_bench_assoc_dlt_10k_C5P4.json 2> $O/c3.err
 python bench.py --no-other-configs --cpu-frames 0 --gpus 2 --backend gloo --share-gpu --frames 4096 --steps 6 --warmup 2 --sustain 20 2> $O/two.err | grep -v "^\[Gloo\]" > $O/r04_bench_two_ranks_one_gpu_gloo.json
 python bench.py --no-other-configs --cpu-frames 0 --gpus 2 --backend gloo --share-gpu --views 8 --people 8 --frames 2048 --occlusion 0.05 --spurious 0.2 --steps 3 --warmup 1 --sustain 0 2> $O/two_occ.err | grep -v "^\[Gloo\]" > $O/r04_bench_two_ranks_one_gpu_gloo_repairs.json
 python - <<'PY'
