@@ -218,6 +218,8 @@ def launch_ranks(n: int) -> int:
 
 
 OTHER_CONFIGS = (
+    ("config 1: the Shelf sequence (300 frames, 5 views) frame by frame through the drop-in MvTracker.update_4d",
+     ["--workload", "shelf", "--steps", "2", "--warmup", "1"]),
     ("config 5: synthetic 25,008 frames/GPU, C=8, P=8 (the per-GPU shard of BASELINE's 200 k frames over 8 GPUs), full path",
      ["--views", "8", "--people", "8", "--frames", "25008", "--seed", "20260104", "--steps", "3", "--warmup", "1"]),
     ("config 3: synthetic 10 k frames, C=5, P=4: epipolar affinity + association + triangulation, every frame independent",
@@ -226,6 +228,60 @@ OTHER_CONFIGS = (
      ["--workload", "dlt", "--people", "1", "--frames", "2000000", "--tile-from", "10000", "--seed", "20260101", "--steps", "20",
       "--warmup", "3"]),
 )
+
+
+def shelf_line(args, d):
+    """BASELINE config 1: the Shelf sequence (tests/golden/shelf_inputs.npz: OpenPose keypoints of 5 views, frames 1 .. 300, the
+    reference's own calibrations) through the mirrored driver loop -- parse -> filter_bad_pose -> MvTracker.update_4d, one frame after the
+    other (motion_capture.py:1077-1111), the device doing association, triangulation and IK of each frame in one launch
+    (mvmc_chain_run on a chain of one frame) and the host reading the frame's tracklets back, as the reference's API requires.  A step
+    = the whole sequence with a fresh tracker.  The reference's NumPy path runs this at 1.7 frames/s."""
+    import multiview_motion_capture_amd.common as common
+    import multiview_motion_capture_amd.inverse_kinematics as ik
+    import multiview_motion_capture_amd.motion_capture as mc
+    import multiview_motion_capture_amd.pose_def as pd
+    with np.load(os.path.join(ROOT, "tests", "golden", "shelf_inputs.npz")) as z:
+        si = {k: z[k] for k in ("K", "Rt", "kps25", "counts")}        # (an NpzFile decompresses an array at every access)
+    calibs = [common.Calib.from_k_rt(si["K"][c], si["Rt"][c], (1032, 776)) for c in range(5)]
+    n_frames = min(300, si["kps25"].shape[0] - 1)
+    frames_all = []
+    for fi in range(1, n_frames + 1):          # the parsed, filtered FrameData of every frame: input preparation, not timed
+        fr = []
+        for c in range(5):
+            poses = {}
+            for p in range(int(si["counts"][fi, c])):
+                coco = pd.conversion_openpose_25_to_coco(si["kps25"][fi, c, p])
+                poses[p] = pd.Pose(pd.KpsFormat.COCO, coco[:, :2], coco[:, 2:], None)
+            fr.append(mc.filter_bad_pose(common.FrameData(fi, poses, calibs[c], c + 1), 0.01, 4, 5))
+        frames_all.append(fr)
+    skel = ik.load_skeleton()
+
+    def one_pass():
+        tracker = mc.MvTracker(skel)
+        for k, fr in enumerate(frames_all):
+            tracker.update_4d(k + 1, fr, None)
+        return tracker
+
+    steps, warm = min(args.steps, 5), min(args.warmup, 1)
+    for _ in range(warm):
+        one_pass()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr = one_pass()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    bpf = 12 * 5 * 8 * 25 + 4 * 5 * 8 + 16 * 4 * 25 + 488 * 4
+    return {"metric": "frames/s (assoc+triangulate+IK), Shelf sequence frame by frame through MvTracker.update_4d",
+            "value": n_frames * steps / dt, "unit": "frames/s", "n_gpus": 1, "steps": steps, "warmup": warm,
+            "ms_per_step": dt / steps * 1e3, "ms_per_frame": dt / steps / n_frames * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "Shelf keypoints (tests/golden/shelf_inputs.npz)",
+            "config": {"workload": f"Shelf, 5 cams, frames 1..{n_frames}, one frame per call of the drop-in MvTracker.update_4d (config 1)",
+                       "frames": n_frames, "views": 5, "tracklets_alive_at_the_end": len(tr.tracklets), "dead": len(tr.dead_tracklets)},
+            "roofline": {"bound": "hbm", "kernel": "chain_kernel<false> (one frame per launch)", "achieved": bpf * n_frames * steps / dt / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bpf * n_frames * steps / dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "note": "latency of one frame's dependent chain (one association, <= 6 solves) + a host round trip per frame: "
+                                 "this leg measures the drop-in API, not the kernels' throughput"}}
 
 
 def other_config_lines():
@@ -241,8 +297,8 @@ def other_config_lines():
         except Exception as exc:      # never at the cost of the headline line
             lines.append({"config": name, "error": repr(exc)[:300]})
             continue
-        keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "tracker_events_per_step",
-                "stages_ms", "accuracy")
+        keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "ms_per_frame", "dtype", "config", "roofline",
+                "tracker_events_per_step", "stages_ms", "accuracy")
         rec = {"name": name, "command": "python bench.py " + " ".join(argv), **{k: line[k] for k in keep if k in line},
                "wall_s": time.perf_counter() - t0}
         lines.append(rec)
@@ -257,9 +313,11 @@ def main():
     ap.add_argument("--frames", type=int, default=10000, help="frames per GPU")
     ap.add_argument("--views", type=int, default=5)
     ap.add_argument("--people", type=int, default=4)
-    ap.add_argument("--workload", default="full", choices=["full", "assoc_dlt", "dlt"],
+    ap.add_argument("--workload", default="full", choices=["full", "assoc_dlt", "dlt", "shelf"],
                     help="full = config 4 (the headline); assoc_dlt = config 3 (affinity + ALS + DLT, every frame independent); "
-                         "dlt = config 2 (triangulation only: ingest + DLT of one cluster per person; use --people 1)")
+                         "dlt = config 2 (triangulation only: ingest + DLT of one cluster per person; use --people 1); "
+                         "shelf = config 1 (the Shelf sequence of tests/golden -- 300 frames, 5 views -- frame by frame through the drop-in "
+                         "MvTracker.update_4d: a step = the whole sequence, one frame after the other, the host in the loop)")
     ap.add_argument("--nfev-cold", type=int, default=50)
     ap.add_argument("--nfev-warm", type=int, default=5)
     ap.add_argument("--chain-len", type=int, default=16,
@@ -331,6 +389,11 @@ def main():
     if world > 1:
         dist.init_process_group(args.backend, rank=rank, world_size=world, **({"device_id": d} if args.backend == "nccl" else {}))
 
+    if args.workload == "shelf":
+        if world != 1:
+            raise SystemExit("--workload shelf is a single-process sequence (the reference's driver loop): --gpus 1")
+        print(json.dumps(shelf_line(args, d)))
+        return
     from multiview_motion_capture_amd import synth
     from multiview_motion_capture_amd.pipeline import HotPath
     from multiview_motion_capture_amd import parallel as par
