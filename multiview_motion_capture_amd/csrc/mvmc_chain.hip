@@ -12,6 +12,7 @@
 // ik1_solve, commit_chain), so the results are the same bit for bit; LDS is one arena reused by the phases:
 //   [ graph scratch | Als4Lds | 4 x Ik1Shared ]  (union)  +  Ik1Tables (persistent)
 #define MVMC_DEVICE_ONLY
+#include <cstdlib>
 #include "mvmc_common.h"
 #include "mvmc_assoc.hip"
 #include "mvmc_track.hip"
@@ -487,7 +488,11 @@ extern "C" int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuff
     Ik1Tables tables_host;   // the skeleton's tables: once per call, on the host, a kernel argument of the launch
     ik1_build_tables_host(tables_host, sk);
     if (!small) return mvmc_chain_launch_big(&tables_host, A, B.n_chains * A.parts, (hipStream_t)stream);
-    hipLaunchKernelGGL(chain_kernel<false>, dim3(B.n_chains * A.parts), dim3(256), sizeof(ChainArena<false>), (hipStream_t)stream, tables_host, A);
+    // (MVMC_CHAIN_EXTRA_LDS: an occupancy experiment -- bytes of LDS nobody uses, so that fewer workgroups share a CU)
+    static const size_t extra_lds = getenv("MVMC_CHAIN_EXTRA_LDS") ? (size_t)atoi(getenv("MVMC_CHAIN_EXTRA_LDS")) : 0;
+    if (extra_lds && hipFuncSetAttribute((const void*)chain_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)(sizeof(ChainArena<false>) + extra_lds)) != hipSuccess) return MVMC_ERR_LAUNCH;
+    hipLaunchKernelGGL(chain_kernel<false>, dim3(B.n_chains * A.parts), dim3(256), sizeof(ChainArena<false>) + extra_lds, (hipStream_t)stream, tables_host, A);
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;
 }
