@@ -276,7 +276,9 @@ def _nccl_main(port, q):
     from multiview_motion_capture_amd.tracker import check_chain_flags, run_chains_fused
     d = torch.device("cuda:0")
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=d)
+    opts = dist.ProcessGroupNCCL.Options()
+    opts.is_high_priority_stream = True            # as bench.py initialises it at N > 1
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=d, pg_options=opts)
     par.FORCE_COLLECTIVE = True        # no world == 1 short-cut: the all-gather is issued through RCCL
     from multiview_motion_capture_amd import synth
     from multiview_motion_capture_amd.pipeline import HotPath
@@ -284,7 +286,7 @@ def _nccl_main(port, q):
     data = synth.generate(Fb, C, P, 20260103, chain_len=Lb, frame_seed=20260103)
     hp = HotPath(data["K"], data["Rt"], device=d)
     kps, counts = torch.from_numpy(data["kps25"]).to(d), torch.from_numpy(data["counts"]).to(d)
-    comm = torch.cuda.Stream(device=d)
+    comm = torch.cuda.Stream(device=d, priority=-1)
     streams = [torch.cuda.Stream(device=d) for _ in range(2)]
     torch.cuda.synchronize()
     keep, n_coll = [], 0
