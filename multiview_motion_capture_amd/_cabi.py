@@ -14,6 +14,7 @@ _LIB_PATH = os.environ.get("MVMC_LIB_PATH") or os.path.join(os.path.dirname(os.p
 _lib = None
 
 MVMC_OK = 0
+MVMC_ABI = 4    # MVMC_ABI_VERSION of include/mvmc.h that the argument types in load() describe
 MVMC_F32, MVMC_F64 = 0, 1
 N_PARAM = 68
 MAX_NODES = 80
@@ -66,6 +67,16 @@ def load():
             f"HIP extension not built: {_LIB_PATH} is missing. There is no CPU fallback; "
             "run __graft_entry__.build() (or make -C multiview_motion_capture_amd/csrc).")
     lib = C.CDLL(_LIB_PATH)
+    # The argument types declared below are those of ABI version MVMC_ABI: a library of another version (an old build loaded through
+    # MVMC_LIB_PATH for an A/B run, a stale .so) would receive shifted pointers and ints -- device faults or silent garbage.  Refuse it.
+    try:
+        lib.mvmc_abi_version.restype = C.c_int
+        have = int(lib.mvmc_abi_version())
+    except AttributeError:
+        have = -1
+    if have != MVMC_ABI:
+        raise MvmcError(f"{_LIB_PATH} has ABI version {have}, this package binds version {MVMC_ABI} (include/mvmc.h): rebuild it "
+                        "(make -C multiview_motion_capture_amd/csrc) or load a build of the same ABI version")
     vp, i32, f64 = C.c_void_p, C.c_int, C.c_double
     SK = C.POINTER(MvmcSkeleton)
     argtypes = {
@@ -101,7 +112,8 @@ def load():
     restypes = {"mvmc_status_string": C.c_char_p, "mvmc_pack_message_words": C.c_longlong, "mvmc_pack_work_words": C.c_longlong,
                 "mvmc_stitch_work_words": C.c_longlong}
     # A build of another revision loaded through MVMC_LIB_PATH for a same-box A/B comparison (tools/lib_diff.py, tools/*_ab.sh) may
-    # lack entry points that were added since; only then is a missing symbol skipped -- the shipped library must export every one.
+    # lack entry points that were added since WITHIN the same ABI version (checked above); only then is a missing symbol skipped -- the
+    # shipped library must export every one.
     ab = bool(os.environ.get("MVMC_LIB_PATH"))
     for name in SYMBOLS:
         if ab and not hasattr(lib, name):

@@ -278,7 +278,7 @@ __device__ __forceinline__ void affinity_wave(double* sm, const double* __restri
     }
 }
 
-__global__ void __launch_bounds__(64, 3)   // (proj_dist is shared with the chain kernel, which runs three workgroups per CU)
+__global__ void __launch_bounds__(64, MVMC_SMALL_WPS)   // (proj_dist is shared with the chain kernel, which runs three workgroups per CU)
 affinity_kernel(const double* __restrict__ kps17, const int32_t* __restrict__ counts, const float* __restrict__ Fm,
                 int C, int P, float* __restrict__ Dg, float* __restrict__ Sg) {
     extern __shared__ double sm[];
@@ -1269,6 +1269,153 @@ __device__ __forceinline__ int als7_iterate(const TW* __restrict__ Wf, int ldw, 
         for (int a = 0; a < R; a += 2) { const double2 v2 = gr[a >> 1]; o0 += v2.x * hv[a]; o1 += v2.y * hv[a + 1]; }
         Fout[i * LDF + sub] = o0 + o1;
     };
+#if MVMC_SMALL_WPS >= 4
+    // ---- the 128-register form (a fourth workgroup per CU: -DMVMC_SMALL_WPS=4; measured in round 5) ----
+    // The end of an iteration, the same on every wave: residuals p_res = sqrt(sP) / n, d_res = mu sqrt(sD) / n only feed thresholds
+    // (stop; mu x 2 or / 2): decide them on the squared sums (mu is a power of two, so mu^2 sD is exact), and only when a comparison is
+    // closer than 1e-9 to its threshold take the IEEE sqrt / divide path that NumPy's expressions round through (uniform over the
+    // workgroup).  Returns true when the iteration stops.
+    auto decide = [&]() {
+        const double sP = (sRed[0] + sRed[1]) + sRed[2], sD = (mu * mu) * ((sRed[3] + sRed[4]) + sRed[5]);
+        bool stop = sP < tol2 && sD < tol2, up = sP > 100.0 * sD, down = sD > 100.0 * sP;
+        {
+            const double eps = 1e-9;
+            const bool amb = !(sP > 1e-200) || !(sD > 1e-200) || fabs(sP - tol2) <= eps * tol2 || fabs(sD - tol2) <= eps * tol2 ||
+                             fabs(sP - 100.0 * sD) <= eps * sP || fabs(sD - 100.0 * sP) <= eps * sD;
+            if (amb) {
+                asm volatile("" ::: "memory");   // (keeps this a branch: the IEEE sqrt / divide sequences stay off the common path)
+                const double p_res = sqrt(sP) / n, d_res = mu * sqrt((sRed[3] + sRed[4]) + sRed[5]) / n;
+                stop = p_res < 1e-4 && d_res < 1e-4; up = p_res > 10 * d_res; down = d_res > 10 * p_res;
+            }
+        }
+        // (sRed is next written after five more barriers)
+        if (stop) return true;
+        if (up) { mu = 2 * mu; inv_mu = 0.5 * inv_mu; }
+        else if (down) { mu = mu / 2; inv_mu = 2 * inv_mu; }
+        return false;
+    };
+    // The solver wave and the worker waves run SEPARATE loops with the same six barriers per iteration (a barrier counts arrivals, not
+    // addresses): each role gets its own register allocation -- in one loop the allocator keeps the union live (the solver's two copies
+    // of the Gram matrix beside the workers' W / Z / Y / X state and right-hand sides), which a 128-register build can only hold with
+    // a dozen scratch reloads per iteration.
+    if (!worker) {
+        // The first three pivots of (A^T A + ridge I)^-1 are made AHEAD, in the solver wave's idle time at the end of the previous iteration
+        // (it waits ~600 cycles for the workers' X / Z / Y step), with the ridge of that iteration: mu changes in few iterations, and only
+        // then are they made again here -- the workers' X1 step used to wait for them (solver 1.0 k cycles against 0.5 k).
+        double ridge_made = 50.0 * inv_mu;
+        form(sA); inv_begin(ridge_made); gj_inv_steps<0, 3>(g, ge, gd, lane);
+        for (int it = 0; it < 1000; ++it) {
+            const double ridge = 50.0 * inv_mu;  // == 50 / mu exactly
+            if (ridge != ridge_made) {   // (wave-uniform: mu moved at the end of the last iteration)
+                inv_begin(ridge);
+                gj_inv_steps<0, 3>(g, ge, gd, lane);
+            }
+            APROF2(0)
+            __syncthreads();
+            APROF2(1)
+            gj_inv_steps<3, 8>(g, ge, gd, lane); inv_store(sInvA);
+            APROF2(2)
+            __syncthreads();
+            APROF2(3)
+            APROF2(4)
+            __syncthreads();
+            APROF2(5)
+            form(sB); inv_begin(ridge); gj_inv_steps<0, 8>(g, ge, gd, lane); inv_store(sInvB);
+            APROF2(6)
+            __syncthreads();
+            APROF2(7)
+            APROF2(8)
+            __syncthreads();
+            APROF2(9)
+            // A^T A for the next iteration
+            form(sA);
+            ridge_made = ridge;   // speculation: mu stays
+            inv_begin(ridge_made);
+            gj_inv_steps<0, 3>(g, ge, gd, lane);
+            APROF2(10)
+            __syncthreads();
+            APROF2(11)
+            const bool stop = decide();
+            APROF2(12)
+            if (stop) { iters = it + 1; break; }
+        }
+    } else {
+        for (int it = 0; it < 1000; ++it) {
+            double hv[R];
+            // ---- X1 = Z - (Y - W + beta)/mu (own entries; the matrix also goes to LDS for the transposed reads) ----
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                double v = 0.0;
+                if ((valid >> c) & 1) {
+                    if (sizeof(TW) == 4 && it == 0) v = (double)(w32[c] - faddr(-w32[c], 0.1f) / 64.f);
+                    else v = z[c] - ((y[c] - w[c]) + 0.1) * inv_mu;
+                }
+                x1[c] = v;
+                sX[i * LDX + sub * NS + c] = v;
+            }
+            APROF2(0)
+            __syncthreads();
+            APROF2(1)
+            // ---- B update: right-hand sides A^T X1[:, i] (column i of X1: through LDS) ----
+            rhs(sA, true, hv);
+            APROF2(2)
+            __syncthreads();
+            APROF2(3)
+            apply(sInvA, hv, sB);
+            APROF2(4)
+            __syncthreads();
+            APROF2(5)
+            // ---- A update: right-hand sides B^T X1[i, :]^T (own row, own columns) ----
+            rhs(sB, false, hv);
+            APROF2(6)
+            __syncthreads();
+            APROF2(7)
+            apply(sInvB, hv, sA);
+            APROF2(8)
+            __syncthreads();
+            APROF2(9)
+            // ---- X = A B^T, Z, Y, residuals ----
+            double acc_p = 0.0, acc_d = 0.0;
+            {
+                double av[R];
+                {
+                    const double2* ar = reinterpret_cast<const double2*>(&sA[i * LDF]);
+#pragma unroll
+                    for (int a = 0; a < R; a += 2) { const double2 v2 = ar[a >> 1]; av[a] = v2.x; av[a + 1] = v2.y; }
+                }
+#pragma unroll
+                for (int c = 0; c < NS; ++c) {
+                    const int j = sub * NS + c;
+                    double xa = 0.0, xb = 0.0;
+                    const double2* br = reinterpret_cast<const double2*>(&sB[j * LDF]);
+#pragma unroll
+                    for (int a = 0; a < R; a += 2) { const double2 v2 = br[a >> 1]; xa += av[a] * v2.x; xb += av[a + 1] * v2.y; }
+                    const double x = xa + xb;
+                    if ((valid >> c) & 1) {
+                        double zz = x + y[c] * inv_mu;
+                        if ((same >> c) & 1) zz = 0.0;
+                        if (i == j) zz = 1.0;
+                        zz = zz < 0.0 ? 0.0 : (zz > 1.0 ? 1.0 : zz);
+                        const double dz = x - zz, dx = x - xp[c];
+                        y[c] = y[c] + mu * dz;
+                        z[c] = zz;
+                        xp[c] = x;
+                        acc_p += dz * dz;
+                        acc_d += dx * dx;
+                    }
+                }
+                acc_p = wave_sum_dpp(acc_p); acc_d = wave_sum_dpp(acc_d);
+                if (lane == 0) { sRed[wv - 1] = acc_p; sRed[3 + wv - 1] = acc_d; }
+            }
+            APROF2(10)
+            __syncthreads();
+            APROF2(11)
+            const bool stop = decide();
+            APROF2(12)
+            if (stop) { iters = it + 1; break; }
+        }
+    }
+#else
     // The first three pivots of (A^T A + ridge I)^-1 are made AHEAD, in the solver wave's idle time at the end of the previous iteration
     // (it waits ~600 cycles for the workers' X / Z / Y step), with the ridge of that iteration: mu changes in few iterations, and only
     // then are they made again here -- the workers' X1 step used to wait for them (solver 1.0 k cycles against 0.5 k).
@@ -1378,6 +1525,7 @@ __device__ __forceinline__ int als7_iterate(const TW* __restrict__ Wf, int ldw, 
         if (up) { mu = 2 * mu; inv_mu = 0.5 * inv_mu; }
         else if (down) { mu = mu / 2; inv_mu = 2 * inv_mu; }
     }
+#endif
     // final X (dense n x n, leading dimension n) for the symmetrise / binarise tail
     __syncthreads();
     if (worker) {

@@ -92,7 +92,7 @@ template <bool BIG> struct ChainCfg;
 // POOL = view blocks (pose + projection of one member of a cluster) the IK phase has room for, for ALL problems of a frame together: the
 // clusters of a frame are disjoint, so a frame with at most POOL poses never runs out, whatever the size of a single cluster
 // (SMALL: the association variants hold 24 pose nodes anyway; BIG: N_MAX).
-template <> struct ChainCfg<false> { static constexpr int POOL = 24, N_MAX = 40, NS_MAX = 48, NT = 256, WG_PER_CU = 3, WAVES_PER_SIMD = 3; };
+template <> struct ChainCfg<false> { static constexpr int POOL = 24, N_MAX = 40, NS_MAX = 48, NT = 256, WG_PER_CU = MVMC_SMALL_WPS, WAVES_PER_SIMD = MVMC_SMALL_WPS; };
 template <> struct ChainCfg<true> { static constexpr int POOL = 64, N_MAX = 64, NS_MAX = 72, NT = 512, WG_PER_CU = 1, WAVES_PER_SIMD = 2; };
 
 
@@ -104,7 +104,7 @@ template <bool BIG> union ChainArena;
 template <> union ChainArena<false> {
     Als4Lds<32> als_st;
     Als4Lds<24> als_sp;
-    struct { Ik1Shared ik[4]; double views[24 * MVMC_IK_VIEW_DOUBLES]; } ikp;
+    struct { Ik1Shared ik[4]; int mq[24]; unsigned short mc[24]; } ikp;   // four solves + the frame's member list (ChainCfg::POOL)
     // graph scratch: st_affinity_wave needs (NS*NS + 6) doubles + 2 NS ints (NS <= 48), affinity_wave N*51 doubles + 2 N*N floats
     // + 2 N ints + 4 words (N <= 40)
     // + the pose-pair block made ahead of the hand-over (st_pose_pairs: N * N doubles behind st_affinity_wave's part)
@@ -112,14 +112,14 @@ template <> union ChainArena<false> {
 };
 template <> union ChainArena<true> {
     Als5Lds<72> als;
-    struct { Ik1Shared ik[8]; double views[64 * MVMC_IK_VIEW_DOUBLES]; } ikp;   // eight waves: the eight people of config 5 are solved side by side
+    struct { Ik1Shared ik[8]; int mq[64]; unsigned short mc[64]; } ikp;   // eight waves: the eight people of config 5 are solved side by side
     // affinity_wave at N = 64: 64 * 51 + 64 * 64 + 64 + 16 = 7440; st_affinity_wave at NS = 72: 72 * 72 + 6 + 72, + the frame's keypoints
     // + the pose-pair block; the line tables of st_pose_pairs_lines (2 * 4 * P * 68 doubles) use st_affinity_wave's part
     double graph[CH_EOFF_BIG + 64 * 64];
 };
 static_assert(CH_EOFF >= 48 * 48 + 10 + 48 && CH_EOFF + 40 * 40 >= 40 * 51 + 40 * 40 + 40 + 8, "graph scratch covers both graph builders");
-static_assert(sizeof(ChainArena<false>) <= 4 * sizeof(Ik1Shared) + 24 * MVMC_IK_VIEW_DOUBLES * 8, "SMALL: the IK blocks set the arena size");
-static_assert(sizeof(ChainArena<false>) <= 52 * 1024, "SMALL: three workgroups per CU");
+static_assert(sizeof(ChainArena<false>) <= 4 * sizeof(Ik1Shared) + 144, "SMALL: the IK blocks set the arena size");
+static_assert(sizeof(ChainArena<false>) + sizeof(Ik1Tables) + 8 <= 40960, "SMALL: four workgroups per CU (160 KB / 4, in granules of 1,280 B)");
 static_assert(CH_EOFF_BIG + 64 * 64 >= 64 * 51 + 64 * 64 + 64 + 16 && CH_KOFF_BIG >= 72 * 72 + 10 + 72, "BIG: graph scratch covers both graph builders");
 static_assert(sizeof(ChainArena<true>) <= 150 * 1024, "BIG: one workgroup per CU");
 
@@ -130,7 +130,8 @@ static_assert(sizeof(ChainArena<true>) <= 150 * 1024, "BIG: one workgroup per CU
 // functions -- with it each phase saved and restored, per call and per lane, every callee-saved vector register it touches (58 for the
 // IK phase), whether the kernel had anything live there or not.
 template <bool BIG>
-__device__ __noinline__ void chain_graph_spatial(ChainArena<BIG>& arena, ChainArgsK& A, int b, int f, int* done) {
+__device__ __noinline__ void chain_graph_spatial(ChainArena<BIG>& arena_in, ChainArgsK& A, int b, int f, int* done) {
+    ChainArena<BIG>& arena = *uni(&arena_in);
     MVMC_ASSUME_LDS(&arena);
     const int C = A.C, P = A.P, N = C * P;
     float* S = A.S_sp + (size_t)b * N * N;
@@ -138,7 +139,8 @@ __device__ __noinline__ void chain_graph_spatial(ChainArena<BIG>& arena, ChainAr
     *done = 0;
 }
 template <bool BIG>
-__device__ __noinline__ void chain_graph_temporal(ChainArena<BIG>& arena, ChainArgsK& A, int b, int f, bool pairs_ready, int* done) {
+__device__ __noinline__ void chain_graph_temporal(ChainArena<BIG>& arena_in, ChainArgsK& A, int b, int f, bool pairs_ready, int* done) {
+    ChainArena<BIG>& arena = *uni(&arena_in);
     MVMC_ASSUME_LDS(&arena);
     const int C = A.C, P = A.P, T = A.T, NS = T + C * P;
     double* W = A.W_st + (size_t)b * NS * NS;
@@ -160,13 +162,15 @@ __device__ __noinline__ void chain_graph_temporal(ChainArena<BIG>& arena, ChainA
     *done = 0;
 }
 // the frame's 2-D / 2-D distances, made while the workgroup waits for its predecessor (they do not depend on the tracklets)
-__device__ __noinline__ void chain_pose_pairs(ChainArena<false>& arena, ChainArgsK& A, int f, int* done) {
+__device__ __noinline__ void chain_pose_pairs(ChainArena<false>& arena_in, ChainArgsK& A, int f, int* done) {
+    ChainArena<false>& arena = *uni(&arena_in);
     MVMC_ASSUME_LDS(&arena);
     st_pose_pairs(arena.graph + CH_EOFF, A.kps17, A.counts, f, A.F2, A.C, A.P, 0.1);
     *done = 0;
 }
 template <bool BIG>
-__device__ __noinline__ void chain_als_spatial(ChainArena<BIG>& arena, ChainArgsK& A, int b, int f, int* done) {
+__device__ __noinline__ void chain_als_spatial(ChainArena<BIG>& arena_in, ChainArgsK& A, int b, int f, int* done) {
+    ChainArena<BIG>& arena = *uni(&arena_in);
     MVMC_ASSUME_LDS(&arena);
     const int C = A.C, N = C * A.P;
     // batch index 0 with pre-offset pointers: the graph, its group counts (the frame's people per view) and outputs
@@ -179,7 +183,8 @@ __device__ __noinline__ void chain_als_spatial(ChainArena<BIG>& arena, ChainArgs
     *done = 0;
 }
 template <bool BIG>
-__device__ __noinline__ void chain_als_temporal(ChainArena<BIG>& arena, ChainArgsK& A, int b, int* done) {
+__device__ __noinline__ void chain_als_temporal(ChainArena<BIG>& arena_in, ChainArgsK& A, int b, int* done) {
+    ChainArena<BIG>& arena = *uni(&arena_in);
     MVMC_ASSUME_LDS(&arena);
     const int C = A.C, NS = A.T + C * A.P;
     if constexpr (BIG)
@@ -201,7 +206,8 @@ __device__ __noinline__ void chain_commit(ChainArgsK& A, int b, int* done) {
     *done = 0;
 }
 template <bool BIG>
-__device__ __noinline__ void chain_ik(ChainArena<BIG>& arena, const Ik1Tables& tables, ChainArgsK& A, int b, int* done) {
+__device__ __noinline__ void chain_ik(ChainArena<BIG>& arena_in, const Ik1Tables& tables, ChainArgsK& A, int b, int* done) {
+    ChainArena<BIG>& arena = *uni(&arena_in);
     MVMC_ASSUME_LDS(&arena);
     MVMC_ASSUME_LDS(&tables);
     constexpr int NW = ChainCfg<BIG>::NT / 64, POOL = ChainCfg<BIG>::POOL;
@@ -218,7 +224,7 @@ __device__ __noinline__ void chain_ik(ChainArena<BIG>& arena, const Ik1Tables& t
         const int p = b * NP + s;
         const int base = uni(__shfl(excl, s, 64)), n_valid = uni(__shfl(cnt, s, 64));
         const int room = base < POOL ? POOL - base : 0;     // (a frame with more poses than POOL: the problem is cut short and flagged)
-        ik1_solve(arena.ikp.ik[wave], arena.ikp.views + (base < POOL ? base : 0) * MVMC_IK_VIEW_DOUBLES, room, tables, A.kps17, A.Pm, A.members,
+        ik1_solve(arena.ikp.ik[wave], arena.ikp.mq + (base < POOL ? base : 0), arena.ikp.mc + (base < POOL ? base : 0), room, tables, A.kps17, A.Pm, A.members,
                   p, A.V, A.C, A.P, A.init, A.cold, A.nfev_cold, A.nfev_warm, A.ik_params, A.ik_joints, A.ik_info,
                   A.ik_scratch + (ptrdiff_t)(b * NW + wave - p) * MVMC_IK_SCRATCH_DOUBLES, 3, nullptr,
                   reinterpret_cast<int32_t*>(A.flags + A.n_chains + 4 + b), n_valid);
@@ -234,7 +240,14 @@ chain_kernel(Ik1Tables tables_arg, ChainArgs A_by_value) {
     typedef const __attribute__((address_space(4))) char* KernargBytes;
     ChainArgsK& A = *(ChainArgsK*)((KernargBytes)__builtin_amdgcn_kernarg_segment_ptr() + A_OFFSET);
     extern __shared__ __attribute__((aligned(16))) unsigned char chain_lds[];   // the arena (BIG: 72 KB, beyond the static limit)
-    ChainArena<BIG>& arena = *reinterpret_cast<ChainArena<BIG>*>(chain_lds);
+    // The arena's address is made OPAQUE here: every call site hands the phases the same pointer, so interprocedural constant propagation
+    // replaces their parameter by the dynamic-LDS symbol itself -- and an out-of-line function finds a dynamic allocation's offset by a
+    // look-up in a table in GLOBAL memory (llvm.amdgcn.dynlds.offset.table), re-done wherever the allocator would rather reload than
+    // keep a register: two global loads per iteration inside the association's loop, in front of its LDS reads.  As an opaque value it
+    // is an ordinary argument, which the phases pin to scalar registers (uni).
+    ChainArena<BIG>* arena_ptr = reinterpret_cast<ChainArena<BIG>*>(chain_lds);
+    asm volatile("" : "+s"(arena_ptr));
+    ChainArena<BIG>& arena = *arena_ptr;
     __shared__ Ik1Tables tables;
     __shared__ int s_nt;
     // Which (chain, part) a workgroup runs -- two protocols, the results are the same bit for bit:

@@ -7,6 +7,12 @@
 
 #define MVMC_WAVE 64
 
+// Waves per SIMD the SMALL layout of the chain kernel (and every kernel that shares out-of-line device functions with it) is built
+// for: 3 = 168 VGPRs, 4 = 128 VGPRs (a fourth workgroup per CU needs the LDS arena <= 40,960 B too)
+#ifndef MVMC_SMALL_WPS
+#define MVMC_SMALL_WPS 3
+#endif
+
 // Ordering point for LDS traffic INSIDE one wave (single-wave routines that may run in a multi-wave workgroup, where
 // __syncthreads() would be a real barrier across waves doing unrelated work).  LDS operations of a wave execute in
 // order, so only the compiler has to be kept from moving accesses across the point.

@@ -50,7 +50,7 @@ enum { SV_D = 0, SV_E = 64, SV_TAU = 128, SV_V0 = 192, SV_WN = 256, SV_COUNT = 3
 
 // skeleton-derived tables: the same for every solve, one copy per workgroup
 struct Ik1Tables {
-    double dirs[18 * 3], ref_side[18];
+    double dirs[18 * 3], ref_side[MVMC_N_SIDE + 1];   // (the side-length slots: n_side <= MVMC_N_SIDE is checked by every launcher)
     unsigned long long rowmask[2][NOBS];
     int anc[18];
     int smask[18];   // joints (bit j) whose bone length is side-length slot s
@@ -84,29 +84,39 @@ struct Ik1Tables {
     }
 };
 
-// per-solve state (one wave).  The problem's observations are NOT part of it: pose18 (nv x 18 x {x, y, score}: COCO-17 + mid-spine) and
-// the projection matrices (nv x 12) live in a VIEW BLOCK of nv * MVMC_IK_VIEW_DOUBLES doubles that the caller hands to ik1_solve -- the
-// stand-alone kernel a block of v_max views per workgroup, the chain kernel a slice of ONE pool per workgroup: the clusters of a frame
-// are disjoint sets of the frame's poses, so the blocks of all of a frame's problems, laid end to end, never exceed the number of poses
-// in the frame, whatever the size of a single cluster (the reference has no cap on it: motion_capture.py:417-446, :618-626).
+// per-solve state (one wave).  The problem's observations are NOT part of it -- and since round 5 not in LDS at all: the evaluation
+// reads a view's keypoint rows (COCO-17; the synthetic mid-spine row, inverse_kinematics.py:339-348, is formed from its four rows on the
+// fly) and its projection matrix straight from the read-only input tensors (15 doubles per lane and view, L1 / L2 hits after the first
+// touch: a frame's keypoints are 8 KB), through a MEMBER LIST of (pose index, camera) per view that the caller hands to ik1_solve: the
+// stand-alone kernel a list of v_max entries per workgroup, the chain kernel a slice of ONE list per workgroup -- the clusters of a frame
+// are disjoint sets of the frame's poses, so the lists of all of a frame's problems, laid end to end, never exceed the number of poses
+// in the frame, whatever the size of a single cluster (the reference has no cap on it: motion_capture.py:417-446, :618-626).  The
+// 12.7 KB view pool (24 views x 66 doubles) this replaces was what kept the SMALL layout's arena above 40,960 B, i.e. a fourth
+// workgroup per CU out of reach.
 struct Ik1Shared {
     __attribute__((aligned(16))) double tmp[256];
     double sv[SV_COUNT];
-    double x[68], xn[68], side[18];
+    double x[68], xn[68], side[MVMC_N_SIDE + 1];
     double Rg[18 * 9], pos[18 * 3], bvec[18 * 3];
     double hs[18 * 4];      // sin, cos of half the x and y Euler angles of every joint (from the last FK)
     double Wk[NOBS * 6], tk[NOBS * 3];
     double sc[12];          // {|g|^2, |g|_inf, alpha, pred, beta0, tau0, |J^T J|_1, coupling, |step|, |x|, fallback rows}
     int nviews, mode3d;
-    int view_off, pad_;     // the view block, in doubles from the start of this struct (3-D-target mode keeps 16 x {x, y, z, weight} there)
+    int mq_off, mc_off;     // the member list, in bytes from the start of this struct: int32 pose index / uint16 camera per view
 #ifdef MVMC_IK_PROFILE
     long long prof[8];
 #endif
 };
-constexpr int MVMC_IK_VIEW_DOUBLES = 54 + 12;
+constexpr int MVMC_IK_VIEW_DOUBLES = 54 + 12;   // a staged view (cold start only, in the solve's global scratch): 18 rows + P
+// where a solve's observations come from: the read-only inputs (reprojection mode) or the 3-D targets (mode3d); wave-uniform
+struct Ik1Obs {
+    const mvmc_gdouble* kps17;   // (.., 17, 3)
+    const mvmc_gdouble* Pm;      // (C, 3, 4)
+    const mvmc_gdouble* tg;      // this problem's 18 x {x, y, z, weight} targets, or NULL
+};
 // (derived from &S, which every out-of-line function declares to be LDS: the accesses stay ds_ instructions)
-__device__ __forceinline__ double* ik1_pose18(Ik1Shared& S) { return reinterpret_cast<double*>(&S) + S.view_off; }
-__device__ __forceinline__ double* ik1_pm(Ik1Shared& S, int nv) { return reinterpret_cast<double*>(&S) + S.view_off + nv * 54; }
+__device__ __forceinline__ const int* ik1_mq(Ik1Shared& S) { return reinterpret_cast<const int*>(reinterpret_cast<const char*>(&S) + S.mq_off); }
+__device__ __forceinline__ const unsigned short* ik1_mc(Ik1Shared& S) { return reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(&S) + S.mc_off); }
 
 __device__ __forceinline__ double wave_max64(double v) { return wave_max_dpp(v); }
 
@@ -134,7 +144,7 @@ __device__ inline void rot_from_half_angles(double sx, double cx, double sy, dou
 // FK + residual; with want_jac also the per-joint normal-equation blocks W_k (S.Wk) and t_k (S.tk).
 // Lane (k, r) = (lane & 15, lane >> 4) handles observed joint k in the views r, r + 4.  Returns 0.5 |f|^2.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double ik1_eval(Ik1Shared& S, const Ik1Tables& T, const double* xs, int stage, bool want_jac) {
+__device__ __forceinline__ double ik1_eval(Ik1Shared& S, const Ik1Tables& T, const double* xs, int stage, bool want_jac, const Ik1Obs& O) {
     const int lane = threadIdx.x & 63;
     double* Rl = S.tmp;
     double* off = S.tmp + 162;
@@ -180,15 +190,16 @@ __device__ __forceinline__ double ik1_eval(Ik1Shared& S, const Ik1Tables& T, con
     }
     const int k = lane & 15, r = lane >> 4;
     const int nviews = uni(S.nviews);
-    const double* pose18 = ik1_pose18(S);
-    const double* Pmv = ik1_pm(S, nviews);
+    const int* mq = ik1_mq(S);
+    const unsigned short* mc = ik1_mc(S);
     const double* X = &S.pos[kIkSkel[k] * 3];
     const double X0 = X[0], X1 = X[1], X2 = X[2];
+    const int obs = kIkObs[k];
     double f2 = 0.0, o[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (S.mode3d) {
         // residual (pos_k - target_k) * w_k (inverse_kinematics.py:280-336): J_k = w_k D_k, so W_k = w_k^2 I, t_k = w_k f_k
         if (r == 0) {
-            const double* tg = &pose18[k * 4];
+            const mvmc_gdouble* tg = O.tg + obs * 4;
             const double w = tg[3], w2 = w * w;
             const double f0 = (X0 - tg[0]) * w, f1 = (X1 - tg[1]) * w, f2c = (X2 - tg[2]) * w;
             f2 = f0 * f0 + f1 * f1 + f2c * f2c;
@@ -197,21 +208,33 @@ __device__ __forceinline__ double ik1_eval(Ik1Shared& S, const Ik1Tables& T, con
         }
     } else
     for (int v = r; v < nviews; v += 4) {
-        const double* P = &Pmv[v * 12];
-        const double h0 = P[0] * X0 + P[1] * X1 + P[2] * X2 + P[3];
-        const double h1 = P[4] * X0 + P[5] * X1 + P[6] * X2 + P[7];
-        const double h2 = P[8] * X0 + P[9] * X1 + P[10] * X2 + P[11];
+        const mvmc_gdouble* kp = O.kps17 + (size_t)mq[v] * 51;
+        const mvmc_gdouble* P = O.Pm + (int)mc[v] * 12;
+        // the observation row: a COCO-17 keypoint, or the mid-spine (a quarter of shoulders + hips, the product of their scores)
+        double ob0, ob1, s;
+        if (obs < 17) { ob0 = kp[obs * 3]; ob1 = kp[obs * 3 + 1]; s = kp[obs * 3 + 2]; }
+        else {
+            const double sh0 = 0.5 * (kp[5 * 3] + kp[6 * 3]), hp0 = 0.5 * (kp[11 * 3] + kp[12 * 3]);
+            const double sh1 = 0.5 * (kp[5 * 3 + 1] + kp[6 * 3 + 1]), hp1 = 0.5 * (kp[11 * 3 + 1] + kp[12 * 3 + 1]);
+            ob0 = 0.5 * (sh0 + hp0); ob1 = 0.5 * (sh1 + hp1);
+            s = kp[5 * 3 + 2] * kp[6 * 3 + 2];
+            s *= kp[11 * 3 + 2] * kp[12 * 3 + 2];
+        }
+        const double P0 = P[0], P1 = P[1], P2 = P[2], P3 = P[3], P4 = P[4], P5 = P[5], P6 = P[6], P7 = P[7], P8 = P[8], P9 = P[9],
+                     P10 = P[10], P11 = P[11];
+        const double h0 = P0 * X0 + P1 * X1 + P2 * X2 + P3;
+        const double h1 = P4 * X0 + P5 * X1 + P6 * X2 + P7;
+        const double h2 = P8 * X0 + P9 * X1 + P10 * X2 + P11;
         const double w = 1e-5 + h2, iw = 1.0 / w;
         const double u = h0 / w, vv = h1 / w;
-        const double* ob = &pose18[(v * 18 + kIkObs[k]) * 3];
-        const double s = ob[2];
-        const double fu = (u - ob[0]) * s, fv = (vv - ob[1]) * s;
+        const double fu = (u - ob0) * s, fv = (vv - ob1) * s;
         f2 += fu * fu + fv * fv;
         if (want_jac) {
+            const double Pr0[3] = {P0, P1, P2}, Pr1[3] = {P4, P5, P6}, Pr2[3] = {P8, P9, P10};
             double du[3], dv[3];
             for (int c = 0; c < 3; ++c) {
-                du[c] = (P[c] - u * P[8 + c]) * iw;
-                dv[c] = (P[4 + c] - vv * P[8 + c]) * iw;
+                du[c] = (Pr0[c] - u * Pr2[c]) * iw;
+                dv[c] = (Pr1[c] - vv * Pr2[c]) * iw;
             }
             const double s2 = s * s;
             o[0] += s2 * (du[0] * du[0] + dv[0] * dv[0]);
@@ -258,10 +281,12 @@ __device__ __forceinline__ double ik1_eval(Ik1Shared& S, const Ik1Tables& T, con
 // Results of a trial: S.xn = the trial point, S.sc[2] = alpha, S.sc[3] = predicted reduction, S.sc[8] = |step|,
 // S.sc[9] = |x|.
 // ---------------------------------------------------------------------------------------------
-__device__ __noinline__ double ik1_eval_nl(Ik1Shared& S, const Ik1Tables& T, int at_trial, int stage, bool want_jac) {
+__device__ __noinline__ double ik1_eval_nl(Ik1Shared& S, const Ik1Tables& T, int at_trial, int stage, bool want_jac,
+                                           const mvmc_gdouble* kps17, const mvmc_gdouble* Pm, const mvmc_gdouble* tg) {
     MVMC_ASSUME_LDS(&S);
     MVMC_ASSUME_LDS(&T);
-    return ik1_eval(S, T, at_trial ? S.xn : S.x, stage, want_jac);
+    const Ik1Obs O = {uni(kps17), uni(Pm), uni(tg)};   // (arrive in vector registers; wave-uniform: scalar bases of the loads)
+    return ik1_eval(S, T, at_trial ? S.xn : S.x, stage, want_jac, O);
 }
 
 // S.xn = S.x + step on the active parameters (stepj: lane j's component), S.sc[9] = |x|
@@ -384,7 +409,11 @@ __device__ __noinline__ void ik1_model_step(Ik1Shared& S, const Ik1Tables& T, in
         // broadcast ds_read_b128 are in flight together instead of one LDS round trip per row.  Four rows per chunk: the 50-row
         // instance has no registers for more operands, and in the 40-row one 8 rows per chunk measured slower (fewer chunks are
         // skipped by the tree sparsity than round trips are saved: IK 37.6 -> 38.6 M cycles per chain)
+#ifdef MVMC_IK_GR
+        constexpr int GR = MVMC_IK_GR, GL = GR * 3 / 2;
+#else
         constexpr int GR = 4, GL = GR * 3 / 2;
+#endif
         const unsigned long long m = T.rowmask[stage][k];
         const unsigned mlo = __builtin_amdgcn_readfirstlane((unsigned)m), mhi = __builtin_amdgcn_readfirstlane((unsigned)(m >> 32));
 #pragma unroll
@@ -572,7 +601,11 @@ __device__ __noinline__ void ik1_model_step_r(Ik1Shared& S, const Ik1Tables& T, 
         // broadcast ds_read_b128 are in flight together instead of one LDS round trip per row.  Four rows per chunk: the 50-row
         // instance has no registers for more operands, and in the 40-row one 8 rows per chunk measured slower (fewer chunks are
         // skipped by the tree sparsity than round trips are saved: IK 37.6 -> 38.6 M cycles per chain)
+#ifdef MVMC_IK_GR
+        constexpr int GR = MVMC_IK_GR, GL = GR * 3 / 2;
+#else
         constexpr int GR = 4, GL = GR * 3 / 2;
+#endif
         const unsigned long long m = T.rmask(STAGE, k, T.anc[K]);
         const unsigned mlo = __builtin_amdgcn_readfirstlane((unsigned)m), mhi = __builtin_amdgcn_readfirstlane((unsigned)(m >> 32));
 #pragma unroll
@@ -733,7 +766,7 @@ __device__ __noinline__ void ik1_retry_trial(Ik1Shared& S, const Ik1Tables& T, i
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void ik1_trf(Ik1Shared& S, const Ik1Tables& T, int stage, int max_nfev, mvmc_gdouble* __restrict__ hh,
                                         double* cost_out, int* nfev_out, int* njev_out, int* status_out, int* fallbacks_out, bool& dump,
-                                        bool& fk_at_x) {
+                                        bool& fk_at_x, const Ik1Obs& O) {
     const int lane = threadIdx.x & 63;
     // wave-uniform state is pinned to scalar registers (uni)
     const int nfull = uni((stage == 0) ? 57 : 57 + T.n_side);
@@ -760,7 +793,7 @@ __device__ __forceinline__ void ik1_trf(Ik1Shared& S, const Ik1Tables& T, int st
         return uni(mode);
     };
     double cost;
-    { P1_T0 cost = uni(ik1_eval_nl(S, T, 0, stage, true)); P1_ADD(0) }
+    { P1_T0 cost = uni(ik1_eval_nl(S, T, 0, stage, true, O.kps17, O.Pm, O.tg)); P1_ADD(0) }
     fk_at_x = true;    // (every other way out of the loop below leaves the FK state of x in LDS: the last evaluation was at the accepted point)
     int nfev = 1, njev = 0, status = -1;
     double Delta;
@@ -798,14 +831,14 @@ __device__ __forceinline__ void ik1_trf(Ik1Shared& S, const Ik1Tables& T, int st
                     // throughput; only the warm solves on demand: -1.6 % of the writes, no change in speed.  The dumps are not where
                     // the launch's 2.3 GB of writes come from; left as it was)
                     dump = dumped = true;
-                    ik1_eval_nl(S, T, 0, stage, true);
+                    ik1_eval_nl(S, T, 0, stage, true, O.kps17, O.Pm, O.tg);
                     model_step(true, Delta, alpha, true);
                 }
             }
             have_trial = false;
             alpha = uni(S.sc[2]);
             const double pred = uni(S.sc[3]), step_norm = uni(S.sc[8]), x_norm = uni(S.sc[9]);
-            { P1_T0 cost_new = uni(ik1_eval_nl(S, T, 1, stage, true)); P1_ADD(0) }
+            { P1_T0 cost_new = uni(ik1_eval_nl(S, T, 1, stage, true, O.kps17, O.Pm, O.tg)); P1_ADD(0) }
             ++nfev;
             if (!isfinite(cost_new)) { Delta = uni(0.25 * step_norm); continue; }
             actual = cost - cost_new;
@@ -837,13 +870,15 @@ __device__ __forceinline__ void ik1_trf(Ik1Shared& S, const Ik1Tables& T, int st
     *cost_out = cost; *nfev_out = nfev; *njev_out = njev; *status_out = status;
 }
 
-// Cold start: DLT of the 18 keypoints + the reference's one-step post-optimisation; hips -> S.xn[0..6)
-__device__ __noinline__ void ik1_cold_root(Ik1Shared& S, int nv) {
+// Cold start: DLT of the 18 keypoints + the reference's one-step post-optimisation; hips -> S.xn[0..6).  `views`: the problem's staged
+// view block (ik1_stage_views: nv x 18 rows, then nv projection matrices) in the solve's global scratch -- chain heads only, one solve
+// in sixteen on the benchmark protocol.
+__device__ __noinline__ void ik1_cold_root(Ik1Shared& S, int nv, const double* views) {
     MVMC_ASSUME_LDS(&S);
     const int lane = threadIdx.x & 63;
     double X[3] = {0, 0, 0};
-    const double* pose18 = ik1_pose18(S);
-    const double* Pmv = ik1_pm(S, nv);
+    const double* pose18 = views;
+    const double* Pmv = views + nv * 54;
     if (lane < 18) dlt_obs_point(pose18, Pmv, nv, lane, 0.01, X);
     postopt::post_optimize_wave(X, pose18 + (lane < 18 ? lane : 0) * 3, 54, Pmv, nv, 18);
     if (lane == 11 || lane == 12)
@@ -862,7 +897,7 @@ __host__ __device__ inline void ik1_tables_section(TB& T, const SkelDev& skarg, 
             for (int k = 0; k < 3; ++k) T.dirs[lane * 3 + k] = skarg.dirs[lane][k];
             T.parents[lane] = (signed char)skarg.parents[lane];
             T.side_map[lane] = (signed char)skarg.side_map[lane];
-            T.ref_side[lane] = skarg.ref_side[lane];
+            if (lane <= MVMC_N_SIDE) T.ref_side[lane] = skarg.ref_side[lane];
         }
     } else if (section == 1) {
         if (lane < 18) {
@@ -996,41 +1031,40 @@ inline void ik1_build_tables_host(Ik1Tables& T, const SkelDev& skarg) {
         for (int lane = 0; lane < 64; ++lane) ik1_tables_section(T, skarg, section, lane);
 }
 
-// The members of problem b ranked into the wave: lane v < nv gets its pose index in q_own; returns the number of views used (at most
-// vcap: more raise bit 0 of *ovf).  members (.., V): pose indices, -1 = none (holes allowed); n_valid >= 0: the row's first n_valid
-// entries are the members (the rest of the row is undefined: the chain kernel's table).
-__device__ __forceinline__ int ik1_rank_members(Ik1Shared& S, int vcap, const int32_t* __restrict__ members, int b, int V, int32_t* ovf,
-                                                int n_valid, int& q_own) {
+// The members of problem b into the member list (mq: pose index, mc: camera; LDS, room for vcap entries): returns the number of views
+// used (at most vcap: more raise bit 0 of *ovf).  members (.., V): pose indices, -1 = none (holes allowed); n_valid >= 0: the row's first
+// n_valid entries are the members (the rest of the row is undefined: the chain kernel's table).
+__device__ __forceinline__ int ik1_rank_members(int* mq, unsigned short* mc, int vcap, const int32_t* __restrict__ members, int b, int V,
+                                                int32_t* ovf, int n_valid, int C, int Pmax) {
     const int lane = threadIdx.x & 63;
-    // lane v looks at member v (64 per pass); the valid ones are ranked by ballot and parked in LDS at their rank (S.tmp is free here)
-    int* ranked = reinterpret_cast<int*>(S.tmp);
+    // lane v looks at member v (64 per pass); the valid ones are ranked by ballot and parked at their rank
     int nv = 0;
     if (n_valid >= 0) {
         nv = n_valid < 64 ? n_valid : 64;
-        if (lane < nv) ranked[lane] = members[(size_t)b * V + lane];
+        if (lane < nv && lane < vcap) { const int m = members[(size_t)b * V + lane]; mq[lane] = m; mc[lane] = (unsigned short)((m / Pmax) % C); }
     } else
     for (int v0 = 0; v0 < V; v0 += 64) {
         const int m = (v0 + lane < V) ? members[(size_t)b * V + v0 + lane] : -1;
         const unsigned long long have = __builtin_amdgcn_ballot_w64(m >= 0);
         const int rank = nv + __popcll(have & ((1ull << lane) - 1ull));
-        if (m >= 0 && rank < 64) ranked[rank] = m;
+        if (m >= 0 && rank < vcap) { mq[rank] = m; mc[rank] = (unsigned short)((m / Pmax) % C); }
         nv += __popcll(have);
     }
-    MVMC_WAVE_SYNC();
-    if (lane < nv) q_own = ranked[lane];
     MVMC_WAVE_SYNC();
     nv = uni(nv);
     if (nv > vcap) { if (ovf && lane == 0) atomicOr(ovf, 1); nv = vcap; }
     return nv;
 }
 
-// The view block of a problem: 17 COCO rows + synthetic mid-spine (inverse_kinematics.py:339-348) per view, then the projection matrices
-__device__ __forceinline__ void ik1_load_views(double* views, int nv, int q_own, const double* __restrict__ kps17,
-                                               const double* __restrict__ Pmats, int C, int Pmax) {
+// The view block of a problem, staged for the cold start (global memory: the solve's scratch, free until the first model): 17 COCO rows
+// + synthetic mid-spine (inverse_kinematics.py:339-348) per view, then the projection matrices.  Lane v writes view v, other lanes read
+// it: an agent-scope release / acquire pair around the hand-over (the same wave, but the loads must not be served from stale L1 lines).
+__device__ __forceinline__ void ik1_stage_views(mvmc_gdouble* views, int nv, const int* mq, const unsigned short* mc,
+                                                const mvmc_gdouble* __restrict__ kps17, const mvmc_gdouble* __restrict__ Pmats) {
     const int lane = threadIdx.x & 63;
     if (lane < nv) {
-        const double* kp = kps17 + (size_t)q_own * 51;
-        double* dst = views + lane * 54;
+        const mvmc_gdouble* kp = kps17 + (size_t)mq[lane] * 51;
+        mvmc_gdouble* dst = views + lane * 54;
         for (int e = 0; e < 51; ++e) dst[e] = kp[e];
         for (int c = 0; c < 2; ++c) {
             const double mid_sh = 0.5 * (kp[5 * 3 + c] + kp[6 * 3 + c]);
@@ -1040,17 +1074,20 @@ __device__ __forceinline__ void ik1_load_views(double* views, int nv, int q_own,
         double sc = kp[5 * 3 + 2] * kp[6 * 3 + 2];
         sc *= kp[11 * 3 + 2] * kp[12 * 3 + 2];
         dst[53] = sc;
-        const double* Pc = Pmats + (size_t)((q_own / Pmax) % C) * 12;
+        const mvmc_gdouble* Pc = Pmats + (int)mc[lane] * 12;
         for (int e = 0; e < 12; ++e) views[nv * 54 + lane * 12 + e] = Pc[e];
     }
-    MVMC_WAVE_SYNC();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
-// One solve on the calling wave (problem b); S is this wave's LDS block, `views` its view block (LDS, room for vcap views).  Used by
+// One solve on the calling wave (problem b); S is this wave's LDS block, (mq, mc) its member list (LDS, room for vcap views).  Used by
 // ik1_kernel (one wave per workgroup) and by the chain kernel (four or eight waves per workgroup, one solve each).
 // More members than vcap: the first vcap are used and bit 0 of *ovf is raised (the result is then not the reference's; with the chain
-// kernel's pool and the stand-alone kernel's v_max block it cannot happen unless the caller's v_max is smaller than a cluster).
-__device__ __forceinline__ void ik1_solve(Ik1Shared& S, double* views, int vcap, const Ik1Tables& T, const double* __restrict__ kps17,
+// kernel's pool and the stand-alone kernel's v_max list it cannot happen unless the caller's v_max is smaller than a cluster).
+__device__ __forceinline__ void ik1_solve(Ik1Shared& S, int* mq, unsigned short* mc, int vcap, const Ik1Tables& T, const double* __restrict__ kps17,
                                           const double* __restrict__ Pmats, const int32_t* __restrict__ members, int b, int V,
                                           int C, int Pmax, const double* __restrict__ init, const uint8_t* __restrict__ cold,
                                           int nfev_cold, int nfev_warm, double* __restrict__ params_out,
@@ -1061,11 +1098,15 @@ __device__ __forceinline__ void ik1_solve(Ik1Shared& S, double* views, int vcap,
     b = uni(b);
     mvmc_gdouble* hh = uni((mvmc_gdouble*)(scratch + (size_t)b * MVMC_IK_SCRATCH_DOUBLES));   // Householder vectors [0, 3200), eigenvectors [3200, 6400)
     double* info = uni(info_out ? info_out + (size_t)b * 8 : nullptr);
-    if (lane == 0) S.view_off = (int)(views - reinterpret_cast<double*>(&S));
+    const Ik1Obs O = {(const mvmc_gdouble*)kps17, (const mvmc_gdouble*)Pmats,
+                      targets3d ? (const mvmc_gdouble*)(targets3d + (size_t)b * 72) : nullptr};
+    if (lane == 0) {
+        S.mq_off = (int)(reinterpret_cast<char*>(mq) - reinterpret_cast<char*>(&S));
+        S.mc_off = (int)(reinterpret_cast<char*>(mc) - reinterpret_cast<char*>(&S));
+    }
     // views of this problem (the reference only solves clusters with >= 2 views: motion_capture.py:927,940)
-    int q_own = -1;
     if (targets3d == nullptr) {
-        const int nv = ik1_rank_members(S, vcap, members, b, V, ovf, n_valid, q_own);
+        const int nv = ik1_rank_members(mq, mc, vcap, members, b, V, ovf, n_valid, C, Pmax);
         if (nv < 2) {
             const double nan = __longlong_as_double(0x7ff8000000000000LL);
             for (int i = lane; i < 68; i += 64) params_out[(size_t)b * 68 + i] = nan;
@@ -1075,22 +1116,20 @@ __device__ __forceinline__ void ik1_solve(Ik1Shared& S, double* views, int vcap,
         }
         if (lane == 0) { S.nviews = nv; S.mode3d = 0; }
     } else {
-        // 3-D-target mode: targets (B,18,4) in the observation row order (COCO-17 + mid-spine)
-        if (lane < NOBS)
-            for (int c = 0; c < 4; ++c) views[lane * 4 + c] = targets3d[(size_t)b * 72 + kIkObs[lane] * 4 + c];
+        // 3-D-target mode: targets (B,18,4) in the observation row order (COCO-17 + mid-spine), read where they lie
         if (lane == 0) { S.nviews = 0; S.mode3d = 1; }
     }
     const int n_side = uni(T.n_side);
     MVMC_WAVE_SYNC();
     const int nv = uni(S.nviews);
-    ik1_load_views(views, nv, q_own, kps17, Pmats, C, Pmax);
     // ---- initial parameters ----
     // stage_mask bit 2: every problem starts from init (mvmc_ik_solve_stages); otherwise cold == NULL means all cold
     const bool is_cold = (stage_mask & 4) ? false : ((cold == nullptr) || uni((int)cold[b]) != 0);
     if (is_cold) {
         // root = midpoint of the triangulated (post-optimised) hips; zero angles; reference lengths
         // (inverse_kinematics.py:390-396 with triangulate(..., 0.01, post_optimize=True))
-        ik1_cold_root(S, nv);
+        ik1_stage_views(hh, nv, mq, mc, O.kps17, O.Pm);
+        ik1_cold_root(S, nv, (const double*)hh);
         if (lane < 54) S.x[3 + lane] = 0.0;
         if (lane < n_side) { S.side[lane] = T.ref_side[lane]; S.x[57 + lane] = T.ref_side[lane]; }
         MVMC_WAVE_SYNC();
@@ -1115,7 +1154,7 @@ __device__ __forceinline__ void ik1_solve(Ik1Shared& S, double* views, int vcap,
         double c = 0.0; int nf = 0, nj = 0, st = 0;
         if ((stage_mask >> stage) & 1) {
             bool at_x = false;
-            ik1_trf(S, T, stage, max_nfev, hh, &c, &nf, &nj, &st, &fallbacks, dump, at_x);
+            ik1_trf(S, T, stage, max_nfev, hh, &c, &nf, &nj, &st, &fallbacks, dump, at_x, O);
             fk_final = at_x && stage == 1;
         }
         costs[stage] = c; nfs[stage] = nf; njs[stage] = nj; sts[stage] = st;
@@ -1123,7 +1162,7 @@ __device__ __forceinline__ void ik1_solve(Ik1Shared& S, double* views, int vcap,
     }
     // final FK at the solution -- unless the solver's last evaluation was at the accepted point (five of six warm solves): the same
     // function of the same numbers, already in LDS
-    if (!fk_final) ik1_eval_nl(S, T, 0, 1, false);
+    if (!fk_final) ik1_eval_nl(S, T, 0, 1, false, O.kps17, O.Pm, O.tg);
     for (int i = lane; i < 57 + n_side; i += 64) params_out[(size_t)b * 68 + i] = S.x[i];
     if (lane < 54) joints_out[(size_t)b * 54 + lane] = S.pos[lane];
     if (lane == 0) {
@@ -1140,7 +1179,7 @@ __device__ __forceinline__ void ik1_solve(Ik1Shared& S, double* views, int vcap,
     }
 }
 
-__global__ void __launch_bounds__(64, 3)
+__global__ void __launch_bounds__(64, MVMC_SMALL_WPS)
 ik1_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restrict__ Pmats,
            const int32_t* __restrict__ members, int B, int V, int vcap, int C, int Pmax, const double* __restrict__ init,
            const uint8_t* __restrict__ cold, int nfev_cold, int nfev_warm, double* __restrict__ params_out,
@@ -1148,9 +1187,9 @@ ik1_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __rest
            const double* __restrict__ targets3d, int32_t* __restrict__ overflow) {
     __shared__ Ik1Shared S;
     __shared__ Ik1Tables T;
-    extern __shared__ __attribute__((aligned(16))) double ik1_views[];   // vcap * MVMC_IK_VIEW_DOUBLES (>= 64: the 3-D targets)
+    extern __shared__ __attribute__((aligned(16))) int ik1_members[];   // the member list: vcap pose indices, then vcap cameras (uint16)
     ik1_build_tables(T, skarg);
-    ik1_solve(S, ik1_views, vcap, T, kps17, Pmats, members, blockIdx.x, V, C, Pmax, init, cold, nfev_cold, nfev_warm, params_out,
+    ik1_solve(S, ik1_members, reinterpret_cast<unsigned short*>(ik1_members + vcap), vcap, T, kps17, Pmats, members, blockIdx.x, V, C, Pmax, init, cold, nfev_cold, nfev_warm, params_out,
               joints_out, info_out, scratch, stage_mask, targets3d, overflow ? overflow + blockIdx.x : nullptr);
 }
 
@@ -1161,26 +1200,30 @@ ik1_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __rest
 // functions are the solver's own (evaluation, model in reduced coordinates or its Euler-space form, fallback trial); the DBG
 // instances of the model functions differ in one store (the gradient).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64, 3)
+__global__ void __launch_bounds__(64, MVMC_SMALL_WPS)
 ik1_step_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* __restrict__ Pmats, const int32_t* __restrict__ members,
                 int V, int vcap, int C, int Pmax, const double* __restrict__ params, int stage, const double* __restrict__ Delta_in,
                 const double* __restrict__ alpha_in, double* __restrict__ out, double* __restrict__ scratch) {
     __shared__ Ik1Shared S;
     __shared__ Ik1Tables T;
-    extern __shared__ __attribute__((aligned(16))) double ik1_views[];
+    extern __shared__ __attribute__((aligned(16))) int ik1_members[];
     const int lane = threadIdx.x & 63, b = blockIdx.x;
     ik1_build_tables(T, skarg);
     mvmc_gdouble* hh = uni((mvmc_gdouble*)(scratch + (size_t)b * MVMC_IK_SCRATCH_DOUBLES));
     double* o = out + (size_t)b * MVMC_IK_STEP_OUT_DOUBLES;
     for (int i = lane; i < MVMC_IK_STEP_OUT_DOUBLES; i += 64) o[i] = 0.0;
-    if (lane == 0) S.view_off = (int)(ik1_views - reinterpret_cast<double*>(&S));
-    int q_own = -1;
-    const int nv = ik1_rank_members(S, vcap, members, b, V, nullptr, -1, q_own);
+    int* mq = ik1_members;
+    unsigned short* mc = reinterpret_cast<unsigned short*>(ik1_members + vcap);
+    const Ik1Obs O = {(const mvmc_gdouble*)kps17, (const mvmc_gdouble*)Pmats, nullptr};
+    if (lane == 0) {
+        S.mq_off = (int)(reinterpret_cast<char*>(mq) - reinterpret_cast<char*>(&S));
+        S.mc_off = (int)(reinterpret_cast<char*>(mc) - reinterpret_cast<char*>(&S));
+    }
+    const int nv = ik1_rank_members(mq, mc, vcap, members, b, V, nullptr, -1, C, Pmax);
     if (nv < 2) { if (lane == 0) o[6] = -1.0; return; }
     if (lane == 0) { S.nviews = nv; S.mode3d = 0; }
     const int n_side = uni(T.n_side);
     MVMC_WAVE_SYNC();
-    ik1_load_views(ik1_views, nv, q_own, kps17, Pmats, C, Pmax);
     const double* p0 = params + (size_t)b * 68;
     for (int i = lane; i < 57 + n_side; i += 64) S.x[i] = p0[i];
     if (lane < n_side) S.side[lane] = p0[57 + lane];
@@ -1188,7 +1231,7 @@ ik1_step_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* _
     const int nfull = (stage == 0) ? 57 : 57 + n_side;
     const int na = uni(T.na[stage]);
     const double Delta = Delta_in[b], alpha0 = alpha_in[b], gtol = 1e-8;
-    const double cost = uni(ik1_eval_nl(S, T, 0, stage, true));
+    const double cost = uni(ik1_eval_nl(S, T, 0, stage, true, O.kps17, O.Pm, O.tg));
     int mode = 3;
     bool reduced = false;
     if (uni(T.arrow_ok)) {
@@ -1209,7 +1252,7 @@ ik1_step_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* _
         for (int i = lane; i < nfull; i += 64) o[80 + i] = S.xn[i] - S.x[i];
         for (int i = lane; i < nfull; i += 64) o[160 + i] = S.xn[i];
         MVMC_WAVE_SYNC();
-        cost_new = uni(ik1_eval_nl(S, T, 1, stage, false));
+        cost_new = uni(ik1_eval_nl(S, T, 1, stage, false, O.kps17, O.Pm, O.tg));
     }
     if (lane == 0) {
         o[0] = cost; o[1] = S.sc[1];
@@ -1228,8 +1271,8 @@ static int mvmc_ik1_launch(const SkelDev& sk, const double* kps17, const double*
                            int stage_mask, const double* targets3d, hipStream_t stream) {
     // the view block holds every member a problem can have (v_max columns), so no cluster is ever cut short here
     const int vcap = v_max < 1 ? 1 : v_max;
-    if (vcap > 64) return MVMC_ERR_UNSUPPORTED;   // (a lane per view when the observations are loaded)
-    const size_t lds = sizeof(double) * (size_t)(vcap * MVMC_IK_VIEW_DOUBLES < 64 ? 64 : vcap * MVMC_IK_VIEW_DOUBLES);
+    if (vcap > 64 || n_views > 65535) return MVMC_ERR_UNSUPPORTED;   // (a lane per view in the member list; the list holds cameras as uint16)
+    const size_t lds = ((size_t)vcap * 6 + 15) / 16 * 16;   // the member list: an int and a short per view
     hipLaunchKernelGGL(ik1_kernel, dim3(n_problems), dim3(64), lds, stream, sk, kps17, Pmats, members, n_problems, v_max, vcap,
                        n_views, p_max, init_params, cold, max_nfev_cold, max_nfev_warm, params_out, joints_out, info_out,
                        scratch, stage_mask, targets3d, (int32_t*)nullptr);
@@ -1281,8 +1324,8 @@ extern "C" int mvmc_debug_ik_model_step(const mvmcSkeleton* skel_host, const dou
     SkelDev sk;
     if (!skel_to_dev(skel_host, &sk)) return MVMC_ERR_ARG;
     if (sk.n_side != MVMC_N_SIDE) return MVMC_ERR_UNSUPPORTED;
-    if (v_max > 64) return MVMC_ERR_UNSUPPORTED;
-    const size_t lds = sizeof(double) * (size_t)(v_max * MVMC_IK_VIEW_DOUBLES < 64 ? 64 : v_max * MVMC_IK_VIEW_DOUBLES);
+    if (v_max > 64 || n_views > 65535) return MVMC_ERR_UNSUPPORTED;
+    const size_t lds = ((size_t)v_max * 6 + 15) / 16 * 16;
     hipLaunchKernelGGL(ik1_step_kernel, dim3(n_problems), dim3(64), lds, (hipStream_t)stream, sk, kps17, Pmats, members, v_max, v_max,
                        n_views, p_max, params, stage, Delta, alpha0, out, scratch);
     MVMC_CHECK_LAUNCH();

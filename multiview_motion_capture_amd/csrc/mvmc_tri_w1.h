@@ -78,7 +78,11 @@ __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, int 
     // so the 40-row model takes as many rows per round trip as its registers hold.  Tried and dropped: a software pipeline over 5-row
     // chunks with two or three chunks of operands in flight (loads of chunk c + 2 in front of the FMAs of chunk c) -- more round trips
     // and branches than it hides, IK 37.9 -> 40.1 M cycles per chain, and the 50-row model spilled v_j / w_j.
+#ifdef MVMC_TRI_HB
+    constexpr int HB = MVMC_TRI_HB;
+#else
     constexpr int HB = N <= 40 ? 5 : 3;   // pairs of rows per batch of the rank-2 update
+#endif
     // (CHB: rows per round trip of the product.  Twenty for the 40-row model measured best while a wave's latency was the limit; with the
     // chip's VALU and LDS pipes as the limit -- two launches in flight, every slot taken -- the ten dead rows a 20-row chunk drags along on
     // average cost more than the round trip they save: 454.0 k -> 456.1 k frames/s, bit-identical)

@@ -65,3 +65,25 @@ def test_chain_buffers_struct_matches_header():
     # 14 int32 fields (56 bytes): the first pointer starts there
     assert len(ints) == 14 and _cabi.MvmcChainBuffers.kps17.offset == 56
     assert ctypes.sizeof(_cabi.MvmcChainBuffers) == 56 + 8 * len(ptrs)
+
+
+def test_a_library_of_another_abi_version_is_refused(tmp_path):
+    """load() declares the argument types of ONE ABI version: a library that reports another (an old build behind MVMC_LIB_PATH for an
+    A/B run) must be refused with a clear error instead of being called with shifted arguments (ADVICE, round 4)."""
+    import subprocess, sys, textwrap
+    src = tmp_path / "stub.c"
+    src.write_text("int mvmc_abi_version(void) { return 3; }\n")
+    so = tmp_path / "libmvmc_stub.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)])
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        from multiview_motion_capture_amd import _cabi
+        try:
+            _cabi.load()
+        except _cabi.MvmcError as e:
+            assert "ABI version 3" in str(e) and "version %%d" %% _cabi.MVMC_ABI in str(e), str(e)
+            print("refused")
+    """ % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MVMC_LIB_PATH=str(so)), capture_output=True, text=True)
+    assert out.returncode == 0 and "refused" in out.stdout, out.stderr

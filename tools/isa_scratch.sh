@@ -7,7 +7,7 @@ set -e
 SRC=${1:-mvmc_chain.hip}
 cd "$(dirname "$0")/../multiview_motion_capture_amd/csrc"
 OUT=/tmp/isa_$(basename $SRC .hip).s
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -o $OUT $SRC 2>/dev/null
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 $EXTRA -S --cuda-device-only -o $OUT $SRC 2>/dev/null
 echo "ISA in $OUT"
 awk '/^[ \t]*\.amdhsa_kernel /{k=$2} /amdhsa_next_free_vgpr|amdhsa_private_segment_fixed_size|amdhsa_group_segment_fixed_size/{print k, $1, $2}' $OUT | grep chain_kernel
 awk '/^[_A-Za-z0-9$.]+:/{ if ($1 !~ /^\.L/) {fn=$1} }

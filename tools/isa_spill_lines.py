@@ -5,7 +5,7 @@ pat = sys.argv[1]
 src = sys.argv[2] if len(sys.argv) > 2 else "mvmc_chain.hip"
 d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "multiview_motion_capture_amd", "csrc")
 out = "/tmp/isa_g_%s.s" % os.path.basename(src)
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-gline-tables-only",
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-gline-tables-only", *os.environ.get("EXTRA", "").split(),
                 "-o", out, src], cwd=d, check=True, stderr=subprocess.DEVNULL)
 files, fn, loc = {}, None, None
 agg = collections.defaultdict(lambda: [0, 0])
