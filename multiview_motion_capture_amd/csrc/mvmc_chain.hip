@@ -12,6 +12,9 @@
 // ik1_solve, commit_chain), so the results are the same bit for bit; LDS is one arena reused by the phases:
 //   [ graph scratch | Als4Lds | 4 x Ik1Shared ]  (union)  +  Ik1Tables (persistent)
 #define MVMC_DEVICE_ONLY
+#if !defined(MVMC_CHAIN_BIG_TU) && !defined(MVMC_SMALL_WPS)
+#define MVMC_SMALL_WPS 4   // the SMALL layout: 128 VGPRs, four workgroups per CU (mvmc_common.h)
+#endif
 #include <cstdlib>
 #include "mvmc_common.h"
 #include "mvmc_assoc.hip"

@@ -7,10 +7,26 @@
 
 #define MVMC_WAVE 64
 
-// Waves per SIMD the SMALL layout of the chain kernel (and every kernel that shares out-of-line device functions with it) is built
-// for: 3 = 168 VGPRs, 4 = 128 VGPRs (a fourth workgroup per CU needs the LDS arena <= 40,960 B too)
+// Waves per SIMD a translation unit's register-critical device functions (IK model, tridiagonalisation, als7) are built for.
+// 4 = 128 VGPRs: the SMALL layout of the chain kernel since round 5 (mvmc_chain.hip sets it for its own unit) -- FOUR workgroups per
+// CU: the arena is 40,944 B since the IK's observations left LDS, and the loops have batch sizes for the smaller file (MVMC_TRI_HB,
+// MVMC_IK_GR, MVMC_IK_PARK below; the als7 loop in its role-split form).  3 = 168 VGPRs, the larger batches: the stand-alone kernels
+// (one solve's or one graph's latency matters there, not the occupancy) and round 4's chain kernel (-DMVMC_SMALL_WPS=3 on the command
+// line builds it again; DESIGN.md section 6a has the same-box comparison).  The knobs can be overridden one by one for experiments
+// (tools/full_variant.sh).
 #ifndef MVMC_SMALL_WPS
 #define MVMC_SMALL_WPS 3
+#endif
+#if MVMC_SMALL_WPS >= 4
+#ifndef MVMC_TRI_HB
+#define MVMC_TRI_HB 3      // pairs of rows per LDS round trip of the tridiagonalisation's rank-2 update (5 in the 168-register build)
+#endif
+#ifndef MVMC_IK_GR
+#define MVMC_IK_GR 2       // rows per chunk of the J^T J accumulation (4 in the 168-register build)
+#endif
+#ifndef MVMC_IK_PARK
+#define MVMC_IK_PARK 1     // the lane's angular velocities wait in LDS during the accumulation
+#endif
 #endif
 
 // Ordering point for LDS traffic INSIDE one wave (single-wave routines that may run in a multi-wave workgroup, where

@@ -561,6 +561,13 @@ __device__ __noinline__ void ik1_model_step_r(Ik1Shared& S, const Ik1Tables& T, 
     }
     const int jl = (kind == 2) ? (int)T.rja[lane] : 0;     // length slot
     const int jcc = (kind == 0) ? (int)T.rjc[lane] : 0;
+#ifdef MVMC_IK_PARK
+    // (128-register build: the lane's two angular velocities wait in LDS -- the solver vectors are dead while the model is built -- and
+    // are re-read per joint: twelve registers less to keep next to the N matrix rows, where they would otherwise travel through scratch)
+    double* wl = S.sv;
+    wl[lane] = wa0; wl[64 + lane] = wa1; wl[128 + lane] = wa2; wl[192 + lane] = wb0; wl[256 + lane] = wb1; S.tmp[192 + lane] = wb2;
+    MVMC_WAVE_SYNC();
+#endif
     double a[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) a[i] = 0.0;
@@ -573,11 +580,17 @@ __device__ __noinline__ void ik1_model_step_r(Ik1Shared& S, const Ik1Tables& T, 
             d0 = jcc == 0 ? 1.0 : 0.0; d1 = jcc == 1 ? 1.0 : 0.0; d2 = jcc == 2 ? 1.0 : 0.0;
         } else if (kind == 1 || kind == 3) {
             const int anc = T.anc[K];
+#ifdef MVMC_IK_PARK
+            const double wa0 = wl[lane], wa1 = wl[64 + lane], wa2 = wl[128 + lane];
+#endif
             if ((anc >> ja) & 1) {
                 const double r0 = S.pos[K * 3] - S.pos[ja * 3], r1 = S.pos[K * 3 + 1] - S.pos[ja * 3 + 1], r2 = S.pos[K * 3 + 2] - S.pos[ja * 3 + 2];
                 d0 = wa1 * r2 - wa2 * r1; d1 = wa2 * r0 - wa0 * r2; d2 = wa0 * r1 - wa1 * r0;
             }
             if (kind == 3 && ((anc >> jb) & 1)) {
+#ifdef MVMC_IK_PARK
+                const double wb0 = wl[192 + lane], wb1 = wl[256 + lane], wb2 = S.tmp[192 + lane];
+#endif
                 const double r0 = S.pos[K * 3] - S.pos[jb * 3], r1 = S.pos[K * 3 + 1] - S.pos[jb * 3 + 1], r2 = S.pos[K * 3 + 2] - S.pos[jb * 3 + 2];
                 d0 += wb1 * r2 - wb2 * r1; d1 += wb2 * r0 - wb0 * r2; d2 += wb0 * r1 - wb1 * r0;
             }

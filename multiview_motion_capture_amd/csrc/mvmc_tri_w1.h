@@ -86,7 +86,11 @@ __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, int 
     // (CHB: rows per round trip of the product.  Twenty for the 40-row model measured best while a wave's latency was the limit; with the
     // chip's VALU and LDS pipes as the limit -- two launches in flight, every slot taken -- the ten dead rows a 20-row chunk drags along on
     // average cost more than the round trip they save: 454.0 k -> 456.1 k frames/s, bit-identical)
+#ifdef MVMC_TRI_CHB
+    constexpr int CH = 10, CHB = MVMC_TRI_CHB;
+#else
     constexpr int CH = 10, CHB = 10;
+#endif
     static_assert(N % CH == 0 && N % CHB == 0, "rows per chunk");
 #ifdef MVMC_TRI_PROFILE   // diagnostic: cycles of a step's four sections into tprof[0, 3, 4, 6] (tools/tri_step_profile.py)
     long long _tt = clock64();
@@ -131,11 +135,26 @@ __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, int 
 #pragma unroll
         for (int c = 0; c < N; c += CHB)
             if (c + CHB - 1 > k) {
+#ifdef MVMC_TRI_PB   // (pairs of rows per batch of loads inside a chunk: the 128-register build has no room for a chunk's ten operands at once)
+                constexpr int PB = MVMC_TRI_PB;
+#pragma unroll
+                for (int u0 = 0; u0 < CHB / 2; u0 += PB) {
+                    double2 v2[PB];
+#pragma unroll
+                    for (int u = 0; u < PB; ++u)
+                        if (u0 + u < CHB / 2) v2[u] = *reinterpret_cast<const double2*>(&vb[c + 2 * (u0 + u)]);
+#pragma unroll
+                    for (int u = 0; u < PB; ++u)
+                        if (u0 + u < CHB / 2) { p0 += a[c + 2 * (u0 + u)] * v2[u].x; p1 += a[c + 2 * (u0 + u) + 1] * v2[u].y; }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#else
                 double2 v2[CHB / 2];
 #pragma unroll
                 for (int u = 0; u < CHB / 2; ++u) v2[u] = *reinterpret_cast<const double2*>(&vb[c + 2 * u]);
 #pragma unroll
                 for (int u = 0; u < CHB / 2; ++u) { p0 += a[c + 2 * u] * v2[u].x; p1 += a[c + 2 * u + 1] * v2[u].y; }
+#endif
             }
         TRSTAMP(3)   // v broadcast + matrix-vector product
         const double p = tk * (p0 + p1);

@@ -1,4 +1,5 @@
 # kernel stats of config 3 (association + triangulation, every frame cold):  bash tools/prof_c3.sh   (inside one GPU call)
+: "${GRAFT_REPO_ROOT:?}"
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c3; rm -rf $O; mkdir -p $O

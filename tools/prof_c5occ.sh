@@ -1,4 +1,5 @@
 # kernel stats of config 5 with occlusion (the repair tier's launches):  bash tools/prof_c5occ.sh   (inside one GPU call)
+: "${GRAFT_REPO_ROOT:?}"
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c5occ; rm -rf $O; mkdir -p $O

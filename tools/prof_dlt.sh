@@ -1,4 +1,5 @@
 # SQ counters of config 2's kernel (separate --pmc passes; kernel-trace only):  [MVMC_INGEST_DLT_V1=1] bash tools/prof_dlt.sh <out name>   (inside one GPU call)
+: "${GRAFT_REPO_ROOT:?}"
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; rm -rf $O; mkdir -p $O

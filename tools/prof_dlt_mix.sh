@@ -1,4 +1,5 @@
 # instruction mix of config 2's kernel:  bash tools/prof_dlt_mix.sh <out name>   (inside one GPU call)
+: "${GRAFT_REPO_ROOT:?}"
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; rm -rf $O; mkdir -p $O

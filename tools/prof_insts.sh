@@ -1,4 +1,5 @@
 # instruction mix of chain_kernel (separate --pmc passes; kernel-trace only):  bash tools/prof_insts.sh   (inside one GPU call)
+: "${GRAFT_REPO_ROOT:?}"
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${MVMC_PROF_OUT:-insts}; rm -rf $O; mkdir -p $O

@@ -1,4 +1,5 @@
 # Round-4 profiling session (ONE GPU call):  bash tools/prof_r04.sh     -> gpurun_out/r04s/*, then tools/refresh_profiles_r04.sh r04
+: "${GRAFT_REPO_ROOT:?}"
 # Every rocprofv3 run has the program itself after "--" (python3 / a binary), kernel-trace only, counters in passes of their own.
 set -e
 cd /tmp && export TMPDIR=/tmp
