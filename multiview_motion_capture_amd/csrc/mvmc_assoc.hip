@@ -1299,6 +1299,9 @@ __device__ __forceinline__ int als7_iterate(const TW* __restrict__ Wf, int ldw, 
     // of the Gram matrix beside the workers' W / Z / Y / X state and right-hand sides), which a 128-register build can only hold with
     // a dozen scratch reloads per iteration.
     if (!worker) {
+#ifdef MVMC_PRIO_SOLVER
+        __builtin_amdgcn_s_setprio(MVMC_PRIO_SOLVER);
+#endif
         // The first three pivots of (A^T A + ridge I)^-1 are made AHEAD, in the solver wave's idle time at the end of the previous iteration
         // (it waits ~600 cycles for the workers' X / Z / Y step), with the ridge of that iteration: mu changes in few iterations, and only
         // then are they made again here -- the workers' X1 step used to wait for them (solver 1.0 k cycles against 0.5 k).
@@ -1339,6 +1342,9 @@ __device__ __forceinline__ int als7_iterate(const TW* __restrict__ Wf, int ldw, 
             APROF2(12)
             if (stop) { iters = it + 1; break; }
         }
+#ifdef MVMC_PRIO_SOLVER
+        __builtin_amdgcn_s_setprio(0);
+#endif
     } else {
         for (int it = 0; it < 1000; ++it) {
             double hv[R];

@@ -15,6 +15,15 @@
 #if !defined(MVMC_CHAIN_BIG_TU) && !defined(MVMC_SMALL_WPS)
 #define MVMC_SMALL_WPS 4   // the SMALL layout: 128 VGPRs, four workgroups per CU (mvmc_common.h)
 #endif
+// Wave priority by PHASE (SMALL layout; s_setprio): graph, association, assignment, commit and outputs run at priority 1, the IK at 0.
+// The association is a latency chain (one solver wave per workgroup on the critical path, the workers mostly waiting), the IK is
+// issue-bound; with four workgroups per CU sharing the SIMDs an association iteration took 12.7 k cycles against 7.4 k alone.  With
+// the priority its phase costs 18.4 M cycles per chain instead of 28.5 M, the IK 41.7 M instead of 33.9 M: a chain 65.0 -> 62.3 M,
+// 513 k -> 530 k frames/s (same box).  Priority 3 instead of 1, or the solver wave above its workers: no further change.
+#if !defined(MVMC_CHAIN_BIG_TU) && !defined(MVMC_PRIO_ALS) && !defined(MVMC_NO_PHASE_PRIO)
+#define MVMC_PRIO_ALS 1
+#define MVMC_PRIO_REST 1
+#endif
 #include <cstdlib>
 #include "mvmc_common.h"
 #include "mvmc_assoc.hip"
@@ -362,6 +371,9 @@ chain_kernel(Ik1Tables tables_arg, ChainArgs A_by_value) {
         __syncthreads();
         const int nt = uni(s_nt);
         // ---- graph + association ----
+#ifdef MVMC_PRIO_ALS
+        if constexpr (!BIG) __builtin_amdgcn_s_setprio(MVMC_PRIO_ALS);
+#endif
         if (nt <= 0) {   // no live tracklets: match_spatial (motion_capture.py:597-631), f32 affinity
             chain_graph_spatial<BIG>(arena, A, b, f, &done);
             __syncthreads();
@@ -373,6 +385,9 @@ chain_kernel(Ik1Tables tables_arg, ChainArgs A_by_value) {
             lap(0);
             chain_als_temporal<BIG>(arena, A, b, &done);
         }
+#if defined(MVMC_PRIO_ALS) && !defined(MVMC_PRIO_REST)
+        if constexpr (!BIG) __builtin_amdgcn_s_setprio(0);
+#endif
         __syncthreads();
         lap(1);
         // a graph with more nodes (or a higher rank) than the workgroup variant of the ALS holds is flagged by it (iters < 0):
@@ -384,7 +399,13 @@ chain_kernel(Ik1Tables tables_arg, ChainArgs A_by_value) {
         if (wave == 0) chain_assign(A, b, f, &done);   // clusters -> IK problems (bulk copies on the wave, the logic on lane 0)
         __syncthreads();
         lap(2);
+#ifdef MVMC_PRIO_REST
+        if constexpr (!BIG) __builtin_amdgcn_s_setprio(0);
+#endif
         chain_ik<BIG>(arena, tables, A, b, &done);
+#ifdef MVMC_PRIO_REST
+        if constexpr (!BIG) __builtin_amdgcn_s_setprio(MVMC_PRIO_REST);
+#endif
         __syncthreads();
         lap(3);
         if (wave == 0) chain_commit(A, b, &done);      // tracklet table after the frame
