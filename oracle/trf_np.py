@@ -14,6 +14,9 @@ below restate, in plain NumPy and without importing SciPy:
   * ``trf``              scipy/optimize/_lsq/trf.py:401-560 trf_no_bounds
   * ``solve_tr_normal``  the same sub-problem from (J^T J, J^T f) only -- the
                          form the HIP kernel uses
+  * ``solve_tr_normal_clean``  the same without LAPACK's rounding noise in the
+                         numerically-null directions: ``trf(..., solver="ne_clean")`` is
+                         the DETERMINISTIC whole-solve oracle of the truncated solves
 
 tests/test_trf_restatement.py checks ``trf`` step for step against SciPy.
 """
@@ -107,19 +110,28 @@ def trf(fun, jac, x0, max_nfev, ftol=1e-8, xtol=1e-8, gtol=1e-8, solver="svd", t
             uf = U.T.dot(f)
         else:
             lam, V, = _eigh_desc(J.T.dot(J))
+        if trace is not None and solver == "ne_clean":
+            trace.append(dict(model=True, nfev=nfev, lam=lam.copy(), g_inf=np.linalg.norm(g, ord=np.inf)))
         actual_reduction = -1.0
         x_new = f_new = cost_new = None
         while actual_reduction <= 0 and nfev < max_nfev:
+            predicted_reduction = None
+            alpha_in = alpha
             if solver == "svd":
                 step, alpha, _ = solve_tr_svd(n, m, uf, s, V, Delta, initial_alpha=alpha)
+            elif solver == "ne_clean":
+                step, alpha, predicted_reduction, step_norm_clean = solve_tr_normal_clean(lam, V, g, Delta, initial_alpha=alpha)
             else:
                 step, alpha, _ = solve_tr_normal(n, m, lam, V, g, Delta, initial_alpha=alpha)
-            Js = J.dot(step)
-            predicted_reduction = -(0.5 * np.dot(Js, Js) + np.dot(step, g))
+            if predicted_reduction is None:
+                Js = J.dot(step)
+                predicted_reduction = -(0.5 * np.dot(Js, Js) + np.dot(step, g))
             x_new = x + step
             f_new = fun(x_new)
             nfev += 1
-            step_norm = np.linalg.norm(step)
+            # (the noise-free form accounts for the step as SciPy does for a rank-deficient model: |p| = Delta, the share of it that
+            # the reference spends on numerically-null directions modelled by the absorber and not taken)
+            step_norm = step_norm_clean if solver == "ne_clean" else np.linalg.norm(step)
             if not np.all(np.isfinite(f_new)):
                 Delta = 0.25 * step_norm
                 continue
@@ -139,7 +151,8 @@ def trf(fun, jac, x0, max_nfev, ftol=1e-8, xtol=1e-8, gtol=1e-8, solver="svd", t
                 Delta_new = Delta * 2.0
             if trace is not None:
                 trace.append(dict(nfev=nfev, alpha=alpha, Delta=Delta, step_norm=step_norm, cost_new=cost_new,
-                                  ratio=ratio, accepted=actual_reduction > 0))
+                                  ratio=ratio, accepted=actual_reduction > 0, x=x.copy(), alpha_in=alpha_in, Delta_new=Delta_new,
+                                  pred=predicted_reduction, cost=cost, step=step.copy()))
             # check_termination, common.py:705-717
             ftol_ok = actual_reduction < ftol * cost and ratio > 0.25
             xtol_ok = step_norm < xtol * (xtol + np.linalg.norm(x))
@@ -156,6 +169,42 @@ def trf(fun, jac, x0, max_nfev, ftol=1e-8, xtol=1e-8, gtol=1e-8, solver="svd", t
     if status is None:
         status = 0
     return dict(x=x, cost=cost, nfev=nfev, njev=njev, status=status, fun=f, grad=g)
+
+
+def solve_tr_normal_clean(lam, V, g, Delta, initial_alpha=0.0, null_tol=1e-13, rtol=0.01, max_iter=10):
+    """solve_lsq_trust_region's rank-deficient branch (common.py:116-168) WITHOUT the rounding noise SciPy's LAPACK leaves in the
+    numerically-null singular directions -- the deterministic form of the reference's step, and the production IK kernel's
+    ("the absorber"; csrc/mvmc_eigh_tri.h tr_solve_tri / tr_solve_eig_w1):
+
+      * the null cluster (lam <= null_tol * lam_max) carries no step;
+      * ONE virtual direction (lam = 0, suf = 1e-8 |g|) stands for what those directions hold in the reference (finite-difference
+        noise s u^T f ~ 1e-8 |g|): it takes part in phi(alpha), in the normalisation |p| = Delta and in the predicted reduction
+        exactly as a singular triplet would, and its coefficient is not applied to x.
+
+    lam, V: eigen-decomposition of J^T J, descending (``_eigh_desc``).  Returns (step, alpha, predicted_reduction, |p| = Delta)."""
+    keep = lam > null_tol * lam[0]
+    lam_k, V_k = lam[keep], V[:, keep]
+    suf = np.append(V_k.T.dot(g), 1e-8 * np.linalg.norm(g))
+    lam_a = np.append(lam_k, 0.0)
+    alpha_upper, alpha_lower = np.linalg.norm(suf) / Delta, 0.0
+    alpha = max(0.001 * alpha_upper, 0.0) if (initial_alpha is None or initial_alpha == 0) else initial_alpha
+    for _ in range(max_iter):
+        if alpha < alpha_lower or alpha > alpha_upper:
+            alpha = max(0.001 * alpha_upper, (alpha_lower * alpha_upper) ** 0.5)
+        den = lam_a + alpha
+        p_norm = np.linalg.norm(suf / den)
+        phi, phi_prime = p_norm - Delta, -np.sum(suf ** 2 / den ** 3) / p_norm
+        if phi < 0:
+            alpha_upper = alpha
+        ratio = phi / phi_prime
+        alpha_lower = max(alpha_lower, alpha - ratio)
+        alpha -= (phi + Delta) * ratio / Delta
+        if abs(phi) < rtol * Delta:
+            break
+    c = -suf / (lam_a + alpha)
+    c *= Delta / np.linalg.norm(c)
+    pred = -(0.5 * np.sum(lam_a * c * c) + np.sum(suf * c))
+    return V_k.dot(c[:-1]), alpha, pred, float(np.linalg.norm(c))
 
 
 def _eigh_desc(A):

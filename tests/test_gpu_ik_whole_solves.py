@@ -1,0 +1,211 @@
+"""GPU: WHOLE truncated solves (5 + 5 evaluations, status 0 -- 94 % of the benchmark's solves) of the production IK solver against a
+DETERMINISTIC oracle, solve by solve.
+
+The reference's own result on these solves is a function of LAPACK rounding (tests/test_trf_traces_cpu.py: a median 97 % of a warm
+step's length lies in numerically-null singular directions, normalised to |p| = Delta; SciPy under another LAPACK build ends up to 1.4
+away in parameter space), so a whole-solve comparison with the recorded reference can only be a band (tests/test_gpu_ik.py).  What CAN
+be pinned per solve is the reference's ALGORITHM without that noise: ``trf_np.trf(fun, analytic jac, x0, 5, solver="ne_clean")`` --
+trf_no_bounds (trf.py:401-560) as called from inverse_kinematics.py:236,274,397-400, stage 1 then stage 2, with
+solve_lsq_trust_region's rank-deficient branch restated from (J^T J, J^T f), the numerically-null cluster carrying no step and one
+virtual direction standing for the noise it holds in the reference (oracle/trf_np.py: solve_tr_normal_clean; pinned step by step to the
+reference's recorded iterates wherever those are not noise, tests/test_trf_traces_cpu.py).
+
+Cases: the 69 warm solves of tests/golden/ik_trf_traces.npz and the warm solves of tests/golden/ik_cases.npz (reference inputs:
+Shelf clusters and synthetic config-4 clusters, warm start = the reference tracker's previous result).
+
+Gates, per solve (mvmc_ik_solve, max_nfev 5 + 5):
+  1. nfev and status of both stages equal the oracle's (the accept / reject sequence decides how many models a budget of five buys);
+  2. cost after stage 1 and after stage 2, and every observed joint (>= 2 views) of the final pose, within 1e-4 (relative; joints
+     relative to the scene scale) -- on EVERY case whose trust-region models have no weak eigenvalue, i.e. none in
+     (1e-13, 1e-6) lam_max: there the split between range and null space is itself a rounding decision; those cases are printed with
+     their weakest eigenvalue and gated at the band of test_gpu_ik.py instead;
+  3. the accept / reject decision and the new radius of every trial of the oracle's sequence, re-made on the device from the oracle's
+     own (x_k, Delta_k, alpha_k) (mvmc_debug_ik_model_step): identical decisions, radii equal;
+  4. the device's final cost <= the REFERENCE's recorded final cost on >= 90 % of the cases (exceptions printed): not following the
+     reference's noise must not cost accuracy.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle_np as o
+import trf_np as t
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+NFEV = 5
+
+
+def _cases():
+    """warm cases of both fixtures as dicts(poses (v,17,3), projs (v,3,4), init (68), ref_cost (2,), ref_joints | None, name)"""
+    out = []
+    g = load_golden("ik_trf_traces.npz")
+    for ci in np.flatnonzero(~g["case_cold"]):
+        v = int(g["case_nviews"][ci])
+        out.append(dict(poses=g["case_poses"][ci, :v], projs=g["case_projs"][ci, :v], init=g["case_init"][ci].copy(),
+                        ref_cost=g["case_cost"][ci], ref_x=g["case_x"][ci, 1], name=f"traces[{ci}]"))
+    h = load_golden("ik_cases.npz")
+    for i in np.flatnonzero(~h["cold"]):
+        v = int(h["n_views"][i])
+        init = np.concatenate([h["init_root"][i], h["init_euler"][i].ravel(), h["init_blens"][i]])
+        out.append(dict(poses=h["poses"][i, :v], projs=h["projs"][i, :v], init=init,
+                        ref_cost=np.array([h["s1_cost"][i], h["s2_cost"][i]]), ref_x=h["s2_x"][i], name=f"ik_cases[{i}]"))
+    return out
+
+
+def _cameras(cases):
+    cams = []
+    for c in cases:
+        m = []
+        for P in c["projs"]:
+            hit = [k for k, Q in enumerate(cams) if np.array_equal(P, Q)]
+            if not hit:
+                cams.append(P.copy())
+                hit = [len(cams) - 1]
+            m.append(hit[0])
+        c["cams"] = m
+    return np.array(cams)
+
+
+def _pack(cases, cams, params=None):
+    B, C = len(cases), len(cams)
+    kps = np.zeros((B, C, 1, 17, 3))
+    mem = -np.ones((B, 6), dtype=np.int32)
+    for b, c in enumerate(cases):
+        for v, cam in enumerate(c["cams"]):
+            kps[b, cam, 0] = c["poses"][v]
+            mem[b, v] = b * C + cam
+    return kps, mem
+
+
+def _oracle(c):
+    bd, _ = o.skeleton_constants()
+    obs = np.array([o.add_mid_spine(p) for p in c["poses"]])[:, o.IK_OBS_IDX, :]
+    projs, side0 = c["projs"], c["init"][57:]
+    f1 = lambda x: o.ik_residual(x[:3], x[3:57], side0, obs, projs, bd)
+    j1 = lambda x, f: t.ik_jacobian(x[:3], x[3:57], side0, obs, projs, False)
+    f2 = lambda x: o.ik_residual(x[:3], x[3:57], x[57:], obs, projs, bd)
+    j2 = lambda x, f: t.ik_jacobian(x[:3], x[3:57], x[57:], obs, projs, True)
+    tr1, tr2 = [], []
+    r1 = t.trf(f1, j1, c["init"][:57], NFEV, solver="ne_clean", trace=tr1)
+    r2 = t.trf(f2, j2, np.concatenate([r1["x"], side0]), NFEV, solver="ne_clean", trace=tr2)
+    pos, _ = o.forward_kinematics(r2["x"][:3], r2["x"][3:57], r2["x"][57:], bd)
+    weak = 1.0
+    for e in tr1 + tr2:
+        if "model" in e:
+            lam = e["lam"] / e["lam"][0]
+            w = lam[(lam > 1e-13) & (lam < 1e-6)]
+            if len(w):
+                weak = min(weak, float(w.min()))
+    seen = o.IK_SKEL_IDX[(obs[:, :, 2] > 0.1).sum(axis=0) >= 2]
+    ref_pos, _ = o.forward_kinematics(c["ref_x"][:3], c["ref_x"][3:57], c["ref_x"][57:], bd)
+    return dict(r1=r1, r2=r2, joints=pos, weak=weak, seen=seen, ref_joints=ref_pos,
+                trials=[(0, e) for e in tr1 if "model" not in e] + [(1, e) for e in tr2 if "model" not in e])
+
+
+@pytest.fixture(scope="module")
+def solved():
+    from multiview_motion_capture_amd import device as dev
+    cases = _cases()
+    cams = _cameras(cases)
+    cases = [c for c in cases if len(set(c["cams"])) == len(c["cams"])]      # a pose index names its camera in the packing
+    d = torch.device("cuda:0")
+    kps, mem = _pack(cases, cams)
+    init = np.array([c["init"] for c in cases])
+    kps_t, cams_t, mem_t = torch.from_numpy(kps).to(d), torch.from_numpy(cams).to(d), torch.from_numpy(mem).to(d)
+    p, j, info = dev.ik_solve(kps_t, cams_t, mem_t, torch.from_numpy(init).to(d), torch.zeros(len(cases), dtype=torch.uint8, device=d), 50, NFEV)
+    torch.cuda.synchronize()
+    orc = [_oracle(c) for c in cases]
+    return dict(dev=dev, d=d, cases=cases, cams=cams, kps=kps_t, cams_t=cams_t, mem=mem_t, p=p.cpu().numpy(), j=j.cpu().numpy(),
+                info=info.cpu().numpy(), orc=orc)
+
+
+def test_whole_warm_solves_equal_the_noise_free_oracle(solved):
+    cases, orc, info, j = solved["cases"], solved["orc"], solved["info"], solved["j"]
+    n = len(cases)
+    assert n >= 100
+    rows = []
+    for b in range(n):
+        q = orc[b]
+        scale = np.abs(q["joints"]).max()
+        rows.append(dict(b=b, name=cases[b]["name"], weak=q["weak"],
+                         nfev_ok=(info[b, 1] == q["r1"]["nfev"] and info[b, 4] == q["r2"]["nfev"]),
+                         status_ok=(info[b, 2] == q["r1"]["status"] and info[b, 5] == q["r2"]["status"]),
+                         c1=abs(info[b, 0] - q["r1"]["cost"]) / q["r1"]["cost"], c2=abs(info[b, 3] - q["r2"]["cost"]) / q["r2"]["cost"],
+                         dj=np.abs(j[b][q["seen"]] - q["joints"][q["seen"]]).max() / scale,
+                         dj_abs=np.abs(j[b][q["seen"]] - q["joints"][q["seen"]]).max()))
+    strong = [r for r in rows if r["weak"] == 1.0]
+    weak = [r for r in rows if r["weak"] < 1.0]
+    qq = lambda a: f"median {np.median(a):.2e}  p90 {np.percentile(a, 90):.2e}  max {np.max(a):.2e}"
+    print(f"\n{n} warm solves (5 + 5 evaluations) on the device against trf_np.trf(solver='ne_clean'), stage 1 -> stage 2")
+    print(f"  cases without a weak eigenvalue in any model: {len(strong)}; with one (printed below): {len(weak)}")
+    print("  strong: cost after stage 1, rel  ", qq([r["c1"] for r in strong]))
+    print("  strong: cost after stage 2, rel  ", qq([r["c2"] for r in strong]))
+    print("  strong: observed joints / scale  ", qq([r["dj"] for r in strong]), "| metres", qq([r["dj_abs"] for r in strong]))
+    print(f"  strong: nfev equal {sum(r['nfev_ok'] for r in strong)} / {len(strong)}, status equal {sum(r['status_ok'] for r in strong)} / {len(strong)}")
+    for r in weak:
+        print(f"  weak  {r['name']:>14}: weakest eigenvalue {r['weak']:.1e} lam_max; nfev equal {r['nfev_ok']}, cost rel {r['c1']:.1e} / {r['c2']:.1e}, "
+              f"joints {r['dj_abs']:.1e} m")
+    bad = [r for r in strong if not (r["nfev_ok"] and r["status_ok"] and r["c1"] < 1e-4 and r["c2"] < 1e-4 and r["dj"] < 1e-4)]
+    for r in bad:
+        print("  FAIL", r)
+    assert not bad
+    assert len(strong) >= 0.9 * n
+    # cases with a weak eigenvalue: the band of tests/test_gpu_ik.py (the two sides may split range and null space differently)
+    if weak:
+        assert np.median([r["dj_abs"] for r in weak]) < 5e-3 and max(r["c2"] for r in weak) < 0.5
+
+
+def test_every_trial_of_the_oracle_sequence_decides_the_same_on_the_device(solved):
+    """Teacher-forced by the ORACLE's iterates: the device makes one model + one trial from (x_k, Delta_k, alpha_k) of every trial of
+    every noise-free solve; accept / reject, the new radius (update_tr_radius, common.py:222-245) and alpha must be the oracle's."""
+    dev, d, cases, orc = solved["dev"], solved["d"], solved["cases"], solved["orc"]
+    n_bad = n_all = 0
+    worst = dict(alpha=0.0, pred=0.0, cost_new=0.0, step=0.0)
+    for st in (0, 1):
+        items = [(b, e) for b in range(len(cases)) for s, e in orc[b]["trials"] if s == st and orc[b]["weak"] == 1.0]
+        par = np.zeros((len(items), 68))
+        for k, (b, e) in enumerate(items):
+            par[k, :len(e["x"])] = e["x"]
+            if st == 0:
+                par[k, 57:] = cases[b]["init"][57:]
+        sel = torch.tensor([b for b, _ in items], device=d)
+        # one problem per trial: the case's keypoints re-used through its member row
+        r = dev.ik_model_step(solved["kps"], solved["cams_t"], solved["mem"][sel].contiguous(), torch.from_numpy(par).to(d), st,
+                              torch.tensor([e["Delta"] for _, e in items], dtype=torch.float64, device=d),
+                              torch.tensor([e["alpha_in"] for _, e in items], dtype=torch.float64, device=d))
+        torch.cuda.synchronize()
+        r = r.cpu().numpy()
+        nn = 57 if st == 0 else 68
+        for k, (b, e) in enumerate(items):
+            n_all += 1
+            actual = r[k, 0] - r[k, 5]
+            pred, step_norm, Delta = r[k, 3], r[k, 4], e["Delta"]
+            ratio = actual / pred if pred > 0 else (1.0 if (pred == 0 and actual == 0) else 0.0)
+            Delta_new = 0.25 * step_norm if ratio < 0.25 else (2.0 * Delta if (ratio > 0.75 and step_norm > 0.95 * Delta) else Delta)
+            same = ((actual > 0) == bool(e["accepted"])) and abs(Delta_new - e["Delta_new"]) <= 1e-9 * Delta
+            if not same:
+                n_bad += 1
+                print(f"  trial differs: {cases[b]['name']} stage {st + 1} nfev {e['nfev']}: device accept {actual > 0} ratio {ratio:.4f} "
+                      f"Delta_new {Delta_new:.6g}; oracle accept {e['accepted']} ratio {e['ratio']:.4f} Delta_new {e['Delta_new']:.6g}")
+            worst["alpha"] = max(worst["alpha"], abs(r[k, 2] - e["alpha"]) / e["alpha"])
+            worst["pred"] = max(worst["pred"], abs(pred - e["pred"]) / abs(e["pred"]))
+            worst["cost_new"] = max(worst["cost_new"], abs(r[k, 5] - e["cost_new"]) / e["cost_new"])
+            worst["step"] = max(worst["step"], np.linalg.norm(r[k, 80:80 + nn] - e["step"]) / Delta)
+    print(f"\n{n_all} trials of the noise-free sequences re-made on the device: decisions / radii differ on {n_bad}; worst relative "
+          f"difference of alpha {worst['alpha']:.1e}, predicted reduction {worst['pred']:.1e}, trial cost {worst['cost_new']:.1e}, "
+          f"step / Delta {worst['step']:.1e}")
+    assert n_bad == 0
+    assert worst["pred"] < 1e-4 and worst["cost_new"] < 1e-4 and worst["step"] < 1e-4
+
+
+def test_device_cost_not_above_the_reference(solved):
+    cases, info = solved["cases"], solved["info"]
+    rel = np.array([(info[b, 3] - c["ref_cost"][1]) / c["ref_cost"][1] for b, c in enumerate(cases)])
+    worse = np.flatnonzero(rel > 0)
+    print(f"\nfinal cost of the device against the reference's recorded final cost on {len(cases)} warm solves: lower or equal on "
+          f"{int((rel <= 0).sum())}; median {np.median(rel):+.2e}")
+    for b in worse:
+        print(f"  above the reference: {cases[b]['name']:>14} by {rel[b]:+.2e}")
+    assert (rel <= 0).mean() >= 0.9

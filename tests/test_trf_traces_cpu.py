@@ -81,7 +81,8 @@ def test_fd_jacobian_is_scipys(tr):
 
 def test_each_recorded_step_is_reproduced(tr):
     sel = _selected_trials(tr)
-    stats = dict(g=[], s=[], step=[], alpha=[], pred=[], cost_new=[], step_n=[], alpha_n=[], null_share=[])
+    stats = dict(g=[], s=[], step=[], alpha=[], pred=[], cost_new=[], step_n=[], alpha_n=[], null_share=[], step_c=[], pred_c=[], out_c=[],
+                 len_c=[])
     n_iter_equal = n_accept_equal = n_radius_equal = 0
     cache = {}
     for ti in sel:
@@ -97,8 +98,10 @@ def test_each_recorded_step_is_reproduced(tr):
             J = t.fd_jacobian(fun, x, f)
             U, s, Vt = np.linalg.svd(J, full_matrices=False)
             lam, V2 = t._eigh_desc(J.T @ J)
-            cache[key] = (f, J, U, s, Vt, lam, V2)
-        f, J, U, s, Vt, lam, V2 = cache[key]
+            obs, projs = _problem(tr, ci)
+            Ja = t.ik_jacobian(x[:3], x[3:57], x[57:] if st else tr["case_init"][ci][57:], obs, projs, st == 1)
+            cache[key] = (f, J, U, s, Vt, lam, V2, t._eigh_desc(Ja.T @ Ja), Ja.T @ f)
+        f, J, U, s, Vt, lam, V2, (lam_a, V_a), g_a = cache[key]
         m = len(f)
         cost, g = 0.5 * f @ f, J.T @ f
         assert abs(cost - tr["t_cost"][ti]) <= 1e-13 * cost
@@ -124,6 +127,16 @@ def test_each_recorded_step_is_reproduced(tr):
         p2, alpha2, _ = t.solve_tr_normal(n, m, lam, V2, g, Delta, initial_alpha=a_in)
         stats["step_n"].append(np.linalg.norm(Vr.T @ (p2 - pr)) / np.linalg.norm(pr))
         stats["alpha_n"].append(abs(alpha2 - tr["t_alpha"][ti]) / max(abs(tr["t_alpha"][ti]), 1e-300) if tr["t_alpha"][ti] > 1e-12 else 0.0)
+        # (c) the noise-free form (analytic Jacobian; solve_tr_normal_clean: null cluster dropped, one virtual absorber) -- the
+        # whole-solve oracle of tests/test_gpu_ik_whole_solves.py: never leaves range(J^T J), never longer than Delta, and where the
+        # reference's step is not noise (null share < 1e-5) it IS the reference's step
+        p3, _, pred3, _ = t.solve_tr_normal_clean(lam_a, V_a, g_a, Delta, initial_alpha=a_in)
+        if not ((lam_a > 1e-13 * lam_a[0]) & (lam_a < 1e-6 * lam_a[0])).any():      # (a weak eigenvalue: range | null is a rounding decision)
+            stats["out_c"].append(np.linalg.norm(p3 - Vr @ (Vr.T @ p3)) / np.linalg.norm(p3))
+        stats["len_c"].append(np.linalg.norm(p3) / Delta)
+        if stats["null_share"][-1] < 1e-5:
+            stats["step_c"].append(np.linalg.norm(p3 - pr) / np.linalg.norm(pr))
+            stats["pred_c"].append(abs(pred3 - tr["t_pred"][ti]) / abs(tr["t_pred"][ti]))
         # the trial point FROM THE RECORDED STEP: cost, accept / reject, radius update (common.py:222-245)
         f_new = fun(x + pr)
         cost_new = 0.5 * f_new @ f_new
@@ -139,7 +152,11 @@ def test_each_recorded_step_is_reproduced(tr):
     for k, label in [("g", "|g - g_ref| / |g|"), ("s", "singular values / s_max"), ("step", "solve_tr_svd step on range(JtJ) / |p|"),
                      ("alpha", "solve_tr_svd alpha rel"), ("pred", "predicted reduction rel"), ("step_n", "solve_tr_normal step on range / |p|"),
                      ("alpha_n", "solve_tr_normal alpha rel"), ("cost_new", "cost at the recorded trial point rel"),
-                     ("null_share", "share of the reference's |step| outside range(JtJ)")]:
+                     ("null_share", "share of the reference's |step| outside range(JtJ)"),
+                     ("step_c", "solve_tr_normal_clean step (where null share < 1e-5) / |p|"),
+                     ("pred_c", "solve_tr_normal_clean predicted reduction (same steps) rel"),
+                     ("out_c", "solve_tr_normal_clean: share of its step outside range(JtJ) (models without a weak eigenvalue)"),
+                     ("len_c", "solve_tr_normal_clean: |step| / Delta")]:
         print(f"  {label:58s} median {q(stats[k])[0]:.2e}  p99 {q(stats[k])[1]:.2e}  max {q(stats[k])[2]:.2e}")
     print(f"  Newton iteration counts equal {n_iter_equal}/{len(sel)}, accept / reject equal {n_accept_equal}/{len(sel)}, "
           f"new radius equal {n_radius_equal}/{len(sel)}")
@@ -152,6 +169,10 @@ def test_each_recorded_step_is_reproduced(tr):
     assert n_iter_equal >= 0.99 * len(sel)
     # the normal-equation form: the same on range(J^T J) to 1e-4 for 99 % of the steps (the rest: see the printed maxima)
     assert np.percentile(stats["step_n"], 95) < 1e-4
+    # the noise-free form: the reference's step wherever that is not noise; inside range(J^T J) and the trust region always
+    assert len(stats["step_c"]) >= 200
+    assert np.percentile(stats["step_c"], 99) < 1e-4 and max(stats["step_c"]) < 5e-4 and np.percentile(stats["pred_c"], 99) < 1e-4
+    assert len(stats["out_c"]) >= 0.8 * len(sel) and max(stats["out_c"]) < 1e-5 and max(stats["len_c"]) <= 1.0 + 1e-12
 
 
 def test_whole_warm_solves_follow_the_recorded_sequence(tr, monkeypatch):
