@@ -15,10 +15,10 @@ Shelf clusters and synthetic config-4 clusters, warm start = the reference track
 
 Gates, per solve (mvmc_ik_solve, max_nfev 5 + 5):
   1. nfev and status of both stages equal the oracle's (the accept / reject sequence decides how many models a budget of five buys);
-  2. cost after stage 1 and after stage 2, and every observed joint (>= 2 views) of the final pose, within 1e-4 (relative; joints
-     relative to the scene scale) -- on EVERY case whose trust-region models have no weak eigenvalue, i.e. none in
-     (1e-13, 1e-6) lam_max: there the split between range and null space is itself a rounding decision; those cases are printed with
-     their weakest eigenvalue and gated at the band of test_gpu_ik.py instead;
+  2. cost after stage 1 and after stage 2, and every observed joint (>= 2 views) of the final pose, within 1e-7 (relative; joints
+     relative to the scene scale; north_star's bar is 1e-4, observed 2e-12) -- on EVERY case whose trust-region models have no weak
+     eigenvalue, i.e. none in (1e-13, 1e-6) lam_max: there the split between range and null space is itself a rounding decision;
+     those cases are printed with their weakest eigenvalue and gated at the band of test_gpu_ik.py at worst (observed: 2e-11 too);
   3. the accept / reject decision and the new radius of every trial of the oracle's sequence, re-made on the device from the oracle's
      own (x_k, Delta_k, alpha_k) (mvmc_debug_ik_model_step): identical decisions, radii equal;
   4. the device's final cost <= the REFERENCE's recorded final cost on >= 90 % of the cases (exceptions printed): not following the
@@ -147,12 +147,15 @@ def test_whole_warm_solves_equal_the_noise_free_oracle(solved):
     for r in weak:
         print(f"  weak  {r['name']:>14}: weakest eigenvalue {r['weak']:.1e} lam_max; nfev equal {r['nfev_ok']}, cost rel {r['c1']:.1e} / {r['c2']:.1e}, "
               f"joints {r['dj_abs']:.1e} m")
-    bad = [r for r in strong if not (r["nfev_ok"] and r["status_ok"] and r["c1"] < 1e-4 and r["c2"] < 1e-4 and r["dj"] < 1e-4)]
+    # north_star's bar is 1e-4; observed (profiles/r05_whole_solves_test.txt): 2e-12 at worst on the strong cases, 2e-11 on the weak
+    # ones -- the gate is set three orders inside the bar so that a regression shows long before it matters
+    bad = [r for r in rows if not (r["nfev_ok"] and r["status_ok"] and r["c1"] < 1e-7 and r["c2"] < 1e-7 and r["dj"] < 1e-7)]
     for r in bad:
         print("  FAIL", r)
-    assert not bad
+    assert not [r for r in bad if r["weak"] == 1.0]
     assert len(strong) >= 0.9 * n
-    # cases with a weak eigenvalue: the band of tests/test_gpu_ik.py (the two sides may split range and null space differently)
+    # cases with a weak eigenvalue may split range and null space differently on the two sides: at worst the band of
+    # tests/test_gpu_ik.py -- today they agree like the others, and a case that stops doing so is printed above
     if weak:
         assert np.median([r["dj_abs"] for r in weak]) < 5e-3 and max(r["c2"] for r in weak) < 0.5
 
