@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BYTES_PER_FRAME = lambda C, P, J=25: 12 * C * P * J + 4 * C * P + 16 * P * J + 488 * P
+DEFAULT_NCCL_MAX_NCHANNELS = "4"   # see main(): RCCL beside the persistent chain kernel; chosen by the sweep in DESIGN.md section 7
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs x 16 fp64 lanes x 2 flop x 2.4 GHz (vector = fp64 MFMA rate on gfx950)
 NOMINAL_CLOCK_HZ = 2.4e9
@@ -157,6 +158,20 @@ def cpu_baseline_twin(data, L, n_frames_total):
                        f"TRF with 2-point Jacobians and an SVD step restated literally): {n_all} chains of {L} frames of the same "
                        f"synthetic workload on {used} threads ({solves} IK solves, {t_all:.1f} s), then {n_one} chain(s) on one thread "
                        f"({t_one:.1f} s)")
+
+
+def als_histogram(iters) -> dict:
+    """the ALS / ADMM iteration histogram of one step (match_als, mv_association.py:275-309: data-dependent trip count,
+    tol 1e-4, maxIter 1000) over the step's association graphs."""
+    it = np.asarray(iters).reshape(-1)
+    it = it[it > 0]
+    if it.size == 0:
+        return None
+    edges = [1, 25, 50, 100, 150, 200, 300, 500, 1000]
+    return {"graphs": int(it.size), "min": int(it.min()), "p50": float(np.percentile(it, 50)), "p90": float(np.percentile(it, 90)),
+            "p99": float(np.percentile(it, 99)), "max": int(it.max()), "mean": float(it.mean()),
+            "share_at_the_1000_cap": float((it >= 1000).mean()),
+            "histogram": {f"[{lo}, {hi})": int(((it >= lo) & (it < hi)).sum()) for lo, hi in zip(edges, edges[1:])} | {"1000": int((it >= 1000).sum())}}
 
 
 def kernel_sources_sha() -> str:
@@ -298,7 +313,7 @@ def other_config_lines():
             lines.append({"config": name, "error": repr(exc)[:300]})
             continue
         keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "ms_per_frame", "dtype", "config", "roofline",
-                "tracker_events_per_step", "stages_ms", "accuracy")
+                "tracker_events_per_step", "stages_ms", "accuracy", "collective", "als_iterations")
         rec = {"name": name, "command": "python bench.py " + " ".join(argv), **{k: line[k] for k in keep if k in line},
                "wall_s": time.perf_counter() - t0}
         lines.append(rec)
@@ -348,6 +363,9 @@ def main():
                     help="synthetic scene: 'chains' restarts the people's random walk at every chain head (the workload the round-1 "
                          "numbers were measured on); 'continuous' is one walk over all frames, so the stitch has identities to find")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="--gpus 1 only: initialise the backend at world size 1 and issue the step's all-gather through it (no world == 1 "
+                         "short-cut) -- RCCL's kernels beside the resident chain workgroups on a one-GPU box; the N > 1 call path")
     ap.add_argument("--hand-over", default="auto", choices=["auto", "ticket", "static", "queue"],
                     help="fused path: how a chain's workgroups follow one another: ticket = (part, chain) from a ticket drawn at start "
                          "(no assumption about dispatch order; the default at every N), static = the same mapping by block index "
@@ -365,7 +383,7 @@ def main():
     ap.add_argument("--no-other-configs", dest="other_configs", action="store_false")
     args = ap.parse_args()
     if args.other_configs is None:
-        args.other_configs = (args.gpus == 1 and args.workload == "full" and (args.frames, args.views, args.people) == (10000, 5, 4)
+        args.other_configs = (args.workload == "full" and (args.frames, args.views, args.people) == (10000, 5, 4)
                               and args.occlusion == 0.0 and args.path == "fused")
     if args.overlap is None:
         # two steps in flight fill the tail of the chain kernel's launches; the memory-bound triangulation-only pass (config 2) has no
@@ -386,7 +404,24 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     d = torch.device("cuda", local_rank)
-    if world > 1:
+    if args.backend == "nccl" and (world > 1 or args.force_collective):
+        # RCCL's channels are workgroups that need a slot beside the resident chain workgroups (768-1024 on the chip, spinning on
+        # hand-over words): cap them.  The messages are small (20-100 MB per rank and step, overlapped with the next step), so the
+        # collective does not need RCCL's default channel count; the cap is part of the record (collective.env)
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", DEFAULT_NCCL_MAX_NCHANNELS)
+    if world > 1 or args.force_collective:
+        if args.force_collective:
+            if world != 1:
+                raise SystemExit("--force-collective is the world-size-1 rehearsal of the N > 1 call path: --gpus 1")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                import socket
+                sk = socket.socket()
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+                sk.close()
+            from multiview_motion_capture_amd import parallel as par0
+            par0.FORCE_COLLECTIVE = True
         kw = {}
         if args.backend == "nccl":
             kw["device_id"] = d
@@ -401,11 +436,44 @@ def main():
         except TypeError:      # (a torch without pg_options / device_id: the plain form)
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
+    res = run_workload(args, rank, world, d)
+    if args.other_configs:
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()       # (the headline workload's tensors died with run_workload's frame)
+        if world == 1:
+            # BASELINE configs 1, 5, 3 and 2 in the same driver-timed record: child runs of this script (fresh processes: their own
+            # inputs, their own timed regions with the same barrier / synchronize bracket)
+            res["other_configs"] = other_config_lines()
+        else:
+            # N > 1: BASELINE config 5 -- the configuration BASELINE defines BY its scaling curve (200 k frames, C8 P8 over 8 GPUs =
+            # 25,008 frames per GPU) -- in the same processes and the same process group, every rank its own shard, the same barrier +
+            # synchronize bracket and max over ranks; the single-GPU configurations (1, 2, 3) are in the N = 1 line
+            a5 = argparse.Namespace(**vars(args))
+            a5.views, a5.people, a5.frames, a5.seed, a5.steps, a5.warmup, a5.sustain, a5.cpu_frames = 8, 8, 25008, 20260104, 3, 1, 0, 0
+            t5 = time.perf_counter()
+            r5 = run_workload(a5, rank, world, d)
+            if rank == 0:
+                keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "per_rank_ms_per_step", "dtype", "config",
+                        "roofline", "tracker_events_per_step", "stages_ms", "accuracy", "collective", "als_iterations")
+                res["other_configs"] = [{"name": OTHER_CONFIGS[1][0] + f", on {world} GPUs (all ranks of this run, one all-gather per step)",
+                                         "command": "in-process: --views 8 --people 8 --frames 25008 --seed 20260104 --steps 3 --warmup 1",
+                                         **{k: r5[k] for k in keep if k in r5}, "wall_s": time.perf_counter() - t5}]
+    if rank == 0:
+        print(json.dumps(res))
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_workload(args, rank, world, d):
+    """One workload on this rank (inside an initialised process group when world > 1): inputs -> warm-up -> the timed region -> the
+    record (rank 0; None elsewhere).  Called once for the headline and, at N > 1, once more for BASELINE config 5."""
+    import torch.distributed as dist
     if args.workload == "shelf":
         if world != 1:
             raise SystemExit("--workload shelf is a single-process sequence (the reference's driver loop): --gpus 1")
-        print(json.dumps(shelf_line(args, d)))
-        return
+        return shelf_line(args, d) if rank == 0 else None
     from multiview_motion_capture_amd import synth
     from multiview_motion_capture_amd.pipeline import HotPath
     from multiview_motion_capture_amd import parallel as par
@@ -462,7 +530,7 @@ def main():
                 ev["total"].append((e[0], e[1]))
             info = out.pop("ik_info", None)
             phase = out.pop("phase_cycles", None)
-            out.pop("als_iters", None)
+            out["als_it"] = out.pop("als_iters", None)
             out["info"] = info
             out["phase"] = phase
             return out
@@ -489,7 +557,7 @@ def main():
         if timed: e[1].record()
         tri = hp.triangulate(assoc)
         if timed: e[2].record()
-        out = dict(labels=assoc["labels"], pts3d=tri["pts3d"])
+        out = dict(labels=assoc["labels"], pts3d=tri["pts3d"], als_it=assoc.get("iters"))
         if with_ik:
             out.update(hp.solve_cold(assoc, tri, args.nfev_cold))
         if timed: e[3].record()
@@ -635,6 +703,22 @@ def main():
         sustained = {"value": F * world * n_sus / dts, "unit": "frames/s", "steps": n_sus, "ms_per_step": dts / n_sus * 1e3}
         for res in stitched:
             par.check_stitch_info(res)
+    # the one collective of a step, as this run saw it (rank 0's events; every rank issues the same call)
+    collective = None
+    if sharded:
+        last = stitched[-1] if stitched else None
+        gather_ms = [e[1].elapsed_time(e[2]) for e in tail_events] if tail_events else []
+        collective = {"backend": (dist.get_backend() if dist.is_initialized() else "none (world size 1: the message is its own gather)"),
+                      "world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                      "forced_at_world_size_1": bool(par.FORCE_COLLECTIVE),
+                      "all_gathers_per_step": 1,
+                      "messages_gathered": int(last["messages"].shape[0]) if last is not None else None,
+                      "message_bytes": int(last["message"].numel() * last["message"].element_size()) if last is not None else None,
+                      "gather_ms": {"p50": float(np.percentile(gather_ms, 50)), "max": float(np.max(gather_ms))} if gather_ms else None,
+                      "chains_stitched": int(last["info"][0].item()) if last is not None else None,
+                      "env": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "MVMC_COMM_PRIORITY")},
+                      "note": "pack -> ONE all-gather of fixed-size messages (live tracklets, f32) -> stitch, on a high-priority "
+                              "communication stream behind an event; gather_ms = events around the collective on that stream"}
     stage_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items() if v}
     if serial_ms is not None:
         stage_ms["one_step_alone"] = serial_ms
@@ -747,6 +831,8 @@ def main():
                        "steps_in_flight": args.overlap, "occlusion": args.occlusion, "spurious": args.spurious,
                        **({"tiled_from_frames": F_gen} if F_gen != F else {}), **extra},
             "sustained": sustained,
+            "collective": collective,
+            "als_iterations": als_histogram(out["als_it"].cpu().numpy()) if out.get("als_it") is not None else None,
             "tracker_events_per_step": tracker_events,
             "stages_ms": stage_ms,
             "roofline": {"bound": "hbm", "kernel": dom_kernel,
@@ -792,16 +878,8 @@ def main():
                     res["cpu_baseline"] = numpy_port
             else:
                 res["cpu_baseline"] = cpu_baseline(data, args.cpu_frames, args.nfev_cold)
-        if args.other_configs and world == 1:
-            # BASELINE configs 5 and 2 in the same driver-timed record: child runs of this script (fresh processes: their own inputs, their
-            # own timed regions with the same barrier / synchronize bracket), after this process has given its device memory back
-            del kps, counts, out
-            stitched.clear()
-            torch.cuda.empty_cache()
-            res["other_configs"] = other_config_lines()
-        print(json.dumps(res))
-    if world > 1:
-        dist.destroy_process_group()
+        return res
+    return None
 
 
 if __name__ == "__main__":

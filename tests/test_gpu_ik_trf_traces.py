@@ -205,8 +205,17 @@ def test_every_recorded_step_from_its_own_iterate(tr):
               f"{int(A['acc_rng'][m].sum())}, by the device {int(A['acc_dev'][m].sum())}; device = range-only decision on {int(same.sum())}")
         print(f"D    relative cost reduction: reference as taken median {np.median(A['red_ref'][m]):+.3f}, its range part {np.median(A['red_rng'][m]):+.3f}, "
               f"device {np.median(A['red_dev'][m]):+.3f};  |device - range part| {_q(dred)}")
+        # every step behind the two margins below is named, so that a regression inside them cannot pass unseen
+        bar = 1e-4 if name == "warm" else 1e-2
+        idx_m = np.flatnonzero(m)
+        for k in idx_m[~same]:
+            ti = sel[k]
+            print(f"D    decision differs from the range-only one: trial {ti} (case {int(tr['t_case'][ti])}, stage {int(tr['t_stage'][ti]) + 1}, "
+                  f"nfev {int(tr['t_nfev'][ti])}): device reduction {A['red_dev'][k]:+.3e}, range part {A['red_rng'][k]:+.3e}, null share {A['null'][k]:.3f}")
+        over = idx_m[dred > bar]
+        print(f"D    |device - range part| above {bar:.0e} on {len(over)} of {int(m.sum())} steps: trials {[int(sel[k]) for k in over]}")
         assert same.mean() >= 0.99 if name == "warm" else same.mean() >= 0.9
-        assert np.percentile(dred, 90) < (1e-4 if name == "warm" else 1e-2)
+        assert np.percentile(dred, 90) < bar
     wm = ~A["cold"]
     print(f"   all warm steps: {int(wm.sum())}; null share {_q(A['null'][wm])}")
     print(f"   all warm steps: step on range {_q(A['rng'][wm])}; predicted reduction {_q(A['pred'][wm])}")
