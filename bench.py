@@ -376,6 +376,9 @@ def main():
     ap.add_argument("--tile-from", type=int, default=0,
                     help="generate this many frames on the host and tile them on the device up to --frames (config 2 at 2 M frames: the "
                          "generator would take minutes; the kernel reads every frame from HBM either way); 0 = generate all frames")
+    ap.add_argument("--dlt-out", default="f32", choices=["f32", "f64"],
+                    help="--workload dlt: dtype of the triangulated points the one-pass kernel stores (float32 = SURVEY 8(d)'s I/O, one "
+                         "16-byte store per point; float64 = mvmc_ingest_dlt's output, 32 bytes per point)")
     ap.add_argument("--other-configs", dest="other_configs", action="store_true", default=None,
                     help="after the headline region also time BASELINE config 5 (C8 P8, 25,008 frames, 3 steps), config 3 (C5 P4, association "
                          "+ triangulation, 10 steps) and config 2 (C5 P1, triangulation only, 2 M frames, 20 launches) as child runs of this script and report them under "
@@ -542,7 +545,11 @@ def run_workload(args, rank, world, d):
             if timed: e[0].record()
             if args.path == "fused":
                 if timed: e[1].record()
-                pts = dev.ingest_dlt(kps, counts, hp.P, dlt_members.view(F, Pn, C))
+                # float32 keypoints in, float32 points out: SURVEY 8(d)'s I/O for this configuration (12 C P J + 16 P J bytes per
+                # frame) -- the float64 arithmetic of the reference, each point rounded once at a 16-byte store; --dlt-out f64 = the
+                # float64 output the parity tests compare bit for bit
+                pts = dev.ingest_dlt(kps, counts, hp.P, dlt_members.view(F, Pn, C),
+                                     out_dtype=torch.float32 if args.dlt_out == "f32" else torch.float64)
             else:
                 k17, c17 = dev.ingest(kps, counts)
                 if timed: e[1].record()
@@ -829,7 +836,8 @@ def run_workload(args, rank, world, d):
                                     if with_ik else ""),
                        "frames_per_gpu": F, "views": C, "people": Pn, "chain_len": L, "seed": args.seed, "parallelism": f"frames x{world}",
                        "steps_in_flight": args.overlap, "occlusion": args.occlusion, "spurious": args.spurious,
-                       **({"tiled_from_frames": F_gen} if F_gen != F else {}), **extra},
+                       **({"tiled_from_frames": F_gen} if F_gen != F else {}),
+                       **({"points_stored_as": args.dlt_out} if args.workload == "dlt" else {}), **extra},
             "sustained": sustained,
             "collective": collective,
             "als_iterations": als_histogram(out["als_it"].cpu().numpy()) if out.get("als_it") is not None else None,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVMC_ABI_VERSION 4
+#define MVMC_ABI_VERSION 5
 
 enum {
     MVMC_OK = 0,
@@ -142,6 +142,15 @@ int mvmc_dlt(const double* kps, const double* Pmats, const int32_t* members, int
 int mvmc_ingest_dlt(const void* kps, int dtype, int n_frames, int n_views, int p_max, int n_joints_in, const int32_t* counts_in,
                     double ingest_min_score, int min_valid, double min_bb_size, const double* Pmats, const int32_t* members,
                     int k_max, int v_max, double min_score, double* out, int32_t* counts_out, mvmcStream_t stream);
+
+/* The same pass with float32 keypoints in AND float32 points out -- SURVEY 8(d)'s I/O for config 2: 12 C P J bytes read and
+ * 16 P J bytes written per frame, each point ONE 16-byte store.  The arithmetic is mvmc_ingest_dlt's (float64; the reference
+ * triangulates in float64, mv_math_util.py:152-187,215-240); out (F,K,17,4) f32 = that result rounded once at the store.
+ * MVMC_ERR_UNSUPPORTED for shapes the pipelined kernel does not hold (k_max * 17 > 192, n_views * p_max > 128, p_max > 16, ...):
+ * use mvmc_ingest_dlt there. */
+int mvmc_ingest_dlt_f32(const float* kps, int n_frames, int n_views, int p_max, int n_joints_in, const int32_t* counts_in,
+                        double ingest_min_score, int min_valid, double min_bb_size, const double* Pmats, const int32_t* members,
+                        int k_max, int v_max, double min_score, float* out, int32_t* counts_out, mvmcStream_t stream);
 
 /* TR-2, post_optimize=True (mv_math_util.py:189-210): scipy least_squares(max_nfev = 2) on the unsigned
  * residual |proj - obs| * score with eps = 1e-6, i.e. one trust-region trial step from the DLT points, kept

@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get("MVMC_LIB_PATH") or os.path.join(os.path.dirname(os.p
 _lib = None
 
 MVMC_OK = 0
-MVMC_ABI = 4    # MVMC_ABI_VERSION of include/mvmc.h that the argument types in load() describe
+MVMC_ABI = 5    # MVMC_ABI_VERSION of include/mvmc.h that the argument types in load() describe
 MVMC_F32, MVMC_F64 = 0, 1
 N_PARAM = 68
 MAX_NODES = 80
@@ -28,7 +28,7 @@ SYMBOLS = (
     "mvmc_abi_version", "mvmc_status_string", "mvmc_als_seed_table", "mvmc_ingest", "mvmc_fmats",
     "mvmc_affinity", "mvmc_als_associate", "mvmc_closure_labels", "mvmc_cluster_members", "mvmc_dlt", "mvmc_triangulate_postopt", "mvmc_fk", "mvmc_ik_solve",
     "mvmc_fmats_from_projections", "mvmc_st_affinity", "mvmc_track_assign", "mvmc_track_commit", "mvmc_debug_eigh",
-    "mvmc_debug_trstep", "mvmc_ik_solve_stages", "mvmc_chain_run", "mvmc_svt_associate", "mvmc_debug_ik_solve_fd", "mvmc_debug_ik_model_step", "mvmc_ingest_dlt", "mvmc_pack_message_words", "mvmc_pack_work_words", "mvmc_stitch_work_words", "mvmc_pack_tracks", "mvmc_stitch_chains",
+    "mvmc_debug_trstep", "mvmc_ik_solve_stages", "mvmc_chain_run", "mvmc_svt_associate", "mvmc_debug_ik_solve_fd", "mvmc_debug_ik_model_step", "mvmc_ingest_dlt", "mvmc_ingest_dlt_f32", "mvmc_pack_message_words", "mvmc_pack_work_words", "mvmc_stitch_work_words", "mvmc_pack_tracks", "mvmc_stitch_chains",
 )
 
 
@@ -90,6 +90,7 @@ def load():
         "mvmc_cluster_members": [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp],
         "mvmc_dlt": [vp, vp, vp, i32, i32, i32, i32, i32, f64, vp, vp],
         "mvmc_ingest_dlt": [vp, i32, i32, i32, i32, i32, vp, f64, i32, f64, vp, vp, i32, i32, f64, vp, vp, vp],
+        "mvmc_ingest_dlt_f32": [vp, i32, i32, i32, i32, vp, f64, i32, f64, vp, vp, i32, i32, f64, vp, vp, vp],
         "mvmc_triangulate_postopt": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp],
         "mvmc_fk": [SK, vp, i32, vp, vp, vp],
         "mvmc_ik_solve": [SK, vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp],

@@ -365,7 +365,7 @@ __device__ __forceinline__ unsigned id3_lds_addr(const void* p) {
 
 struct Id3Args {
     const float* kps; const double* Pm; int F, G, C, P, J_in; const int32_t* counts_in; double min_score_in; int min_valid; double min_bb;
-    const int32_t* members; int K, V; double min_score; double* out; int32_t* counts_out;
+    const int32_t* members; int K, V; double min_score; void* out; int32_t* counts_out;   // out: (F,K,17,4) f64, or f32 in the OUT32 instance
 };
 
 // the loader wave: group grp -> buffer b (DMA, wait, filter + compaction)
@@ -434,7 +434,7 @@ __device__ __forceinline__ void id3_load_group(const Id3Args& A, Id3Buf& b, int 
 }
 
 // a triangulating thread: point dt = (frame in group, cluster, joint) of group grp out of buffer b
-template <int VU>
+template <int VU, bool OUT32>
 __device__ __forceinline__ void id3_point(const Id3Args& A, const Id3Buf& b, const double* __restrict__ sP, int grp, int dt,
                                           unsigned p_magic) {
     const int nq = A.C * A.P, K = A.K, V = A.V, f0 = grp * A.G, g_n = min(A.G, A.F - f0);
@@ -447,7 +447,10 @@ __device__ __forceinline__ void id3_point(const Id3Args& A, const Id3Buf& b, con
     const int base = (f0 + g) * nq;
     const int* so = b.src_of + g * nq;
     const float4* pg = reinterpret_cast<const float4*>(b.pose) + (size_t)g * nq * 17 + j;
-    double* o = A.out + ((size_t)f0 * K * 17 + dt) * 4;
+    // OUT32: the point leaves as ONE 16-byte store (x, y, z, score as float32: SURVEY 8(d)'s 16 P J bytes per frame) -- the values
+    // are the float64 result rounded once, at the store
+    double r4[4];
+    double* o = OUT32 ? r4 : reinterpret_cast<double*>(A.out) + ((size_t)f0 * K * 17 + dt) * 4;
     if constexpr (VU > 0) {
         // member -> slot -> keypoint of ALL views first: three rounds of independent LDS reads instead of three dependent reads per view
         int dd[VU], qq[VU];
@@ -479,9 +482,11 @@ __device__ __forceinline__ void id3_point(const Id3Args& A, const Id3Buf& b, con
             return true;
         }, o);
     }
+    if constexpr (OUT32)
+        reinterpret_cast<float4*>(A.out)[(size_t)f0 * K * 17 + dt] = make_float4((float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]);
 }
 
-template <int VU>
+template <int VU, bool OUT32>
 __global__ void __launch_bounds__(256, 4)
 ingest_dlt3_kernel(Id3Args A) {
     __shared__ Id3Buf bufA;
@@ -508,11 +513,11 @@ ingest_dlt3_kernel(Id3Args A) {
     for (; grp < n_groups; grp += 2 * stride) {
         // group grp out of bufA while grp + stride is prepared in bufB, then the other way round
         if (loader) { if (grp + stride < n_groups) id3_load_group(A, bufB, grp + stride, score_thr); }
-        else id3_point<VU>(A, bufA, sP, grp, dt, p_magic);
+        else id3_point<VU, OUT32>(A, bufA, sP, grp, dt, p_magic);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (grp + stride >= n_groups) break;
         if (loader) { if (grp + 2 * stride < n_groups) id3_load_group(A, bufA, grp + 2 * stride, score_thr); }
-        else id3_point<VU>(A, bufB, sP, grp + stride, dt, p_magic);
+        else id3_point<VU, OUT32>(A, bufB, sP, grp + stride, dt, p_magic);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 }
@@ -616,10 +621,11 @@ extern "C" int mvmc_dlt(const double* kps17, const double* Pmats, const int32_t*
     return MVMC_OK;
 }
 
-extern "C" int mvmc_ingest_dlt(const void* kps, int dtype, int n_frames, int n_views, int p_max, int n_joints_in,
-                               const int32_t* counts_in, double ingest_min_score, int min_valid, double min_bb_size,
-                               const double* Pmats, const int32_t* members, int k_max, int v_max, double min_score, double* out,
-                               int32_t* counts_out, mvmcStream_t stream) {
+static int ingest_dlt_launch(const void* kps, int dtype, int n_frames, int n_views, int p_max, int n_joints_in,
+                             const int32_t* counts_in, double ingest_min_score, int min_valid, double min_bb_size,
+                             const double* Pmats, const int32_t* members, int k_max, int v_max, double min_score, void* out_any, bool out32,
+                             int32_t* counts_out, mvmcStream_t stream) {
+    double* out = reinterpret_cast<double*>(out_any);
     if (!kps || !Pmats || !members || !out || n_frames < 0 || n_views <= 0 || p_max <= 0 || k_max <= 0 || v_max <= 0) return MVMC_ERR_ARG;
     if (n_joints_in != 25 && n_joints_in != 17) return MVMC_ERR_ARG;
     if (dtype != MVMC_F32 && dtype != MVMC_F64) return MVMC_ERR_ARG;
@@ -645,12 +651,18 @@ extern "C" int mvmc_ingest_dlt(const void* kps, int dtype, int n_frames, int n_v
             long long blocks = ((long long)n_frames + G3 - 1) / G3;
             const long long cap = (long long)cus * 4;      // persistent and resident (35 KB of LDS each): the workgroups stride over the groups
             if (blocks > cap) blocks = cap;
-            if (v_max <= 5) hipLaunchKernelGGL(ingest_dlt3_kernel<5>, dim3((unsigned)blocks), dim3(256), 0, s, A);
-            else hipLaunchKernelGGL(ingest_dlt3_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, A);
+            if (out32) {
+                if (v_max <= 5) hipLaunchKernelGGL((ingest_dlt3_kernel<5, true>), dim3((unsigned)blocks), dim3(256), 0, s, A);
+                else hipLaunchKernelGGL((ingest_dlt3_kernel<0, true>), dim3((unsigned)blocks), dim3(256), 0, s, A);
+            } else {
+                if (v_max <= 5) hipLaunchKernelGGL((ingest_dlt3_kernel<5, false>), dim3((unsigned)blocks), dim3(256), 0, s, A);
+                else hipLaunchKernelGGL((ingest_dlt3_kernel<0, false>), dim3((unsigned)blocks), dim3(256), 0, s, A);
+            }
             MVMC_CHECK_LAUNCH();
             return MVMC_OK;
         }
     }
+    if (out32) return MVMC_ERR_UNSUPPORTED;     // float32 results: the pipelined kernel's shapes only (float32 input, k_max * 17 <= 192, ...)
     const size_t per_frame = (size_t)nq * 51 * (dtype == MVMC_F32 ? 4 : 8) + ((size_t)2 * nq + n_views + (size_t)k_max * v_max) * sizeof(int);
     // frames per group: TWO full trips of the 256 threads through the DLT stage (30 frames at C5 P1: the stages' barriers and the
     // 75-thread filter / compaction stages are per group, and with 15 frames they were a sixth of the time: 1.71 -> 1.49 ms per 2 M
@@ -676,6 +688,22 @@ extern "C" int mvmc_ingest_dlt(const void* kps, int dtype, int n_frames, int n_v
                            v_max, min_score, out, counts_out);
     MVMC_CHECK_LAUNCH();
     return MVMC_OK;
+}
+
+extern "C" int mvmc_ingest_dlt(const void* kps, int dtype, int n_frames, int n_views, int p_max, int n_joints_in,
+                               const int32_t* counts_in, double ingest_min_score, int min_valid, double min_bb_size,
+                               const double* Pmats, const int32_t* members, int k_max, int v_max, double min_score, double* out,
+                               int32_t* counts_out, mvmcStream_t stream) {
+    return ingest_dlt_launch(kps, dtype, n_frames, n_views, p_max, n_joints_in, counts_in, ingest_min_score, min_valid, min_bb_size, Pmats,
+                             members, k_max, v_max, min_score, out, false, counts_out, stream);
+}
+
+extern "C" int mvmc_ingest_dlt_f32(const float* kps, int n_frames, int n_views, int p_max, int n_joints_in,
+                                   const int32_t* counts_in, double ingest_min_score, int min_valid, double min_bb_size,
+                                   const double* Pmats, const int32_t* members, int k_max, int v_max, double min_score, float* out,
+                                   int32_t* counts_out, mvmcStream_t stream) {
+    return ingest_dlt_launch(kps, MVMC_F32, n_frames, n_views, p_max, n_joints_in, counts_in, ingest_min_score, min_valid, min_bb_size,
+                             Pmats, members, k_max, v_max, min_score, out, true, counts_out, stream);
 }
 
 extern "C" int mvmc_fk(const mvmcSkeleton* skel_host, const double* params, int n_problems, double* joints,

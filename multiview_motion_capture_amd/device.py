@@ -225,9 +225,10 @@ def dlt(kps: torch.Tensor, Pmats: torch.Tensor, members: torch.Tensor, min_score
 
 
 def ingest_dlt(kps: torch.Tensor, counts: Optional[torch.Tensor], Pmats: torch.Tensor, members: torch.Tensor, min_score=0.01,
-               ingest_min_score=0.01, min_valid=4, min_bb=5.0, want_counts=False):
+               ingest_min_score=0.01, min_valid=4, min_bb=5.0, want_counts=False, out_dtype=torch.float64):
     """ingest() + dlt() in one pass (include/mvmc.h: mvmc_ingest_dlt).  kps (F,C,P,25|17,3) f32|f64; members (F,K,V) i32 in ingest()'s
-    output numbering, every cluster inside its own frame -> pts3d (F,K,17,4) f64 [, counts (F,C)]."""
+    output numbering, every cluster inside its own frame -> pts3d (F,K,17,4) f64 [, counts (F,C)].  out_dtype=torch.float32
+    (float32 keypoints only; mvmc_ingest_dlt_f32): the same float64 arithmetic, the points rounded once at a 16-byte store."""
     if kps.dtype not in (torch.float32, torch.float64):
         raise ValueError("ingest_dlt: kps must be float32 or float64")
     _req(kps, kps.dtype, "kps")
@@ -241,8 +242,15 @@ def ingest_dlt(kps: torch.Tensor, counts: Optional[torch.Tensor], Pmats: torch.T
         raise ValueError("ingest_dlt: members must be (F,K,V)")
     _req(members, torch.int32, "members")
     K, V = members.shape[1:]
-    out = torch.empty((F, K, 17, 4), dtype=torch.float64, device=kps.device)
+    if out_dtype not in (torch.float32, torch.float64) or (out_dtype == torch.float32 and kps.dtype != torch.float32):
+        raise ValueError("ingest_dlt: out_dtype float32 needs float32 keypoints")
+    out = torch.empty((F, K, 17, 4), dtype=out_dtype, device=kps.device)
     cnt = torch.empty((F, Cn), dtype=torch.int32, device=kps.device) if want_counts else None
+    if out_dtype == torch.float32:
+        check(_cabi.load().mvmc_ingest_dlt_f32(_p(kps), F, Cn, P, J, _p(counts), float(ingest_min_score), int(min_valid), float(min_bb),
+                                               _p(Pmats), _p(members), K, V, float(min_score), _p(out), _p(cnt), _stream()),
+              "mvmc_ingest_dlt_f32")
+        return (out, cnt) if want_counts else out
     dt = _cabi.MVMC_F32 if kps.dtype == torch.float32 else _cabi.MVMC_F64
     check(_cabi.load().mvmc_ingest_dlt(_p(kps), dt, F, Cn, P, J, _p(counts), float(ingest_min_score), int(min_valid), float(min_bb),
                                        _p(Pmats), _p(members), K, V, float(min_score), _p(out), _p(cnt), _stream()), "mvmc_ingest_dlt")

@@ -22,7 +22,7 @@ def test_header_symbols_exported():
     for name in declared:
         assert hasattr(lib, name), name
     header = open(os.path.join(ROOT, "include", "mvmc.h")).read()
-    assert lib.mvmc_abi_version() == int(re.search(r"#define\s+MVMC_ABI_VERSION\s+(\d+)", header).group(1)) == 4
+    assert lib.mvmc_abi_version() == int(re.search(r"#define\s+MVMC_ABI_VERSION\s+(\d+)", header).group(1)) == 5
 
 
 def test_seed_table_is_numpy_randomstate0():

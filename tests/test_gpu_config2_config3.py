@@ -37,6 +37,14 @@ def test_config2_triangulation_only_10k_c5p1():
     # the one-pass form (mvmc_ingest_dlt: the 17-joint tensor stays in LDS) gives the same numbers bit for bit
     fused, c_f = dev.ingest_dlt(kps, cnt, Pm, mem.view(F, 1, C), want_counts=True)
     assert torch.equal(fused.view(F, 17, 4), torch.from_numpy(pts).to(d)) and torch.equal(c_f, c17)
+    # float32 points out (mvmc_ingest_dlt_f32: one 16-byte store per point, SURVEY 8(d)'s I/O -- what bench.py times): the float64
+    # result rounded ONCE, hence within 1e-6 of the oracle like it
+    f32, c_32 = dev.ingest_dlt(kps, cnt, Pm, mem.view(F, 1, C), want_counts=True, out_dtype=torch.float32)
+    assert f32.dtype == torch.float32 and torch.equal(f32, fused.float()) and torch.equal(c_32, c17)
+    w32 = max(np.abs(f32[f, 0, :, :3].cpu().numpy() - o.triangulate_groups(data["P"], [k17_o[f, c, 0] for c in range(C)], 0.01, False)[:, :3]).max()
+              / np.abs(pts[f, :, :3]).max() for f in range(64))
+    print("config 2: float32 points vs oracle on 64 frames, worst relative error %.2e" % w32)
+    assert w32 < 1e-6
     k64 = kps.double()[:, :, :, [0, 16, 15, 18, 17, 5, 2, 6, 3, 7, 4, 12, 9, 13, 10, 14, 11]].contiguous()   # COCO-17, float64 input
     assert torch.equal(dev.ingest_dlt(k64, None, Pm, mem.view(F, 1, C)), fused)
     # full size: against the generator's ground truth (2 px noise -> about a centimetre), joints seen by >= 2 views
@@ -156,3 +164,11 @@ def test_one_pass_triangulation_equals_the_two_kernels_on_ragged_shapes(C, P, K,
     a, b = one.cpu().numpy(), two.cpu().numpy()
     assert np.array_equal(a, b, equal_nan=True), (np.argwhere(~((a == b) | (np.isnan(a) & np.isnan(b))))[:5])
     assert np.isfinite(a[..., 3]).sum() > 0
+    # the float32-output entry: the same numbers rounded once where the pipeline holds the shape, a clean refusal where it does not
+    if K * 17 <= 192:
+        o32 = dev.ingest_dlt(kd, cd, Pd, md, out_dtype=torch.float32)
+        assert np.array_equal(o32.cpu().numpy(), a.astype(np.float32), equal_nan=True)
+    else:
+        from multiview_motion_capture_amd._cabi import MvmcError
+        with pytest.raises(MvmcError):
+            dev.ingest_dlt(kd, cd, Pd, md, out_dtype=torch.float32)
