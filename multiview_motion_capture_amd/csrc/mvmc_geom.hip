@@ -327,11 +327,26 @@ ingest_dlt_kernel(const T* __restrict__ kps, int F, int G, int C, int P, int J_i
 // History of the round (2 M frames, C5 P1): first version (four stages behind barriers, register staging) 1.52 ms; LDS-DMA double
 // buffering with every wave doing everything 1.25 ms; this form: see DESIGN.md section 6.
 // ------------------------------------------------------------------------------------------------
+#ifndef ID3_GENERIC_VIEWS
+#define ID3_GENERIC_VIEWS 1  // the generic view loop for every shape.  0 = up to five views unrolled with member -> slot -> keypoint of all
+                             // views read in three rounds before the arithmetic (round 4's form: 126 registers against 107).  Measured in
+                             // round 5 on the same box, 2 M frames at C5 P1, float32 points: 1.102 ms unrolled, 1.073 ms generic -- with the
+                             // loads out of the triangulating waves since round 4, the fifteen staged operands only cost registers
+#endif
+#ifndef ID3_WPC
+#define ID3_WPC 4            // workgroups per CU the kernel is built for (registers: launch bounds; LDS: the buffer sizes below)
+#endif
+#ifndef ID3_TRIPLES_N
+#define ID3_TRIPLES_N 960
+#define ID3_MISC_N 256
+#define ID3_SLOT_N 128
+#define ID3_SP_VIEWS 16
+#endif
 constexpr int ID3_DLT_THREADS = 192;     // three triangulating waves
-constexpr int ID3_TRIPLES = 960;         // per buffer: G frames x nq poses x 17 joints (11 frames at C5 P1), FOUR floats each: the
+constexpr int ID3_TRIPLES = ID3_TRIPLES_N;         // per buffer: G frames x nq poses x 17 joints (11 frames at C5 P1), FOUR floats each: the
                                          // hardware writes a lane's 12 bytes at 16-byte lane stride (tools/glds12_test.hip)
-constexpr int ID3_MISC_INTS = 256;       // view counts [G][C], then cluster members [G][K][V]
-constexpr int ID3_SLOT_INTS = 128;       // ingest slot -> source pose [G][nq]
+constexpr int ID3_MISC_INTS = ID3_MISC_N;       // view counts [G][C], then cluster members [G][K][V]
+constexpr int ID3_SLOT_INTS = ID3_SLOT_N;       // ingest slot -> source pose [G][nq]
 struct Id3Buf {
     __attribute__((aligned(16))) float pose[ID3_TRIPLES * 4];
     int small[ID3_MISC_INTS];
@@ -487,11 +502,11 @@ __device__ __forceinline__ void id3_point(const Id3Args& A, const Id3Buf& b, con
 }
 
 template <int VU, bool OUT32>
-__global__ void __launch_bounds__(256, 4)
+__global__ void __launch_bounds__(256, ID3_WPC)
 ingest_dlt3_kernel(Id3Args A) {
     __shared__ Id3Buf bufA;
     __shared__ Id3Buf bufB;
-    __shared__ double sP[16 * 12];                                  // the projection matrices (C <= 16 checked by the launcher)
+    __shared__ double sP[ID3_SP_VIEWS * 12];                                  // the projection matrices (C <= 16 checked by the launcher)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int e = tid; e < A.C * 12; e += 256) sP[e] = A.Pm[e];
     const int n_groups = (A.F + A.G - 1) / A.G, stride = gridDim.x;
@@ -645,17 +660,17 @@ static int ingest_dlt_launch(const void* kps, int dtype, int n_frames, int n_vie
         while (G3 > 0 && ((long long)G3 * nq * 17 > ID3_TRIPLES || (long long)G3 * (n_views + (long long)k_max * v_max) > ID3_MISC_INTS ||
                           G3 * nq > ID3_SLOT_INTS)) --G3;
         if (G3 > n_frames) G3 = n_frames;
-        if (G3 > 0 && nq <= 128 && p_max <= 16) {
+        if (G3 > 0 && nq <= 128 && p_max <= 16 && n_views <= ID3_SP_VIEWS) {
             Id3Args A{(const float*)kps, Pmats, n_frames, G3, n_views, p_max, n_joints_in, counts_in, ingest_min_score, min_valid, min_bb_size,
                       members, k_max, v_max, min_score, out, counts_out};
             long long blocks = ((long long)n_frames + G3 - 1) / G3;
-            const long long cap = (long long)cus * 4;      // persistent and resident (35 KB of LDS each): the workgroups stride over the groups
+            const long long cap = (long long)cus * ID3_WPC;      // persistent and resident (35 KB of LDS each): the workgroups stride over the groups
             if (blocks > cap) blocks = cap;
             if (out32) {
-                if (v_max <= 5) hipLaunchKernelGGL((ingest_dlt3_kernel<5, true>), dim3((unsigned)blocks), dim3(256), 0, s, A);
+                if (v_max <= 5 && !ID3_GENERIC_VIEWS) hipLaunchKernelGGL((ingest_dlt3_kernel<5, true>), dim3((unsigned)blocks), dim3(256), 0, s, A);
                 else hipLaunchKernelGGL((ingest_dlt3_kernel<0, true>), dim3((unsigned)blocks), dim3(256), 0, s, A);
             } else {
-                if (v_max <= 5) hipLaunchKernelGGL((ingest_dlt3_kernel<5, false>), dim3((unsigned)blocks), dim3(256), 0, s, A);
+                if (v_max <= 5 && !ID3_GENERIC_VIEWS) hipLaunchKernelGGL((ingest_dlt3_kernel<5, false>), dim3((unsigned)blocks), dim3(256), 0, s, A);
                 else hipLaunchKernelGGL((ingest_dlt3_kernel<0, false>), dim3((unsigned)blocks), dim3(256), 0, s, A);
             }
             MVMC_CHECK_LAUNCH();

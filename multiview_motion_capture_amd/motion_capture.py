@@ -256,6 +256,7 @@ class MvTracker:
         self._p_max, self._t_max = p_max, t_max
         self._chain = None
         self._by_id = {}
+        self._calm = 0      # consecutive frames a widened tracker has stayed below t_max (update_4d narrows it back after eight)
 
     def _ensure(self, d_frames):
         if self._chain is None:
@@ -287,7 +288,7 @@ class MvTracker:
         else:
             ch.step(k_d, c_d)
         try:
-            ch.check()
+            host = ch.read_back()      # the frame's verdict AND its tables: one transfer, one synchronisation
         except ValueError:
             # The reference has no capacities (motion_capture.py:417-446, :763-808).  The frame is redone from the state saved before
             # it with the widest tables the kernels hold (tracker.T_WIDE tracklet slots, the per-stage path); only a frame beyond
@@ -300,7 +301,7 @@ class MvTracker:
             wsnap = wide.snapshot()
             wide.step(k_d, c_d)
             try:
-                wide.check()
+                host = wide.read_back()
             except ValueError:
                 wide.restore(wsnap)
                 raise
@@ -308,13 +309,16 @@ class MvTracker:
         # (only now, the frame having gone through: a frame that raises leaves the tracker -- host side included -- as it was)
         for t in self.tracklets:
             t.time_since_update += 1
-        n = int(ch.n_tracks[0])
-        if ch.T > self._t_max and n <= self._t_max:
+        n = int(host["n_tracks"][0])
+        meta, params, joints = host["meta"][0, :n], host["params"][0, :n], host["joints"][0, :n]   # (views of a buffer the next frame overwrites: copied below)
+        if ch.T > self._t_max:
             # the crowd has thinned out: back to the tables the one-launch path runs on (a wide tracker takes seven launches per frame)
-            self._chain = ch = ch.narrowed(self._t_max)
-        meta = ch.meta[0, :n].cpu().numpy()
-        params = ch.params[0, :n].cpu().numpy()
-        joints = ch.joints[0, :n].cpu().numpy()
+            # -- once it has STAYED at or below t_max - 1 for a few frames: a scene that hovers around t_max would otherwise pay a voided
+            # launch, a restore and a widened replay every other frame
+            self._calm = self._calm + 1 if n <= self._t_max - 1 else 0
+            if self._calm >= 8:
+                self._chain = ch = ch.narrowed(self._t_max)
+                self._calm = 0
         alive = []
         for k in range(n):
             tid, state, hits, length = (int(v) for v in meta[k])

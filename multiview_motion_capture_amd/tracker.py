@@ -43,17 +43,25 @@ class ChainTracker:
                              "reported by check())")
         self.F2 = dev.fmats_from_projections(hp.P)
         B, T = n_chains, t_max
-        self.params = torch.zeros((B, T, 68), dtype=torch.float64, device=d)
-        self.joints = torch.zeros((B, T, 18, 3), dtype=torch.float64, device=d)
-        self.meta = torch.zeros((B, T, 4), dtype=torch.int32, device=d)
-        self.n_tracks = torch.zeros((B,), dtype=torch.int32, device=d)
-        self.next_id = torch.zeros((B,), dtype=torch.int32, device=d)
-        self.n_dead = torch.zeros((B,), dtype=torch.int32, device=d)
+        # The tracker state is ONE device allocation with typed views into it: snapshot() / restore() are one copy each (update_4d
+        # saves the state in front of every frame), and the per-frame driver reads it back in one transfer (read_back()).
+        # overflow -- per chain: bit 0 cluster / view capacity, bit 1 tracklet table, bit 2 a graph the association kernel could not
+        # hold (iters < 0); accumulated on the device, read by check(): a non-zero word voids the chain's results
+        layout = (("params", (B, T, 68), torch.float64), ("joints", (B, T, 18, 3), torch.float64), ("meta", (B, T, 4), torch.int32),
+                  ("n_tracks", (B,), torch.int32), ("next_id", (B,), torch.int32), ("n_dead", (B,), torch.int32),
+                  ("slot_src", (B, T), torch.int32), ("overflow", (B,), torch.int32))
+        offs, total = {}, 0
+        for name, shape, dt in layout:
+            nbytes = int(torch.Size(shape).numel()) * (8 if dt == torch.float64 else 4)
+            offs[name] = (total, nbytes, shape, dt)
+            total += (nbytes + 15) & ~15
+        self._flat = torch.zeros((total,), dtype=torch.uint8, device=d)
+        self._layout = offs
+        for name, (o, nb, shape, dt) in offs.items():
+            setattr(self, name, self._flat[o:o + nb].view(dt).view(shape))
+        self.slot_src.fill_(-1)
         self.frame_idx = torch.arange(B, dtype=torch.int32, device=d)
-        self.slot_src = torch.full((B, T), -1, dtype=torch.int32, device=d)
-        # per chain: bit 0 cluster / view capacity, bit 1 tracklet table, bit 2 a graph the association kernel could not hold
-        # (iters < 0); accumulated on the device, read by check() -- a non-zero word voids the chain's results
-        self.overflow = torch.zeros((B,), dtype=torch.int32, device=d)
+        self._host = None   # pinned host mirror of _flat (+ the chain kernel's time-out words), allocated by read_back()
         self._fused = None  # workspaces of step_fused (allocated on first use)
         self.events = None  # set to a list to collect (start, end) CUDA events around every IK launch
         self.als_events = None  # same for the association (ALS) launches of the spatio-temporal graph
@@ -167,13 +175,41 @@ class ChainTracker:
     _STATE = ("params", "joints", "meta", "n_tracks", "next_id", "n_dead", "slot_src")
 
     def snapshot(self):
-        """The tracker state (device copies): restore() brings it back, e.g. to redo a frame that exceeded a capacity."""
-        return {k: getattr(self, k).clone() for k in self._STATE}
+        """The tracker state (one device copy): restore() brings it back, e.g. to redo a frame that exceeded a capacity."""
+        return self._flat.clone()
 
     def restore(self, snap) -> None:
-        for k in self._STATE:
-            getattr(self, k).copy_(snap[k])
+        self._flat.copy_(snap)
         self.overflow.zero_()
+
+    def read_back(self):
+        """The state on the host after ONE transfer and ONE synchronisation (the per-frame driver's end of frame: check() and four
+        tensor reads took six round trips): dict of NumPy views (params, joints, meta, n_tracks, ..., overflow) of a pinned buffer
+        that the next call overwrites, + 'timeout' (the chain kernel's hand-over word).  Clears the capacity / time-out words on the
+        device like check(); raises like check()."""
+        n = self._flat.numel()
+        if self._host is None:
+            self._host = torch.empty((n + 16,), dtype=torch.uint8).pin_memory()
+        h = self._host
+        h[:n].copy_(self._flat, non_blocking=True)
+        fl = None
+        if self._fused is not None:
+            fl = self._fused["flags"][self.B:self.B + 4]
+            h[n:n + 16].view(torch.int32).copy_(fl, non_blocking=True)
+        self.overflow.zero_()            # (stream-ordered behind the copy)
+        if fl is not None:
+            fl.zero_()
+        torch.cuda.current_stream(self._flat.device).synchronize()
+        out = {name: h[o:o + nb].view(dt).view(shape).numpy() for name, (o, nb, shape, dt) in self._layout.items()}
+        if fl is not None and int(h[n:n + 4].view(torch.int32)[0]):
+            raise RuntimeError("mvmc_chain_run: a hand-over between the workgroups of a chain timed out; results are void")
+        ov = int(out["overflow"].max()) if out["overflow"].size else 0
+        if ov:
+            what = [m for bit, m in ((1, "a cluster, a member or a view block did not fit (k_max / v_max / the frame's poses)"),
+                                     (2, "more than t_max live tracklets"),
+                                     (4, "a graph larger than the association kernel holds")) if ov & bit]
+            raise ValueError("ChainTracker: capacity exceeded (" + "; ".join(what) + "): the frame's results are void")
+        return out
 
     def widened(self, t_max: int) -> "ChainTracker":
         """A tracker with t_max tracklet slots (> the present number) holding this tracker's state."""
@@ -187,6 +223,8 @@ class ChainTracker:
     def narrowed(self, t_max: int) -> "ChainTracker":
         """The inverse of widened(): a tracker with t_max slots holding this one's first t_max (the caller has checked that no chain
         has more live tracklets than that) -- back on the tables the chain kernel runs on once a crowded scene has thinned out."""
+        if int(self.n_tracks.max()) > t_max:      # (live tracklets occupy the first n_tracks slots: track_commit compacts the table)
+            raise ValueError(f"ChainTracker.narrowed: a chain has more than {t_max} live tracklets")
         n = ChainTracker(self.hp, self.B, self.P, t_max, nfev_cold=self.nfev_cold, nfev_warm=self.nfev_warm)
         n.params.copy_(self.params[:, :t_max]); n.joints.copy_(self.joints[:, :t_max]); n.meta.copy_(self.meta[:, :t_max])
         n.slot_src.copy_(self.slot_src[:, :t_max])

@@ -165,7 +165,10 @@ def test_stitch_cost_does_not_grow_with_the_number_of_ranks():
         assert (np.sort(gid, axis=1) == np.arange(Pc)[None]).all()
     print(f"config-5 shard (1,563 chains, 8 tracklets): pack + own stitch {t_pack:.3f} ms; gathered stitch at world 1 / 2 / 5 / 8: "
           + " / ".join(f"{times[w]:.3f}" for w in (1, 2, 5, 8)) + " ms")
-    assert times[1] < 0.5 and times[8] < 0.5 + 0.1 * 8        # (round 3: 5.08 ms at world 1, growing with the world)
+    # the property under test is NON-GROWTH with the number of ranks (round 3: 5.08 ms at world 1, growing with the world) -- a ratio,
+    # so that a shared or throttled GPU, or a profiler, does not fail it; the absolute figures are in the print above
+    assert times[8] < 3.0 * times[1] + 0.2 and times[5] < 3.0 * times[1] + 0.2
+    assert times[1] < 5.0                                     # (sanity only: an order of magnitude above the 0.04 - 0.10 ms measured)
 
 
 def test_global_identities_follow_the_ground_truth_people(run):

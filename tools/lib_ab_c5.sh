@@ -1,3 +1,4 @@
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it), or set it to the repo root}"
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 L=multiview_motion_capture_amd/lib
 python3 tools/lib_diff.py $L/libmvmc_base.so $L/libmvmc_hip.so 2048 8 8 | tail -5

@@ -1,5 +1,6 @@
 # throughput against frames per launch, workgroups per chain and steps in flight (one GPU call):
 #   bash tools/parts_sweep.sh [frames:parts:overlap ...]
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it), or set it to the repo root}"
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/parts

@@ -1,4 +1,5 @@
 # LDS counters of the chain kernel:  bash tools/pmc_lds.sh [bench flags]
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it), or set it to the repo root}"
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/lds; rm -rf $O; mkdir -p $O

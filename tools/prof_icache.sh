@@ -1,4 +1,5 @@
 # instruction / scalar cache counters of the chain kernel (one --pmc pass each):  bash tools/prof_icache.sh
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it), or set it to the repo root}"
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/icache; rm -rf $O; mkdir -p $O

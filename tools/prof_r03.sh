@@ -1,5 +1,6 @@
 # Round-3 profiling session (ONE GPU call):  bash tools/prof_r03.sh     -> gpurun_out/r03s/*, then tools/refresh_profiles_r03.sh r03
 # Every rocprofv3 run has the program itself after "--" (python3 ...), kernel-trace only, counters in passes of their own.
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it), or set it to the repo root}"
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03s; rm -rf $O; mkdir -p $O

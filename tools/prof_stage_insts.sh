@@ -1,5 +1,6 @@
 # VALU / SALU / LDS instructions per KERNEL of the launch-per-stage path (the same device functions as the chain kernel's phases):
 # where the chain kernel's instructions come from.   bash tools/prof_stage_insts.sh   (inside one GPU call)
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it), or set it to the repo root}"
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/stage_insts; rm -rf $O; mkdir -p $O

@@ -1,4 +1,5 @@
 # bench + FETCH_SIZE / WRITE_SIZE of the chain kernel in one GPU call:  bash tools/quick_traffic.sh [bench flags]
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it), or set it to the repo root}"
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/qt; rm -rf $O; mkdir -p $O

@@ -1,3 +1,4 @@
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it), or set it to the repo root}"
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for seed in 1 2 3 4 5; do
 python3 bench.py --no-other-configs --cpu-frames 0 --sustain 0 --steps 30 --warmup 2 --seed $seed --occlusion 0.02 --spurious 0.05 2>/dev/null > gpurun_out/seed_$seed.json || { echo "seed $seed FAILED"; exit 1; }
