@@ -820,8 +820,11 @@ def run_workload(args, rank, world, d):
                         "f64_share_of_valu_insts": mix["f64_share_of_valu"], "lanes_active_per_valu_inst": mix["lanes_active_per_valu_inst"],
                         "valu_pipe_busy": mix["valu_busy_simd_cycles"] / (1024 * NOMINAL_CLOCK_HZ * step_s),
                         "lds_pipe_busy": mix["lds_busy_cu_cycles"] / (256 * NOMINAL_CLOCK_HZ * step_s),
+                        **({"matrix_core_share_of_flop": mix["mfma_share_of_flop"], "matrix_core_insts_per_launch": mix["mfma_insts"]}
+                           if "mfma_share_of_flop" in mix else {}),
                         "source": f"profiles/{mix.get('source')}",
-                        "note": "flop = 64 lanes x (2 FMA + ADD + MUL + TRANS) fp64 wave instructions of one launch (one step) / this run's "
+                        "note": "flop = 64 lanes x (2 FMA + ADD + MUL + TRANS) fp64 wave instructions (+ 2,048 per v_mfma_f64_16x16x4_f64: same pipe, "
+                                "same peak) of one launch (one step) / this run's "
                                 "time per step; pipe shares = busy cycles of the launch's VALU (1024 SIMDs) and LDS (256 CUs) / the step at 2.4 GHz"}
         res = {
             "metric": "frames/s (assoc+triangulate+IK) at C=5,P=4,J=25" if with_ik else

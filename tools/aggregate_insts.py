@@ -22,10 +22,13 @@ def means(d, sub):
 def main():
     insts, sq, prefix, key = sys.argv[1:5]
     sub = sys.argv[5] if len(sys.argv) > 5 else "chain_kernel"
+    mfma_dir = sys.argv[6] if len(sys.argv) > 6 else None      # optional: the pass with SQ_INSTS_MFMA (config 5: als5's matrix-core products)
     c = {}
     for p in ("a", "b", "c", "d"):
         c.update(means(os.path.join(insts, p), sub))
     c.update(means(sq, sub))
+    if mfma_dir:
+        c.update(means(mfma_dir, sub))
     valu = c["SQ_INSTS_VALU"]
     f64 = {k: c[f"SQ_INSTS_VALU_{k}_F64"] for k in ("FMA", "ADD", "MUL", "TRANS")}
     flop = 64.0 * (2 * f64["FMA"] + f64["ADD"] + f64["MUL"] + f64["TRANS"])      # all 64 lanes of every wave instruction
@@ -38,6 +41,13 @@ def main():
         "lds_bank_conflict_cycles": c["SQ_LDS_BANK_CONFLICT"], "salu_insts": c["SQ_INSTS_SALU"], "lds_insts": c["SQ_INSTS_LDS"],
         "wave_cycles": 4.0 * c["SQ_WAVE_CYCLES"], "src_sha": kernel_sources_sha(), "source": f"{prefix}_inst_mix.txt",
     }
+    if "SQ_INSTS_MFMA" in c:
+        # v_mfma_f64_16x16x4_f64: 16 x 16 x 4 multiply-adds = 2,048 flop per wave instruction, on the SAME pipe as the vector FMAs
+        # (profiles/r03_mfma_f64_rate.txt), so vector + matrix flop share one peak
+        rec["mfma_insts"] = c["SQ_INSTS_MFMA"]
+        rec["mfma_flop_per_launch"] = 2048.0 * c["SQ_INSTS_MFMA"]
+        rec["flop_per_launch"] = flop + rec["mfma_flop_per_launch"]
+        rec["mfma_share_of_flop"] = rec["mfma_flop_per_launch"] / rec["flop_per_launch"]
     with open(os.path.join(ROOT, "profiles", f"{prefix}_inst_mix.txt"), "w") as f:
         f.write(f"# per-launch means of {sub} (rocprofv3 --pmc, separate passes: tools/prof_insts.sh, tools/prof_r02.sh)\n")
         for k in sorted(c):

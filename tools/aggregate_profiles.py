@@ -75,8 +75,11 @@ def main():
         print("FETCH_SIZE calibration (known bytes / counter):", {k: round(v, 3) for k, v in calib.items()})
     for key, kern in (("ik", "ik1_kernel<6>"), ("als", "als4_kernel<double, 32>"), ("chain", "chain_kernel<false>"), ("chain", "chain_kernel<true>"),
                       ("tri", "dlt_kernel"), ("tri", "ingest_dlt_kernel<float>"), ("tri", "ingest_dlt_kernel<double>"), ("tri", "ingest_dlt3_kernel<5>"),
-                      ("tri", "ingest_dlt3_kernel<0>")):
-        if kern not in fe:
+                      ("tri", "ingest_dlt3_kernel<0>"), ("tri", "ingest_dlt3_kernel<5, false>"), ("tri", "ingest_dlt3_kernel<0, false>"),
+                      ("tri", "ingest_dlt3_kernel<5, true>"), ("tri", "ingest_dlt3_kernel<0, true>"), ("assoc", "als4_kernel<float, 24>")):
+        if kern not in fe or (key == "assoc" and not wkey.startswith("assoc_dlt:")):
+            continue
+        if key != "assoc" and wkey.startswith("assoc_dlt:"):
             continue
         kf = sum(fe[kern]) / len(fe[kern]) * 1024
         kw = sum(wr[kern]) / len(wr[kern]) * 1024
@@ -92,12 +95,13 @@ def main():
                 corr = {"fetch_counter_bytes": kf, "fetch_correction": 2.0,
                         "why": "gfx950 FETCH_SIZE counts 64 B per 128-B request of a coalesced streaming read (MI355X_MICROARCH.md); not calibrated in this session"}
             kf *= corr["fetch_correction"]
-        mix = (rec.get(f"{key}:{wkey}") or {}).get("inst_mix")   # tools/aggregate_insts.py's record carries its own source hash
-        rec[f"{key}:{wkey}"] = {"kernel": kern, "fetch_bytes": kf, "write_bytes": kw, "bytes": kf + kw,
+        wk = wkey.split(":", 1)[-1]     # ("assoc_dlt:10000x5x4" selects config 3's record: its dominant kernel also runs at the chain heads of config 4)
+        mix = (rec.get(f"{key}:{wk}") or {}).get("inst_mix")   # tools/aggregate_insts.py's record carries its own source hash
+        rec[f"{key}:{wk}"] = {"kernel": kern, "fetch_bytes": kf, "write_bytes": kw, "bytes": kf + kw,
                                 "source": os.path.basename(out2), "src_sha": kernel_sources_sha(), "unit": unit}
         if mix:
-            rec[f"{key}:{wkey}"]["inst_mix"] = mix
-        rec[f"{key}:{wkey}"].update(corr)
+            rec[f"{key}:{wk}"]["inst_mix"] = mix
+        rec[f"{key}:{wk}"].update(corr)
     json.dump(rec, open(tp, "w"), indent=1)
     print(open(out).read())
     print(open(out2).read())
