@@ -850,8 +850,11 @@ def run_workload(args, rank, world, d):
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "launch_ms": launch_ms,
                          "traffic": traffic, "traffic_source": traffic_note, "bytes_per_frame": bpf, "fp64": fp64,
-                         "note": "latency-bound path (dependent fp64 chains), not HBM bound (SURVEY.md F6); achieved = algorithmic "
-                                 "bytes of the frames one launch serves / mean launch duration of the dominant kernel" +
+                         "note": ("HBM-bound pass (one read of the keypoints, one store per point) beside fp64 issue; achieved = algorithmic "
+                                  "bytes of the frames one launch serves / mean launch duration of the dominant kernel"
+                                  if args.workload == "dlt" else
+                                  "latency-bound path (dependent fp64 chains), not HBM bound (SURVEY.md F6); achieved = algorithmic "
+                                  "bytes of the frames one launch serves / mean launch duration of the dominant kernel") +
                                  (f" ({args.overlap} launches share the GPU, so a launch lasts longer than ms_per_step)" if args.overlap > 1 else "") +
                                  "; see DESIGN.md"},
         }
