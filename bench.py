@@ -602,7 +602,7 @@ def run_workload(args, rank, world, d):
         with stream_ctx(i):
             if not sharded:
                 return out
-            res = par.run_sharded(lambda: out, L, (F // L) * world, rank, world, rows_per_frame=min(Pn + 1, 8), comm_stream=comm,
+            res = par.run_sharded(lambda: out, L, (F // L) * world, rank, world, rows_per_frame=min(Pn + 1, par.T_MSG), comm_stream=comm,
                                   timing=timed, t_msg=par.T_MSG)
             res["step"], res["timed"] = i, timed
             return res
@@ -627,7 +627,7 @@ def run_workload(args, rank, world, d):
                     repaired_per_step.append(repair_chains(hp, kps, counts, out, nfev_cold=args.nfev_cold, nfev_warm=args.nfev_warm))
                     check_chain_flags(out)
                     timed = res["timed"]
-                    res = par.run_sharded(lambda: out, L, (F // L) * world, rank, world, rows_per_frame=min(Pn + 1, 8), comm_stream=comm,
+                    res = par.run_sharded(lambda: out, L, (F // L) * world, rank, world, rows_per_frame=min(Pn + 1, par.T_MSG), comm_stream=comm,
                                           timing=timed, t_msg=par.T_MSG)
                     res["timed"] = timed
                     par.check_stitch_info(res)

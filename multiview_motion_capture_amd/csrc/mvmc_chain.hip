@@ -105,11 +105,15 @@ template <bool BIG> struct ChainCfg;
 // clusters of a frame are disjoint, so a frame with at most POOL poses never runs out, whatever the size of a single cluster
 // (SMALL: the association variants hold 24 pose nodes anyway; BIG: N_MAX).
 template <> struct ChainCfg<false> { static constexpr int POOL = 24, N_MAX = 40, NS_MAX = 48, NT = 256, WG_PER_CU = MVMC_SMALL_WPS, WAVES_PER_SIMD = MVMC_SMALL_WPS; };
-template <> struct ChainCfg<true> { static constexpr int POOL = 64, N_MAX = 64, NS_MAX = 72, NT = 512, WG_PER_CU = 1, WAVES_PER_SIMD = 2; };
+// (BIG, round 5: sixteen tracklet slots, graphs of up to 80 nodes.  The fast association variant -- als5: n <= 72, rank <= 16, i.e. eight
+// live tracklets at C8 P8 -- runs wherever the frame's graph fits it; a frame with a ninth tracklet -- rank 2 x 9 = 18, n = 73 -- takes
+// the generic variant (n <= 80, rank <= 32) IN the same workgroup, so its chain stays in the launch instead of going through the
+// repair tier: that frame's association is ~3 x slower, the chain is not re-run stage by stage.)
+template <> struct ChainCfg<true> { static constexpr int POOL = 64, N_MAX = 64, NS_MAX = 80, NT = 512, WG_PER_CU = 1, WAVES_PER_SIMD = 2; };
 
 
 constexpr int CH_EOFF = 2368;   // SMALL: doubles of graph scratch in front of the pose-pair block (NS <= 48: 48 * 48 + 6 + 48 = 2358)
-constexpr int CH_KOFF_BIG = 5280;                  // BIG: the frame's keypoints behind st_affinity_wave's part (72 * 72 + 10 + 72 = 5266)
+constexpr int CH_KOFF_BIG = 6496;                  // BIG: the frame's keypoints behind st_affinity_wave's part (80 * 80 + 10 + 80 = 6490)
 constexpr int CH_EOFF_BIG = CH_KOFF_BIG + 64 * 51; // BIG: the pose-pair block (64 x 64) behind the keypoints
 
 template <bool BIG> union ChainArena;
@@ -124,15 +128,16 @@ template <> union ChainArena<false> {
 };
 template <> union ChainArena<true> {
     Als5Lds<72> als;
+    AlsGenLds<80, 32, 512> als_wide;   // graphs beyond als5 (a ninth tracklet and more: rank 18 .. 32, n <= 80)
     struct { Ik1Shared ik[8]; int mq[64]; unsigned short mc[64]; } ikp;   // eight waves: the eight people of config 5 are solved side by side
-    // affinity_wave at N = 64: 64 * 51 + 64 * 64 + 64 + 16 = 7440; st_affinity_wave at NS = 72: 72 * 72 + 6 + 72, + the frame's keypoints
+    // affinity_wave at N = 64: 64 * 51 + 64 * 64 + 64 + 16 = 7440; st_affinity_wave at NS = 80: 80 * 80 + 6 + 80, + the frame's keypoints
     // + the pose-pair block; the line tables of st_pose_pairs_lines (2 * 4 * P * 68 doubles) use st_affinity_wave's part
     double graph[CH_EOFF_BIG + 64 * 64];
 };
 static_assert(CH_EOFF >= 48 * 48 + 10 + 48 && CH_EOFF + 40 * 40 >= 40 * 51 + 40 * 40 + 40 + 8, "graph scratch covers both graph builders");
 static_assert(sizeof(ChainArena<false>) <= 4 * sizeof(Ik1Shared) + 144, "SMALL: the IK blocks set the arena size");
 static_assert(sizeof(ChainArena<false>) + sizeof(Ik1Tables) + 8 <= 40960, "SMALL: four workgroups per CU (160 KB / 4, in granules of 1,280 B)");
-static_assert(CH_EOFF_BIG + 64 * 64 >= 64 * 51 + 64 * 64 + 64 + 16 && CH_KOFF_BIG >= 72 * 72 + 10 + 72, "BIG: graph scratch covers both graph builders");
+static_assert(CH_EOFF_BIG + 64 * 64 >= 64 * 51 + 64 * 64 + 64 + 16 && CH_KOFF_BIG >= 80 * 80 + 10 + 80, "BIG: graph scratch covers both graph builders");
 static_assert(sizeof(ChainArena<true>) <= 150 * 1024, "BIG: one workgroup per CU");
 
 // The phases as separate (non-inlined) functions: each gets its own register allocation inside the workgroup's budget
@@ -199,10 +204,20 @@ __device__ __noinline__ void chain_als_temporal(ChainArena<BIG>& arena_in, Chain
     ChainArena<BIG>& arena = *uni(&arena_in);
     MVMC_ASSUME_LDS(&arena);
     const int C = A.C, NS = A.T + C * A.P;
-    if constexpr (BIG)
-        als5_graph<double, 72>(arena.als, 0, A.W_st + (size_t)b * NS * NS, A.gc + (size_t)b * (C + 1), C + 1, NS, A.seed,
-                                           A.seed_len, nullptr, nullptr, A.labels_st + (size_t)b * NS, A.ncl_st + b, A.iters_st + b);
-    else
+    if constexpr (BIG) {
+        // the frame's graph: n nodes, rank 2 x its largest group (mv_association.py:251-269); wave-uniform (every lane reads the same words)
+        const int32_t* gc = A.gc + (size_t)b * (C + 1);
+        int n = 0, gmax = 0;
+        for (int g = 0; g <= C; ++g) { int c = gc[g]; c = c < 0 ? 0 : c; n += c; gmax = c > gmax ? c : gmax; }
+        n = uni(n); gmax = uni(gmax);
+        const int r = 2 * gmax < n ? 2 * gmax : n;
+        if (n <= 72 && r <= 16)
+            als5_graph<double, 72>(arena.als, 0, A.W_st + (size_t)b * NS * NS, gc, C + 1, NS, A.seed,
+                                               A.seed_len, nullptr, nullptr, A.labels_st + (size_t)b * NS, A.ncl_st + b, A.iters_st + b);
+        else
+            als_gen_graph<double, 80, 32, 512>(arena.als_wide, 0, A.W_st + (size_t)b * NS * NS, gc, C + 1, NS, A.seed,
+                                               A.seed_len, nullptr, nullptr, A.labels_st + (size_t)b * NS, A.ncl_st + b, A.iters_st + b);
+    } else
         als4_graph<double, 32>(arena.als_st, 0, A.W_st + (size_t)b * NS * NS, A.gc + (size_t)b * (C + 1), C + 1, NS, A.seed, A.seed_len,
                                nullptr, nullptr, A.labels_st + (size_t)b * NS, A.ncl_st + b, A.iters_st + b);
     *done = 0;
@@ -484,12 +499,14 @@ extern "C" int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuff
     if (B.max_nfev_cold < 1 || B.max_nfev_warm < 1) return MVMC_ERR_ARG;
     // sizes the two LDS layouts are built for (the launch-per-stage path covers everything else).  SMALL: padded sizes N <= 40,
     // N + T <= 48, and a frame's ACTUAL graph must have <= 24 nodes on the match_spatial path and <= 32 on the match_spatial_time
-    // path -- checked on the device, flags[n_chains + 1].  BIG (C8 P8): N <= 64, N + T <= 72: every graph of those sizes fits.
+    // path -- checked on the device, flags[n_chains + 1].  BIG (C8 P8): N <= 64, T <= 16, N + T <= 80: every graph of those sizes fits.
     const int N = B.n_views * B.p_max, NS = B.t_max + N;
-    if (B.n_views > 16 || 2 * B.p_max > 16 || 2 * (B.t_max > B.p_max ? B.t_max : B.p_max) > 16) return MVMC_ERR_UNSUPPORTED;
+    if (B.n_views > 16 || 2 * B.p_max > 16) return MVMC_ERR_UNSUPPORTED;
     if (B.t_max + B.k_max > 64 || B.v_max > 64) return MVMC_ERR_UNSUPPORTED;   // a lane per problem slot / per member
-    const bool small = N <= ChainCfg<false>::N_MAX && NS <= ChainCfg<false>::NS_MAX && !B.force_big;
-    const bool big = N <= ChainCfg<true>::N_MAX && NS <= ChainCfg<true>::NS_MAX;
+    // SMALL: rank 2 max(t_max, p_max) <= 16 (its association variants); BIG: up to sixteen tracklet slots (rank <= 32 in its wide variant)
+    const bool small = N <= ChainCfg<false>::N_MAX && NS <= ChainCfg<false>::NS_MAX && !B.force_big &&
+                       2 * (B.t_max > B.p_max ? B.t_max : B.p_max) <= 16;
+    const bool big = N <= ChainCfg<true>::N_MAX && NS <= ChainCfg<true>::NS_MAX && B.t_max <= 16;
     if (!small && !big) return MVMC_ERR_UNSUPPORTED;
     const void* need[] = {B.kps17, B.counts, B.Pmats, B.Fmats, B.F2, B.seed_table, B.params, B.joints, B.meta, B.n_tracks,
                           B.next_id, B.n_dead, B.slot_src, B.S_sp, B.W_st, B.group_counts, B.labels_sp, B.labels_st, B.n_clusters_sp,

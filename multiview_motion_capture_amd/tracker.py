@@ -236,9 +236,9 @@ class ChainTracker:
     def fused_ok(self) -> bool:
         """Whether this tracker's padded sizes fit the chain kernel (include/mvmc.h: mvmc_chain_run)."""
         N = self.C * self.P
-        small = N <= 40 and self.T + N <= 48
-        big = N <= 64 and self.T + N <= 72
-        return (small or big) and self.P <= 8 and self.T <= 8 and self.C <= 16 and self.T + self.K <= 64
+        small = N <= 40 and self.T + N <= 48 and self.T <= 8
+        big = N <= 64 and self.T + N <= 80 and self.T <= T_WIDE
+        return (small or big) and self.P <= 8 and self.C <= 16 and self.T + self.K <= 64
 
 
 def run_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], chain_len: int, t_max=8,
@@ -311,7 +311,7 @@ def run_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], c
     return res
 
 
-def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], chain_len: int, t_max=8,
+def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], chain_len: int, t_max: Optional[int] = None,
                      nfev_cold=50, nfev_warm=5, want_info=False, k_max: Optional[int] = None, v_max: Optional[int] = None,
                      parts: Optional[int] = None, kernel_events: Optional[list] = None, force_big: bool = False,
                      hand_over: Optional[str] = None):
@@ -335,7 +335,9 @@ def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tens
     B = F // L
     if parts is None:
         parts = L   # one workgroup per chain-frame: the finest hand-over, the best balance
-    T = t_max
+    # tracklet slots: 8 on the SMALL layout (views x people <= 40: its association variants hold rank 16), 16 on the BIG one (C8 P8),
+    # whose workgroup takes a frame with a ninth tracklet (rank 18, 73 nodes) through its generic association variant in place
+    T = t_max if t_max is not None else (T_WIDE if Cn * P > 40 else 8)
     k_def, v_def = default_caps(Cn, P)
     K = k_max or k_def
     V = v_max or v_def

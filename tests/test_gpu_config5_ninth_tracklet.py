@@ -1,0 +1,94 @@
+"""Config 5 geometry (C8 P8) with occlusions and false detections: a NINTH live tracklet -- a graph of 73 nodes and rank
+2 x 9 = 18 (r = 2 x the largest group, mv_association.py:251-269) -- which the BIG layout's fast association variant (als5: n <= 72,
+rank <= 16) does not hold.  The reference has no such limit (motion_capture.py:417-446, :763-808, :937-958).  Since round 5 the chain
+kernel's BIG layout has sixteen tracklet slots and takes such a frame through its generic association variant (n <= 80, rank <= 32)
+IN the same workgroup: the chain stays in the launch, nothing goes through the repair tier.
+
+  * the launch is valid (no void word), holds frames with more than eight live tracklets, and equals the launch-per-stage path on
+    sixteen-slot tables (the same device functions; the staged path runs every graph through the generic variant, the chain kernel
+    only the ones als5 cannot hold -- the cluster labels are the same, so the tables are bit-identical);
+  * the rank >= 18 graphs against the oracle (oracle_np.match_als on the device's own affinity matrix): labels and cluster counts
+    exact, iteration counts within +- 2, on >= 100 graphs."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_np as o
+
+pytestmark = pytest.mark.gpu
+C, P, L = 8, 8, 16
+CHAINS = 512
+
+
+@pytest.fixture(scope="module")
+def occ():
+    from multiview_motion_capture_amd import synth
+    from multiview_motion_capture_amd.pipeline import HotPath
+    data = synth.generate(CHAINS * L, C, P, 20260104, chain_len=L, occlusion=0.05, spurious=0.2)
+    d = torch.device("cuda:0")
+    hp = HotPath(data["K"], data["Rt"], device=d)
+    return dict(hp=hp, kps=torch.from_numpy(data["kps25"]).to(d), cnt=torch.from_numpy(data["counts"]).to(d))
+
+
+def test_a_ninth_tracklet_stays_in_the_launch(occ):
+    from multiview_motion_capture_amd.tracker import T_WIDE, check_chain_flags, run_chains, run_chains_fused
+    hp, kps, cnt = occ["hp"], occ["kps"], occ["cnt"]
+    b = run_chains_fused(hp, kps, cnt, L)                       # default tables: sixteen slots on the BIG layout
+    torch.cuda.synchronize()
+    check_chain_flags(b)                                        # no void word: nothing for the repair tier
+    assert b["params"].shape[1] == T_WIDE and int(b["void"].max()) == 0
+    n = b["n_tracks"].cpu().numpy()
+    crowded = n.reshape(CHAINS, L).max(axis=1) > 8
+    print(f"\nC8 P8, 5 % occlusion, 20 % false detections, {CHAINS} chains: {int(crowded.sum())} chains with more than eight live tracklets "
+          f"({int((n > 8).sum())} frames, up to {int(n.max())} tracklets) -- all inside the launch")
+    assert crowded.sum() >= 5 and n.max() <= T_WIDE
+    a = run_chains(hp, kps, cnt, L, t_max=T_WIDE)
+    torch.cuda.synchronize()
+    assert int(a["overflow"].max()) == 0
+    assert torch.equal(a["n_tracks"], b["n_tracks"]) and torch.equal(a["n_dead"], b["n_dead"]) and torch.equal(a["next_id"], b["next_id"])
+    ma, mb = a["meta"].cpu().numpy(), b["meta"].cpu().numpy()
+    ja, jb, pa, pb = a["joints"].cpu().numpy(), b["joints"].cpu().numpy(), a["params"].cpu().numpy(), b["params"].cpu().numpy()
+    for f in np.flatnonzero(np.repeat(crowded, L)):             # the crowded chains frame by frame (the others: the test of the BIG layout)
+        assert np.array_equal(ma[f, :n[f]], mb[f, :n[f]]), f
+        assert np.array_equal(ja[f, :n[f]], jb[f, :n[f]]) and np.array_equal(pa[f, :n[f]], pb[f, :n[f]]), f
+    # and the repair tier agrees that there is nothing to repair
+    from multiview_motion_capture_amd.tracker import repair_chains
+    assert repair_chains(hp, kps, cnt, b) == 0
+
+
+def test_rank_18_graphs_against_the_oracle(occ):
+    """Every graph with nine or more tracklets that the crowded chains produce, step by step through the launch-per-stage path (the
+    generic association variant the chain kernel calls for them), against oracle_np.match_als on the same affinity matrix."""
+    from multiview_motion_capture_amd import device as dev
+    from multiview_motion_capture_amd.tracker import T_WIDE, ChainTracker, run_chains_fused
+    hp, kps, cnt = occ["hp"], occ["kps"], occ["cnt"]
+    n = run_chains_fused(hp, kps, cnt, L)["n_tracks"].cpu().numpy().reshape(CHAINS, L)
+    sel = np.flatnonzero(n.max(axis=1) > 8)
+    B = len(sel)
+    k17, c17 = dev.ingest(kps, cnt)
+    k5 = k17.view(CHAINS, L, C, P, 17, 3)[torch.from_numpy(sel).to(kps.device)]
+    c5 = c17.view(CHAINS, L, C)[torch.from_numpy(sel).to(kps.device)]
+    tr = ChainTracker(hp, B, P, t_max=T_WIDE)
+    checked = worst = n_it_diff = 0
+    ranks = []
+    for t in range(L):
+        out = tr.step(k5[:, t].contiguous(), c5[:, t].contiguous(), want_debug=True)
+        torch.cuda.synchronize()
+        gc = out["group_counts"].cpu().numpy()
+        W, lab, it, ncl = out["W"].cpu().numpy(), out["st"]["labels"].cpu().numpy(), out["st"]["iters"].cpu().numpy(), out["st"]["n_clusters"].cpu().numpy()
+        for b in np.flatnonzero(gc[:, 0] >= 9):
+            dim = np.concatenate([[0], np.cumsum(gc[b])]).tolist()
+            nn = dim[-1]
+            mm_o, xb_o, it_o = o.match_als(W[b, :nn, :nn], dim, return_iters=True)
+            lab_o = o.cluster_labels(mm_o, nn)
+            assert np.array_equal(lab[b, :nn], lab_o), (t, b)
+            assert ncl[b] == lab_o.max() + 1
+            d_it = abs(int(it[b]) - it_o)
+            worst = max(worst, d_it)
+            n_it_diff += d_it > 0
+            checked += 1
+            ranks.append(min(nn, 2 * int(gc[b].max())))
+    tr.check()
+    print(f"\n{checked} graphs with nine or more tracklets (rank {min(ranks)} .. {max(ranks)}, 73+ nodes) against the oracle: labels and cluster "
+          f"counts exact; iteration counts differ on {n_it_diff} (by at most {worst})")
+    assert checked >= 100 and min(ranks) >= 18 and worst <= 2
