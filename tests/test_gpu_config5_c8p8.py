@@ -243,7 +243,7 @@ def test_config5_at_full_size_on_the_persistent_kernel():
     for r in (a, b, s0, s1):
         check_chain_flags(r)
         assert int(r["void"].max()) == 0
-    sub = run_chains(hp, kps[:4096].contiguous(), cnt[:4096].contiguous(), L)
+    sub = run_chains(hp, kps[:4096].contiguous(), cnt[:4096].contiguous(), L, t_max=a["params"].shape[1])   # (sixteen slots on the BIG layout)
     assert not sub["overflow"].any()
     for k in ("meta", "n_tracks"):
         assert torch.equal(sub[k], a[k][:4096]), f"fused and per-stage paths differ in {k}"

@@ -17,7 +17,7 @@ import oracle_np as o
 
 pytestmark = pytest.mark.gpu
 C, P, L = 8, 8, 16
-CHAINS = 512
+CHAINS = 3072     # ~1 % of the chains grow a ninth tracklet: ~40 chains, > 100 graphs of rank >= 18
 
 
 @pytest.fixture(scope="module")
@@ -42,15 +42,21 @@ def test_a_ninth_tracklet_stays_in_the_launch(occ):
     print(f"\nC8 P8, 5 % occlusion, 20 % false detections, {CHAINS} chains: {int(crowded.sum())} chains with more than eight live tracklets "
           f"({int((n > 8).sum())} frames, up to {int(n.max())} tracklets) -- all inside the launch")
     assert crowded.sum() >= 5 and n.max() <= T_WIDE
-    a = run_chains(hp, kps, cnt, L, t_max=T_WIDE)
+    # the staged path on the crowded chains and on 64 others
+    sel = np.unique(np.concatenate([np.flatnonzero(crowded), np.arange(0, CHAINS, CHAINS // 64)]))
+    idx = torch.from_numpy(sel).to(kps.device)
+    a = run_chains(hp, kps.view(CHAINS, L, *kps.shape[1:])[idx].reshape(len(sel) * L, *kps.shape[1:]).contiguous(),
+                   cnt.view(CHAINS, L, C)[idx].reshape(len(sel) * L, C).contiguous(), L, t_max=T_WIDE)
     torch.cuda.synchronize()
     assert int(a["overflow"].max()) == 0
-    assert torch.equal(a["n_tracks"], b["n_tracks"]) and torch.equal(a["n_dead"], b["n_dead"]) and torch.equal(a["next_id"], b["next_id"])
-    ma, mb = a["meta"].cpu().numpy(), b["meta"].cpu().numpy()
-    ja, jb, pa, pb = a["joints"].cpu().numpy(), b["joints"].cpu().numpy(), a["params"].cpu().numpy(), b["params"].cpu().numpy()
-    for f in np.flatnonzero(np.repeat(crowded, L)):             # the crowded chains frame by frame (the others: the test of the BIG layout)
-        assert np.array_equal(ma[f, :n[f]], mb[f, :n[f]]), f
-        assert np.array_equal(ja[f, :n[f]], jb[f, :n[f]]) and np.array_equal(pa[f, :n[f]], pb[f, :n[f]]), f
+    pick = lambda t: t.view(CHAINS, L, *t.shape[1:])[idx].reshape(len(sel) * L, *t.shape[1:])
+    assert torch.equal(a["n_tracks"], pick(b["n_tracks"])) and torch.equal(a["n_dead"], b["n_dead"][idx]) and torch.equal(a["next_id"], b["next_id"][idx])
+    ns = pick(b["n_tracks"]).cpu().numpy()
+    ma, mb = a["meta"].cpu().numpy(), pick(b["meta"]).cpu().numpy()
+    ja, jb, pa, pb = a["joints"].cpu().numpy(), pick(b["joints"]).cpu().numpy(), a["params"].cpu().numpy(), pick(b["params"]).cpu().numpy()
+    for f in range(len(sel) * L):
+        assert np.array_equal(ma[f, :ns[f]], mb[f, :ns[f]]), f
+        assert np.array_equal(ja[f, :ns[f]], jb[f, :ns[f]]) and np.array_equal(pa[f, :ns[f]], pb[f, :ns[f]]), f
     # and the repair tier agrees that there is nothing to repair
     from multiview_motion_capture_amd.tracker import repair_chains
     assert repair_chains(hp, kps, cnt, b) == 0
