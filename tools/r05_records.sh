@@ -10,6 +10,7 @@ python bench.py --no-other-configs --cpu-frames 0 --occlusion 0.05 --spurious 0.
 python bench.py --no-other-configs --cpu-frames 0 --workload assoc_dlt --seed 20260102 > $O/r05_bench_assoc_dlt_10k_C5P4.json 2> $O/c3.err
 python bench.py --cpu-frames 0 --gpus 2 --backend gloo --share-gpu --steps 3 --warmup 1 --sustain 0 2> $O/two.err | grep -v "^\[Gloo\]" > $O/r05_bench_two_ranks_one_gpu_gloo.json
 python bench.py --no-other-configs --cpu-frames 0 --gpus 2 --backend gloo --share-gpu --views 8 --people 8 --frames 2048 --occlusion 0.05 --spurious 0.2 --steps 3 --warmup 1 --sustain 0 2> $O/two_occ.err | grep -v "^\[Gloo\]" > $O/r05_bench_two_ranks_one_gpu_gloo_repairs.json
+python bench.py --no-other-configs --cpu-frames 0 --views 8 --people 8 --frames 8192 --seed 20260104 --occlusion 0.05 --spurious 0.2 --steps 5 --warmup 1 > $O/r05_bench_fused_8k_C8P8_occluded.json 2> $O/c5occ.err
 python bench.py --workload shelf --steps 3 --warmup 1 > $O/r05_bench_shelf_update_4d.json 2> $O/shelf.err
 python bench.py --no-other-configs --cpu-frames 0 --force-collective > $O/r05_bench_fused_10k_C5P4_forced_rccl_world1.json 2> $O/force.err
 python - <<'PY'
