@@ -376,6 +376,9 @@ def main():
     ap.add_argument("--tile-from", type=int, default=0,
                     help="generate this many frames on the host and tile them on the device up to --frames (config 2 at 2 M frames: the "
                          "generator would take minutes; the kernel reads every frame from HBM either way); 0 = generate all frames")
+    ap.add_argument("--big-split", action="store_true",
+                    help="C8 P8 sizes (config 5) only, an experiment: association and IK as two co-resident persistent kernels "
+                         "(csrc/mvmc_chain_split.h) instead of one 512-thread workgroup per chain-frame; bit-identical results")
     ap.add_argument("--dlt-out", default="f32", choices=["f32", "f64"],
                     help="--workload dlt: dtype of the triangulated points the one-pass kernel stores (float32 = SURVEY 8(d)'s I/O, one "
                          "16-byte store per point; float64 = mvmc_ingest_dlt's output, 32 bytes per point)")
@@ -522,7 +525,7 @@ def run_workload(args, rank, world, d):
                 kev = []
                 out = run_chains_fused(hp, kps, counts, L, nfev_cold=args.nfev_cold, nfev_warm=args.nfev_warm, want_info=timed,
                                        parts=args.parts or None, kernel_events=kev,
-                                       hand_over=None if args.hand_over == "auto" else args.hand_over)
+                                       hand_over=None if args.hand_over == "auto" else args.hand_over, split=args.big_split)
                 kern_events.append((timed, kev[0][0], kev[0][1]))
             else:
                 out = run_chains(hp, kps, counts, L, nfev_cold=args.nfev_cold, nfev_warm=args.nfev_warm,
@@ -839,6 +842,7 @@ def run_workload(args, rank, world, d):
                                     if with_ik else ""),
                        "frames_per_gpu": F, "views": C, "people": Pn, "chain_len": L, "seed": args.seed, "parallelism": f"frames x{world}",
                        "steps_in_flight": args.overlap, "occlusion": args.occlusion, "spurious": args.spurious,
+                       **({"big_split": True} if args.big_split else {}),
                        **({"tiled_from_frames": F_gen} if F_gen != F else {}),
                        **({"points_stored_as": args.dlt_out} if args.workload == "dlt" else {}), **extra},
             "sustained": sustained,

@@ -427,6 +427,10 @@ typedef struct mvmcChainBuffers {
                                    ticket counter (hand_over 1, 2), the ready queue's tail and ring (hand_over == 1) */
     double* out_phase_cycles;   /* (B,8) diagnostic: shader cycles of each chain by phase {graph, ALS, assignment, IK, commit,
                                    outputs, whole chain, 0}, or NULL */
+    double* wsym;               /* (B, 72 * 74) f64 workspace or NULL.  With it, C8 P8 sizes (views x people > 40) run as TWO co-resident
+                                   persistent kernels -- graph + association + assignment of one chain-frame beside the IK + commit of
+                                   another on the same CU (csrc/mvmc_chain_split.h) -- instead of one 512-thread workgroup per CU;
+                                   same results bit for bit.  NULL, force_big == 2 or MVMC_BIG_SPLIT=0: the one-kernel path */
 } mvmcChainBuffers;
 int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuffers* buffers, mvmcStream_t stream);
 

@@ -45,7 +45,7 @@ class MvmcChainBuffers(C.Structure):
     _PTRS = ("kps17", "counts", "Pmats", "Fmats", "F2", "seed_table", "params", "joints", "meta", "n_tracks", "next_id",
              "n_dead", "slot_src", "S_sp", "W_st", "group_counts", "labels_sp", "labels_st", "n_clusters_sp", "n_clusters_st",
              "iters_sp", "iters_st", "members", "n_members", "cold", "init", "status", "n_new", "ik_params", "ik_joints", "ik_info",
-             "ik_scratch", "out_params", "out_joints", "out_meta", "out_n_tracks", "out_info", "out_als_iters", "flags", "out_phase_cycles")
+             "ik_scratch", "out_params", "out_joints", "out_meta", "out_n_tracks", "out_info", "out_als_iters", "flags", "out_phase_cycles", "wsym")
     _fields_ = [(n, C.c_int32) for n in _INTS] + [(n, C.c_void_p) for n in _PTRS]
 
 

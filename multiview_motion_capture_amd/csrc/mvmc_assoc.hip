@@ -1692,14 +1692,17 @@ als4_kernel(const TW* __restrict__ W, const int32_t* __restrict__ gcounts, int G
 // (Tried: the fifth column block -- half empty at n = 72 -- split over the k range on the waves 4 .. 6 so that no SIMD carries two
 // full chains: 93.0 k -> 90.7 k frames/s; the solver wave's pivots are the critical path, and more matrix work beside them slows them.)
 // ------------------------------------------------------------------------------------------------
-template <int NMAX>
+// WLDS = false (the split BIG path, mvmc_chain_assoc.hip): the symmetrised affinity lives in a per-graph GLOBAL buffer (NMAX * LD doubles,
+// L2-resident: one 12-double tile read per thread and iteration) instead of LDS -- 42.6 KB less, which is what lets an association
+// workgroup and a solver workgroup share a CU's 160 KB.  Same values, same arithmetic: bit-identical results.
+template <int NMAX, bool WLDS = true>
 struct Als5Lds {
     // Row strides chosen against LDS bank conflicts (64 banks of 4 bytes): the matrices are walked by rows 3 or 4 apart (the tiles),
     // and a stride of 72 or 16 doubles would put every such row on the same banks (an 18-way conflict on the factor rows)
     static constexpr int LD = NMAX + 2;     // X1 / W / H rows: 74 doubles
     static constexpr int FS = 18;           // factor rows: 16 rank slots + 2
     __attribute__((aligned(16))) double sX[NMAX * LD];
-    __attribute__((aligned(16))) double sW[NMAX * LD];      // the symmetrised affinity (constant over the iteration): LDS, not registers
+    __attribute__((aligned(16))) double sW[WLDS ? NMAX * LD : 2];      // the symmetrised affinity (constant over the iteration): LDS, not registers
     __attribute__((aligned(16))) double sA[NMAX * FS];
     __attribute__((aligned(16))) double sB[NMAX * FS];
     __attribute__((aligned(16))) double sH[16 * LD];
@@ -1862,15 +1865,17 @@ __device__ __forceinline__ int als5_decide(double sum_p, double sum_d, double mu
 }
 
 // One graph (index f of the batch) on a 512-thread workgroup; every thread of the workgroup must call it.
-template <typename TW, int NMAX>
-__device__ __forceinline__ void als5_graph(Als5Lds<NMAX>& L, int f, const TW* __restrict__ W,
+template <typename TW, int NMAX, bool WLDS = true>
+__device__ __forceinline__ void als5_graph(Als5Lds<NMAX, WLDS>& L, int f, const TW* __restrict__ W,
                                            const int32_t* __restrict__ gcounts, int G, int ldw,
                                            const double* __restrict__ seed, int seed_len, uint8_t* __restrict__ x_bin,
                                            uint8_t* __restrict__ match_mat, int32_t* __restrict__ labels,
-                                           int32_t* __restrict__ n_clusters, int32_t* __restrict__ iters_out) {
+                                           int32_t* __restrict__ n_clusters, int32_t* __restrict__ iters_out,
+                                           double* __restrict__ wsym_g = nullptr) {
     static_assert(NMAX == 72, "tile grid: 24 x 18 tiles of 3 x 4 elements");
-    constexpr int NT5 = 512, TR = 3, TC = 4, LD = Als5Lds<NMAX>::LD, FS = Als5Lds<NMAX>::FS, NW5 = NT5 / 64, SOLVER = NW5 - 1;
-    double *sX = L.sX, *sW = L.sW, *sA = L.sA, *sB = L.sB, *sH = L.sH, *sG = L.sG, *sGin = L.sGin, *sRed = L.sRed;
+    constexpr int NT5 = 512, TR = 3, TC = 4, LD = Als5Lds<NMAX, WLDS>::LD, FS = Als5Lds<NMAX, WLDS>::FS, NW5 = NT5 / 64, SOLVER = NW5 - 1;
+    double *sX = L.sX, *sA = L.sA, *sB = L.sB, *sH = L.sH, *sG = L.sG, *sGin = L.sGin, *sRed = L.sRed;
+    double* sW = WLDS ? L.sW : wsym_g;      // (WLDS = false: global memory, written below and read back by the same threads' workgroup)
     int *sGid = L.sGid, *sKeep = L.sKeep;
     uint8_t* sVis = L.sVis;
     int &s_n = L.s_n, &s_r = L.s_r;

@@ -77,6 +77,7 @@ struct MvmcChainArgs {
     double* out_info;         // (F,NP,8) or NULL
     int32_t* out_iters;       // (F) ALS iterations of the frame's graph, or NULL
     double* out_cycles;       // (B,8) shader cycles by phase {graph, ALS, assign, IK, commit, outputs, total}, or NULL
+    double* wsym;             // (B, MVMC_WSYM_DOUBLES) the association's symmetrised affinity (split BIG path, mvmc_chain_split.h), or NULL
     int parts;                // workgroups per chain (consecutive frame ranges, handed over through flags)
     int queue;                // 0: workgroup (part, chain) = block index (part * n_chains + chain), a part waits for its chain's flag;
                               // 1: a workgroup draws a ticket when it starts and takes the chain that has been ready longest;
@@ -86,6 +87,8 @@ struct MvmcChainArgs {
                               // too large for the layout's association variant); [2B+4] ticket counter, [2B+5] ring tail,
                               // [2B+6 ...) ready ring of B * (parts - 1) entries (queue mode).  Zeroed by the launcher
 };
+
+constexpr int MVMC_WSYM_DOUBLES = 72 * 74;   // Als5Lds<72>'s W block (row stride 74)
 
 namespace {
 
@@ -478,8 +481,13 @@ chain_kernel(Ik1Tables tables_arg, ChainArgs A_by_value) {
 // budget from the loosest kernel that reaches them, so in one unit the BIG kernel (one workgroup per CU, 512 VGPRs) let them grow to
 // 248 VGPRs and dropped the SMALL kernel from three workgroups per CU to one (measured: 370 k -> 167 k frames/s on config 4).
 int mvmc_chain_launch_big(const void* tables_host, const MvmcChainArgs& A, int n_blocks, hipStream_t stream);   // (Ik1Tables: a type of each unit)
+// the split BIG path (mvmc_chain_split.h): kernel A and kernel B, each in its own unit
+int mvmc_chain_launch_assoc(const MvmcChainArgs& A, int n_blocks, hipStream_t stream);
+int mvmc_chain_launch_solve(const void* tables_host, const MvmcChainArgs& A, int n_blocks, hipStream_t stream);
 
-#ifdef MVMC_CHAIN_BIG_TU
+#if defined(MVMC_CHAIN_SPLIT_TU)
+// (mvmc_chain_assoc.hip / mvmc_chain_solve.hip define their kernel and its launcher after including this file)
+#elif defined(MVMC_CHAIN_BIG_TU)
 int mvmc_chain_launch_big(const void* tables_host, const MvmcChainArgs& A, int n_blocks, hipStream_t stream) {
     // per call: the attribute belongs to the function ON THE CURRENT DEVICE, and a cached flag would be neither per device nor
     // thread-safe (it costs ~1 us beside a launch of hundreds of milliseconds)
@@ -491,6 +499,28 @@ int mvmc_chain_launch_big(const void* tables_host, const MvmcChainArgs& A, int n
     return MVMC_OK;
 }
 #else
+// Side streams of the split BIG path: created once per (device, slot) and never destroyed; the slot comes from the caller's stream
+// handle, so that two callers' streams (bench.py keeps two steps in flight) do not queue their B kernels behind one another.
+#include <mutex>
+static std::mutex g_side_mutex;
+static hipStream_t g_side_stream[16][4];
+static hipEvent_t g_side_event[16][4];
+static int chain_side_slot(hipStream_t s) { return (int)((((unsigned long long)(size_t)s) >> 6) % 4u); }
+static hipStream_t chain_side_stream(int dev, hipStream_t s) {
+    if (dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> lock(g_side_mutex);
+    hipStream_t& q = g_side_stream[dev][chain_side_slot(s)];
+    if (!q && hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) q = nullptr;
+    return q;
+}
+static hipEvent_t chain_side_event(int dev, hipStream_t s) {
+    if (dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> lock(g_side_mutex);
+    hipEvent_t& e = g_side_event[dev][chain_side_slot(s)];
+    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+    return e;
+}
+
 extern "C" int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuffers* buf, mvmcStream_t stream) {
     if (!skel_host || !buf) return MVMC_ERR_ARG;
     const mvmcChainBuffers& B = *buf;
@@ -530,7 +560,7 @@ extern "C" int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuff
     A.members = B.members; A.n_members = B.n_members; A.cold = B.cold; A.init = B.init; A.status = B.status;
     A.n_new = B.n_new; A.ik_params = B.ik_params; A.ik_joints = B.ik_joints; A.ik_info = B.ik_info; A.ik_scratch = B.ik_scratch;
     A.out_params = B.out_params; A.out_joints = B.out_joints; A.out_meta = B.out_meta; A.out_n = B.out_n_tracks;
-    A.out_info = B.out_info; A.out_iters = B.out_als_iters; A.out_cycles = B.out_phase_cycles;
+    A.out_info = B.out_info; A.out_iters = B.out_als_iters; A.out_cycles = B.out_phase_cycles; A.wsym = B.wsym;
     A.parts = B.n_parts > 1 ? B.n_parts : 1;
     if (A.parts > 1 && B.chain_len % A.parts != 0) return MVMC_ERR_ARG;
     if (B.hand_over < 0 || B.hand_over > 2) return MVMC_ERR_ARG;
@@ -541,7 +571,34 @@ extern "C" int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuff
         return MVMC_ERR_LAUNCH;
     Ik1Tables tables_host;   // the skeleton's tables: once per call, on the host, a kernel argument of the launch
     ik1_build_tables_host(tables_host, sk);
-    if (!small) return mvmc_chain_launch_big(&tables_host, A, B.n_chains * A.parts, (hipStream_t)stream);
+    if (!small) {
+        // The split path (two co-resident persistent kernels, mvmc_chain_split.h) where the caller provides its workspace and the
+        // tables fit its wide association variant (rank <= 20: ten tracklet slots in use at most -- beyond, the chain's void word);
+        // MVMC_BIG_SPLIT=0 or force_big = 2 keep the one-kernel path.
+        static const bool split_off = getenv("MVMC_BIG_SPLIT") && atoi(getenv("MVMC_BIG_SPLIT")) == 0;
+        if (A.wsym && !split_off && B.force_big != 2 && B.n_chains * B.chain_len >= 2) {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) {
+                int v = 0;
+                if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+            }
+            const long long n_tasks = (long long)B.n_chains * B.chain_len;
+            const int blocks = (int)(n_tasks < cus ? n_tasks : cus);
+            hipStream_t side = chain_side_stream(dev, (hipStream_t)stream);
+            hipEvent_t ev = chain_side_event(dev, (hipStream_t)stream);
+            if (!side || !ev) return MVMC_ERR_LAUNCH;
+            // B on a side stream behind everything queued on the caller's stream (the flags' memset included), A on the caller's stream;
+            // the caller's stream then waits for B: to the caller it is one asynchronous call
+            if (hipEventRecord(ev, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(side, ev, 0) != hipSuccess) return MVMC_ERR_LAUNCH;
+            int st = mvmc_chain_launch_assoc(A, blocks, (hipStream_t)stream);
+            if (st != MVMC_OK) return st;
+            st = mvmc_chain_launch_solve(&tables_host, A, blocks, side);
+            if (st != MVMC_OK) return st;
+            if (hipEventRecord(ev, side) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, ev, 0) != hipSuccess) return MVMC_ERR_LAUNCH;
+            return MVMC_OK;
+        }
+        return mvmc_chain_launch_big(&tables_host, A, B.n_chains * A.parts, (hipStream_t)stream);
+    }
     // (MVMC_CHAIN_EXTRA_LDS: an occupancy experiment -- bytes of LDS nobody uses, so that fewer workgroups share a CU)
     static const size_t extra_lds = getenv("MVMC_CHAIN_EXTRA_LDS") ? (size_t)atoi(getenv("MVMC_CHAIN_EXTRA_LDS")) : 0;
     if (extra_lds && hipFuncSetAttribute((const void*)chain_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
