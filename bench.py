@@ -391,6 +391,12 @@ def main():
     if args.other_configs is None:
         args.other_configs = (args.workload == "full" and (args.frames, args.views, args.people) == (10000, 5, 4)
                               and args.occlusion == 0.0 and args.path == "fused")
+    if args.big_split and args.overlap is None:
+        # the split path's two kernels must be co-resident: they need hardware queues of their own, and HIP multiplexes a process's
+        # streams onto a few of them -- with two steps in flight (four kernels, two side streams, the communication streams) two kernels
+        # that wait for each other can land in ONE queue, in order, and the bounded hand-over wait times out (a loud failure, seen with
+        # MVMC_SPLIT_A=240 MVMC_SPLIT_B=304).  One step at a time keeps it to two queues.
+        args.overlap = 1
     if args.overlap is None:
         # two steps in flight fill the tail of the chain kernel's launches; the memory-bound triangulation-only pass (config 2) has no
         # such tail, and two overlapped launches would only make each of them last twice as long

@@ -583,16 +583,23 @@ extern "C" int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuff
                 if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
             }
             const long long n_tasks = (long long)B.n_chains * B.chain_len;
-            const int blocks = (int)(n_tasks < cus ? n_tasks : cus);
+            // Grid sizes.  A CU holds one A workgroup (LDS) with ONE B workgroup beside it (registers), or THREE B workgroups alone; a
+            // frame's eight solves take two rounds on B's four waves, so B is the longer stage (76 M against 67 M cycles per chain):
+            // with a_wgs < CUs the A-less CUs fill up with B workgroups and the two stages balance (tasks go by ticket either way).
+            static const int a_env = getenv("MVMC_SPLIT_A") ? atoi(getenv("MVMC_SPLIT_A")) : 0;
+            static const int b_env = getenv("MVMC_SPLIT_B") ? atoi(getenv("MVMC_SPLIT_B")) : 0;
+            int a_wgs = a_env > 0 ? a_env : cus, b_wgs = b_env > 0 ? b_env : cus + 3 * (cus - a_wgs);
+            if (a_wgs > n_tasks) a_wgs = (int)n_tasks;
+            if (b_wgs > n_tasks) b_wgs = (int)n_tasks;
             hipStream_t side = chain_side_stream(dev, (hipStream_t)stream);
             hipEvent_t ev = chain_side_event(dev, (hipStream_t)stream);
             if (!side || !ev) return MVMC_ERR_LAUNCH;
             // B on a side stream behind everything queued on the caller's stream (the flags' memset included), A on the caller's stream;
             // the caller's stream then waits for B: to the caller it is one asynchronous call
             if (hipEventRecord(ev, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(side, ev, 0) != hipSuccess) return MVMC_ERR_LAUNCH;
-            int st = mvmc_chain_launch_assoc(A, blocks, (hipStream_t)stream);
+            int st = mvmc_chain_launch_assoc(A, a_wgs, (hipStream_t)stream);
             if (st != MVMC_OK) return st;
-            st = mvmc_chain_launch_solve(&tables_host, A, blocks, side);
+            st = mvmc_chain_launch_solve(&tables_host, A, b_wgs, side);
             if (st != MVMC_OK) return st;
             if (hipEventRecord(ev, side) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, ev, 0) != hipSuccess) return MVMC_ERR_LAUNCH;
             return MVMC_OK;

@@ -15,6 +15,13 @@
 // lowest outstanding task of either kind has its predecessor finished or running, as long as one workgroup of each kernel is resident --
 // A is launched first and cannot share a CU with another A (LDS), B fits beside it (registers and LDS counted above).
 // The device functions are those of chain_kernel<true>; results are bit-identical (tests/test_gpu_config5_c8p8.py).
+//
+// STATUS: an experiment, off by default (run_chains_fused(split=True), bench.py --big-split).  Measured on config 5 (25,008 frames):
+// 115 - 119 k frames/s against 108 k for chain_kernel<true> (+ 7 - 10 %) -- kernel B is the longer stage (a CU's registers leave room for
+// four IK waves beside the association's eight, so a frame's eight solves take two rounds).  HAZARD: A and B wait for each other, so they
+// must run CONCURRENTLY -- i.e. sit in different hardware queues.  HIP multiplexes a process's streams onto a few hardware queues; when
+// the two kernels (or those of two steps in flight) share one, the queue runs them in order and the bounded wait times out (loud, 4 s;
+// seen with bench.py's two steps in flight).  A caller that uses it keeps the number of live streams small.
 #pragma once
 
 // lane 0 of a workgroup: wait until *word >= need; false = the launch's error word is set (by this wait's time-out or another's)
