@@ -1,6 +1,7 @@
 // Kernel B of the split BIG layout (mvmc_chain_split.h): the IK problems of a chain-frame (four at a time, a wave each), commit and the
-// per-frame outputs; persistent, one workgroup per CU beside kernel A's.  Its own translation unit: 128 VGPRs (the IK's batch sizes of
-// the four-workgroups-per-CU build, mvmc_common.h).
+// per-frame outputs; persistent, one workgroup per CU beside kernel A's (three on a CU without one).  Its own translation unit: 168 VGPRs
+// -- one wave per SIMD beside kernel A's two of 168 -- and the IK's batch sizes of the 168-register build (mvmc_common.h; the 128-register
+// build measured 6 % slower here: 110.0 k against 115.3 k frames/s on config 5).
 #define MVMC_SMALL_WPS 3
 #define MVMC_NO_PHASE_PRIO
 #define MVMC_CHAIN_SPLIT_TU

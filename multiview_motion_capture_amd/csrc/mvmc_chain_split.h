@@ -5,7 +5,7 @@
 // such workgroup fits neither the registers (256 per lane) nor the LDS (129 KB).  Split by PHASE the two halves do fit one CU together:
 //   A  chain_assoc_kernel (mvmc_chain_assoc.hip): 512 threads, <= 168 VGPRs (two waves per SIMD), 111 KB of LDS (the symmetrised affinity
 //      of als5 in a global buffer instead of LDS) -- graph, association, assignment of one chain-frame;
-//   B  chain_solve_kernel (mvmc_chain_solve.hip): 256 threads, <= 128 VGPRs (one wave per SIMD beside A's two), 42 KB of LDS -- the frame's
+//   B  chain_solve_kernel (mvmc_chain_solve.hip): 256 threads, <= 168 VGPRs (one wave per SIMD beside A's two), 42 KB of LDS -- the frame's
 //      IK problems four at a time, commit, the per-frame outputs.
 // Both are PERSISTENT (one workgroup per CU each) and draw chain-frames in ticket order (frame-major: ticket = t * n_chains + chain), so a
 // CU associates one chain while it solves another.  Per chain the two alternate strictly -- A(b, t) waits for B(b, t - 1)'s tracklet table,
