@@ -6,6 +6,14 @@
 //   members               labels -> per-cluster member lists
 // One frame per workgroup; the frame's whole working set lives in LDS / VGPRs, HBM is touched
 // once on the way in and once on the way out (the path is ALU/latency bound).
+// As a translation unit of its own (the stand-alone kernels: MVMC_DEVICE_ONLY is what the chain kernels' units define before they include
+// this file) it is built for 128 VGPRs and FOUR workgroups per CU like the chain kernel's SMALL layout: als4_kernel -- config 3's
+// dominant kernel, a workgroup per graph -- keeps 1,024 graphs resident instead of 768: 844 k -> 905 k frames/s on config 3 (same box),
+// the same als7 code the chain kernel runs, results unchanged.
+#if !defined(MVMC_DEVICE_ONLY) && !defined(MVMC_SMALL_WPS)
+#define MVMC_SMALL_WPS 4
+#define ALS4_WG_PER_CU 4
+#endif
 #include "mvmc_common.h"
 
 namespace {
