@@ -25,3 +25,19 @@ def test_kernel_source_hash_is_stable_and_sensitive():
     import bench
     a = bench.kernel_sources_sha()
     assert a == bench.kernel_sources_sha() and len(a) == 16
+
+
+def test_als_histogram_and_the_defaults_of_the_command_line():
+    """The ALS iteration histogram of a bench line and the flags added in round 5."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    h = bench.als_histogram(np.array([[44, 140, 0], [205, 1000, 999]]))
+    assert h["graphs"] == 5 and h["min"] == 44 and h["max"] == 1000 and h["share_at_the_1000_cap"] == 0.2
+    assert sum(h["histogram"].values()) == 5 and h["histogram"]["1000"] == 1 and h["histogram"]["[500, 1000)"] == 1
+    assert bench.als_histogram(np.zeros(4, dtype=np.int32)) is None
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0
+    for flag in ("--force-collective", "--dlt-out", "--big-split", "--other-configs"):
+        assert flag in r.stdout
+    assert bench.DEFAULT_NCCL_MAX_NCHANNELS == "4" and bench.OTHER_CONFIGS[1][1][:6] == ["--views", "8", "--people", "8", "--frames", "25008"]
