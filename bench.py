@@ -9,8 +9,8 @@ the timed region).  Frames shard across ranks as contiguous chain ranges (weak s
 collective; each step ends with the multi-GPU tail of parallel.run_sharded on a communication stream: pack the live tracklets
 (float32, ~0.5 KB per tracklet-frame) -> ONE all-gather (RCCL) -> stitch the identities across all chain boundaries on the device.
 The tail runs at N = 1 too (the stitch over the shard's own chain boundaries), so the per-N values compare like with like.
-Consecutive steps are independent batches and are issued on two alternating HIP streams (--overlap 2: the next launch's first
-frames fill the workgroup slots the slowest chains of the previous one leave idle; --overlap 1 = one step at a time).
+Consecutive steps are independent batches and are issued on alternating HIP streams (--overlap N, default 3 for config 4: the next
+launch's first frames fill the workgroup slots the slowest chains of the previous one leave idle; --overlap 1 = one step at a time).
 
 `python bench.py --gpus N` started WITHOUT torch.distributed.run launches its N ranks itself, as fresh child processes, before this
 process touches the GPU; under torch.distributed.run (RANK / WORLD_SIZE in the environment) it is one of the ranks.
@@ -398,9 +398,12 @@ def main():
         # MVMC_SPLIT_A=240 MVMC_SPLIT_B=304).  One step at a time keeps it to two queues.
         args.overlap = 1
     if args.overlap is None:
-        # two steps in flight fill the tail of the chain kernel's launches; the memory-bound triangulation-only pass (config 2) has no
-        # such tail, and two overlapped launches would only make each of them last twice as long
-        args.overlap = 1 if args.workload == "dlt" else 2
+        # steps in flight fill the tail of the chain kernel's launches; the memory-bound triangulation-only pass (config 2) has no
+        # such tail, and overlapped launches would only make each of them last longer.  Three since round 5 on the SMALL layout (four
+        # workgroups per CU: 1,024 slots against 10,000 workgroups per launch): 531.3 k -> 536.4 k frames/s over the 20 timed steps
+        # (three runs each, same box; sustained 535 - 537 k either way; four in flight: - 9 %); config 5 (one workgroup per CU) does not
+        # care (109.9 k / 109.7 k) and keeps two
+        args.overlap = 1 if args.workload == "dlt" else (3 if args.views * args.people <= 40 and args.workload == "full" else 2)
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks as fresh child processes.  Nothing in this process has touched the GPU
