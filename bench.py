@@ -23,6 +23,13 @@ import os
 import sys
 import time
 
+# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels of different streams that share a queue
+# run in order.  This program keeps three steps in flight on streams of their own beside a communication stream, a check stream and
+# the default stream: with four queues a step's pack kernel sat behind another step's chain kernel (1.55 ms per tail against 0.85 ms)
+# and config 4 ran at 532 k frames/s instead of 548 k (same box, three runs each; 6, 8, 12, 16, 24 queues: the same 547 - 550 k).
+# Read when the HIP runtime library is loaded, hence set before torch is imported; the environment overrides it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -401,8 +408,10 @@ def main():
         # steps in flight fill the tail of the chain kernel's launches; the memory-bound triangulation-only pass (config 2) has no
         # such tail, and overlapped launches would only make each of them last longer.  Three since round 5 on the SMALL layout (four
         # workgroups per CU: 1,024 slots against 10,000 workgroups per launch): 531.3 k -> 536.4 k frames/s over the 20 timed steps
-        # (three runs each, same box; sustained 535 - 537 k either way; four in flight: - 9 %); config 5 (one workgroup per CU) does not
-        # care (109.9 k / 109.7 k) and keeps two
+        # with four hardware queues, 530 k -> 547 - 550 k with eight (see the top of this file).  An ODD number matters more than its
+        # size: 2 and 4 in flight give 530 - 534 k, 3 / 5 / 6 give 547 - 553 k (eight or sixteen queues) -- with an even number of
+        # launches over a CU's four workgroup slots the launches' phases lock (all of a CU's workgroups in the issue-bound IK at once,
+        # then all in the latency-bound association).  Config 5 (one workgroup per CU) does not care (109.9 k / 109.7 k) and keeps two
         args.overlap = 1 if args.workload == "dlt" else (3 if args.views * args.people <= 40 and args.workload == "full" else 2)
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -850,7 +859,8 @@ def run_workload(args, rank, world, d):
                                      f"warm 5+5 after), {('one launch per step, ' + (str(args.parts or L) + ' workgroup(s) per chain')) if args.path == 'fused' else 'one launch per stage'}" + (f", {args.overlap} steps in flight on alternating streams" if args.overlap > 1 else "") if L > 1 else "+IK, every frame cold-started (chain length 1, max_nfev 50+50)")
                                     if with_ik else ""),
                        "frames_per_gpu": F, "views": C, "people": Pn, "chain_len": L, "seed": args.seed, "parallelism": f"frames x{world}",
-                       "steps_in_flight": args.overlap, "occlusion": args.occlusion, "spurious": args.spurious,
+                       "steps_in_flight": args.overlap, "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "occlusion": args.occlusion, "spurious": args.spurious,
                        **({"big_split": True} if args.big_split else {}),
                        **({"tiled_from_frames": F_gen} if F_gen != F else {}),
                        **({"points_stored_as": args.dlt_out} if args.workload == "dlt" else {}), **extra},
