@@ -28,7 +28,10 @@ import time
 # the default stream: with four queues a step's pack kernel sat behind another step's chain kernel (1.55 ms per tail against 0.85 ms)
 # and config 4 ran at 532 k frames/s instead of 548 k (same box, three runs each; 6, 8, 12, 16, 24 queues: the same 547 - 550 k).
 # Read when the HIP runtime library is loaded, hence set before torch is imported; the environment overrides it.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Only for the chain workloads (the default): the single-stream workloads keep the runtime's default (config 2 at BASELINE's literal
+# 10 k frames, a 38 us launch, is slower with eight queues: 145 M against 266 M frames/s).
+if "--workload" not in sys.argv or sys.argv[sys.argv.index("--workload") + 1:][:1] == ["full"]:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
 import torch
