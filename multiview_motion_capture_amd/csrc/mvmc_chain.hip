@@ -485,8 +485,19 @@ int mvmc_chain_launch_big(const void* tables_host, const MvmcChainArgs& A, int n
 int mvmc_chain_launch_assoc(const MvmcChainArgs& A, int n_blocks, hipStream_t stream);
 int mvmc_chain_launch_solve(const void* tables_host, const MvmcChainArgs& A, int n_blocks, hipStream_t stream);
 
+// the SMALL layout built for 256 VGPRs (two workgroups per CU, mvmc_chain_lat.hip): what a launch of few workgroups runs -- a frame at
+// a time through MvTracker.update_4d, short sequences --, where one chain's latency counts and the other workgroup slots stay empty anyway
+int mvmc_chain_launch_small_lat(const void* tables_host, const MvmcChainArgs& A, int n_blocks, hipStream_t stream);
+
 #if defined(MVMC_CHAIN_SPLIT_TU)
 // (mvmc_chain_assoc.hip / mvmc_chain_solve.hip define their kernel and its launcher after including this file)
+#elif defined(MVMC_CHAIN_LAT_TU)
+int mvmc_chain_launch_small_lat(const void* tables_host, const MvmcChainArgs& A, int n_blocks, hipStream_t stream) {
+    static_assert(MVMC_SMALL_WPS == 2, "the latency build: 256 VGPRs, two workgroups per CU");
+    hipLaunchKernelGGL(chain_kernel<false>, dim3(n_blocks), dim3(256), sizeof(ChainArena<false>), stream, *static_cast<const Ik1Tables*>(tables_host), A);
+    MVMC_CHECK_LAUNCH();
+    return MVMC_OK;
+}
 #elif defined(MVMC_CHAIN_BIG_TU)
 int mvmc_chain_launch_big(const void* tables_host, const MvmcChainArgs& A, int n_blocks, hipStream_t stream) {
     // per call: the attribute belongs to the function ON THE CURRENT DEVICE, and a cached flag would be neither per device nor
@@ -605,6 +616,19 @@ extern "C" int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuff
             return MVMC_OK;
         }
         return mvmc_chain_launch_big(&tables_host, A, B.n_chains * A.parts, (hipStream_t)stream);
+    }
+    {
+        // Few workgroups (a frame at a time, short sequences): the 256-register build of the same kernel (mvmc_chain_lat.hip) -- a
+        // frame's dependent chain is ~10 % shorter with the larger batches and fewer spills of that build, and with at most two
+        // workgroups per CU to place, the other slots buy nothing.  Same results bit for bit.  MVMC_CHAIN_NO_LAT=1: the 128-register build.
+        static const bool no_lat = getenv("MVMC_CHAIN_NO_LAT") && atoi(getenv("MVMC_CHAIN_NO_LAT")) != 0;
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        }
+        if (!no_lat && (long long)B.n_chains * A.parts <= 2LL * cus)
+            return mvmc_chain_launch_small_lat(&tables_host, A, B.n_chains * A.parts, (hipStream_t)stream);
     }
     // (MVMC_CHAIN_EXTRA_LDS: an occupancy experiment -- bytes of LDS nobody uses, so that fewer workgroups share a CU)
     static const size_t extra_lds = getenv("MVMC_CHAIN_EXTRA_LDS") ? (size_t)atoi(getenv("MVMC_CHAIN_EXTRA_LDS")) : 0;
