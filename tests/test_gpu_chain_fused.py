@@ -168,3 +168,31 @@ def test_launches_in_flight_on_several_streams_do_not_interact():
             assert torch.equal(r[k], ref[k]), (i, k)
         for k in ("params", "joints"):
             assert torch.equal(torch.nan_to_num(r[k]), torch.nan_to_num(ref[k])), (i, k)
+
+
+def test_throughput_build_and_latency_build_give_the_same_bits():
+    """mvmc_chain_run launches the SMALL layout's 256-register LATENCY build (csrc/mvmc_chain_lat.hip) when a call has at most two
+    workgroups per CU and the 128-register THROUGHPUT build (csrc/mvmc_chain.hip, four workgroups per CU) above that.  The same source
+    at different batch sizes: 1,024 chain-frames in one call (throughput build) against the same chains in two calls of 512 (latency
+    build) -- tables, iteration counts and solver records must be equal bit for bit."""
+    from multiview_motion_capture_amd import synth
+    from multiview_motion_capture_amd.pipeline import HotPath
+    from multiview_motion_capture_amd.tracker import check_chain_flags, run_chains_fused
+    d = torch.device("cuda:0")
+    cus = torch.cuda.get_device_properties(d).multi_processor_count
+    L = 16
+    n_chains = 2 * ((2 * cus) // L)            # the whole: more than 2 x CUs workgroups; each half: at most 2 x CUs
+    assert n_chains * L > 2 * cus >= (n_chains // 2) * L
+    data = synth.generate(n_chains * L, 5, 4, 20260103, chain_len=L, occlusion=0.03, spurious=0.2)
+    hp = HotPath(data["K"], data["Rt"], device=d)
+    kps, cnt = torch.from_numpy(data["kps25"]).to(d), torch.from_numpy(data["counts"]).to(d)
+    whole = run_chains_fused(hp, kps, cnt, L, want_info=True)
+    h = (n_chains // 2) * L
+    halves = [run_chains_fused(hp, kps[s].contiguous(), cnt[s].contiguous(), L, want_info=True) for s in (slice(0, h), slice(h, 2 * h))]
+    torch.cuda.synchronize()
+    for r in [whole] + halves:
+        check_chain_flags(r)
+    for k in ("params", "joints", "meta", "n_tracks", "als_iters", "ik_info"):
+        a = torch.nan_to_num(whole[k].double())
+        b = torch.nan_to_num(torch.cat([halves[0][k], halves[1][k]]).double())
+        assert torch.equal(a, b), f"the two builds differ in {k}"
