@@ -309,3 +309,37 @@ def ik_jacobian(root, euler, side_blens, obs, projs, with_blens):
             J[v, r, 0] = obs[v, r, 2] * (du @ dX[r])
             J[v, r, 1] = obs[v, r, 2] * (dv @ dX[r])
     return J.reshape(V * 32, n)
+
+
+def pose_solver_solve_clean(cam_poses_2d, cam_projs, init=None, return_info=False):
+    """PoseSolver(...).solve() (inverse_kinematics.py:351-433) with both least_squares calls replaced by the NOISE-FREE restatement of the
+    same algorithm (``trf(solver="ne_clean")``, analytic Jacobian): oracle_np.pose_solver_solve's cold start (DLT + the reference's
+    post-optimisation, root = midpoint of the hips, zero angles, reference lengths; budget 50) and warm start (budget 5), deterministic
+    where SciPy's result depends on LAPACK's rounding.  The per-solve oracle of tests/test_gpu_ik_whole_solves.py as a drop-in for
+    tracker_np.OracleTracker(solver=...): the whole-sequence oracle of tests/test_gpu_tracker.py."""
+    projs = np.asarray(cam_projs, np.float64)
+    poses18 = [o.add_mid_spine(p) for p in cam_poses_2d]
+    obs = np.array(poses18)[:, o.IK_OBS_IDX, :]
+    bone_dirs, ref_side = o.skeleton_constants()
+    if init is None:
+        p3d = o.triangulate_groups(projs, poses18, 0.01, True)
+        root = 0.5 * (p3d[o.COCO_L_HIP, :3] + p3d[o.COCO_R_HIP, :3])
+        euler = np.zeros((o.N_SKEL, 3))
+        blens = ref_side.copy()
+        nfev = 50
+    else:
+        root, euler, blens = (np.asarray(a, np.float64) for a in init)
+        nfev = 5
+    side0 = np.asarray(blens, np.float64).copy()
+    f1 = lambda x: o.ik_residual(x[:3], x[3:57], side0, obs, projs, bone_dirs)
+    j1 = lambda x, f: ik_jacobian(x[:3], x[3:57], side0, obs, projs, False)
+    f2 = lambda x: o.ik_residual(x[:3], x[3:57], x[57:], obs, projs, bone_dirs)
+    j2 = lambda x, f: ik_jacobian(x[:3], x[3:57], x[57:], obs, projs, True)
+    r1 = trf(f1, j1, np.concatenate([np.ravel(root), np.ravel(euler)]), nfev, solver="ne_clean")
+    r2 = trf(f2, j2, np.concatenate([r1["x"], side0]), nfev, solver="ne_clean")
+    x = r2["x"]
+    joints, _ = o.forward_kinematics(x[:3], x[3:57], x[57:], bone_dirs)
+    out = (x[:3].copy(), x[3:57].reshape(-1, 3).copy(), x[57:].copy())
+    if return_info:
+        return out, joints, dict(res1=r1, res2=r2)
+    return out, joints

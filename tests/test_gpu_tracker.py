@@ -133,6 +133,60 @@ def test_shelf_end_to_end_tracker_vs_reference_log(shelf):
     assert np.median(jd) < 1e-2
 
 
+def test_shelf_tracker_equals_the_noise_free_oracle_tracker_frame_by_frame(shelf):
+    """Config 1 END TO END against a deterministic oracle.  The reference's own 300-frame log can only be followed until rounding noise
+    tips a knife-edge association (frame 104 here; the reference with a float-equivalent re-ordering of its own residual leaves its own
+    log at frame 92, tests/test_tracker_oracle_cpu.py).  The reference's ALGORITHM without that noise -- tracker_np.OracleTracker
+    (match_spatial_time + MvTracker.update_4d restated, bit-exact against the reference's log with SciPy's solver) driving
+    trf_np.pose_solver_solve_clean (the reference's two least_squares calls as trf(solver="ne_clean")) -- is a whole-sequence oracle:
+    the device must give its tracker tables on EVERY frame, and its joints to 1e-6 wherever the solves are well posed."""
+    import tracker_np as tk
+    import trf_np as t
+    from multiview_motion_capture_amd.tracker import check_chain_flags, run_chains_fused
+    hp, d, si = shelf["hp"], shelf["d"], shelf["si"]
+    n_frames = 300
+    kps = torch.from_numpy(si["kps25"][1:n_frames + 1]).to(d)
+    cnt = torch.from_numpy(si["counts"][1:n_frames + 1].astype(np.int32)).to(d)
+    out = run_chains_fused(hp, kps, cnt, n_frames, t_max=8)          # the sequence as ONE chain
+    torch.cuda.synchronize()
+    check_chain_flags(out)
+    n_dev, meta_dev, j_dev = out["n_tracks"].cpu().numpy(), out["meta"].cpu().numpy(), out["joints"].cpu().numpy()
+    orc = tk.OracleTracker(si["K"], si["Rt"], si["P"], solver=lambda poses, projs, init: t.pose_solver_solve_clean(poses, projs, init))
+    first_div, worst = None, 0.0
+    n_tracklet_frames = 0
+    diffs = []
+    for fi in range(1, n_frames + 1):
+        views = []
+        for c in range(5):
+            poses = [o.openpose25_to_coco17(si["kps25"][fi, c, p]) for p in range(int(si["counts"][fi, c]))]
+            views.append([p for p in poses if o.pose_is_good(p)])
+        orc.update(fi, views)
+        exp = np.array([[tr.tid, tr.state, tr.hits, tr.length] for tr in orc.tracklets], dtype=np.int32).reshape(-1, 4)
+        k = fi - 1
+        same = n_dev[k] == len(exp) and np.array_equal(meta_dev[k, :len(exp)], exp)
+        if not same:
+            first_div = first_div or fi
+            continue
+        for s, tr in enumerate(orc.tracklets):
+            dj = float(np.abs(j_dev[k, s] - tr.joints).max())
+            diffs.append((dj, fi, s, tr.tid, tr.hits, int(np.abs(j_dev[k, s] - tr.joints).max(axis=1).argmax())))
+            worst = max(worst, dj)
+            n_tracklet_frames += 1
+    print(f"\nShelf, {n_frames} frames, device tracker against the noise-free oracle tracker: first frame with a different table "
+          f"{first_div}; {n_tracklet_frames} tracklet-frames compared, worst joint difference {worst:.2e} m; tracklets born "
+          f"{orc.next_id} (device {int(out['next_id'][0])}), died {orc.n_dead} (device {int(out['n_dead'][0])})")
+    dd = np.array([x[0] for x in diffs])
+    print("    joint difference over the tracklet-frames: median %.1e p90 %.1e p99 %.1e; above 1e-6: %d; first such (frame, slot, id, hits, joint):" %
+          (np.median(dd), np.percentile(dd, 90), np.percentile(dd, 99), int((dd > 1e-6).sum())), [x[1:] for x in diffs if x[0] > 1e-6][:8])
+    # Tables: every frame.  Joints: the same solve sequence gives 1e-15 .. 1e-8; the few solves above it (35 of 1,000 tracklet-frames,
+    # all of the third, mostly occluded person, in joints that at most two low-score views see) are models with a weak eigenvalue, where
+    # range | null space of J^T J is a rounding decision (tests/test_gpu_ik_whole_solves.py prints such cases); they stay at the
+    # millimetre level and do not propagate: the next well-observed solve is back at 1e-8
+    assert first_div is None
+    assert np.percentile(dd, 90) < 1e-6 and (dd > 1e-6).mean() < 0.05 and worst < 5e-3
+    assert orc.next_id == int(out["next_id"][0]) and orc.n_dead == int(out["n_dead"][0])
+
+
 def test_shelf_through_the_persistent_chain_kernel(shelf):
     """Config 1 through mvmc_chain_run: the 300 Shelf frames as ONE chain (5 cameras, up to 6 people per view, padded to
     40 graph nodes) give the same tracker tables, frame by frame, as the launch-per-stage tracker -- which the test above
