@@ -30,7 +30,8 @@ import time
 # Read when the HIP runtime library is loaded, hence set before torch is imported; the environment overrides it.
 # Only for the chain workloads (the default): the single-stream workloads keep the runtime's default (config 2 at BASELINE's literal
 # 10 k frames, a 38 us launch, is slower with eight queues: 145 M against 266 M frames/s).
-if "--workload" not in sys.argv or sys.argv[sys.argv.index("--workload") + 1:][:1] == ["full"]:
+_wl = [a for i, a in enumerate(sys.argv) if a.startswith("--workload=") or (i and sys.argv[i - 1] == "--workload")]
+if not _wl or _wl[-1].split("=")[-1] == "full":
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
