@@ -315,7 +315,7 @@ def other_config_lines():
     import subprocess
     lines = []
     for name, argv in OTHER_CONFIGS:
-        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--sustain", "0", "--cpu-frames", "0", "--no-other-configs"]
+        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--sustain", "0", "--host-io", "0", "--cpu-frames", "0", "--no-other-configs"]
         t0 = time.perf_counter()
         try:
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
@@ -381,6 +381,9 @@ def main():
                     help="fused path: how a chain's workgroups follow one another: ticket = (part, chain) from a ticket drawn at start "
                          "(no assumption about dispatch order; the default at every N), static = the same mapping by block index "
                          "(relies on in-order dispatch), queue = ready queue (no assumption, ~3 %% slower); auto = ticket")
+    ap.add_argument("--host-io", type=int, default=20,
+                    help="after the timed region: this many further steps with the host buffers of the boundary inside the bracket (inputs "
+                         "from pinned host memory, results back to it), reported as 'host_io' beside 'value'; 0 = skip")
     ap.add_argument("--sustain", type=int, default=300,
                     help="after the timed region: this many further consecutive steps of the same command (capped at ~15 s of work), "
                          "reported as 'sustained' beside 'value'; 0 = skip")
@@ -479,6 +482,7 @@ def main():
             # synchronize bracket and max over ranks; the single-GPU configurations (1, 2, 3) are in the N = 1 line
             a5 = argparse.Namespace(**vars(args))
             a5.views, a5.people, a5.frames, a5.seed, a5.steps, a5.warmup, a5.sustain, a5.cpu_frames = 8, 8, 25008, 20260104, 3, 1, 0, 0
+            a5.host_io = 0
             t5 = time.perf_counter()
             r5 = run_workload(a5, rank, world, d)
             if rank == 0:
@@ -538,7 +542,7 @@ def run_workload(args, rank, world, d):
     ik_events, als_events, hand_over_flags = [], [], []
     kern_events = []   # every launch of the chain kernel in this process: (timed?, start, end)
 
-    def step(timed):
+    def step(timed, kps=kps, counts=counts):
         if with_ik and L > 1:
             # temporal protocol: chains of L frames, MvTracker.update_4d semantics
             e = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if timed else None
@@ -612,10 +616,37 @@ def run_workload(args, rank, world, d):
     def stream_ctx(i):
         return torch.cuda.stream(streams[i % len(streams)]) if streams is not None else contextlib.nullcontext()
 
-    def issue(i, timed):
+    # --host-io: the same steps with the boundary's host buffers inside the timed region -- the shard's keypoints and counts from pinned
+    # host memory before a step, its tables (or points) back to pinned host memory after it, on the step's own stream, so that the
+    # copies of one step overlap the kernels of the others.  Reported as "host_io", never as "value".
+    io_in, io_out, io_bytes = None, {}, [0, 0]
+    if args.host_io > 0 and F_gen == F:
+        kps_h, counts_h = torch.from_numpy(data["kps25"]).pin_memory(), torch.from_numpy(data["counts"]).pin_memory()
+        io_in = [(torch.empty_like(kps), torch.empty_like(counts)) for _ in range(max(1, args.overlap))]
+        io_bytes[0] = kps_h.numel() * kps_h.element_size() + counts_h.numel() * counts_h.element_size()
+
+    def issue(i, timed, io=False):
         """Launch the compute of step i (asynchronous); finish() completes the step."""
         with stream_ctx(i):
-            return (i, timed, step(timed))
+            if io:
+                kb, cb = io_in[i % len(io_in)]      # (the slot's previous user ran on this same stream)
+                kb.copy_(kps_h, non_blocking=True)
+                cb.copy_(counts_h, non_blocking=True)
+                return (i, timed, step(timed, kb, cb), True)
+            return (i, timed, step(timed), False)
+
+    def to_host(i, out):
+        """the step's results to pinned host memory (its own stream, behind its kernels)"""
+        n = 0
+        for k in ("params", "joints", "meta", "n_tracks", "pts3d", "labels"):
+            v = out.get(k)
+            if isinstance(v, torch.Tensor):
+                h = io_out.get((i % len(io_in), k))
+                if h is None or h.shape != v.shape:
+                    h = io_out[(i % len(io_in), k)] = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                h.copy_(v, non_blocking=True)
+                n += v.numel() * v.element_size()
+        io_bytes[1] = n
 
     check_stream = torch.cuda.Stream(device=d) if sharded else None
 
@@ -623,8 +654,10 @@ def run_workload(args, rank, world, d):
         """The end of a step's compute: pack (+ the shard's own stitch) -> all-gather -> stitch on the communication stream, behind an
         event -- no device word is read here.  The chain kernel's validity words (hand-over time-out, capacities) travel in the message,
         so every rank learns of a void step from the gathered messages; settle() looks at them a few steps later."""
-        i, timed, out = rec
+        i, timed, out, io = rec
         with stream_ctx(i):
+            if io:
+                to_host(i, out)
             if not sharded:
                 return out
             res = par.run_sharded(lambda: out, L, (F // L) * world, rank, world, rows_per_frame=min(Pn + 1, par.T_MSG), comm_stream=comm,
@@ -667,12 +700,12 @@ def run_workload(args, rank, world, d):
         out["stitch"] = res
         return out
 
-    def run_steps(n, timed):
+    def run_steps(n, timed, io=False):
         """n steps, args.overlap of them in flight: step i + 1 is launched before step i's tail is queued, and a step is settled
         (its validity read) `overlap` steps after its tail was queued -- the only place the host waits for the device."""
         pending, tails, last = [], [], None
         for i in range(n):
-            pending.append(issue(i, timed))
+            pending.append(issue(i, timed, io))
             if len(pending) >= max(1, args.overlap):
                 tails.append(finish(pending.pop(0)))
             while len(tails) > max(1, args.overlap):
@@ -733,6 +766,29 @@ def run_workload(args, rank, world, d):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dts = float(t.item())
         sustained = {"value": F * world * n_sus / dts, "unit": "frames/s", "steps": n_sus, "ms_per_step": dts / n_sus * 1e3}
+        for res in stitched:
+            par.check_stitch_info(res)
+    host_io = None
+    if io_in is not None:
+        n_io = args.host_io
+        run_steps(min(3, n_io), False, io=True)      # the pinned result buffers are made here
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(n_io, False, io=True)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dti = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dti], dtype=torch.float64, device=d if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dti = float(t.item())
+        host_io = {"value": F * world * n_io / dti, "unit": "frames/s", "steps": n_io, "ms_per_step": dti / n_io * 1e3,
+                   "h2d_bytes_per_step": io_bytes[0], "d2h_bytes_per_step": io_bytes[1],
+                   "note": "the same steps with every step's keypoints + counts copied from pinned host memory and its tables (or points) "
+                           "copied back to pinned host memory inside the bracket, on the step's stream (PCIe-inclusive; not `value`)"}
         for res in stitched:
             par.check_stitch_info(res)
     # the one collective of a step, as this run saw it (rank 0's events; every rank issues the same call)
@@ -869,6 +925,7 @@ def run_workload(args, rank, world, d):
                        **({"tiled_from_frames": F_gen} if F_gen != F else {}),
                        **({"points_stored_as": args.dlt_out} if args.workload == "dlt" else {}), **extra},
             "sustained": sustained,
+            "host_io": host_io,
             "collective": collective,
             "als_iterations": als_histogram(out["als_it"].cpu().numpy()) if out.get("als_it") is not None else None,
             "tracker_events_per_step": tracker_events,

@@ -33,6 +33,9 @@ def test_two_ranks_print_config_4_and_config_5_with_their_collectives():
     h = line["als_iterations"]
     assert h["graphs"] == 10000 and 1 <= h["min"] <= h["p50"] <= h["p90"] <= h["max"] <= 1000
     assert sum(h["histogram"].values()) == h["graphs"]
+    # the boundary's host buffers inside the bracket (pinned host memory -> device before a step, its tables back after it)
+    hio = line["host_io"]
+    assert hio["h2d_bytes_per_step"] == 10000 * 5 * 4 * 25 * 3 * 4 + 10000 * 5 * 4 and hio["d2h_bytes_per_step"] > 0 and 0 < hio["value"]
     oc = line["other_configs"]
     assert len(oc) == 1
     c5 = oc[0]

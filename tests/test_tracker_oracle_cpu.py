@@ -70,6 +70,8 @@ def test_noise_free_oracle_tracker_agrees_with_the_reference_log_where_that_is_r
     si, g = load_golden("shelf_inputs.npz"), load_golden("shelf_tracker.npz")
     k17, cnt = oracle_ingest(si["kps25"][:n + 1], si["counts"][:n + 1].astype(np.int32))
     tr = tk.OracleTracker(si["K"], si["Rt"], si["P"], solver=lambda poses, projs, init: t.pose_solver_solve_clean(poses, projs, init))
+    fx = load_golden("shelf_clean_oracle_tracker.npz")     # the same oracle over all 300 frames (oracle/gen_golden_shelf_clean.py)
+    fx_worst = 0.0
     for fi in range(1, n + 1):
         views = [[k17[fi, c, p] for p in range(cnt[fi, c])] for c in range(5)]
         n0 = len(tr.solves)
@@ -77,6 +79,12 @@ def test_noise_free_oracle_tracker_agrees_with_the_reference_log_where_that_is_r
         exp = [tuple(int(v) for v in r) for r in g["alive_after"][fi - 1] if r[0] >= 0]
         assert [(x.tid, x.state, x.hits, x.length) for x in tr.tracklets] == exp, fi
         assert tr.n_dead == g["n_dead"][fi - 1] and len(tr.solves) - n0 == g["n_solves"][fi - 1], fi
+        # ... and the committed whole-sequence fixture is what this oracle gives here (another host's LAPACK may differ in the last bits)
+        assert fx["n_tracks"][fi - 1] == len(exp) and [tuple(int(v) for v in r) for r in fx["meta"][fi - 1, :len(exp)]] == exp, fi
+        for s_, x in enumerate(tr.tracklets):
+            fx_worst = max(fx_worst, float(np.abs(fx["joints"][fi - 1, s_] - x.joints).max()))
+    print(f"fixture shelf_clean_oracle_tracker.npz vs the oracle run here, {n} frames: worst joint difference {fx_worst:.1e} m")
+    assert fx_worst < 1e-7
     joints = np.array([s[4] for s in tr.solves])
     ref = g["solve_joints"][:len(joints)]
     d = np.abs(joints - ref)[:, o.IK_SKEL_IDX].max(axis=(1, 2))
