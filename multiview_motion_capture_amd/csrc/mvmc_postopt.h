@@ -138,8 +138,16 @@ __device__ inline void post_optimize_wave(double* X, const double* obs_j, int st
             if (fabs(phi) < 0.01 * Delta) break;
         }
         // a last Newton update that overshoots below zero is clamped (mvmc_trf_faithful.h, solve_lsq_trust_region: SciPy's LAPACK
-        // noise triplets stop it at ~ -1e-20): the step is then the minimum-norm Gauss-Newton step stretched to |p| = Delta
-        if (!full_rank && alpha < 0.0) alpha = 0.0;
+        // noise triplets stop it at ~ -1e-20): the step is then the minimum-norm Gauss-Newton step stretched to |p| = Delta.
+        // Only where SciPy's thin SVD HAS such triplets: rank < min(m, n).  A two-view cluster whose joints are all scored by both
+        // views (m = 2 J independent rows < n = 3 J) has none, nothing stops the last update, and the reference's step is the one with
+        // the negative alpha of ordinary size that it leaves (found by tools/oracle_soak.py on a cluster of two false detections:
+        // profiles/r05_oracle_soak.txt); with a joint that a view scores 0 (a zero row) the triplets are there and the clamp holds
+        // (ik_cases case 7, tests/test_trf_faithful_cpu.py).
+        int rk = 0;
+        for (int k = 0; k < 3; ++k) rk += (on && lam[k] > 0.0) ? 1 : 0;
+        const int rank = (int)wave_sum((double)rk);
+        if (!full_rank && alpha < 0.0 && rank < (m < n ? m : n)) alpha = 0.0;
         double pn = 0.0;
         for (int k = 0; k < 3; ++k) {
             coef[k] = (on && suf[k] != 0.0) ? -suf[k] / (lam[k] + alpha) : 0.0;

@@ -261,7 +261,12 @@ MVMC_HD inline double solve_lsq_trust_region(const Ex& ex, int n, int m, const d
     // makes phi cross zero at alpha ~ 1e-20 and so stops that last update at ~ -1e-20; the Jacobi SVD above returns exact zeros
     // there, and the same update would end at a negative alpha of ordinary size.  Clamping it restores SciPy's outcome: the step
     // is the minimum-norm Gauss-Newton step stretched to |p| = Delta.
-    if (!full_rank && alpha < 0.0) alpha = 0.0;
+    // That is the m >= n case.  With FEWER residuals than unknowns (the triangulation post-optimisation of a two-view cluster: 36 x 54)
+    // SciPy's thin SVD holds null triplets only where J has dependent ROWS (a joint that a view scores 0: the factorisation above
+    // leaves them at rounding level, like LAPACK, and they stop the update by themselves); with independent rows nothing stops it, and the
+    // reference really takes -V (suf / (s^2 + alpha)) with that negative alpha of ordinary size (denominators of both signs),
+    // stretched to Delta: kept as it is.
+    if (!full_rank && alpha < 0.0 && m >= n) alpha = 0.0;
     const double pn = form_step(alpha, false);
     const double sc = Delta / pn;
     for (int i = ex.lane(); i < n; i += ex.lanes()) p[i] *= sc;
