@@ -266,7 +266,11 @@ MVMC_HD inline double solve_lsq_trust_region(const Ex& ex, int n, int m, const d
     // leaves them at rounding level, like LAPACK, and they stop the update by themselves); with independent rows nothing stops it, and the
     // reference really takes -V (suf / (s^2 + alpha)) with that negative alpha of ordinary size (denominators of both signs),
     // stretched to Delta: kept as it is.
-    if (!full_rank && alpha < 0.0 && m >= n) alpha = 0.0;
+    // (Which of the two a build sees for a zero row -- an exact zero or a triplet at rounding level -- depends on its contraction of
+    // multiply-adds; the rule covers both: clamp where the thin SVD has an exactly-null triplet, rank < min(m, n).)
+    int rank = 0;
+    for (int k = 0; k < n; ++k) rank += s[k] > 0.0 ? 1 : 0;
+    if (!full_rank && alpha < 0.0 && rank < (m < n ? m : n)) alpha = 0.0;
     const double pn = form_step(alpha, false);
     const double sc = Delta / pn;
     for (int i = ex.lane(); i < n; i += ex.lanes()) p[i] *= sc;

@@ -23,6 +23,14 @@ def oracle_chain(job):
     import tracker_np as tk
     import trf_np as t
     K, Rt, P, kps25, counts = job
+    its = []
+    orig = o.match_als
+
+    def recording(W, dim, return_iters=False):      # the frame's ALS iteration count (tracker_np calls o.match_als once per frame)
+        mm, xb, it = orig(W, dim, return_iters=True)
+        its.append(it)
+        return (mm, xb, it) if return_iters else (mm, xb)
+    o.match_als = recording
     orc = tk.OracleTracker(K, Rt, P, solver=lambda poses, projs, init: t.pose_solver_solve_clean(poses, projs, init))
     rows = []
     for tt in range(kps25.shape[0]):
@@ -36,7 +44,8 @@ def oracle_chain(job):
             rows.append(("raise", repr(exc)))
             break
         rows.append((np.array([[x.tid, x.state, x.hits, x.length] for x in orc.tracklets], dtype=np.int32).reshape(-1, 4),
-                     np.array([x.joints for x in orc.tracklets]).reshape(-1, 18, 3)))
+                     np.array([x.joints for x in orc.tracklets]).reshape(-1, 18, 3), its[-1] if len(its) == tt + 1 else -1))
+    o.match_als = orig
     return rows, orc.next_id, orc.n_dead
 
 
@@ -50,14 +59,15 @@ def main():
     seeds = [int(s) for s in os.environ.get("SOAK_SEEDS", "1 2 3 4 5 6").split()]
     with ProcessPoolExecutor(max_workers=int(os.environ.get("SOAK_WORKERS", "14"))) as pool:
         for C, P, n_chains, occ, spur in workloads:
-            frames = same = void = 0
+            frames = same = void = als_frames = als_same = als_cap = 0
             dd, first_bad = [], None
             for seed in seeds:
                 data = synth.generate(n_chains * L, C, P, seed, chain_len=L, occlusion=occ, spurious=spur)
                 hp = HotPath(data["K"], data["Rt"], device=d)
-                out = run_chains_fused(hp, torch.from_numpy(data["kps25"]).to(d), torch.from_numpy(data["counts"]).to(d), L)
+                out = run_chains_fused(hp, torch.from_numpy(data["kps25"]).to(d), torch.from_numpy(data["counts"]).to(d), L, want_info=True)
                 torch.cuda.synchronize()
                 n_t, meta, joints = out["n_tracks"].cpu().numpy(), out["meta"].cpu().numpy(), out["joints"].cpu().numpy()
+                als_dev = out["als_iters"].cpu().numpy().reshape(-1)
                 vw = out["void"].cpu().numpy()
                 k64 = data["kps25"].astype(np.float64)
                 jobs = [(data["K"], data["Rt"], data["P"], k64[b * L:(b + 1) * L], data["counts"][b * L:(b + 1) * L]) for b in range(n_chains)]
@@ -71,7 +81,10 @@ def main():
                             break
                         f = b * L + tt
                         frames += 1
-                        exp, jo = row
+                        exp, jo, it_o = row
+                        als_frames += 1
+                        als_same += int(it_o == als_dev[f])
+                        als_cap += int(it_o >= 1000)
                         if ok_chain and n_t[f] == len(exp) and np.array_equal(meta[f, :len(exp)], exp):
                             same += 1
                             for s in range(len(exp)):
@@ -79,7 +92,9 @@ def main():
                                 dd.append(dj)
                                 if dj > 1e-6:
                                     tag = f"C{C}P{P}_occ{occ}_sp{spur}_seed{seed}_chain{b}"
-                                    print(f"    above 1e-6: {tag} frame {tt} slot {s} (id, state, hits, length) {exp[s].tolist()}: {dj:.2e} m", flush=True)
+                                    print(f"    above 1e-6: {tag} frame {tt} slot {s} (id, state, hits, length) {exp[s].tolist()}: {dj:.2e} m; the frame's ALS "
+                                          f"iterations: oracle {it_o}, device {als_dev[f]}" + (" (AT THE CAP: the result of an unconverged iteration)" if it_o >= 1000 else ""),
+                                          flush=True)
                                     if os.environ.get("SOAK_DUMP"):
                                         np.savez(os.path.join(os.environ["SOAK_DUMP"], tag + ".npz"), K=data["K"], Rt=data["Rt"], P=data["P"],
                                                  kps25=k64[b * L:(b + 1) * L], counts=data["counts"][b * L:(b + 1) * L],
@@ -93,7 +108,7 @@ def main():
             print(f"C{C} P{P} occlusion {occ} spurious {spur}: {len(seeds)} seeds x {n_chains} chain(s) of {L}: tables equal on {same} / {frames} "
                   f"frames (first difference: {first_bad}; chains with a void word, not compared: {void}); {len(dd)} tracklet-frames, joint "
                   f"difference median {np.nanmedian(dd):.1e} p90 {np.nanpercentile(dd, 90):.1e} p99 {np.nanpercentile(dd, 99):.1e} max {np.nanmax(dd):.1e} m; "
-                  f"above 1e-6: {int((dd > 1e-6).sum())}", flush=True)
+                  f"above 1e-6: {int((dd > 1e-6).sum())}; ALS iteration counts equal on {als_same} / {als_frames} frames ({als_cap} at the cap of 1000)", flush=True)
 
 
 if __name__ == "__main__":

@@ -1,6 +1,6 @@
 """Where does a device solve leave the noise-free oracle's sequence?  (test infrastructure; GPU box)
 
-    python tools/replay_solve.py case.npz        # case.npz: poses (v, 17, 3), projs (v, 3, 4); a COLD solve (budget 50 + 50)
+    python tools/replay_solve.py tests/golden/two_view_junk_cluster.npz    # poses (v, 17, 3), projs (v, 3, 4); a COLD solve (50 + 50)
 
 Runs trf_np.pose_solver_solve_clean with traces, the device's whole solve (mvmc_ik_solve, cold), then re-makes every trial of the oracle's
 sequence on the device (mvmc_debug_ik_model_step from the oracle's x_k, Delta_k, alpha_k) and prints the first trial whose accept / reject
@@ -41,7 +41,7 @@ def main(path):
     d = torch.device("cuda:0")
     kps = np.zeros((1, v, 1, 17, 3))
     kps[0, :, 0] = poses
-    mem = -np.ones((1, 6), dtype=np.int32)
+    mem = -np.ones((1, max(6, v)), dtype=np.int32)
     mem[0, :v] = np.arange(v)
     kps_t, cams_t, mem_t = torch.from_numpy(kps).to(d), torch.from_numpy(np.ascontiguousarray(projs)).to(d), torch.from_numpy(mem).to(d)
     p, j, info = dev.ik_solve(kps_t, cams_t, mem_t, torch.zeros((1, 68), dtype=torch.float64, device=d), torch.ones(1, dtype=torch.uint8, device=d), 50, 5)
@@ -76,7 +76,7 @@ def main(path):
             par[k, :len(e["x"])] = e["x"]
             if st == 0:
                 par[k, 57:] = side0
-        r = dev.ik_model_step(kps_t, cams_t, mem_t.expand(len(trials), 6).contiguous(), torch.from_numpy(par).to(d), st,
+        r = dev.ik_model_step(kps_t, cams_t, mem_t.expand(len(trials), mem_t.shape[1]).contiguous(), torch.from_numpy(par).to(d), st,
                               torch.tensor([e["Delta"] for e in trials], dtype=torch.float64, device=d),
                               torch.tensor([e["alpha_in"] for e in trials], dtype=torch.float64, device=d))
         torch.cuda.synchronize()
