@@ -278,8 +278,8 @@ __device__ __forceinline__ void affinity_wave(double* sm, const double* __restri
             d = D[i * n + j];
             float a = -(d - s_mean) / s_std;
             float t = fmulr(-5.f, a);
-            float ex = (float)exp((double)t);  // correctly-rounded f32 exp (NumPy's SIMD expf is <1 ulp)
-            s = 1.f / faddr(1.f, ex);
+            float ex = np_exp_f32(t);          // NumPy's float32 exp, which is not the correctly-rounded one (mvmc_common.h)
+            s = __fdiv_rn(1.f, faddr(1.f, ex));
         }
         if (Do) Do[e] = d;
         if (So) So[e] = s;

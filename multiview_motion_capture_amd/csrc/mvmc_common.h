@@ -76,6 +76,30 @@ __device__ __forceinline__ double dmul(double a, double b) { return __dmul_rn(a,
 __device__ __forceinline__ double dadd(double a, double b) { return __dadd_rn(a, b); }
 __device__ __forceinline__ float fmulr(float a, float b) { return __fmul_rn(a, b); }
 __device__ __forceinline__ float faddr(float a, float b) { return __fadd_rn(a, b); }
+// NumPy's float32 exp (numpy/core/src/umath/loops_exponent_log.dispatch.c.src, AVX2 and AVX-512F paths, NumPy >= 1.17; constants of
+// numpy/core/include/numpy/npy_math.h): k = rint(x log2 e) by the 1.5 * 2^23 trick, Cody-Waite reduction r = x - k ln 2 in two fused
+// steps, exp(r) = P5(r) / Q2(r) in Horner form with fused multiply-adds, IEEE division, result scaled by 2^k.  It is NOT correctly
+// rounded (13 % of the affinities of a C8 P8 frame differ from the correctly-rounded value by one ulp), and an ALS run of 600 - 1000
+// iterations on the float32 affinity notices: with this form S is the reference's bit for bit (checked here against np.exp on 4 M
+// arguments; profiles/r05_oracle_soak.txt).  Hosts without AVX2 take libm's expf in NumPy: not this function.
+__device__ __forceinline__ float np_exp_f32(float x) {
+    if (x != x) return x;
+    if (x > 88.72283935546875f) return __builtin_inff();
+    if (x < -103.97208404541015625f) return 0.f;
+    const float magic = 0x1.8p+23f;
+    float k = fmulr(x, 1.442695040888963407359924681001892137f);
+    k = __fsub_rn(faddr(k, magic), magic);
+    float r = __fmaf_rn(k, -0x1.62e400p-1f, x);
+    r = __fmaf_rn(k, -0x1.7f7d1cp-20f, r);
+    float num = __fmaf_rn(5.082762527590693718096e-04f, r, 6.757896990527504603057e-03f);
+    num = __fmaf_rn(num, r, 5.114512081637298353406e-02f);
+    num = __fmaf_rn(num, r, 2.473615434895520810817e-01f);
+    num = __fmaf_rn(num, r, 7.257664613233124478488e-01f);
+    num = __fmaf_rn(num, r, 9.999999999980870924916e-01f);
+    float den = __fmaf_rn(2.159509375685829852307e-02f, r, -2.742335390411667452936e-01f);
+    den = __fmaf_rn(den, r, 1.000000000000000000000e+00f);
+    return ldexpf(__fdiv_rn(num, den), (int)k);
+}
 
 // DPP cross-lane helpers (no LDS crossbar round trip): quad exchanges and a full-wave sum.
 template <int CTRL>

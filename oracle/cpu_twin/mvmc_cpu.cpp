@@ -132,6 +132,26 @@ void fmats(const double* K, const double* Rt, int C, float* F) {
 // ---------------------------------------------------------------------------------------------------------------------------------
 // AS-2 / AS-3 (operation order of NumPy, as csrc/mvmc_assoc.hip restates it; this file is built with -ffp-contract=off)
 // ---------------------------------------------------------------------------------------------------------------------------------
+// NumPy's float32 exp (AVX2 / AVX-512F paths; the device's np_exp_f32 in csrc/mvmc_common.h, same constants, same fused steps)
+static inline float np_exp_f32(float x) {
+    if (x != x) return x;
+    if (x > 88.72283935546875f) return INFINITY;
+    if (x < -103.97208404541015625f) return 0.f;
+    const volatile float magic = 0x1.8p+23f;
+    float k = x * 1.442695040888963407359924681001892137f;
+    k = (k + magic) - magic;
+    float r = fmaf(k, -0x1.62e400p-1f, x);
+    r = fmaf(k, -0x1.7f7d1cp-20f, r);
+    float num = fmaf(5.082762527590693718096e-04f, r, 6.757896990527504603057e-03f);
+    num = fmaf(num, r, 5.114512081637298353406e-02f);
+    num = fmaf(num, r, 2.473615434895520810817e-01f);
+    num = fmaf(num, r, 7.257664613233124478488e-01f);
+    num = fmaf(num, r, 9.999999999980870924916e-01f);
+    float den = fmaf(2.159509375685829852307e-02f, r, -2.742335390411667452936e-01f);
+    den = fmaf(den, r, 1.000000000000000000000e+00f);
+    return ldexpf(num / den, (int)k);
+}
+
 float np_pairwise_sum_f32(const float* a, int n) {
     if (n < 8) {
         float r = -0.0f;
@@ -194,7 +214,7 @@ void geometry_affinity(const std::vector<const double*>& pose, const std::vector
     for (int e = 0; e < nn; ++e) {
         const float a = -(D[e] - mean) / sd;
         const float t = -5.f * a;
-        S[e] = 1.f / (1.f + (float)exp((double)t));
+        S[e] = 1.f / (1.f + np_exp_f32(t));
     }
 }
 

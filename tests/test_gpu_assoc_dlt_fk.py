@@ -62,7 +62,7 @@ def test_fmats(shelf):
     assert rel.max() < 2e-7  # f64 math, f32 storage: 1 ulp of the largest entry
 
 
-def test_affinity_D_bit_exact_S_1ulp(dev, shelf):
+def test_affinity_D_and_S_bit_exact(dev, shelf):
     # feed the oracle's F so that both sides see identical float32 fundamental matrices
     F_o = o.pairwise_f_mats(shelf["K"], shelf["Rt"])
     D, S = dev.affinity(shelf["kps17"], shelf["cnt"], torch.from_numpy(F_o).to(shelf["d"]))
@@ -76,7 +76,11 @@ def test_affinity_D_bit_exact_S_1ulp(dev, shelf):
         u = ulp_diff_f32(S[i, :n, :n], S_o).max()
         worst = max(worst, u)
         assert (D[i, n:, :] == 0).all() and (S[i, :, n:] == 0).all()
-    assert worst <= 4.0, worst  # exp(): NumPy SIMD expf (<1 ulp) vs correctly rounded, then 1/(1+e)
+    # S too since round 5: the sigmoid's exp is NumPy's float32 exp restated (csrc/mvmc_common.h np_exp_f32: P5 / Q2 after a Cody-Waite
+    # reduction, not correctly rounded) -- a one-ulp difference in 13 % of a C8 P8 frame's affinities changed the iteration count of every
+    # chain head's ALS run there and, at the iteration cap, its clusters (profiles/r05_oracle_soak.txt).  Holds where NumPy takes its
+    # AVX2 / AVX-512F path (any x86-64 host of the last decade); the fixture's S (recorded from the reference here) is matched likewise.
+    assert worst == 0.0, worst
 
 
 def test_als_association_bit_exact(dev, shelf):

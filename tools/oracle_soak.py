@@ -56,10 +56,12 @@ def main():
     from multiview_motion_capture_amd.tracker import run_chains_fused
     d = torch.device("cuda:0")
     workloads = [(5, 4, 4, 0.0, 0.0), (5, 4, 4, 0.05, 0.2), (5, 4, 4, 0.15, 0.5), (8, 8, 1, 0.0, 0.0), (8, 8, 1, 0.05, 0.2)]
+    if os.environ.get("SOAK_WORKLOADS"):      # e.g. "3 4": indices into the list above
+        workloads = [workloads[int(i)] for i in os.environ["SOAK_WORKLOADS"].split()]
     seeds = [int(s) for s in os.environ.get("SOAK_SEEDS", "1 2 3 4 5 6").split()]
     with ProcessPoolExecutor(max_workers=int(os.environ.get("SOAK_WORKERS", "14"))) as pool:
         for C, P, n_chains, occ, spur in workloads:
-            frames = same = void = als_frames = als_same = als_cap = 0
+            frames = same = void = als_frames = als_same = als_cap = als_unexplained = 0
             dd, first_bad = [], None
             for seed in seeds:
                 data = synth.generate(n_chains * L, C, P, seed, chain_len=L, occlusion=occ, spurious=spur)
@@ -76,6 +78,7 @@ def main():
                         void += 1     # beyond the layout's tables: the repair tier's case, not compared here
                         continue
                     ok_chain = True
+                    capped = False       # has this chain had a frame whose ALS ran into the cap (on either side)?
                     for tt, row in enumerate(rows):
                         if isinstance(row[0], str):
                             break
@@ -85,6 +88,11 @@ def main():
                         als_frames += 1
                         als_same += int(it_o == als_dev[f])
                         als_cap += int(it_o >= 1000)
+                        capped = capped or it_o >= 1000 or als_dev[f] >= 1000
+                        als_unexplained += int(it_o != als_dev[f] and not capped)
+                        if it_o != als_dev[f] and os.environ.get("SOAK_VERBOSE"):
+                            print(f"    ALS count: seed {seed} chain {b} frame {tt}: oracle {it_o} device {als_dev[f]} (live tracklets {len(row[0])}, "
+                                  f"chain has met the cap: {capped})", flush=True)
                         if ok_chain and n_t[f] == len(exp) and np.array_equal(meta[f, :len(exp)], exp):
                             same += 1
                             for s in range(len(exp)):
@@ -108,7 +116,7 @@ def main():
             print(f"C{C} P{P} occlusion {occ} spurious {spur}: {len(seeds)} seeds x {n_chains} chain(s) of {L}: tables equal on {same} / {frames} "
                   f"frames (first difference: {first_bad}; chains with a void word, not compared: {void}); {len(dd)} tracklet-frames, joint "
                   f"difference median {np.nanmedian(dd):.1e} p90 {np.nanpercentile(dd, 90):.1e} p99 {np.nanpercentile(dd, 99):.1e} max {np.nanmax(dd):.1e} m; "
-                  f"above 1e-6: {int((dd > 1e-6).sum())}; ALS iteration counts equal on {als_same} / {als_frames} frames ({als_cap} at the cap of 1000)", flush=True)
+                  f"above 1e-6: {int((dd > 1e-6).sum())}; ALS iteration counts equal on {als_same} / {als_frames} frames ({als_cap} at the cap of 1000; different counts in a chain that has not met the cap: {als_unexplained})", flush=True)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,69 @@
+"""Soak of the triangulation + post-optimisation entry point (mv_math_util.triangulate_point_groups_from_multiple_views_linear,
+post_optimize=True -> mvmc_dlt + mvmc_triangulate_postopt) against the oracle's SciPy run, on clusters of 2 .. 6 views drawn from a
+synthetic C8 P8 sequence: matched people and mismatched ones (false clusters), with and without joints that a view scores 0.
+Test infrastructure; run on the GPU box:   python tools/postopt_soak.py > gpurun_out/postopt_soak.txt"""
+import os
+import sys
+from concurrent.futures import ProcessPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def oracle_case(job):
+    import oracle_np as o
+    projs, poses = job
+    a = o.triangulate_groups(projs, poses, 0.01, False)
+    b = o.triangulate_groups(projs, poses, 0.01, True)
+    return a, b
+
+
+def main():
+    import oracle_np as o
+    from multiview_motion_capture_amd import mv_math_util as mu
+    from multiview_motion_capture_amd import synth
+    n_cases = int(os.environ.get("SOAK_CASES", "1500"))
+    rng = np.random.default_rng(20261005)
+    jobs, tags = [], []
+    for drop in (0.05, 0.0):
+        data = synth.generate(64, 8, 8, 4242, chain_len=16, shuffle=False, drop=drop)
+        k = data["kps25"].astype(np.float64)
+        while len(jobs) < n_cases * (1 if drop else 2) // 2:
+            f = int(rng.integers(0, 64))
+            V = int(rng.integers(2, 7))
+            views = rng.choice(8, V, replace=False)
+            junk = rng.uniform() < 0.35
+            p0 = int(rng.integers(0, 8))
+            people = [int(rng.integers(0, 8)) if junk else p0 for _ in views]
+            poses = [o.openpose25_to_coco17(k[f, v, p]) for v, p in zip(views, people)]
+            if not all(o.pose_is_good(q) for q in poses):
+                continue
+            jobs.append((np.array([data["P"][v] for v in views]), poses))
+            zero = int(sum((q[:, 2] == 0).sum() for q in poses))
+            tags.append((V, junk and len(set(people)) > 1, zero > 0))
+    with ProcessPoolExecutor(max_workers=int(os.environ.get("SOAK_WORKERS", "14"))) as pool:
+        refs = list(pool.map(oracle_case, jobs, chunksize=8))
+    stats = {}
+    for (projs, poses), (V, junk, zero), (a, b) in zip(jobs, tags, refs):
+        out = mu.triangulate_point_groups_from_multiple_views_linear(projs, poses, 0.01, True)
+        move = float(np.abs(a[:, :3] - b[:, :3]).max())
+        seen = np.array([sum(q[j, 2] >= 0.01 for q in poses) >= 2 for j in range(17)])
+        d = float(np.abs(out[seen, :3] - b[seen, :3]).max()) / max(1.0, move) if seen.any() else 0.0
+        key = ("2 views" if V == 2 else "3+ views", "false cluster" if junk else "one person", "a zero score" if zero else "all scored",
+               "trial kept" if move > 0 else "trial rejected")
+        st = stats.setdefault(key, [0, 0, 0.0, 0.0])
+        st[0] += 1
+        st[1] += int(d > 1e-6)
+        st[2] = max(st[2], d)
+        st[3] = max(st[3], move)
+    print(f"{len(jobs)} clusters; difference = max |device - oracle| over the joints two views score, relative to max(1 m, the reference's move)")
+    for key in sorted(stats):
+        n, bad, worst, mv = stats[key]
+        print("  %-9s %-14s %-13s %-15s: %5d clusters, above 1e-6: %4d, worst %.1e (largest move of the reference %.2f m)" % (*key, n, bad, worst, mv))
+
+
+if __name__ == "__main__":
+    main()
