@@ -26,17 +26,23 @@ def main(path):
     bd, ref_side = o.skeleton_constants()
     poses18 = [o.add_mid_spine(p) for p in poses]
     obs = np.array(poses18)[:, o.IK_OBS_IDX, :]
-    p3d = o.triangulate_groups(projs, poses18, 0.01, True)
-    root = 0.5 * (p3d[o.COCO_L_HIP, :3] + p3d[o.COCO_R_HIP, :3])
-    x0 = np.concatenate([root, np.zeros(54)])
-    side0 = ref_side.copy()
+    warm = "init" in z.files       # a WARM solve: init (68) = the previous frame's parameters, budget 5 + 5
+    budget = 5 if warm else 50
+    if warm:
+        x0, side0 = z["init"][:57].copy(), z["init"][57:].copy()
+        root = x0[:3]
+    else:
+        p3d = o.triangulate_groups(projs, poses18, 0.01, True)
+        root = 0.5 * (p3d[o.COCO_L_HIP, :3] + p3d[o.COCO_R_HIP, :3])
+        x0 = np.concatenate([root, np.zeros(54)])
+        side0 = ref_side.copy()
     f1 = lambda x: o.ik_residual(x[:3], x[3:57], side0, obs, projs, bd)
     j1 = lambda x, f: t.ik_jacobian(x[:3], x[3:57], side0, obs, projs, False)
     f2 = lambda x: o.ik_residual(x[:3], x[3:57], x[57:], obs, projs, bd)
     j2 = lambda x, f: t.ik_jacobian(x[:3], x[3:57], x[57:], obs, projs, True)
     tr1, tr2 = [], []
-    r1 = t.trf(f1, j1, x0, 50, solver="ne_clean", trace=tr1)
-    r2 = t.trf(f2, j2, np.concatenate([r1["x"], side0]), 50, solver="ne_clean", trace=tr2)
+    r1 = t.trf(f1, j1, x0, budget, solver="ne_clean", trace=tr1)
+    r2 = t.trf(f2, j2, np.concatenate([r1["x"], side0]), budget, solver="ne_clean", trace=tr2)
     print(f"oracle: stage 1 nfev {r1['nfev']} status {r1['status']} cost {r1['cost']:.6f}; stage 2 nfev {r2['nfev']} status {r2['status']} cost {r2['cost']:.6f}")
     d = torch.device("cuda:0")
     kps = np.zeros((1, v, 1, 17, 3))
@@ -44,14 +50,18 @@ def main(path):
     mem = -np.ones((1, max(6, v)), dtype=np.int32)
     mem[0, :v] = np.arange(v)
     kps_t, cams_t, mem_t = torch.from_numpy(kps).to(d), torch.from_numpy(np.ascontiguousarray(projs)).to(d), torch.from_numpy(mem).to(d)
-    p, j, info = dev.ik_solve(kps_t, cams_t, mem_t, torch.zeros((1, 68), dtype=torch.float64, device=d), torch.ones(1, dtype=torch.uint8, device=d), 50, 5)
+    init_t = torch.from_numpy(np.concatenate([x0, side0])[None]).to(d) if warm else torch.zeros((1, 68), dtype=torch.float64, device=d)
+    p, j, info = dev.ik_solve(kps_t, cams_t, mem_t, init_t, torch.full((1,), 0 if warm else 1, dtype=torch.uint8, device=d), 50, 5)
     torch.cuda.synchronize()
     info, p = info.cpu().numpy()[0], p.cpu().numpy()[0]
     print(f"device: stage 1 nfev {int(info[1])} status {int(info[2])} cost {info[0]:.6f}; stage 2 nfev {int(info[4])} status {int(info[5])} cost {info[3]:.6f}; "
           f"models {int(info[6])}, eigensolver fallbacks {int(info[7])}")
     # (a) the starting point: the device's cold root (DLT + post-optimisation in the solve's wave) against the oracle's
-    p1, _, _ = dev.ik_solve(kps_t, cams_t, mem_t, torch.zeros((1, 68), dtype=torch.float64, device=d), torch.ones(1, dtype=torch.uint8, device=d), 1, 1)
-    print(f"cold root: device {p1.cpu().numpy()[0, :3]} oracle {root}; difference {np.abs(p1.cpu().numpy()[0, :3] - root).max():.1e} m")
+    pos_o, _ = o.forward_kinematics(r2["x"][:3], r2["x"][3:57], r2["x"][57:], bd)
+    print(f"joints: device against oracle {np.abs(j.cpu().numpy()[0] - pos_o).max():.1e} m")
+    if not warm:
+      p1, _, _ = dev.ik_solve(kps_t, cams_t, mem_t, torch.zeros((1, 68), dtype=torch.float64, device=d), torch.ones(1, dtype=torch.uint8, device=d), 1, 1)
+      print(f"cold root: device {p1.cpu().numpy()[0, :3]} oracle {root}; difference {np.abs(p1.cpu().numpy()[0, :3] - root).max():.1e} m")
     # (b) free-running: stage 1 from the ORACLE's start with budgets 2 .. 50 against the oracle's iterate after as many evaluations
     xs, x = {1: x0.copy()}, x0.copy()
     for e in (e for e in tr1 if "model" not in e):
