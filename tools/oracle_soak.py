@@ -49,18 +49,28 @@ def oracle_chain(job):
     return rows, orc.next_id, orc.n_dead
 
 
+WORKLOADS = [(5, 4, 4, 0.0, 0.0), (5, 4, 4, 0.05, 0.2), (5, 4, 4, 0.15, 0.5), (8, 8, 1, 0.0, 0.0), (8, 8, 1, 0.05, 0.2)]
+
+
 def main():
+    workloads = WORKLOADS
+    if os.environ.get("SOAK_WORKLOADS"):      # e.g. "3 4": indices into the list above
+        workloads = [workloads[int(i)] for i in os.environ["SOAK_WORKLOADS"].split()]
+    seeds = [int(s) for s in os.environ.get("SOAK_SEEDS", "1 2 3 4 5 6").split()]
+    run(workloads, seeds, int(os.environ.get("SOAK_WORKERS", "14")))
+
+
+def run(workloads, seeds, workers=14):
+    """-> one dict per workload: frames, tables_equal, als_equal, als_capped, tracklet_frames, above_1e6 [(dj, hits)], worst"""
     import torch
     from multiview_motion_capture_amd import synth
     from multiview_motion_capture_amd.pipeline import HotPath
     from multiview_motion_capture_amd.tracker import run_chains_fused
     d = torch.device("cuda:0")
-    workloads = [(5, 4, 4, 0.0, 0.0), (5, 4, 4, 0.05, 0.2), (5, 4, 4, 0.15, 0.5), (8, 8, 1, 0.0, 0.0), (8, 8, 1, 0.05, 0.2)]
-    if os.environ.get("SOAK_WORKLOADS"):      # e.g. "3 4": indices into the list above
-        workloads = [workloads[int(i)] for i in os.environ["SOAK_WORKLOADS"].split()]
-    seeds = [int(s) for s in os.environ.get("SOAK_SEEDS", "1 2 3 4 5 6").split()]
-    with ProcessPoolExecutor(max_workers=int(os.environ.get("SOAK_WORKERS", "14"))) as pool:
+    results = []
+    with ProcessPoolExecutor(max_workers=workers) as pool:
         for C, P, n_chains, occ, spur in workloads:
+            offenders = []
             frames = same = void = als_frames = als_same = als_cap = als_unexplained = 0
             dd, first_bad = [], None
             for seed in seeds:
@@ -99,6 +109,7 @@ def main():
                                 dj = float(np.abs(joints[f, s] - jo[s]).max())
                                 dd.append(dj)
                                 if dj > 1e-6:
+                                    offenders.append((dj, int(exp[s][2])))
                                     tag = f"C{C}P{P}_occ{occ}_sp{spur}_seed{seed}_chain{b}"
                                     print(f"    above 1e-6: {tag} frame {tt} slot {s} (id, state, hits, length) {exp[s].tolist()}: {dj:.2e} m; the frame's ALS "
                                           f"iterations: oracle {it_o}, device {als_dev[f]}" + (" (AT THE CAP: the result of an unconverged iteration)" if it_o >= 1000 else ""),
@@ -117,6 +128,9 @@ def main():
                   f"frames (first difference: {first_bad}; chains with a void word, not compared: {void}); {len(dd)} tracklet-frames, joint "
                   f"difference median {np.nanmedian(dd):.1e} p90 {np.nanpercentile(dd, 90):.1e} p99 {np.nanpercentile(dd, 99):.1e} max {np.nanmax(dd):.1e} m; "
                   f"above 1e-6: {int((dd > 1e-6).sum())}; ALS iteration counts equal on {als_same} / {als_frames} frames ({als_cap} at the cap of 1000; different counts in a chain that has not met the cap: {als_unexplained})", flush=True)
+            results.append(dict(workload=(C, P, n_chains, occ, spur), frames=frames, tables_equal=same, als_equal=als_same, als_capped=als_cap,
+                                tracklet_frames=len(dd), above_1e6=offenders, worst=float(np.nanmax(dd))))
+    return results
 
 
 if __name__ == "__main__":
