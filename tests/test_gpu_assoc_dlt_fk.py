@@ -54,6 +54,29 @@ def test_ingest_f32_and_17_joint_inputs(dev, shelf):
     assert np.array_equal(cnt2.cpu().numpy(), shelf["cnt_o"])
 
 
+def test_ingest_filter_at_its_thresholds_on_random_sparse_poses(dev, shelf):
+    """filter_bad_pose (motion_capture.py:1023-1043) where its three comparisons are decided: scores AT 0.01 (kept only above), poses with
+    3 / 4 / 5 scored keypoints, boxes of exactly 5 px and a hair less, ragged and zero counts, float32 and float64 input -- 10,000 poses;
+    the compacted tensor and the counts must be the oracle's bit for bit."""
+    rng = np.random.default_rng(77)
+    F, C, P = 500, 4, 10
+    k = np.zeros((F, C, P, 25, 3))
+    k[..., :2] = rng.uniform(100, 900, (F, C, P, 1, 2)) + rng.choice([0.0, 2.5, 4.999999, 5.0, 5.000001, 40.0], (F, C, P, 1, 2)) * rng.uniform(0, 1, (F, C, P, 25, 2)).round()
+    sc = rng.choice([0.0, 0.005, 0.01, 0.010001, 0.3, 0.9], (F, C, P, 25), p=[0.55, 0.05, 0.05, 0.05, 0.15, 0.15])
+    k[..., 2] = sc
+    cnt = rng.integers(0, P + 1, (F, C)).astype(np.int32)
+    d = shelf["d"]
+    for dt in (np.float64, np.float32):
+        kk = k.astype(dt)
+        out, c_dev = dev.ingest(torch.from_numpy(kk).to(d), torch.from_numpy(cnt).to(d))
+        ref, c_ref = oracle_ingest(kk.astype(np.float64), cnt)
+        assert np.array_equal(c_dev.cpu().numpy(), c_ref), dt
+        assert np.array_equal(out.cpu().numpy(), ref), dt
+    kept = c_ref.sum() / max(1, cnt.sum())
+    print(f"ingest at the thresholds: {int(cnt.sum())} poses, {kept:.0%} kept")
+    assert 0.05 < kept < 0.95
+
+
 def test_fmats(shelf):
     F_o = o.pairwise_f_mats(shelf["K"], shelf["Rt"])
     F_g = shelf["Fm"].cpu().numpy()
