@@ -3,11 +3,14 @@ oracle on synthetic frames with ragged counts (occlusion, false detections): clu
 the triangulated points of every frame.  Test infrastructure; GPU box:   python tools/assoc_soak.py > gpurun_out/assoc_soak.txt"""
 import os
 import sys
+import multiprocessing
 from concurrent.futures import ProcessPoolExecutor
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# worker processes are SPAWNED, not forked: the parent has initialised the GPU, and a forked child would inherit its HIP state
+SPAWN = multiprocessing.get_context("spawn")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
@@ -46,7 +49,7 @@ def main():
     d = torch.device("cuda:0")
     F = int(os.environ.get("SOAK_FRAMES", "64"))
     seeds = [int(s) for s in os.environ.get("SOAK_SEEDS", "1 2 3").split()]
-    with ProcessPoolExecutor(max_workers=int(os.environ.get("SOAK_WORKERS", "14"))) as pool:
+    with ProcessPoolExecutor(max_workers=int(os.environ.get("SOAK_WORKERS", "14")), mp_context=SPAWN) as pool:
         for C, P, occ, spur in [(5, 4, 0.0, 0.0), (5, 4, 0.2, 0.5), (8, 8, 0.0, 0.0), (8, 8, 0.1, 0.5), (5, 8, 0.3, 0.3)]:
             n_fr = lab_ok = it_ok = ncl_ok = raised = 0
             worst = 0.0

@@ -8,11 +8,14 @@ chain).  Reported per workload: frames whose tracker table equals the oracle's, 
 the same comparison on two fixed seeds (tests/test_gpu_synth_tracker.py); this is the wider net."""
 import os
 import sys
+import multiprocessing
 from concurrent.futures import ProcessPoolExecutor
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# worker processes are SPAWNED, not forked: the parent has initialised the GPU, and a forked child would inherit its HIP state
+SPAWN = multiprocessing.get_context("spawn")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 L = 16
@@ -68,7 +71,7 @@ def run(workloads, seeds, workers=14):
     from multiview_motion_capture_amd.tracker import run_chains_fused
     d = torch.device("cuda:0")
     results = []
-    with ProcessPoolExecutor(max_workers=workers) as pool:
+    with ProcessPoolExecutor(max_workers=workers, mp_context=SPAWN) as pool:
         for C, P, n_chains, occ, spur in workloads:
             offenders = []
             frames = same = void = als_frames = als_same = als_cap = als_unexplained = 0

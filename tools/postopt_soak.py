@@ -4,11 +4,14 @@ synthetic C8 P8 sequence: matched people and mismatched ones (false clusters), w
 Test infrastructure; run on the GPU box:   python tools/postopt_soak.py > gpurun_out/postopt_soak.txt"""
 import os
 import sys
+import multiprocessing
 from concurrent.futures import ProcessPoolExecutor
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# worker processes are SPAWNED, not forked: the parent has initialised the GPU, and a forked child would inherit its HIP state
+SPAWN = multiprocessing.get_context("spawn")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
@@ -44,7 +47,7 @@ def main():
             jobs.append((np.array([data["P"][v] for v in views]), poses))
             zero = int(sum((q[:, 2] == 0).sum() for q in poses))
             tags.append((V, junk and len(set(people)) > 1, zero > 0))
-    with ProcessPoolExecutor(max_workers=int(os.environ.get("SOAK_WORKERS", "14"))) as pool:
+    with ProcessPoolExecutor(max_workers=int(os.environ.get("SOAK_WORKERS", "14")), mp_context=SPAWN) as pool:
         refs = list(pool.map(oracle_case, jobs, chunksize=8))
     stats = {}
     for (projs, poses), (V, junk, zero), (a, b) in zip(jobs, tags, refs):

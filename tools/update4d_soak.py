@@ -4,11 +4,14 @@ with occlusion and false detections (births, deaths, more live tracklets than th
     python tools/update4d_soak.py > gpurun_out/update4d_soak.txt"""
 import os
 import sys
+import multiprocessing
 from concurrent.futures import ProcessPoolExecutor
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# worker processes are SPAWNED, not forked: the parent has initialised the GPU, and a forked child would inherit its HIP state
+SPAWN = multiprocessing.get_context("spawn")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -24,7 +27,7 @@ def main():
     if os.environ.get("SOAK_WORKLOADS"):
         workloads = [workloads[int(i)] for i in os.environ["SOAK_WORKLOADS"].split()]
     seeds = [int(s) for s in os.environ.get("SOAK_SEEDS", "1 2 3").split()]
-    with ProcessPoolExecutor(max_workers=int(os.environ.get("SOAK_WORKERS", "14"))) as pool:
+    with ProcessPoolExecutor(max_workers=int(os.environ.get("SOAK_WORKERS", "14")), mp_context=SPAWN) as pool:
         for C, P, occ, spur in workloads:
             datas = [synth.generate(n_frames, C, P, seed, chain_len=n_frames, occlusion=occ, spurious=spur) for seed in seeds]
             futs = [pool.submit(oracle_chain, (d["K"], d["Rt"], d["P"], d["kps25"].astype(np.float64), d["counts"])) for d in datas]
