@@ -83,7 +83,9 @@ int mvmc_fmats(const double* K, const double* Rt, int n_views, float* F, mvmcStr
 
 /* AS-2 + AS-3: geometry_affinity (mv_math_util.py:320-351) with projected_distance (:288-317).
  * Graph nodes of frame f = its poses in (view, person) order; n_f = sum_c counts[f,c].
- *   D, S  (F,N,N) f32 out with N = C*P (only [0:n_f,0:n_f] is meaningful, rest 0); either may be NULL */
+ *   D, S  (F,N,N) f32 out with N = C*P (only [0:n_f,0:n_f] is meaningful, rest 0); either may be NULL
+ * Both are the reference's bit for bit: the float32 statistics in NumPy's pairwise order, and the sigmoid's exp as NumPy's float32 exp
+ * (AVX2 / AVX-512F form: Cody-Waite reduction, P5 / Q2, fused steps -- not the correctly-rounded function; np_exp_f32 in csrc/mvmc_common.h). */
 int mvmc_affinity(const double* kps17, const int32_t* counts, const float* Fmats, int n_frames, int n_views,
                   int p_max, float* D, float* S, mvmcStream_t stream);
 
