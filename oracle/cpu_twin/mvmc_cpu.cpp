@@ -669,6 +669,10 @@ int trf_check_ik(const double* dirs, const int* parents, const int* side_map, in
     out4[0] = r.cost; out4[1] = r.nfev; out4[2] = r.status; out4[3] = r.njev;
     return 0;
 }
+int check_np_exp_f32(const float* x, int n, float* y) {   // NumPy's float32 exp as restated here and in csrc/mvmc_common.h
+    for (int i = 0; i < n; ++i) y[i] = np_exp_f32(x[i]);
+    return 0;
+}
 int trf_check_postopt(const double* pose, const double* Pm, int nv, int n_pts, int max_nfev, double* x, double* out4) {
     PostoptResidual fun{pose, Pm, nv, n_pts};
     const int n = 3 * n_pts, m = fun.m();

@@ -1,6 +1,7 @@
 """CPU: the C++ CPU twin (oracle/cpu_twin/mvmc_cpu.cpp -- the second CPU restatement of the path, timed by bench.py as a cpu_baseline)
 against the same golden fixtures as the NumPy oracle: the reference's own outputs on Shelf and on the synthetic config-4 subset."""
 import ctypes
+import pytest
 
 import numpy as np
 
@@ -100,3 +101,28 @@ def test_chain_run_follows_the_reference_log_on_shelf(shelf_inputs):
         got = [tuple(int(v) for v in out["meta"][fi, s]) for s in range(out["n_tracks"][fi])]
         assert got == exp, (fi, got, exp)
         assert out["n_dead"][fi] == g["n_dead"][fi] and out["n_solves"][fi] == g["n_solves"][fi]
+
+
+def test_np_exp_f32_is_numpys_float32_exp():
+    """The affinity's sigmoid goes through NumPy's float32 exp, which is not the correctly-rounded function (AVX2 / AVX-512F paths: Cody-Waite
+    reduction, P5 / Q2, fused multiply-adds).  The restatement (oracle/cpu_twin and, with the same constants and steps, np_exp_f32 in
+    csrc/mvmc_common.h) must give np.exp's bits -- on hosts where NumPy takes that path; elsewhere (no AVX2: libm's expf) the test says so."""
+    import ctypes
+    lib = cpu_twin()
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-25, 25, 1_000_000), rng.uniform(-104, 89, 200_000), [0.0, -0.0, 88.72, 88.73, -103.9, -104.0, 1e-30, -1e-30]]).astype(np.float32)
+    y = np.zeros_like(x)
+    lib.check_np_exp_f32(x.ctypes.data_as(ctypes.c_void_p), len(x), y.ctypes.data_as(ctypes.c_void_p))
+    with np.errstate(over="ignore", under="ignore"):
+        ref = np.exp(x)
+    try:
+        from numpy._core._multiarray_umath import __cpu_features__ as feat
+    except ImportError:
+        from numpy.core._multiarray_umath import __cpu_features__ as feat
+    if not (feat.get("AVX2") and feat.get("FMA3")):
+        pytest.skip("NumPy takes libm's expf on this host (no AVX2 + FMA): a different function")
+    normal = (ref == 0) | (np.abs(ref) >= np.finfo(np.float32).tiny)     # (denormal results: the SIMD scale step flushes differently)
+    same = (y == ref) | (np.isnan(y) & np.isnan(ref))
+    print(f"np_exp_f32 against np.exp: {int(same.sum())} of {len(x)} equal; normal-range arguments that differ: {int((~same & normal).sum())}")
+    assert (same | ~normal).all()
+    assert same[:1_000_000].all()        # the affinity's range
