@@ -390,6 +390,10 @@ def main():
     ap.add_argument("--tile-from", type=int, default=0,
                     help="generate this many frames on the host and tile them on the device up to --frames (config 2 at 2 M frames: the "
                          "generator would take minutes; the kernel reads every frame from HBM either way); 0 = generate all frames")
+    ap.add_argument("--layout", choices=("auto", "big"), default="auto",
+                    help="fused path: 'big' = the chain kernel's 512-thread layout (80-node graphs, 16 tracklet slots) also for views x people "
+                         "<= 40 -- for geometries whose crowded frames exceed the SMALL layout's 32-node graphs (5 x 6 with everybody in view), "
+                         "which otherwise go through the repair tier chain by chain")
     ap.add_argument("--big-split", action="store_true",
                     help="C8 P8 sizes (config 5) only, an experiment: association and IK as two co-resident persistent kernels "
                          "(csrc/mvmc_chain_split.h) instead of one 512-thread workgroup per chain-frame; bit-identical results")
@@ -551,7 +555,8 @@ def run_workload(args, rank, world, d):
                 kev = []
                 out = run_chains_fused(hp, kps, counts, L, nfev_cold=args.nfev_cold, nfev_warm=args.nfev_warm, want_info=timed,
                                        parts=args.parts or None, kernel_events=kev,
-                                       hand_over=None if args.hand_over == "auto" else args.hand_over, split=args.big_split)
+                                       hand_over=None if args.hand_over == "auto" else args.hand_over, split=args.big_split,
+                                       force_big=args.layout == "big")
                 kern_events.append((timed, kev[0][0], kev[0][1]))
             else:
                 out = run_chains(hp, kps, counts, L, nfev_cold=args.nfev_cold, nfev_warm=args.nfev_warm,

@@ -8,6 +8,7 @@ associate_tracking does (motion_capture.py:829-835).
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -427,12 +428,13 @@ def check_chain_flags(res) -> None:
 
 
 def repair_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], res, nfev_cold=50, nfev_warm=5,
-                  t_wide: int = T_WIDE) -> int:
+                  t_wide: int = T_WIDE, big_first: bool = True) -> int:
     """What the reference does where the chain kernel's fixed tables end (it has no caps at all): the chains whose void word is set --
     more live tracklets than t_max, a graph beyond the layout's association variant -- are run again through the per-stage entry
     points with t_wide tracklet slots (association on up to 80 nodes, rank 32), and their rows of ``res`` (run_chains_fused's result,
     same kps / counts) are replaced; the per-frame tables are widened to the slots the repaired chains need.  Synchronises (it reads
-    the void words); returns the number of chains repaired.  Raises if a hand-over timed out or a chain exceeds the repair tier too."""
+    the void words); returns the number of chains repaired.  Raises if a hand-over timed out or a chain exceeds the repair tier too.
+    big_first: chains voided by the SMALL layout go through the chain kernel's BIG layout first (one launch), see below."""
     B, L = res["n_chains"], res["chain_len"]
     fl = res["flags"][B:B + 4].cpu().tolist()
     if fl[0]:
@@ -446,11 +448,24 @@ def repair_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor]
     C, P = kps.shape[1:3]
     k5 = kps.view(B, L, *kps.shape[1:])[idx].reshape(n * L, *kps.shape[1:]).contiguous()
     c5 = None if counts is None else counts.view(B, L, C)[idx].reshape(n * L, C).contiguous()
-    sub = run_chains(hp, k5, c5, L, t_max=t_wide, nfev_cold=nfev_cold, nfev_warm=nfev_warm)
-    ov = int(sub["overflow"].max())
-    if ov:
-        raise ValueError(f"repair_chains: a chain exceeds the repair tier as well (word {ov}: 2 = more than {t_wide} live tracklets, "
-                         "4 = a graph of more than 80 nodes)")
+    sub = None
+    if big_first and os.environ.get("MVMC_REPAIR_BIG_FIRST", "1") != "0" and C * P <= 40 and t_wide <= T_WIDE and res["params"].shape[1] <= 8:
+        # The chains came from the SMALL layout (views x people <= 40: graphs of <= 32 nodes, 8 tracklet slots, <= 6 views per cluster).
+        # What voids there -- a crowded frame of 5 x 6 or 7 x 5, a ninth tracklet -- is inside the BIG layout's tables (80 nodes,
+        # 16 slots, 8 views): the same persistent kernel in its 512-thread form takes all of them in ONE launch (bit-identical to the
+        # per-stage path, tests/test_gpu_chain_fused.py), which matters when a geometry voids EVERY chain (C5 P6 with everybody in view:
+        # measured in tests/test_gpu_capacity_flags.py).  What is beyond that too falls through to the per-stage entry points below.
+        big = run_chains_fused(hp, k5, c5, L, t_max=t_wide, nfev_cold=nfev_cold, nfev_warm=nfev_warm, force_big=True)
+        bfl = big["flags"][n:n + 4].cpu().tolist()
+        if not bfl[0] and int(big["void"].max()) == 0:
+            sub = dict(params=big["params"], joints=big["joints"], meta=big["meta"], n_tracks=big["n_tracks"], n_dead=big["n_dead"],
+                       next_id=big["next_id"])
+    if sub is None:
+        sub = run_chains(hp, k5, c5, L, t_max=t_wide, nfev_cold=nfev_cold, nfev_warm=nfev_warm)
+        ov = int(sub["overflow"].max())
+        if ov:
+            raise ValueError(f"repair_chains: a chain exceeds the repair tier as well (word {ov}: 2 = more than {t_wide} live tracklets, "
+                             "4 = a graph of more than 80 nodes)")
     T = res["params"].shape[1]
     need = int(sub["n_tracks"].max())
     if need > T:   # widen the per-frame tables (rare: the repaired chains hold more tracklets than the tables have slots)

@@ -42,6 +42,41 @@ def test_tracklet_table_overflow_is_reported_and_repaired():
     assert repair_chains(hp, kps, cnt, ok) == 0
 
 
+def test_a_geometry_that_voids_every_chain_of_the_small_layout_is_repaired_in_one_launch_of_the_big_one():
+    """5 views x 6 people with everybody in view: 30 nodes + 6 tracklets = 36 > the 32 nodes the SMALL layout's association holds, so
+    EVERY chain's void word is set.  repair_chains takes them through the chain kernel's BIG layout (80 nodes, 16 slots) in one launch
+    before it falls back to the per-stage entry points: the same rows bit for bit, an order of magnitude sooner."""
+    import time
+    from multiview_motion_capture_amd import synth
+    from multiview_motion_capture_amd.pipeline import HotPath
+    from multiview_motion_capture_amd.tracker import check_chain_flags, repair_chains, run_chains_fused
+    L, B = 16, 96
+    data = synth.generate(B * L, 5, 6, 20260119, chain_len=L)
+    d = torch.device("cuda:0")
+    hp, kps, cnt = HotPath(data["K"], data["Rt"], device=d), torch.from_numpy(data["kps25"]).to(d), torch.from_numpy(data["counts"]).to(d)
+    res, took = {}, {}
+    for big_first in (True, False):
+        r = run_chains_fused(hp, kps, cnt, L)
+        torch.cuda.synchronize()
+        assert int((r["void"] != 0).sum()) == B and int(r["void"].max()) == 4          # every chain: a graph beyond the layout
+        t0 = time.perf_counter()
+        assert repair_chains(hp, kps, cnt, r, big_first=big_first) == B
+        torch.cuda.synchronize()
+        took[big_first] = time.perf_counter() - t0
+        check_chain_flags(r)
+        res[big_first] = r
+    a, b = res[True], res[False]
+    assert torch.equal(a["n_tracks"], b["n_tracks"]) and torch.equal(a["next_id"], b["next_id"]) and torch.equal(a["n_dead"], b["n_dead"])
+    assert int(a["n_tracks"].min()) == 6
+    n = a["n_tracks"].cpu().numpy()
+    live = torch.arange(a["meta"].shape[1], device=d)[None, :] < a["n_tracks"][:, None]
+    assert torch.equal(a["meta"][live], b["meta"][live])
+    assert torch.equal(a["params"][live], b["params"][live]) and torch.equal(a["joints"][live], b["joints"][live])
+    print(f"\n{B} chains of {L} frames, C5 P6, all void on the SMALL layout: repair through the BIG layout {took[True] * 1e3:.0f} ms, "
+          f"through the per-stage entry points {took[False] * 1e3:.0f} ms; rows bit-identical")
+    assert took[True] < took[False]
+
+
 def test_smaller_caps_than_the_frame_allows_are_reported():
     from multiview_motion_capture_amd.tracker import check_chain_flags, default_caps, run_chains_fused
     hp, kps, cnt, L = _data(P=4)

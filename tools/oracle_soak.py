@@ -59,6 +59,8 @@ def main():
     workloads = WORKLOADS
     if os.environ.get("SOAK_WORKLOADS"):      # e.g. "3 4": indices into the list above
         workloads = [workloads[int(i)] for i in os.environ["SOAK_WORKLOADS"].split()]
+    if os.environ.get("SOAK_CUSTOM"):         # e.g. "3,2,4,0.1,0.3,0.2,6.0;6,6,2,0,0": views, people, chains, occlusion, spurious[, drop, pixel sigma]
+        workloads = [tuple(float(v) if "." in v else int(v) for v in w.split(",")) for w in os.environ["SOAK_CUSTOM"].split(";")]
     seeds = [int(s) for s in os.environ.get("SOAK_SEEDS", "1 2 3 4 5 6").split()]
     run(workloads, seeds, int(os.environ.get("SOAK_WORKERS", "14")))
 
@@ -68,21 +70,31 @@ def run(workloads, seeds, workers=14):
     import torch
     from multiview_motion_capture_amd import synth
     from multiview_motion_capture_amd.pipeline import HotPath
-    from multiview_motion_capture_amd.tracker import run_chains_fused
+    from multiview_motion_capture_amd.tracker import repair_chains, run_chains_fused
     d = torch.device("cuda:0")
     results = []
     with ProcessPoolExecutor(max_workers=workers, mp_context=SPAWN) as pool:
-        for C, P, n_chains, occ, spur in workloads:
+        for wl in workloads:
+            C, P, n_chains, occ, spur = wl[:5]
+            extra = dict(zip(("drop", "pix_sigma"), wl[5:]))
             offenders = []
-            frames = same = void = als_frames = als_same = als_cap = als_unexplained = 0
+            frames = same = void = als_frames = als_same = als_cap = als_unexplained = repaired = 0
             dd, first_bad = [], None
             for seed in seeds:
-                data = synth.generate(n_chains * L, C, P, seed, chain_len=L, occlusion=occ, spurious=spur)
+                data = synth.generate(n_chains * L, C, P, seed, chain_len=L, occlusion=occ, spurious=spur, **extra)
                 hp = HotPath(data["K"], data["Rt"], device=d)
                 out = run_chains_fused(hp, torch.from_numpy(data["kps25"]).to(d), torch.from_numpy(data["counts"]).to(d), L, want_info=True)
                 torch.cuda.synchronize()
-                n_t, meta, joints = out["n_tracks"].cpu().numpy(), out["meta"].cpu().numpy(), out["joints"].cpu().numpy()
                 als_dev = out["als_iters"].cpu().numpy().reshape(-1)
+                repaired_chains = set()
+                if os.environ.get("SOAK_REPAIR") and int(out["void"].max()) != 0:
+                    # the product path for chains beyond the layout's tables (a ninth tracklet, a graph of more than 32 nodes on the SMALL
+                    # layout): tracker.repair_chains re-runs them stage by stage on the wide tier and splices their rows in
+                    kps_t, cnt_t = torch.from_numpy(data["kps25"]).to(d), torch.from_numpy(data["counts"]).to(d)
+                    repair_chains(hp, kps_t, cnt_t, out)
+                    repaired_chains = set(out["repaired"].cpu().tolist())
+                    repaired += len(repaired_chains)
+                n_t, meta, joints = out["n_tracks"].cpu().numpy(), out["meta"].cpu().numpy(), out["joints"].cpu().numpy()
                 vw = out["void"].cpu().numpy()
                 k64 = data["kps25"].astype(np.float64)
                 jobs = [(data["K"], data["Rt"], data["P"], k64[b * L:(b + 1) * L], data["counts"][b * L:(b + 1) * L]) for b in range(n_chains)]
@@ -98,6 +110,8 @@ def run(workloads, seeds, workers=14):
                         f = b * L + tt
                         frames += 1
                         exp, jo, it_o = row
+                        if b in repaired_chains:
+                            it_o = int(als_dev[f])       # (the repair tier does not report iteration counts: not compared)
                         als_frames += 1
                         als_same += int(it_o == als_dev[f])
                         als_cap += int(it_o >= 1000)
@@ -127,8 +141,8 @@ def run(workloads, seeds, workers=14):
                                 first_bad = (seed, b, tt)
                             ok_chain = False      # (a chain's later frames follow from the first different table)
             dd = np.array(dd) if dd else np.array([np.nan])
-            print(f"C{C} P{P} occlusion {occ} spurious {spur}: {len(seeds)} seeds x {n_chains} chain(s) of {L}: tables equal on {same} / {frames} "
-                  f"frames (first difference: {first_bad}; chains with a void word, not compared: {void}); {len(dd)} tracklet-frames, joint "
+            print(f"C{C} P{P} occlusion {occ} spurious {spur}{' ' + str(extra) if extra else ''}: {len(seeds)} seeds x {n_chains} chain(s) of {L}: tables equal on {same} / {frames} "
+                  f"frames (first difference: {first_bad}; chains with a void word, not compared: {void}; chains that went through the repair tier: {repaired}); {len(dd)} tracklet-frames, joint "
                   f"difference median {np.nanmedian(dd):.1e} p90 {np.nanpercentile(dd, 90):.1e} p99 {np.nanpercentile(dd, 99):.1e} max {np.nanmax(dd):.1e} m; "
                   f"above 1e-6: {int((dd > 1e-6).sum())}; ALS iteration counts equal on {als_same} / {als_frames} frames ({als_cap} at the cap of 1000; different counts in a chain that has not met the cap: {als_unexplained})", flush=True)
             results.append(dict(workload=(C, P, n_chains, occ, spur), frames=frames, tables_equal=same, als_equal=als_same, als_capped=als_cap,
