@@ -24,6 +24,14 @@
 #define MVMC_PRIO_ALS 1
 #define MVMC_PRIO_REST 1
 #endif
+// Two stage-1 IK models on one wave (mvmc_ik_pair.h), for the throughput build of the SMALL layout: built and measured in round 6, NOT
+// shipped (-DMVMC_WITH_IK_PAIR builds it).  Bit-identical; 96 % of the stage-1 models of a warm solve are made in pairs, the launch
+// issues 10 % fewer instructions -- and runs 1.5 - 2 % SLOWER (541 - 544 k against 552 - 553 k frames/s, same box): a wave's dependent chain,
+// not the issue rate, bounds the IK phase, and a pair costs the later of its two waves nothing while the earlier one waits
+// (docs/design_measurement.md, "Round 6").
+#if defined(MVMC_WITH_IK_PAIR) && !defined(MVMC_CHAIN_BIG_TU) && !defined(MVMC_CHAIN_LAT_TU) && MVMC_SMALL_WPS >= 4
+#define MVMC_IK_PAIR 1
+#endif
 #include <cstdlib>
 #include "mvmc_common.h"
 #include "mvmc_assoc.hip"
@@ -249,6 +257,17 @@ __device__ __noinline__ void chain_ik(ChainArena<BIG>& arena_in, const Ik1Tables
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
     const int excl = incl - cnt;
+    // Two stage-1 models on one wave (mvmc_ik_pair.h): the waves (0, 1), (2, 3) are pairs.  The pair words lie in the solve blocks, which
+    // the other phases overwrite: mailbox empty, both waves away, before any solve of the frame starts.
+    int pair_dS = 0, pair_dhh = 0;
+#ifdef MVMC_IK_PAIR
+    if constexpr (!BIG) {
+        pair_dS = (wave & 1) ? -(int)sizeof(Ik1Shared) : (int)sizeof(Ik1Shared);
+        pair_dhh = (wave & 1) ? -MVMC_IK_SCRATCH_DOUBLES : MVMC_IK_SCRATCH_DOUBLES;
+        if (lane == 0) arena.ikp.ik[wave].pairw = (wave & 1) ? (3 << 16) : 0;
+        __syncthreads();
+    }
+#endif
     // wave w takes the problem slots w, w + NW, ... of this chain
     for (int s = wave; s < NP; s += NW) {
         const int p = b * NP + s;
@@ -257,7 +276,7 @@ __device__ __noinline__ void chain_ik(ChainArena<BIG>& arena_in, const Ik1Tables
         ik1_solve(arena.ikp.ik[wave], arena.ikp.mq + (base < POOL ? base : 0), arena.ikp.mc + (base < POOL ? base : 0), room, tables, A.kps17, A.Pm, A.members,
                   p, A.V, A.C, A.P, A.init, A.cold, A.nfev_cold, A.nfev_warm, A.ik_params, A.ik_joints, A.ik_info,
                   A.ik_scratch + (ptrdiff_t)(b * NW + wave - p) * MVMC_IK_SCRATCH_DOUBLES, 3, nullptr,
-                  reinterpret_cast<int32_t*>(A.flags + A.n_chains + 4 + b), n_valid);
+                  reinterpret_cast<int32_t*>(A.flags + A.n_chains + 4 + b), n_valid, pair_dS, pair_dhh, wave & 1);
     }
     *done = 0;
 }
@@ -444,7 +463,7 @@ chain_kernel(Ik1Tables tables_arg, ChainArgs A_by_value) {
     }
     // the chain's void word (assignment, IK pool, commit) into the launch's capacity word
     if (tid == 0) {
-        const unsigned v = __hip_atomic_load(A.flags + A.n_chains + 4 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 3u;
+        const unsigned v = __hip_atomic_load(A.flags + A.n_chains + 4 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xBu;   // (bit 3: mvmc_ik_pair.h's net)
         if (v) atomicOr(A.flags + A.n_chains + 2, v);
     }
     if (done != 0) return;   // (never: the phases write 0)

@@ -163,6 +163,22 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
         t += __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * r), __builtin_amdgcn_readlane(lo, 16 * r));
     return t;
 }
+// The same sum for a vector that vanishes on the lanes >= 16 ROWS: the row totals that are zeros are not fetched.  Bit-identical to
+// wave_sum_dpp (t = 0 + r0 + .. is never -0, and adding the zero rows changes nothing).
+template <int ROWS>
+__device__ __forceinline__ double wave_sum_rows(double v) {
+    static_assert(ROWS >= 1 && ROWS <= 4, "rows of 16 lanes");
+    v += dpp_mov<0x128>(v);  // row_ror:8
+    v += dpp_mov<0x124>(v);  // row_ror:4
+    v += dpp_mov<0x122>(v);  // row_ror:2
+    v += dpp_mov<0x121>(v);  // row_ror:1
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+        t += __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * r), __builtin_amdgcn_readlane(lo, 16 * r));
+    return t;
+}
 // A wave-uniform value as a scalar: the compiler keeps it in SGPRs from here on.  A value that VALU code computed (a wave
 // reduction, an LDS read) lives in a vector register per lane even when every lane holds the same number, and around a call to an
 // out-of-line function every live vector register is a 256-byte scratch store + load, where 64 live SGPRs share ONE.

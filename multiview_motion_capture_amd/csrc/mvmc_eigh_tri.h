@@ -197,10 +197,15 @@ __device__ inline void tridiag_regs(double (&a)[4][4], double (&rq)[4], double* 
 // multipliers of the first solve are kept in registers and replayed on the second right-hand side.
 // lmul, dinv, yb, zb are unused (kept for the signature); cout: LDS, the step's coefficients c = -y Delta/|p|.
 // Returns alpha; *pred = predicted reduction, *pnorm = |step| including the absorber's share.
-template <bool DUAL>
+// NMAX: an upper bound of n known at compile time (the model's row count).  Below 33 rows the sixth elimination round is an exact
+// no-op -- after round t the rows j < 2^t have no lower neighbour left and the rows j + 2^t >= n no upper one: both multipliers are
+// zeros -- and is dropped; the sums fetch only the rows of 16 lanes that can hold anything.  Same bits as NMAX = 64.
+template <bool DUAL, int NMAX = 64>
 __device__ inline double tr_solve_tri(const double* d, const double* e, const double* rh, int n, double Delta, double alpha0,
                                       double gg, double pivmin, double* lmul, double* dinv, double* yb, double* zb,
                                       double* cout, double* pred, double* pnorm) {
+    constexpr int ROUNDS = NMAX <= 32 ? 5 : 6;
+    auto wave_sum_dpp = [](double v) { return wave_sum_rows<(NMAX + 15) / 16>(v); };
     const int lane = threadIdx.x & 63;
     const bool on = lane < n;
     const double a2 = 1e-16 * gg;  // absorber weight squared: suf_abs = 1e-8 |g|
@@ -209,9 +214,9 @@ __device__ inline double tr_solve_tri(const double* d, const double* e, const do
     double yj, yy, yw, ww, rw, ry, yz, wz;
     auto evaluate = [&](double alpha, bool want_z) {
         double a = el, bq = on ? dj + alpha : 1.0, c = eu, r = rj;
-        double k1[6], k2[6];
+        double k1[ROUNDS], k2[ROUNDS];
 #pragma unroll
-        for (int t = 0; t < 6; ++t) {
+        for (int t = 0; t < ROUNDS; ++t) {
             const int sft = 1 << t;
             // (shuffles first, selections after: every lane must take part in the exchange)
             const bool lo_ok = lane >= sft, hi_ok = lane + sft < 64;
@@ -239,7 +244,7 @@ __device__ inline double tr_solve_tri(const double* d, const double* e, const do
         if (want_z) {
             double rz = yj;
 #pragma unroll
-            for (int t = 0; t < 6; ++t) {
+            for (int t = 0; t < ROUNDS; ++t) {
                 const int sft = 1 << t;
                 double rm = __shfl_up(rz, sft, 64), rp = __shfl_down(rz, sft, 64);
                 rm = lane >= sft ? rm : 0.0; rp = lane + sft < 64 ? rp : 0.0;

@@ -102,7 +102,11 @@ struct Ik1Shared {
     double Wk[NOBS * 6], tk[NOBS * 3];
     double sc[12];          // {|g|^2, |g|_inf, alpha, pred, beta0, tau0, |J^T J|_1, coupling, |step|, |x|, fallback rows}
     int nviews, mode3d;
-    int mq_off, mc_off;     // the member list, in bytes from the start of this struct: int32 pose index / uint16 camera per view
+    // the member list (int32 pose index / uint16 camera per view), in units of TWO bytes from the start of this struct (the lists lie
+    // behind the solve blocks of their arena: up to 78 KB away in the BIG layout)
+    unsigned short mq_off2, mc_off2;
+    // pairing word (mvmc_ik_pair.h): the even wave of a pair holds the pair's mailbox here, the odd wave its completion counter
+    int pairw;
 #ifdef MVMC_IK_PROFILE
     long long prof[8];
 #endif
@@ -115,8 +119,8 @@ struct Ik1Obs {
     const mvmc_gdouble* tg;      // this problem's 18 x {x, y, z, weight} targets, or NULL
 };
 // (derived from &S, which every out-of-line function declares to be LDS: the accesses stay ds_ instructions)
-__device__ __forceinline__ const int* ik1_mq(Ik1Shared& S) { return reinterpret_cast<const int*>(reinterpret_cast<const char*>(&S) + S.mq_off); }
-__device__ __forceinline__ const unsigned short* ik1_mc(Ik1Shared& S) { return reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(&S) + S.mc_off); }
+__device__ __forceinline__ const int* ik1_mq(Ik1Shared& S) { return reinterpret_cast<const int*>(reinterpret_cast<const char*>(&S) + 2 * (int)S.mq_off2); }
+__device__ __forceinline__ const unsigned short* ik1_mc(Ik1Shared& S) { return reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(&S) + 2 * (int)S.mc_off2); }
 
 __device__ __forceinline__ double wave_max64(double v) { return wave_max_dpp(v); }
 
@@ -462,8 +466,8 @@ __device__ __noinline__ void ik1_model_step(Ik1Shared& S, const Ik1Tables& T, in
         rh[lane] = lane == 0 ? beta0 : 0.0;
         MVMC_WAVE_SYNC();
         double pred, step_norm;
-        alpha = eightri::tr_solve_tri<false>(S.sv + SV_D, S.sv + SV_E, rh, kk, Delta, alpha, gg, pivmin, nullptr, nullptr, nullptr,
-                                             nullptr, cv, &pred, &step_norm);
+        alpha = eightri::tr_solve_tri<false, N>(S.sv + SV_D, S.sv + SV_E, rh, kk, Delta, alpha, gg, pivmin, nullptr, nullptr, nullptr,
+                                                nullptr, cv, &pred, &step_norm);
         MVMC_WAVE_SYNC();
         double c = lane < kk ? cv[lane] : 0.0;
         if (kk < na) {
@@ -503,6 +507,10 @@ __device__ __noinline__ void ik1_model_step(Ik1Shared& S, const Ik1Tables& T, in
 // code of ik1_model_step on the smaller matrix; the step is mapped back to Euler space before the trial point is formed.
 // *mode_out as ik1_model_step, plus 3 = a joint at gimbal lock (the closed-form null vectors need cos(e_y) != 0): not applicable.
 // ---------------------------------------------------------------------------------------------
+// (Round 6, measured: the LAST model of a truncated stage -- no evaluation left: 2 of a warm solve's 10 models -- is only asked for its
+// gradient, the test SciPy makes before it looks at the budget (trf.py:451-460).  An instance of this function without the matrix for
+// those calls, bit-identical and free of scratch: 550 k -> 535 k frames/s on the chain kernel, twice, with the IK phase 6 % LONGER per
+// chain.  Not kept; docs/design_measurement.md, "Round 6".)
 template <int N, int STAGE, bool DBG = false>
 __device__ __noinline__ void ik1_model_step_r(Ik1Shared& S, const Ik1Tables& T, bool budget_left, double gtol,
                                             mvmc_gdouble* __restrict__ hh, double Delta, double alpha, bool dump, int* mode_out) {
@@ -674,8 +682,8 @@ __device__ __noinline__ void ik1_model_step_r(Ik1Shared& S, const Ik1Tables& T, 
         rh[lane] = lane == 0 ? beta0 : 0.0;
         MVMC_WAVE_SYNC();
         double pred, step_norm;
-        alpha = eightri::tr_solve_tri<false>(S.sv + SV_D, S.sv + SV_E, rh, kk, Delta, alpha, gg, pivmin, nullptr, nullptr, nullptr,
-                                             nullptr, cv, &pred, &step_norm);
+        alpha = eightri::tr_solve_tri<false, N>(S.sv + SV_D, S.sv + SV_E, rh, kk, Delta, alpha, gg, pivmin, nullptr, nullptr, nullptr,
+                                                nullptr, cv, &pred, &step_norm);
         MVMC_WAVE_SYNC();
         double c = lane < kk ? cv[lane] : 0.0;
         if (kk < na) {
@@ -774,12 +782,39 @@ __device__ __noinline__ void ik1_retry_trial(Ik1Shared& S, const Ik1Tables& T, i
 }
 
 // ---------------------------------------------------------------------------------------------
+// Two stage-1 models on one wave (mvmc_ik_pair.h; the SMALL layout of the chain kernel defines MVMC_IK_PAIR): what every build needs
+// of it -- the pairing descriptor of a solve (dS = 0: not paired) and a wave's "away" bit.
+// ---------------------------------------------------------------------------------------------
+// bytes to the partner's solve block, doubles to its scratch, 0 / 1 = even / odd wave of the pair, the chain's void word (bit 3: a
+// meeting timed out -- a bug, not a capacity: the results are void)
+struct Ik1Pair { int dS, dhh, me; int32_t* ovf; };   // dS = 0: no pairing (every other kernel than the SMALL chain kernel)
+
+__device__ __forceinline__ int* ik1_pair_mailbox(Ik1Shared& S, const Ik1Pair& P) {
+    return &reinterpret_cast<Ik1Shared*>(reinterpret_cast<char*>(&S) + (P.me ? P.dS : 0))->pairw;
+}
+__device__ __forceinline__ int* ik1_pair_counter(Ik1Shared& S, const Ik1Pair& P) {
+    return &reinterpret_cast<Ik1Shared*>(reinterpret_cast<char*>(&S) + (P.me ? 0 : P.dS))->pairw;
+}
+// the wave's "away" bit (one lane acts for the wave)
+__device__ __forceinline__ void ik1_pair_away(Ik1Shared& S, const Ik1Pair& P, bool away) {
+    if (P.dS == 0) return;
+    if ((threadIdx.x & 63) == 0) {
+        int* C = ik1_pair_counter(S, P);
+        if (away) __hip_atomic_fetch_or(C, 1 << (16 + P.me), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_fetch_and(C, ~(1 << (16 + P.me)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+#ifdef MVMC_IK_PAIR
+#include "mvmc_ik_pair.h"
+#endif
+
+// ---------------------------------------------------------------------------------------------
 // trf_no_bounds (trf.py:401-560) with x_scale = 1, linear loss, ftol = xtol = gtol = 1e-8 -- the loop of ik_trf
 // on one wave.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void ik1_trf(Ik1Shared& S, const Ik1Tables& T, int stage, int max_nfev, mvmc_gdouble* __restrict__ hh,
                                         double* cost_out, int* nfev_out, int* njev_out, int* status_out, int* fallbacks_out, bool& dump,
-                                        bool& fk_at_x, const Ik1Obs& O) {
+                                        bool& fk_at_x, const Ik1Obs& O, const Ik1Pair& pair) {
     const int lane = threadIdx.x & 63;
     // wave-uniform state is pinned to scalar registers (uni)
     const int nfull = uni((stage == 0) ? 57 : 57 + T.n_side);
@@ -789,13 +824,24 @@ __device__ __forceinline__ void ik1_trf(Ik1Shared& S, const Ik1Tables& T, int st
     // joint sits at gimbal lock (mode 3, decided before anything is touched): then the Euler-space model.  A solve stays with its
     // choice while it can: a rebuilt model (first rejected trial) asks again and gets the same answer from the same FK state.
     bool reduced = false;
-    auto model_step = [&](bool budget_left, double Delta, double alpha, bool dump) {
+    auto model_step = [&](bool budget_left, double Delta, double alpha, bool dump, bool may_pair) {
         // (the result comes back through the caller's stack on purpose: a call that is handed a pointer into its caller's frame is not
         // marked as a tail-call candidate, and only then does the compiler drop the callee-saved convention for this local function --
         // with it, the function's prologue saved and restored 58 vector registers that its caller does not even use)
         int mode = 3;
         if (uni(T.arrow_ok)) {
-            if (stage == 0) ik1_model_step_r<30, 0>(S, T, budget_left, gtol, hh, Delta, alpha, dump, &mode);
+            if (stage == 0) {
+                int code = -1;
+#ifdef MVMC_IK_PAIR
+                // a stage-1 model with evaluations left: together with the partner wave's, if it is at the same point (mvmc_ik_pair.h)
+                if (pair.dS != 0 && may_pair && budget_left) { ik1_pair_sync(S, T, gtol, hh, Delta, alpha, dump, pair.dS, pair.dhh, pair.me, pair.ovf, &code); code = uni(code); }
+#endif
+#ifdef MVMC_PAIR_STATS   // diagnostic build (tools/pair_stats.py): meetings by outcome instead of the fallback count
+                if (pair.dS != 0 && may_pair && budget_left) *fallbacks_out += code == 1 ? 1 : code == 2 ? 100 : 10000;
+#endif
+                if (code >= 1) mode = 1;
+                else ik1_model_step_r<30, 0>(S, T, budget_left, gtol, hh, Delta, alpha, dump, &mode);
+            }
             else ik1_model_step_r<40, 1>(S, T, budget_left, gtol, hh, Delta, alpha, dump, &mode);
         }
         reduced = uni(mode) != 3;
@@ -817,10 +863,12 @@ __device__ __forceinline__ void ik1_trf(Ik1Shared& S, const Ik1Tables& T, int st
     }
     if (Delta == 0.0) Delta = 1.0;
     double alpha = 0.0;
+    if (stage == 0) ik1_pair_away(S, pair, false);   // this wave comes to the pair's meetings from here on
     while (true) {
         // the model at x (whose FK state and blocks are in LDS) and, unless it stops the iteration, the first trial from it
         int mode;
-        { P1_T0 mode = model_step(nfev < max_nfev, Delta, alpha, dump); P1_ADD(2) }
+        if (stage == 0 && !(nfev < max_nfev)) ik1_pair_away(S, pair, true);   // (the last model of the stage is the gradient only: not paired)
+        { P1_T0 mode = model_step(nfev < max_nfev, Delta, alpha, dump, true); P1_ADD(2) }
         bool dumped = dump;   // are this model's reflectors in the global scratch?
         ++njev;
         if (uni(S.sc[1]) < gtol) status = 1;
@@ -845,7 +893,7 @@ __device__ __forceinline__ void ik1_trf(Ik1Shared& S, const Ik1Tables& T, int st
                     // the launch's 2.3 GB of writes come from; left as it was)
                     dump = dumped = true;
                     ik1_eval_nl(S, T, 0, stage, true, O.kps17, O.Pm, O.tg);
-                    model_step(true, Delta, alpha, true);
+                    model_step(true, Delta, alpha, true, false);
                 }
             }
             have_trial = false;
@@ -879,6 +927,7 @@ __device__ __forceinline__ void ik1_trf(Ik1Shared& S, const Ik1Tables& T, int st
         // the accepted point's FK state and blocks are still in LDS (the last evaluation was at xn)
         if (!(status == -1 && nfev < max_nfev)) break;
     }
+    if (stage == 0) ik1_pair_away(S, pair, true);
     if (status == -1) status = 0;
     *cost_out = cost; *nfev_out = nfev; *njev_out = njev; *status_out = status;
 }
@@ -1106,7 +1155,7 @@ __device__ __forceinline__ void ik1_solve(Ik1Shared& S, int* mq, unsigned short*
                                           int nfev_cold, int nfev_warm, double* __restrict__ params_out,
                                           double* __restrict__ joints_out, double* __restrict__ info_out,
                                           double* __restrict__ scratch, int stage_mask, const double* __restrict__ targets3d,
-                                          int32_t* ovf = nullptr, int n_valid = -1) {
+                                          int32_t* ovf = nullptr, int n_valid = -1, int pair_dS = 0, int pair_dhh = 0, int pair_me = 0) {
     const int lane = threadIdx.x & 63;
     b = uni(b);
     mvmc_gdouble* hh = uni((mvmc_gdouble*)(scratch + (size_t)b * MVMC_IK_SCRATCH_DOUBLES));   // Householder vectors [0, 3200), eigenvectors [3200, 6400)
@@ -1114,8 +1163,8 @@ __device__ __forceinline__ void ik1_solve(Ik1Shared& S, int* mq, unsigned short*
     const Ik1Obs O = {(const mvmc_gdouble*)kps17, (const mvmc_gdouble*)Pmats,
                       targets3d ? (const mvmc_gdouble*)(targets3d + (size_t)b * 72) : nullptr};
     if (lane == 0) {
-        S.mq_off = (int)(reinterpret_cast<char*>(mq) - reinterpret_cast<char*>(&S));
-        S.mc_off = (int)(reinterpret_cast<char*>(mc) - reinterpret_cast<char*>(&S));
+        S.mq_off2 = (unsigned short)((reinterpret_cast<char*>(mq) - reinterpret_cast<char*>(&S)) >> 1);
+        S.mc_off2 = (unsigned short)((reinterpret_cast<char*>(mc) - reinterpret_cast<char*>(&S)) >> 1);
     }
     // views of this problem (the reference only solves clusters with >= 2 views: motion_capture.py:927,940)
     if (targets3d == nullptr) {
@@ -1159,6 +1208,7 @@ __device__ __forceinline__ void ik1_solve(Ik1Shared& S, int* mq, unsigned short*
     MVMC_WAVE_SYNC();
 #endif
     const int max_nfev = uni(is_cold ? nfev_cold : nfev_warm);
+    const Ik1Pair pair = {(targets3d || !uni(T.arrow_ok)) ? 0 : uni(pair_dS), uni(pair_dhh), uni(pair_me), uni(ovf)};
     double costs[2];
     int nfs[2], njs[2], sts[2], fallbacks = 0;
     bool dump = false, fk_final = false;   // fk_final: the FK state in LDS is that of the solution with stage-2 lengths
@@ -1167,7 +1217,7 @@ __device__ __forceinline__ void ik1_solve(Ik1Shared& S, int* mq, unsigned short*
         double c = 0.0; int nf = 0, nj = 0, st = 0;
         if ((stage_mask >> stage) & 1) {
             bool at_x = false;
-            ik1_trf(S, T, stage, max_nfev, hh, &c, &nf, &nj, &st, &fallbacks, dump, at_x, O);
+            ik1_trf(S, T, stage, max_nfev, hh, &c, &nf, &nj, &st, &fallbacks, dump, at_x, O, pair);
             fk_final = at_x && stage == 1;
         }
         costs[stage] = c; nfs[stage] = nf; njs[stage] = nj; sts[stage] = st;
@@ -1229,8 +1279,8 @@ ik1_step_kernel(SkelDev skarg, const double* __restrict__ kps17, const double* _
     unsigned short* mc = reinterpret_cast<unsigned short*>(ik1_members + vcap);
     const Ik1Obs O = {(const mvmc_gdouble*)kps17, (const mvmc_gdouble*)Pmats, nullptr};
     if (lane == 0) {
-        S.mq_off = (int)(reinterpret_cast<char*>(mq) - reinterpret_cast<char*>(&S));
-        S.mc_off = (int)(reinterpret_cast<char*>(mc) - reinterpret_cast<char*>(&S));
+        S.mq_off2 = (unsigned short)((reinterpret_cast<char*>(mq) - reinterpret_cast<char*>(&S)) >> 1);
+        S.mc_off2 = (unsigned short)((reinterpret_cast<char*>(mc) - reinterpret_cast<char*>(&S)) >> 1);
     }
     const int nv = ik1_rank_members(mq, mc, vcap, members, b, V, nullptr, -1, C, Pmax);
     if (nv < 2) { if (lane == 0) o[6] = -1.0; return; }

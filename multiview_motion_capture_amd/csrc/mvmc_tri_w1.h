@@ -46,6 +46,9 @@ __device__ __forceinline__ int tridiag_krylov_w1(double (&a)[N], double gj, int 
                                                  long long* tprof = nullptr) {
     static_assert(N % 2 == 0 && N <= 50, "row count");
     const int lane = threadIdx.x & 63;
+    // (Round 6, bit-identical and measured on the chain kernel: the two sums of a step over the rows of 16 lanes that can hold anything
+    // -- wave_sum_rows<(N + 15) / 16> -- take four instructions off each reduction, and the 40-row model then carries 79 scratch loads
+    // instead of 60: 550 k -> 540 k frames/s.  The full-wave sum stays here; apply_q_packed below takes the short one.)
     auto wave_max = [](double v) { return wave_max_dpp(v); };
     auto lane_value = [](double v, int src) {  // v of lane src (uniform) as a scalar
         return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
@@ -252,6 +255,7 @@ __device__ __forceinline__ double apply_q_packed(const double (&pk)[(N - 2) / 2]
                                                  int kk, int n, double cj) {
     constexpr int H = (N - 2) / 2;
     const int lane = threadIdx.x & 63;
+    auto wave_sum_dpp = [](double v) { return wave_sum_rows<(N + 15) / 16>(v); };   // (v vanishes on the lanes >= n; same bits)
     auto lane_value = [](double v, int src) {
         return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
     };

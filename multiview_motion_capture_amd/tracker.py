@@ -419,6 +419,8 @@ def check_chain_flags(res) -> None:
         raise RuntimeError("mvmc_chain_run: a hand-over between the workgroups of a chain timed out; results are void")
     void = res["flags"][B + 4:2 * B + 4]
     ov = int(void.max()) if B else 0
+    if ov & 8:
+        raise RuntimeError("mvmc_chain_run: a meeting of two IK waves timed out (mvmc_ik_pair.h); results are void")
     if ov & 4:
         raise ValueError("mvmc_chain_run: a frame's graph has more nodes than the chain kernel's layout supports (small layout: 24 "
                          "without, 32 with tracklets); repair_chains / run_chains take such data")
@@ -439,6 +441,8 @@ def repair_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor]
     fl = res["flags"][B:B + 4].cpu().tolist()
     if fl[0]:
         raise RuntimeError("mvmc_chain_run: a hand-over between the workgroups of a chain timed out; results are void")
+    if fl[2] & 8:
+        raise RuntimeError("mvmc_chain_run: a meeting of two IK waves timed out (mvmc_ik_pair.h); results are void")
     if not (fl[1] or fl[2]):
         return 0
     idx = torch.nonzero(res["void"]).flatten()
