@@ -186,15 +186,15 @@ def als_histogram(iters) -> dict:
 
 
 def kernel_sources_sha() -> str:
-    """Hash of the HIP sources the library is built from (stamps profiles/pmc_traffic.json records)."""
-    import hashlib
-    src = os.path.join(ROOT, "multiview_motion_capture_amd", "csrc")
-    h = hashlib.sha256()
-    for name in sorted(os.listdir(src)):
-        if name.endswith((".hip", ".h")):
-            h.update(name.encode())
-            h.update(open(os.path.join(src, name), "rb").read())
-    return h.hexdigest()[:16]
+    """Hash of the HIP sources the library is built from (stamps profiles/pmc_traffic.json records; the same hash
+    lib/BUILD_INFO.json carries and _cabi.load() checks)."""
+    from multiview_motion_capture_amd import _buildinfo
+    return _buildinfo.sources_sha()
+
+
+def _cabi_build_info():
+    from multiview_motion_capture_amd import _cabi
+    return _cabi.build_info()
 
 
 def launch_ranks(n: int) -> int:
@@ -394,9 +394,6 @@ def main():
                     help="fused path: 'big' = the chain kernel's 512-thread layout (80-node graphs, 16 tracklet slots) also for views x people "
                          "<= 40 -- for geometries whose crowded frames exceed the SMALL layout's 32-node graphs (5 x 6 with everybody in view), "
                          "which otherwise go through the repair tier chain by chain")
-    ap.add_argument("--big-split", action="store_true",
-                    help="C8 P8 sizes (config 5) only, an experiment: association and IK as two co-resident persistent kernels "
-                         "(csrc/mvmc_chain_split.h) instead of one 512-thread workgroup per chain-frame; bit-identical results")
     ap.add_argument("--dlt-out", default="f32", choices=["f32", "f64"],
                     help="--workload dlt: dtype of the triangulated points the one-pass kernel stores (float32 = SURVEY 8(d)'s I/O, one "
                          "16-byte store per point; float64 = mvmc_ingest_dlt's output, 32 bytes per point)")
@@ -409,12 +406,6 @@ def main():
     if args.other_configs is None:
         args.other_configs = (args.workload == "full" and (args.frames, args.views, args.people) == (10000, 5, 4)
                               and args.occlusion == 0.0 and args.path == "fused")
-    if args.big_split and args.overlap is None:
-        # the split path's two kernels must be co-resident: they need hardware queues of their own, and HIP multiplexes a process's
-        # streams onto a few of them -- with two steps in flight (four kernels, two side streams, the communication streams) two kernels
-        # that wait for each other can land in ONE queue, in order, and the bounded hand-over wait times out (a loud failure, seen with
-        # MVMC_SPLIT_A=240 MVMC_SPLIT_B=304).  One step at a time keeps it to two queues.
-        args.overlap = 1
     if args.overlap is None:
         # steps in flight fill the tail of the chain kernel's launches; the memory-bound triangulation-only pass (config 2) has no
         # such tail, and overlapped launches would only make each of them last longer.  Three since round 5 on the SMALL layout (four
@@ -555,7 +546,7 @@ def run_workload(args, rank, world, d):
                 kev = []
                 out = run_chains_fused(hp, kps, counts, L, nfev_cold=args.nfev_cold, nfev_warm=args.nfev_warm, want_info=timed,
                                        parts=args.parts or None, kernel_events=kev,
-                                       hand_over=None if args.hand_over == "auto" else args.hand_over, split=args.big_split,
+                                       hand_over=None if args.hand_over == "auto" else args.hand_over,
                                        force_big=args.layout == "big")
                 kern_events.append((timed, kev[0][0], kev[0][1]))
             else:
@@ -926,9 +917,11 @@ def run_workload(args, rank, world, d):
                        "frames_per_gpu": F, "views": C, "people": Pn, "chain_len": L, "seed": args.seed, "parallelism": f"frames x{world}",
                        "steps_in_flight": args.overlap, "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "occlusion": args.occlusion, "spurious": args.spurious,
-                       **({"big_split": True} if args.big_split else {}),
                        **({"tiled_from_frames": F_gen} if F_gen != F else {}),
                        **({"points_stored_as": args.dlt_out} if args.workload == "dlt" else {}), **extra},
+            # what the measured library was built from (lib/BUILD_INFO.json; _cabi.load() has already refused a library whose
+            # kernel-source hash is not this tree's); an MVMC_LIB_PATH library is an A/B partner and says so
+            "build": (_cabi_build_info() or {"library": os.environ.get("MVMC_LIB_PATH"), "note": "MVMC_LIB_PATH: not the tree's build"}),
             "sustained": sustained,
             "host_io": host_io,
             "collective": collective,

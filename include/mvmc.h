@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVMC_ABI_VERSION 5
+#define MVMC_ABI_VERSION 6
 
 enum {
     MVMC_OK = 0,
@@ -355,10 +355,14 @@ int mvmc_debug_ik_solve_fd(const mvmcSkeleton* skel_host, const double* kps17, c
  * mvmc_track_commit issued frame by frame, and the same results.  Chain b owns frames [b chain_len, (b+1) chain_len).
  * All pointers are device memory owned by the caller (N = n_views p_max, NS = t_max + N, NP = t_max + k_max,
  * B = n_chains, F = B chain_len).  Two LDS layouts (MVMC_ERR_UNSUPPORTED outside them: use the per-stage entry points), both with
- * p_max <= 8, t_max <= 8, NP <= 64, v_max <= 64:
- *   small  N <= 40, NS <= 48 (configs 1-4; three workgroups per CU); every frame's actual graph must have <= 24 nodes without
- *          tracklets and <= 32 with them, and the frame <= 24 poses in clusters (the IK phase's view pool) -- checked on the device;
- *   big    N <= 64, NS <= 72 (config 5, C8 P8; one 512-thread workgroup per CU); every graph of those sizes fits.
+ * n_views <= 16, p_max <= 8, NP <= 64, v_max <= 64:
+ *   small  N <= 40, NS <= 48, max(t_max, p_max) <= 8 (its association variants hold rank 16) (configs 1-4; 128 VGPRs, four
+ *          workgroups per CU; launches of at most two workgroups per CU run the 256-VGPR build of the same kernel); every frame's
+ *          actual graph must have <= 24 nodes without tracklets and <= 32 with them, and the frame <= 24 poses in clusters (the IK
+ *          phase's view pool) -- checked on the device;
+ *   big    N <= 64, NS <= 80, t_max <= 16 (config 5, C8 P8; one 512-thread workgroup per CU; also taken with force_big): graphs of
+ *          up to 72 nodes and rank 16 on the fast association variant, up to 80 nodes and rank 32 (sixteen live tracklets) on the
+ *          generic one inside the same workgroup: every graph of those sizes fits.
  * Capacities the reference does not have (motion_capture.py:417-446, :763-808 accept any cluster size and any number of clusters and
  * tracklets): with k_max >= N / 2 (a new tracklet needs two poses) and v_max >= min(N, 64) (clusters are disjoint sets of the
  * frame's poses; the view blocks of a frame's IK problems share one pool, so a cluster may be as large as the frame) neither a
@@ -424,15 +428,12 @@ typedef struct mvmcChainBuffers {
                                    flags[B] != 0 = a workgroup timed out waiting for its predecessor, flags[B + 1] != 0 = a graph was
                                    too large for the kernel's ALS variant, flags[B + 2] != 0 = a capacity was exceeded in some chain
                                    (bit 0: a cluster, a member or a view block dropped, bit 1: more than t_max tracklets),
-                                   flags[B + 4 + b] = the void word of chain b (bits 0, 1 as before, bit 2 = graph too large): a
+                                   flags[B + 4 + b] = the void word of chain b (bits 0, 1 as before, bit 2 = graph too large, bit 3 =
+                                   internal: a meeting of two IK waves timed out, builds with -DMVMC_WITH_IK_PAIR only): a
                                    non-zero word voids the chain's results (all chains' after a time-out); from 2 B + 4 on: the
                                    ticket counter (hand_over 1, 2), the ready queue's tail and ring (hand_over == 1) */
     double* out_phase_cycles;   /* (B,8) diagnostic: shader cycles of each chain by phase {graph, ALS, assignment, IK, commit,
                                    outputs, whole chain, 0}, or NULL */
-    double* wsym;               /* (B, 72 * 74) f64 workspace or NULL.  With it, C8 P8 sizes (views x people > 40) run as TWO co-resident
-                                   persistent kernels -- graph + association + assignment of one chain-frame beside the IK + commit of
-                                   another on the same CU (csrc/mvmc_chain_split.h) -- instead of one 512-thread workgroup per CU;
-                                   same results bit for bit.  NULL, force_big == 2 or MVMC_BIG_SPLIT=0: the one-kernel path */
 } mvmcChainBuffers;
 int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuffers* buffers, mvmcStream_t stream);
 

@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get("MVMC_LIB_PATH") or os.path.join(os.path.dirname(os.p
 _lib = None
 
 MVMC_OK = 0
-MVMC_ABI = 5    # MVMC_ABI_VERSION of include/mvmc.h that the argument types in load() describe
+MVMC_ABI = 6    # MVMC_ABI_VERSION of include/mvmc.h that the argument types in load() describe
 MVMC_F32, MVMC_F64 = 0, 1
 N_PARAM = 68
 MAX_NODES = 80
@@ -45,7 +45,7 @@ class MvmcChainBuffers(C.Structure):
     _PTRS = ("kps17", "counts", "Pmats", "Fmats", "F2", "seed_table", "params", "joints", "meta", "n_tracks", "next_id",
              "n_dead", "slot_src", "S_sp", "W_st", "group_counts", "labels_sp", "labels_st", "n_clusters_sp", "n_clusters_st",
              "iters_sp", "iters_st", "members", "n_members", "cold", "init", "status", "n_new", "ik_params", "ik_joints", "ik_info",
-             "ik_scratch", "out_params", "out_joints", "out_meta", "out_n_tracks", "out_info", "out_als_iters", "flags", "out_phase_cycles", "wsym")
+             "ik_scratch", "out_params", "out_joints", "out_meta", "out_n_tracks", "out_info", "out_als_iters", "flags", "out_phase_cycles")
     _fields_ = [(n, C.c_int32) for n in _INTS] + [(n, C.c_void_p) for n in _PTRS]
 
 
@@ -57,6 +57,14 @@ def lib_path() -> str:
     return _LIB_PATH
 
 
+def build_info():
+    """lib/BUILD_INFO.json of the shipped library (kernel-source hash, compiler, host, time), or None for an MVMC_LIB_PATH library."""
+    if os.environ.get("MVMC_LIB_PATH"):
+        return None
+    from . import _buildinfo
+    return _buildinfo.read()
+
+
 def load():
     """Load libmvmc_hip.so (once) and declare the argument types."""
     global _lib
@@ -66,6 +74,16 @@ def load():
         raise MvmcError(
             f"HIP extension not built: {_LIB_PATH} is missing. There is no CPU fallback; "
             "run __graft_entry__.build() (or make -C multiview_motion_capture_amd/csrc).")
+    if not os.environ.get("MVMC_LIB_PATH"):
+        # the shipped library must be a build of THIS tree's kernel sources (lib/BUILD_INFO.json, written by csrc/Makefile): a stale
+        # .so -- built before an edit, or carried to the GPU box from another checkout -- would be measured and tested in place of the
+        # code under review.  (A library named through MVMC_LIB_PATH is a deliberate A/B partner and is not checked.)
+        from . import _buildinfo
+        info, want = _buildinfo.read(), _buildinfo.sources_sha()
+        if info is None or info.get("kernel_sources_sha") != want:
+            have = "no BUILD_INFO.json beside it" if info is None else f"built from kernel sources {info.get('kernel_sources_sha')}"
+            raise MvmcError(f"{_LIB_PATH} is stale: {have}, the tree's are {want}.  Rebuild it: python -c \"import __graft_entry__ as g; "
+                            "g.build()\" (or make -C multiview_motion_capture_amd/csrc)")
     lib = C.CDLL(_LIB_PATH)
     # The argument types declared below are those of ABI version MVMC_ABI: a library of another version (an old build loaded through
     # MVMC_LIB_PATH for an A/B run, a stale .so) would receive shifted pointers and ints -- device faults or silent garbage.  Refuse it.

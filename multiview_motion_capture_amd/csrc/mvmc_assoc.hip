@@ -1700,9 +1700,10 @@ als4_kernel(const TW* __restrict__ W, const int32_t* __restrict__ gcounts, int G
 // (Tried: the fifth column block -- half empty at n = 72 -- split over the k range on the waves 4 .. 6 so that no SIMD carries two
 // full chains: 93.0 k -> 90.7 k frames/s; the solver wave's pivots are the critical path, and more matrix work beside them slows them.)
 // ------------------------------------------------------------------------------------------------
-// WLDS = false (the split BIG path, mvmc_chain_assoc.hip): the symmetrised affinity lives in a per-graph GLOBAL buffer (NMAX * LD doubles,
-// L2-resident: one 12-double tile read per thread and iteration) instead of LDS -- 42.6 KB less, which is what lets an association
-// workgroup and a solver workgroup share a CU's 160 KB.  Same values, same arithmetic: bit-identical results.
+// WLDS = false: the symmetrised affinity in a per-graph GLOBAL buffer (NMAX * LD doubles, L2-resident: one 12-double tile read per thread
+// and iteration) instead of LDS -- 42.6 KB less.  Same values, same arithmetic.  It was what let an association workgroup and a solver
+// workgroup share a CU in round 5's two-kernel form of the BIG chain kernel (+ 7 - 10 %, retired in round 6: DESIGN.md section 9); no
+// kernel instantiates it now.
 template <int NMAX, bool WLDS = true>
 struct Als5Lds {
     // Row strides chosen against LDS bank conflicts (64 banks of 4 bytes): the matrices are walked by rows 3 or 4 apart (the tiles),

@@ -85,7 +85,6 @@ struct MvmcChainArgs {
     double* out_info;         // (F,NP,8) or NULL
     int32_t* out_iters;       // (F) ALS iterations of the frame's graph, or NULL
     double* out_cycles;       // (B,8) shader cycles by phase {graph, ALS, assign, IK, commit, outputs, total}, or NULL
-    double* wsym;             // (B, MVMC_WSYM_DOUBLES) the association's symmetrised affinity (split BIG path, mvmc_chain_split.h), or NULL
     int parts;                // workgroups per chain (consecutive frame ranges, handed over through flags)
     int queue;                // 0: workgroup (part, chain) = block index (part * n_chains + chain), a part waits for its chain's flag;
                               // 1: a workgroup draws a ticket when it starts and takes the chain that has been ready longest;
@@ -96,7 +95,6 @@ struct MvmcChainArgs {
                               // [2B+6 ...) ready ring of B * (parts - 1) entries (queue mode).  Zeroed by the launcher
 };
 
-constexpr int MVMC_WSYM_DOUBLES = 72 * 74;   // Als5Lds<72>'s W block (row stride 74)
 
 namespace {
 
@@ -500,17 +498,12 @@ chain_kernel(Ik1Tables tables_arg, ChainArgs A_by_value) {
 // budget from the loosest kernel that reaches them, so in one unit the BIG kernel (one workgroup per CU, 512 VGPRs) let them grow to
 // 248 VGPRs and dropped the SMALL kernel from three workgroups per CU to one (measured: 370 k -> 167 k frames/s on config 4).
 int mvmc_chain_launch_big(const void* tables_host, const MvmcChainArgs& A, int n_blocks, hipStream_t stream);   // (Ik1Tables: a type of each unit)
-// the split BIG path (mvmc_chain_split.h): kernel A and kernel B, each in its own unit
-int mvmc_chain_launch_assoc(const MvmcChainArgs& A, int n_blocks, hipStream_t stream);
-int mvmc_chain_launch_solve(const void* tables_host, const MvmcChainArgs& A, int n_blocks, hipStream_t stream);
 
 // the SMALL layout built for 256 VGPRs (two workgroups per CU, mvmc_chain_lat.hip): what a launch of few workgroups runs -- a frame at
 // a time through MvTracker.update_4d, short sequences --, where one chain's latency counts and the other workgroup slots stay empty anyway
 int mvmc_chain_launch_small_lat(const void* tables_host, const MvmcChainArgs& A, int n_blocks, hipStream_t stream);
 
-#if defined(MVMC_CHAIN_SPLIT_TU)
-// (mvmc_chain_assoc.hip / mvmc_chain_solve.hip define their kernel and its launcher after including this file)
-#elif defined(MVMC_CHAIN_LAT_TU)
+#if defined(MVMC_CHAIN_LAT_TU)
 int mvmc_chain_launch_small_lat(const void* tables_host, const MvmcChainArgs& A, int n_blocks, hipStream_t stream) {
     static_assert(MVMC_SMALL_WPS == 2, "the latency build: 256 VGPRs, two workgroups per CU");
     hipLaunchKernelGGL(chain_kernel<false>, dim3(n_blocks), dim3(256), sizeof(ChainArena<false>), stream, *static_cast<const Ik1Tables*>(tables_host), A);
@@ -529,28 +522,6 @@ int mvmc_chain_launch_big(const void* tables_host, const MvmcChainArgs& A, int n
     return MVMC_OK;
 }
 #else
-// Side streams of the split BIG path: created once per (device, slot) and never destroyed; the slot comes from the caller's stream
-// handle, so that two callers' streams (bench.py keeps two steps in flight) do not queue their B kernels behind one another.
-#include <mutex>
-static std::mutex g_side_mutex;
-static hipStream_t g_side_stream[16][4];
-static hipEvent_t g_side_event[16][4];
-static int chain_side_slot(hipStream_t s) { return (int)((((unsigned long long)(size_t)s) >> 6) % 4u); }
-static hipStream_t chain_side_stream(int dev, hipStream_t s) {
-    if (dev < 0 || dev >= 16) return nullptr;
-    std::lock_guard<std::mutex> lock(g_side_mutex);
-    hipStream_t& q = g_side_stream[dev][chain_side_slot(s)];
-    if (!q && hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) q = nullptr;
-    return q;
-}
-static hipEvent_t chain_side_event(int dev, hipStream_t s) {
-    if (dev < 0 || dev >= 16) return nullptr;
-    std::lock_guard<std::mutex> lock(g_side_mutex);
-    hipEvent_t& e = g_side_event[dev][chain_side_slot(s)];
-    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
-    return e;
-}
-
 extern "C" int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuffers* buf, mvmcStream_t stream) {
     if (!skel_host || !buf) return MVMC_ERR_ARG;
     const mvmcChainBuffers& B = *buf;
@@ -590,7 +561,7 @@ extern "C" int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuff
     A.members = B.members; A.n_members = B.n_members; A.cold = B.cold; A.init = B.init; A.status = B.status;
     A.n_new = B.n_new; A.ik_params = B.ik_params; A.ik_joints = B.ik_joints; A.ik_info = B.ik_info; A.ik_scratch = B.ik_scratch;
     A.out_params = B.out_params; A.out_joints = B.out_joints; A.out_meta = B.out_meta; A.out_n = B.out_n_tracks;
-    A.out_info = B.out_info; A.out_iters = B.out_als_iters; A.out_cycles = B.out_phase_cycles; A.wsym = B.wsym;
+    A.out_info = B.out_info; A.out_iters = B.out_als_iters; A.out_cycles = B.out_phase_cycles;
     A.parts = B.n_parts > 1 ? B.n_parts : 1;
     if (A.parts > 1 && B.chain_len % A.parts != 0) return MVMC_ERR_ARG;
     if (B.hand_over < 0 || B.hand_over > 2) return MVMC_ERR_ARG;
@@ -601,41 +572,8 @@ extern "C" int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuff
         return MVMC_ERR_LAUNCH;
     Ik1Tables tables_host;   // the skeleton's tables: once per call, on the host, a kernel argument of the launch
     ik1_build_tables_host(tables_host, sk);
-    if (!small) {
-        // The split path (two co-resident persistent kernels, mvmc_chain_split.h) where the caller provides its workspace and the
-        // tables fit its wide association variant (rank <= 20: ten tracklet slots in use at most -- beyond, the chain's void word);
-        // MVMC_BIG_SPLIT=0 or force_big = 2 keep the one-kernel path.
-        static const bool split_off = getenv("MVMC_BIG_SPLIT") && atoi(getenv("MVMC_BIG_SPLIT")) == 0;
-        if (A.wsym && !split_off && B.force_big != 2 && B.n_chains * B.chain_len >= 2) {
-            int dev = 0, cus = 256;
-            if (hipGetDevice(&dev) == hipSuccess) {
-                int v = 0;
-                if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-            }
-            const long long n_tasks = (long long)B.n_chains * B.chain_len;
-            // Grid sizes.  A CU holds one A workgroup (LDS) with ONE B workgroup beside it (registers), or THREE B workgroups alone; a
-            // frame's eight solves take two rounds on B's four waves, so B is the longer stage (76 M against 67 M cycles per chain):
-            // with a_wgs < CUs the A-less CUs fill up with B workgroups and the two stages balance (tasks go by ticket either way).
-            static const int a_env = getenv("MVMC_SPLIT_A") ? atoi(getenv("MVMC_SPLIT_A")) : 0;
-            static const int b_env = getenv("MVMC_SPLIT_B") ? atoi(getenv("MVMC_SPLIT_B")) : 0;
-            int a_wgs = a_env > 0 ? a_env : cus, b_wgs = b_env > 0 ? b_env : cus + 3 * (cus - a_wgs);
-            if (a_wgs > n_tasks) a_wgs = (int)n_tasks;
-            if (b_wgs > n_tasks) b_wgs = (int)n_tasks;
-            hipStream_t side = chain_side_stream(dev, (hipStream_t)stream);
-            hipEvent_t ev = chain_side_event(dev, (hipStream_t)stream);
-            if (!side || !ev) return MVMC_ERR_LAUNCH;
-            // B on a side stream behind everything queued on the caller's stream (the flags' memset included), A on the caller's stream;
-            // the caller's stream then waits for B: to the caller it is one asynchronous call
-            if (hipEventRecord(ev, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(side, ev, 0) != hipSuccess) return MVMC_ERR_LAUNCH;
-            int st = mvmc_chain_launch_assoc(A, a_wgs, (hipStream_t)stream);
-            if (st != MVMC_OK) return st;
-            st = mvmc_chain_launch_solve(&tables_host, A, b_wgs, side);
-            if (st != MVMC_OK) return st;
-            if (hipEventRecord(ev, side) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, ev, 0) != hipSuccess) return MVMC_ERR_LAUNCH;
-            return MVMC_OK;
-        }
+    if (!small)
         return mvmc_chain_launch_big(&tables_host, A, B.n_chains * A.parts, (hipStream_t)stream);
-    }
     {
         // Few workgroups (a frame at a time, short sequences): the 256-register build of the same kernel (mvmc_chain_lat.hip) -- a
         // frame's dependent chain is ~10 % shorter with the larger batches and fewer spills of that build, and with at most two

@@ -138,7 +138,7 @@ class ChainTracker:
         w = self._fused
         t = dict(w, kps17=kps17, counts=counts, Pmats=self.hp.P, Fmats=self.hp.F, F2=self.F2, params=self.params,
                  joints=self.joints, meta=self.meta, n_tracks=self.n_tracks, next_id=self.next_id, n_dead=self.n_dead,
-                 slot_src=self.slot_src, out_info=None, out_als_iters=None, out_phase_cycles=None, wsym=None)
+                 slot_src=self.slot_src, out_info=None, out_als_iters=None, out_phase_cycles=None)
         buf = _cabi.MvmcChainBuffers()
         for name, val in dict(n_chains=B, chain_len=1, n_views=Cn, p_max=P, t_max=T, k_max=K, v_max=V,
                               max_nfev_cold=self.nfev_cold, max_nfev_warm=self.nfev_warm, n_inits=3,
@@ -315,7 +315,7 @@ def run_chains(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], c
 def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tensor], chain_len: int, t_max: Optional[int] = None,
                      nfev_cold=50, nfev_warm=5, want_info=False, k_max: Optional[int] = None, v_max: Optional[int] = None,
                      parts: Optional[int] = None, kernel_events: Optional[list] = None, force_big: bool = False,
-                     hand_over: Optional[str] = None, split: bool = False):
+                     hand_over: Optional[str] = None):
     """run_chains in ONE launch (mvmc_chain_run): a persistent workgroup per chain runs graph -> ALS -> assignment ->
     IK -> commit for the chain's frames, so every chain advances at its own pace instead of waiting, stage by stage,
     for the slowest member of every launch.  Same device code and the same results as run_chains.
@@ -326,10 +326,7 @@ def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tens
     hand_over: "ticket" (default: a workgroup draws a ticket when it starts, ticket = part * n_chains + chain; a part's predecessor
     holds a lower ticket, so it has started: no assumption about the order of dispatch), "static" (the same mapping by block index:
     relies on in-order dispatch, bounded wait) or "queue" (ready queue: a freed slot goes to the chain that has been ready longest;
-    no assumption either, ~3 % slower).  Same results bit for bit.
-    split (C8 P8 sizes only; an experiment, off by default): True = association and IK as two co-resident persistent kernels, a CU
-    associating one chain-frame while it solves another (csrc/mvmc_chain_split.h: + 7 - 10 % on config 5); False =
-    one 512-thread workgroup per chain-frame.  Same results bit for bit."""
+    no assumption either, ~3 % slower).  Same results bit for bit."""
     import ctypes as C
     from . import _cabi
     F, Cn, P = kps.shape[:3]
@@ -366,9 +363,7 @@ def run_chains_fused(hp: HotPath, kps: torch.Tensor, counts: Optional[torch.Tens
         out_params=e((F, T, 68), f64), out_joints=e((F, T, 18, 3), f64), out_meta=e((F, T, 4), i32), out_n_tracks=e((F,), i32),
         out_info=e((F, NP, 8), f64) if want_info else None, out_als_iters=e((F,), i32) if want_info else None,
         flags=z((B * (parts + 1) + 8,), torch.int32),
-        out_phase_cycles=e((B, 8), f64) if want_info else None,
-        # C8 P8 sizes: the workspace of the split path (two co-resident persistent kernels, csrc/mvmc_chain_split.h)
-        wsym=e((B, 72 * 74), f64) if (N > 40 and split and parts > 1) else None)
+        out_phase_cycles=e((B, 8), f64) if want_info else None)
     if parts > 1 and L % parts:
         raise ValueError("run_chains_fused: parts must divide the chain length")
     if hand_over is None:

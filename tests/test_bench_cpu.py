@@ -38,6 +38,6 @@ def test_als_histogram_and_the_defaults_of_the_command_line():
     assert bench.als_histogram(np.zeros(4, dtype=np.int32)) is None
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0
-    for flag in ("--force-collective", "--dlt-out", "--big-split", "--other-configs"):
+    for flag in ("--force-collective", "--dlt-out", "--other-configs"):
         assert flag in r.stdout
     assert bench.DEFAULT_NCCL_MAX_NCHANNELS == "4" and bench.OTHER_CONFIGS[1][1][:6] == ["--views", "8", "--people", "8", "--frames", "25008"]

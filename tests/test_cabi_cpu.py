@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 import numpy as np
 
 from conftest import ROOT
@@ -22,7 +24,7 @@ def test_header_symbols_exported():
     for name in declared:
         assert hasattr(lib, name), name
     header = open(os.path.join(ROOT, "include", "mvmc.h")).read()
-    assert lib.mvmc_abi_version() == int(re.search(r"#define\s+MVMC_ABI_VERSION\s+(\d+)", header).group(1)) == 5
+    assert lib.mvmc_abi_version() == int(re.search(r"#define\s+MVMC_ABI_VERSION\s+(\d+)", header).group(1)) == _cabi.MVMC_ABI == 6
 
 
 def test_seed_table_is_numpy_randomstate0():
@@ -87,3 +89,23 @@ def test_a_library_of_another_abi_version_is_refused(tmp_path):
     """ % ROOT)
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MVMC_LIB_PATH=str(so)), capture_output=True, text=True)
     assert out.returncode == 0 and "refused" in out.stdout, out.stderr
+
+
+def test_a_library_built_from_other_kernel_sources_is_refused(tmp_path, monkeypatch):
+    """lib/BUILD_INFO.json (written by csrc/Makefile after linking) carries the hash of the kernel sources the library was built from;
+    _cabi.load() refuses a library whose hash is not the tree's -- a stale .so that travelled to the GPU box -- or that has no record."""
+    import json
+    from multiview_motion_capture_amd import _buildinfo, _cabi
+    info = _buildinfo.read()
+    assert info is not None and info["kernel_sources_sha"] == _buildinfo.sources_sha(), "build() leaves a record of this tree"
+    assert _cabi.build_info()["kernel_sources_sha"] == info["kernel_sources_sha"]
+    monkeypatch.delenv("MVMC_LIB_PATH", raising=False)
+    monkeypatch.setattr(_cabi, "_lib", None)
+    stale = tmp_path / "BUILD_INFO.json"
+    stale.write_text(json.dumps(dict(info, kernel_sources_sha="0" * 16)))
+    monkeypatch.setattr(_buildinfo, "INFO_PATH", str(stale))
+    with pytest.raises(_cabi.MvmcError, match="stale"):
+        _cabi.load()
+    monkeypatch.setattr(_buildinfo, "INFO_PATH", str(tmp_path / "missing.json"))
+    with pytest.raises(_cabi.MvmcError, match="no BUILD_INFO.json"):
+        _cabi.load()

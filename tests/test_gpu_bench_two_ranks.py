@@ -48,16 +48,3 @@ def test_two_ranks_print_config_4_and_config_5_with_their_collectives():
     print(f"two ranks on one GPU (gloo): config 4 {line['value'] / 1e3:.0f} k frames/s, config 5 {c5['value'] / 1e3:.0f} k frames/s; gather p50 "
           f"{line['collective']['gather_ms']['p50']:.2f} / {c5['collective']['gather_ms']['p50']:.2f} ms, messages of "
           f"{line['collective']['message_bytes'] / 1e6:.1f} / {c5['collective']['message_bytes'] / 1e6:.1f} MB")
-
-
-def test_bench_big_split_flag_runs_config_5_geometry():
-    """`bench.py --big-split` (the BIG layout as two co-resident persistent kernels, an opt-in experiment): a short config-5-shaped run
-    completes without a void word, one step at a time."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--views", "8", "--people", "8", "--frames", "2048", "--seed", "20260104",
-                        "--big-split", "--steps", "2", "--warmup", "1", "--no-other-configs", "--cpu-frames", "0", "--sustain", "0"],
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line["config"]["big_split"] is True and line["config"]["steps_in_flight"] == 1
-    assert line["value"] > 0 and line["tracker_events_per_step"]["capacity_word"] == 0
-    assert line["als_iterations"]["graphs"] == 2048

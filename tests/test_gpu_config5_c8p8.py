@@ -193,39 +193,6 @@ def test_chain_kernel_big_layout_is_bit_identical_to_the_staged_path(c5):
     assert (n == P).mean() > 0.9 and np.median(errs) < 0.05
 
 
-def test_split_big_path_is_bit_identical_to_the_one_kernel_path(c5):
-    """The BIG layout as two co-resident persistent kernels (csrc/mvmc_chain_split.h: graph + association + assignment of one chain-frame
-    beside the IK + commit of another, handed over through two words per chain) against the one-kernel form: the same device functions,
-    so the same tables, iteration counts and solver records bit for bit -- with eight and with sixteen tracklet slots, and on the
-    occluded workload whose ninth tracklets take the split path's wide association variant."""
-    from multiview_motion_capture_amd import synth
-    from multiview_motion_capture_amd.pipeline import HotPath
-    from multiview_motion_capture_amd.tracker import check_chain_flags, run_chains_fused
-    d = torch.device("cuda:0")
-    occ = synth.generate(256 * L, C, P, 20260104, chain_len=L, occlusion=0.05, spurious=0.2)
-    hp_o = HotPath(occ["K"], occ["Rt"], device=d)
-    sets = [(c5["hp"], c5["kps"], c5["cnt"], 8), (c5["hp"], c5["kps"], c5["cnt"], None),
-            (hp_o, torch.from_numpy(occ["kps25"]).to(d), torch.from_numpy(occ["counts"]).to(d), None)]
-    crowded = 0
-    for hp, kps, cnt, t_max in sets:
-        a = run_chains_fused(hp, kps, cnt, L, t_max=t_max, want_info=True, split=False)
-        b = run_chains_fused(hp, kps, cnt, L, t_max=t_max, want_info=True, split=True)
-        torch.cuda.synchronize()
-        check_chain_flags(a)
-        check_chain_flags(b)
-        assert b["_keepalive"]["wsym"] is not None and a["_keepalive"]["wsym"] is None
-        for k in ("n_tracks", "n_dead", "next_id", "als_iters", "void"):
-            assert torch.equal(a[k], b[k]), k
-        n = a["n_tracks"].cpu().numpy()
-        crowded += int((n > 8).sum())
-        for k in ("meta", "params", "joints"):
-            x, y = a[k].cpu().numpy(), b[k].cpu().numpy()
-            for f in range(len(n)):
-                assert np.array_equal(x[f, :n[f]], y[f, :n[f]], equal_nan=True), (k, f)
-        assert torch.equal(torch.nan_to_num(a["ik_info"]), torch.nan_to_num(b["ik_info"]))
-    assert crowded >= 3      # (the occluded set: frames with a ninth tracklet went through the split path's wide variant)
-
-
 def test_temporal_graph_n72_t8_vs_oracle(c5):
     """The 72-node graph of the BIG layout (8 tracklets + 64 poses; the 256-thread generic ALS, n <= 72) against the oracle."""
     from multiview_motion_capture_amd import device as dev
