@@ -283,7 +283,8 @@ class MvTracker:
         n_nodes = int(cnt.sum())
         snap = ch.snapshot()
         # one launch per frame (the chain kernel) when the frame's graph fits its association variants, seven otherwise
-        if ch.fused_ok and (C * P > 40 or (n_nodes <= 24 and n_nodes + len(self.tracklets) <= 32)):
+        one_launch = ch.fused_ok and (C * P > 40 or (n_nodes <= 24 and n_nodes + len(self.tracklets) <= 32))
+        if one_launch:
             ch.step_fused(k_d, c_d)
         else:
             ch.step(k_d, c_d)
@@ -295,8 +296,8 @@ class MvTracker:
             # those raises, and then the tracker is left as it was before the frame.
             from .tracker import T_WIDE
             ch.restore(snap)
-            if ch.T >= T_WIDE and not ch.fused_ok:
-                raise
+            if ch.T >= T_WIDE and not one_launch:
+                raise          # (already the widest tables, through the per-stage path: the replay below would be the same frame again)
             wide = ch if ch.T >= T_WIDE else ch.widened(T_WIDE)
             wsnap = wide.snapshot()
             wide.step(k_d, c_d)
@@ -312,7 +313,8 @@ class MvTracker:
         n = int(host["n_tracks"][0])
         meta, params, joints = host["meta"][0, :n], host["params"][0, :n], host["joints"][0, :n]   # (views of a buffer the next frame overwrites: copied below)
         if ch.T > self._t_max:
-            # the crowd has thinned out: back to the tables the one-launch path runs on (a wide tracker takes seven launches per frame)
+            # the crowd has thinned out: back to the tables of the SMALL layout (a wide tracker's frame is one launch too, but of the BIG
+            # layout -- a 512-thread workgroup with 129 KB of LDS, ~2 x the latency of the SMALL one's frame)
             # -- once it has STAYED at or below t_max - 1 for a few frames: a scene that hovers around t_max would otherwise pay a voided
             # launch, a restore and a widened replay every other frame
             self._calm = self._calm + 1 if n <= self._t_max - 1 else 0

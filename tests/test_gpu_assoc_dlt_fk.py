@@ -101,9 +101,29 @@ def test_affinity_D_and_S_bit_exact(dev, shelf):
         assert (D[i, n:, :] == 0).all() and (S[i, :, n:] == 0).all()
     # S too since round 5: the sigmoid's exp is NumPy's float32 exp restated (csrc/mvmc_common.h np_exp_f32: P5 / Q2 after a Cody-Waite
     # reduction, not correctly rounded) -- a one-ulp difference in 13 % of a C8 P8 frame's affinities changed the iteration count of every
-    # chain head's ALS run there and, at the iteration cap, its clusters (profiles/r05_oracle_soak.txt).  Holds where NumPy takes its
-    # AVX2 / AVX-512F path (any x86-64 host of the last decade); the fixture's S (recorded from the reference here) is matched likewise.
-    assert worst == 0.0, worst
+    # chain head's ALS run there and, at the iteration cap, its clusters (profiles/r05_oracle_soak.txt).
+    # The stable pin is the S the REFERENCE recorded (tests/golden/shelf_spatial.npz, nine frames): equal bit for bit on any host.
+    g = load_golden("shelf_spatial.npz")
+    pinned = 0
+    for fi in sorted({int(k.split("_")[0][1:]) for k in g.files}):
+        if fi not in FRAMES:
+            continue
+        i = FRAMES.index(fi)
+        n = g[f"f{fi}_S"].shape[0]
+        assert np.array_equal(S[i, :n, :n], g[f"f{fi}_S"]) and np.array_equal(D[i, :n, :n], g[f"f{fi}_D"]), f"recorded frame {fi}"
+        pinned += 1
+    assert pinned >= 5
+    # Against the oracle's LIVE NumPy on all 83 frames: the same bits where NumPy takes its AVX2 / AVX-512F float32 exp (any x86-64 host
+    # of the last decade); without AVX2 + FMA NumPy falls back to libm's expf -- a different function -- and one ulp is allowed there.
+    try:
+        from numpy._core._multiarray_umath import __cpu_features__ as feat
+    except ImportError:
+        from numpy.core._multiarray_umath import __cpu_features__ as feat
+    if feat.get("AVX2") and feat.get("FMA3"):
+        assert worst == 0.0, worst
+    else:
+        print("host NumPy without AVX2 + FMA3: live S compared to one ulp (the recorded S above is the bit-exact pin)")
+        assert worst <= 1.0, worst
 
 
 def test_als_association_bit_exact(dev, shelf):
@@ -123,7 +143,6 @@ def test_als_association_bit_exact(dev, shelf):
                             want_mats=True)
     lab, ncl, iters = (res[k].cpu().numpy() for k in ("labels", "n_clusters", "iters"))
     xb, mm = res["x_bin"].cpu().numpy(), res["match_mat"].cpu().numpy()
-    n_iter_diff = 0
     for k, i in enumerate(sel):
         n = dims[k][-1]
         mm_o, xb_o, it_o = o.match_als(S_list[k], dims[k], return_iters=True)
@@ -133,10 +152,9 @@ def test_als_association_bit_exact(dev, shelf):
         assert (lab[k, n:] == -1).all()
         keep = (mm_o.astype(float).sum(axis=0) > 1.9).sum()
         assert ncl[k] == keep
-        n_iter_diff += int(iters[k] != it_o)
-        assert abs(int(iters[k]) - it_o) <= 2, (FRAMES[i], iters[k], it_o)
-    # iteration counts are decided by thresholds on fp64 norms; a rare +-1 is rounding
-    assert n_iter_diff <= max(1, len(sel) // 10), n_iter_diff
+        # (the iteration count too, since S is the reference's bit for bit: none of these runs reaches the cap of 1,000, where the result
+        # depends on the summation order of a BLAS -- tests/test_gpu_als_cap.py gates that regime)
+        assert int(iters[k]) == it_o, (FRAMES[i], iters[k], it_o)
 
 
 def test_members_and_dlt(dev, shelf):
@@ -150,7 +168,7 @@ def test_members_and_dlt(dev, shelf):
     pts3d = dev.dlt(shelf["kps17"], torch.from_numpy(shelf["P"]).to(d), mem.reshape(-1, V_MAX)).cpu().numpy()
     pts3d = pts3d.reshape(len(FRAMES), K_MAX, 17, 4)
     mem, nm, lab = mem.cpu().numpy(), nm.cpu().numpy(), res["labels"].cpu().numpy()
-    worst_rel, n_checked = 0.0, 0
+    worst_rel, n_checked, n_nan, n_same, n_other = 0.0, 0, 0, 0, 0
     for i in range(len(FRAMES)):
         pts, sc, dim, q = frame_nodes(shelf["k17_o"][i], shelf["cnt_o"][i])
         n = len(pts)
@@ -167,15 +185,31 @@ def test_members_and_dlt(dev, shelf):
             ref = o.triangulate_groups(projs, grps, 0.01, False)
             got = pts3d[i, k]
             rel = np.linalg.norm(got[:, :3] - ref[:, :3], axis=1) / np.linalg.norm(ref[:, :3], axis=1)
-            # joints undetected in every view (all rows built from (0,0)) have a degenerate null space
+            # Joints with fewer than two scored views: the reference falls back to ALL views (mv_math_util.py:171-182).  Where at least one
+            # view has the joint that is an ordinary (if meaningless) intersection and must match like the rest; where NO view has it, every
+            # row is built from the pixel (0, 0), the null space of the system is not a line, and the reference returns whatever vector
+            # LAPACK's SVD happens to deliver -- there the device says NaN (csrc/mvmc_geom.hip; tests/test_gpu_dlt_nullvector.py) with
+            # the same score column, 0: the joint has no weight downstream.  Counted and reported, not skipped.
             well = np.array([sum(g[j, 2] >= 0.01 for g in grps) >= 2 for j in range(17)])
             if well.any():
                 worst_rel = max(worst_rel, rel[well].max())
             assert np.allclose(got[:, 3], ref[:, 3], rtol=1e-14, atol=0)
             n_checked += int(well.sum())
+            for j in np.nonzero(~well)[0]:
+                unseen = all(g[j, 2] == 0.0 and g[j, 0] == 0.0 and g[j, 1] == 0.0 for g in grps)
+                if np.isnan(got[j, :3]).any():
+                    n_nan += 1
+                    assert unseen and ref[j, 3] == 0.0, (FRAMES[i], k, j, "NaN although a view has the joint")
+                elif rel[j] < 1e-6:
+                    n_same += 1
+                else:
+                    n_other += 1
+                    assert unseen and ref[j, 3] == 0.0, (FRAMES[i], k, j, rel[j], "differs although a view has the joint")
     assert n_checked > 2000
     assert worst_rel < 1e-6, worst_rel  # north star: 1e-4
-    print("DLT worst relative error", worst_rel, "over", n_checked, "points")
+    print("DLT worst relative error", worst_rel, "over", n_checked, "points;  joints with < 2 scored views:", n_nan + n_same + n_other,
+          "-- equal to the reference's", n_same, ", NaN where no view has the joint (score 0)", n_nan,
+          ", finite but different where no view has the joint (score 0)", n_other)
     # the one-pass form on the RAW Shelf keypoints (poses dropped by filter_bad_pose, ragged counts, clusters of up to 40 members):
     # bit for bit the two-kernel result
     fused = dev.ingest_dlt(torch.from_numpy(shelf["kps25"]).to(d), torch.from_numpy(shelf["counts"]).to(d),

@@ -38,7 +38,7 @@ def test_spatial_association_n64_vs_oracle_and_truth(c5):
         mm_o, xb_o, it_o = o.match_als(assoc["S"][f, :n, :n].cpu().numpy(), dim, return_iters=True)
         assert np.array_equal(assoc["x_bin"][f, :n, :n].cpu().numpy().astype(bool), xb_o)
         assert np.array_equal(assoc["labels"][f, :n].cpu().numpy(), o.cluster_labels(mm_o, n))
-        assert abs(int(assoc["iters"][f]) - it_o) <= 2
+        assert int(assoc["iters"][f]) == it_o
     lab = assoc["labels"].cpu().numpy().reshape(F, C, P)
     order = data["gt_order"]
     ok = 0
