@@ -253,6 +253,9 @@ OTHER_CONFIGS = (
     ("config 2: synthetic 2 M frames, C=5, P=1: triangulation only (10 k generated frames tiled on the device)",
      ["--workload", "dlt", "--people", "1", "--frames", "2000000", "--tile-from", "10000", "--seed", "20260101", "--steps", "200",
       "--warmup", "20"]),      # (a launch lasts ~1 ms: 200 timed launches, so that the timed region is not the first 20 ms after an idle GPU)
+    ("config 2 with float64 points out (the reference's output dtype, mv_math_util.py:152-187; 32 B per point instead of 16)",
+     ["--workload", "dlt", "--people", "1", "--frames", "2000000", "--tile-from", "10000", "--seed", "20260101", "--steps", "200",
+      "--warmup", "20", "--dlt-out", "f64"]),
 )
 
 
@@ -845,6 +848,7 @@ def run_workload(args, rank, world, d):
         frames_total = F * world * args.steps
         value = frames_total / dt
         bpf = BYTES_PER_FRAME(C, Pn)
+        extra_roof = {}
         dom = "ik" if with_ik else "assoc"
         dom_kernel = "ik1_kernel" if with_ik else "als4_kernel<float, 24>"
         if fused:
@@ -862,9 +866,15 @@ def run_workload(args, rank, world, d):
                 launch_ms = float(np.mean(ik_launch_ms))
             achieved = bpf * (F // L) / (launch_ms * 1e-3) / 1e9
         elif args.workload == "dlt":
-            # config 2: 12 C P J bytes read + 16 P J written per frame; the DLT kernel dominates
+            # config 2, the bytes the pass MOVES per frame: 12 C P 25 read (the OpenPose rows: x, y, score as float32) + one point of
+            # {x, y, z, score} per person and per COCO-17 joint written, 16 B as float32 / 32 B as float64.  SURVEY.md 8(d) prices the
+            # output at 25 joints (1,900 B at C5 P1); the path triangulates the 17 joints it uses (pose_def.py:262-270), so that figure
+            # flattered `frac` by 7 % -- kept beside it as bytes_per_frame_survey_8d.  The DLT kernel dominates.
             dom, dom_kernel = "tri", "ingest_dlt3_kernel" if args.path == "fused" else "dlt_kernel"
-            bpf = 12 * C * Pn * 25 + 16 * Pn * 25
+            out_b = 16 if args.dlt_out == "f32" else 32
+            bpf = 12 * C * Pn * 25 + out_b * Pn * 17
+            extra_roof = {"bytes_per_frame_survey_8d": 12 * C * Pn * 25 + 16 * Pn * 25,
+                          "bytes_per_frame_is": f"12 C P 25 read + {out_b} P 17 written (the COCO-17 joints, {args.dlt_out} points)"}
             launch_ms = stage_ms["tri"]
             achieved = bpf * F / (launch_ms * 1e-3) / 1e9
         else:
@@ -931,7 +941,7 @@ def run_workload(args, rank, world, d):
             "roofline": {"bound": "hbm", "kernel": dom_kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "launch_ms": launch_ms,
-                         "traffic": traffic, "traffic_source": traffic_note, "bytes_per_frame": bpf, "fp64": fp64,
+                         "traffic": traffic, "traffic_source": traffic_note, "bytes_per_frame": bpf, **extra_roof, "fp64": fp64,
                          "note": ("HBM-bound pass (one read of the keypoints, one store per point) beside fp64 issue; achieved = algorithmic "
                                   "bytes of the frames one launch serves / mean launch duration of the dominant kernel"
                                   if args.workload == "dlt" else
