@@ -192,6 +192,55 @@ def kernel_sources_sha() -> str:
     return _buildinfo.sources_sha()
 
 
+def identities_carried(par, last, world):
+    """What the stitch of one step carried: pairs matched across the chain boundaries INSIDE the shards (every rank's own, from the
+    gathered messages' local sections), across the world - 1 boundaries BETWEEN shards, and the global identities that remain --
+    with a continuous scene and everybody tracked: (chains - 1) x people pairs in all and `people` identities."""
+    if last is None:
+        return {}
+    info = [int(v) for v in last["info"].cpu().tolist()]
+    msgs = last["messages"].cpu().numpy()
+    within = 0
+    for r in range(msgs.shape[0]):
+        within += int(par.unpack_message(msgs[r], last["b_cap"], par.T_MSG, last["row_cap"]).get("local_pairs", 0))
+    return {"identities_carried_within_shard": within, "identities_carried_across_shards": info[3] - within,
+            "global_identities": info[1], "shard_boundaries": world - 1}
+
+
+def carries_against_ground_truth(out, data, L, Pn):
+    """Rank 0's shard: every identity the stitch carried across one of the shard's chain boundaries, checked against the generator's
+    ground truth -- the tracklet on either side of the boundary is the ground-truth person it lies on (mean joint distance), and a
+    carry is right when both sides are the same person."""
+    st = out.get("stitch")
+    if st is None or "gid" not in st:
+        return None
+    gid = st["gid"].cpu().numpy()
+    meta, n_t, jo = out["meta"].cpu().numpy(), out["n_tracks"].cpu().numpy(), out["joints"].cpu().numpy()
+    gt = data["gt_joints"]
+    F = meta.shape[0]
+    B = F // L
+
+    def people(f):   # {global identity: ground-truth person} of frame f's live tracklets
+        b, n = f // L, int(n_t[f])
+        if n == 0:
+            return {}
+        dm = np.linalg.norm(jo[f, :n, None] - gt[f][None], axis=-1).mean(axis=-1)      # (n, P)
+        who = dm.argmin(axis=1)
+        ok = dm.min(axis=1) < 0.25
+        return {int(gid[b, int(meta[f, s, 0])]): int(who[s]) for s in range(n) if ok[s] and 0 <= meta[f, s, 0] < gid.shape[1]}
+
+    carried = right = possible = 0
+    for b in range(1, B):
+        prev, nxt = people(b * L - 1), people(b * L)
+        possible += len(set(prev.values()) & set(nxt.values()))
+        for g, p in nxt.items():
+            if g in prev:
+                carried += 1
+                right += int(prev[g] == p)
+    return {"chain_boundaries_checked": B - 1, "people_on_both_sides": possible, "identities_carried": carried,
+            "carried_to_the_right_person": right}
+
+
 def _cabi_build_info():
     from multiview_motion_capture_amd import _cabi
     return _cabi.build_info()
@@ -373,9 +422,14 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the one all-gather: nccl = RCCL over xGMI (one rank per GPU); gloo only to "
                          "rehearse several ranks on a box with one GPU (host-staged)")
-    ap.add_argument("--walk", default="chains", choices=["chains", "continuous"],
-                    help="synthetic scene: 'chains' restarts the people's random walk at every chain head (the workload the round-1 "
-                         "numbers were measured on); 'continuous' is one walk over all frames, so the stitch has identities to find")
+    ap.add_argument("--walk", default="continuous", choices=["chains", "continuous"],
+                    help="synthetic scene: 'continuous' (default since round 6) = ONE smooth walk of the people over the whole sequence "
+                         "(synth.scene_walk, SURVEY 8d), the same seed on every rank, rank r owning the r-th contiguous range of it: the "
+                         "stitch has identities to carry across chain and shard boundaries; 'chains' restarts the people at every chain "
+                         "head and gives every rank a scene of its own (rounds 1 - 5: nothing to carry)")
+    ap.add_argument("--frames-total", type=int, default=0,
+                    help="STRONG scaling: this many frames in all, split into contiguous ranges over the --gpus ranks (BASELINE config 5: "
+                         "--views 8 --people 8 --frames-total 200064); overrides --frames (frames per GPU, weak scaling: the default)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--force-collective", action="store_true",
                     help="--gpus 1 only: initialise the backend at world size 1 and issue the step's all-gather through it (no world == 1 "
@@ -406,6 +460,11 @@ def main():
                          "'other_configs' (default: on for the default headline command at N = 1)")
     ap.add_argument("--no-other-configs", dest="other_configs", action="store_false")
     args = ap.parse_args()
+    args.scaling = "weak"
+    if args.frames_total:
+        if args.frames_total % (args.gpus * args.chain_len):
+            raise SystemExit("--frames-total must be a multiple of --gpus x --chain-len (whole chains per rank)")
+        args.frames, args.scaling = args.frames_total // args.gpus, "strong"
     if args.other_configs is None:
         args.other_configs = (args.workload == "full" and (args.frames, args.views, args.people) == (10000, 5, 4)
                               and args.occlusion == 0.0 and args.path == "fused")
@@ -510,7 +569,7 @@ def run_workload(args, rank, world, d):
     from multiview_motion_capture_amd.tracker import check_chain_flags, repair_chains, run_chains, run_chains_fused
 
     F, C, Pn = args.frames, args.views, args.people
-    # same cameras on every rank (seed), a different frame shard per rank (frame_seed)
+    # same cameras on every rank (seed); the frames: see --walk
     L = args.chain_len
     if F % L:
         raise SystemExit("--frames must be a multiple of --chain-len")
@@ -519,8 +578,13 @@ def run_workload(args, rank, world, d):
         if args.workload != "dlt" or F % args.tile_from or args.tile_from % L:
             raise SystemExit("--tile-from: only with --workload dlt (independent frames), and it must divide --frames")
         F_gen = args.tile_from
-    data = synth.generate(F_gen, C, Pn, args.seed, chain_len=L if args.walk == "chains" else 0, frame_seed=args.seed + 1000 * rank,
-                          shuffle=args.workload != "dlt", occlusion=args.occlusion, spurious=args.spurious)
+    if args.walk == "continuous":
+        # one scene (the same seed everywhere), this rank's contiguous range of it: segment `rank` of `world`
+        data = synth.generate(F_gen, C, Pn, args.seed, shuffle=args.workload != "dlt", occlusion=args.occlusion, spurious=args.spurious,
+                              walk="scene", segment=rank)
+    else:
+        data = synth.generate(F_gen, C, Pn, args.seed, chain_len=L, frame_seed=args.seed + 1000 * rank,
+                              shuffle=args.workload != "dlt", occlusion=args.occlusion, spurious=args.spurious)
     hp = HotPath(data["K"], data["Rt"], device=d)
     kps = torch.from_numpy(data["kps25"]).to(d)
     counts = torch.from_numpy(data["counts"]).to(d)
@@ -803,6 +867,7 @@ def run_workload(args, rank, world, d):
                       "message_bytes": int(last["message"].numel() * last["message"].element_size()) if last is not None else None,
                       "gather_ms": {"p50": float(np.percentile(gather_ms, 50)), "max": float(np.max(gather_ms))} if gather_ms else None,
                       "chains_stitched": int(last["info"][0].item()) if last is not None else None,
+                      **identities_carried(par, last, world),
                       "env": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "MVMC_COMM_PRIORITY")},
                       "note": "pack -> ONE all-gather of fixed-size messages (live tracklets, f32) -> stitch, on a high-priority "
                               "communication stream behind an event; gather_ms = events around the collective on that stream"}
@@ -917,14 +982,16 @@ def run_workload(args, rank, world, d):
             "metric": "frames/s (assoc+triangulate+IK) at C=5,P=4,J=25" if with_ik else
                       ("frames/s (triangulate)" if args.workload == "dlt" else "frames/s (assoc+triangulate)"),
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "per_rank_ms_per_step": per_rank_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "per_rank_ms_per_step": per_rank_ms, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"synthetic {F} frames/GPU, C={C}, P={Pn}, J=25: " + ("ingest + DLT of one cluster per person (config 2)"
                                     if args.workload == "dlt" else "affinity+ALS+DLT") +
                                    ((f"+IK, temporal chains of {L} frames (match_spatial_time + tracker; cold 50+50 nfev at the head, "
                                      f"warm 5+5 after), {('one launch per step, ' + (str(args.parts or L) + ' workgroup(s) per chain')) if args.path == 'fused' else 'one launch per stage'}" + (f", {args.overlap} steps in flight on alternating streams" if args.overlap > 1 else "") if L > 1 else "+IK, every frame cold-started (chain length 1, max_nfev 50+50)")
                                     if with_ik else ""),
-                       "frames_per_gpu": F, "views": C, "people": Pn, "chain_len": L, "seed": args.seed, "parallelism": f"frames x{world}",
+                       "frames_per_gpu": F, "frames_total": F * world, "views": C, "people": Pn, "chain_len": L, "seed": args.seed,
+                       "parallelism": f"frames x{world}" + (" (contiguous ranges of one scene)" if args.walk == "continuous" else " (a scene per rank)"),
+                       "walk": args.walk,
                        "steps_in_flight": args.overlap, "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "occlusion": args.occlusion, "spurious": args.spurious,
                        **({"tiled_from_frames": F_gen} if F_gen != F else {}),
@@ -966,6 +1033,11 @@ def run_workload(args, rank, world, d):
                                "joint_error_vs_ground_truth_cm": {"median": float(np.median(errs) * 100),
                                                                   "p95": float(np.quantile(errs, 0.95) * 100)},
                                "note": "synthetic ground truth (2 px keypoint noise); parity with the reference: tests/"}
+            if sharded and args.walk == "continuous":
+                try:
+                    res["accuracy"]["stitch_vs_ground_truth_rank0"] = carries_against_ground_truth(out, data, L, Pn)
+                except Exception as exc:      # (a diagnostic: never at the cost of the line)
+                    res["accuracy"]["stitch_vs_ground_truth_rank0"] = {"error": repr(exc)[:200]}
         if args.cpu_frames > 0 and world == 1:
             if chain:
                 workers = max(1, min(args.cpu_workers or min(16, os.cpu_count() or 1), F // L))

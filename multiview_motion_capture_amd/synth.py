@@ -68,8 +68,36 @@ def batched_fk(root: np.ndarray, euler: np.ndarray, side_lens: np.ndarray) -> np
     return np.stack(pos, axis=-2)
 
 
+def scene_walk(n_frames: int, n_people: int, seed: int, segment: int = 0, kappa: float = 4.5e-3):
+    """One smooth, BOUNDED walk of the scene's people, cut into consecutive segments of ``n_frames`` frames:
+    -> root (n_frames, P, 3), angles (n_frames, P, 18, 3) of segment ``segment``.  Every person wanders around a home position and a
+    home pose (drawn from ``seed``): the increments of generate()'s random walk (2 cm and 0.02 rad per frame) with a pull of ``kappa``
+    per frame towards home, started in its stationary state, so that a sequence of any length stays in front of the cameras (a plain
+    random walk drifts by 9 m over the 200 k frames of BASELINE config 5).  With kappa = 4.5e-3 the wander has a standard deviation of
+    0.21 rad / 0.21 m around a home pose of 0.21 rad: joint angles of 0.30 rad in all -- the distribution generate() draws at its chain
+    heads, so the poses the solver sees are those of the chain-restart workload of rounds 1 - 5.  Segment s draws its increments from
+    its own stream (seed, 3, s) and starts where segment s - 1 ends, so the segments of one seed (and one segment length) tile ONE
+    scene whoever generates them: rank r of a sharded run generates segment r, replaying the cheap increments of the segments before
+    it for its start state."""
+    from scipy.signal import lfilter
+    rng0 = np.random.default_rng([seed, 3])
+    home_root = np.concatenate([rng0.uniform(-2, 2, size=(n_people, 2)), rng0.uniform(0.95, 1.1, size=(n_people, 1))], -1)
+    home_ang = rng0.normal(0, 0.3 / np.sqrt(2.0), size=(n_people, 18, 3))
+    sd = np.concatenate([0.02 * np.array([1, 1, 0.1]), np.full(54, 0.02)])                    # per-frame increments
+    y0 = rng0.normal(0, 1.0, size=(n_people, 57)) * sd / np.sqrt(1.0 - (1.0 - kappa) ** 2)    # the stationary state
+    a = [1.0, -(1.0 - kappa)]
+    zi = ((1.0 - kappa) * y0).reshape(1, n_people * 57)
+    y = None
+    for s in range(segment + 1):
+        rng = np.random.default_rng([seed, 3, s])
+        d = (rng.normal(0, 1.0, size=(n_frames, n_people, 57)) * sd).reshape(n_frames, n_people * 57)
+        y, zi = lfilter([1.0], a, d, axis=0, zi=zi)      # x_t = (1 - kappa) x_{t-1} + d_t, carried across the segments
+    y = y.reshape(n_frames, n_people, 57)
+    return home_root[None] + y[..., :3], home_ang[None] + y[..., 3:].reshape(n_frames, n_people, 18, 3)
+
+
 def generate(n_frames: int, n_views: int, n_people: int, seed: int, chain_len: int = 0, dtype=np.float32,
-             drop=0.05, pix_sigma=2.0, shuffle=True, frame_seed=None, occlusion=0.0, spurious=0.0):
+             drop=0.05, pix_sigma=2.0, shuffle=True, frame_seed=None, occlusion=0.0, spurious=0.0, walk=None, segment: int = 0):
     """-> dict(kps25 (F,C,P,25,3), counts (F,C) int32, K, Rt, P, gt_joints (F,P,18,3), gt_order (F,C,P)).
 
     occlusion: probability that a person is missed entirely by a view in a frame (the view's list gets shorter: ragged counts,
@@ -82,22 +110,36 @@ def generate(n_frames: int, n_views: int, n_people: int, seed: int, chain_len: i
 
     chain_len > 0 restarts the random walk every chain_len frames (independent sub-sequences).
     Cameras depend on ``seed`` only; ``frame_seed`` (default: seed) drives people, noise and shuffles,
-    so ranks can share one calibration and still own different frame shards."""
+    so ranks can share one calibration and still own different frame shards.
+
+    walk="scene": ONE scene for any number of shards -- the people follow scene_walk(seed) (a smooth bounded walk, no restarts; chain_len
+    is ignored), bone lengths come from ``seed``, and this call returns segment ``segment`` of it (frames [segment n_frames,
+    (segment + 1) n_frames)); noise, scores, drops and shuffles of a segment come from (seed, 1, segment).  The same seed on every rank
+    with segment = rank cuts one sequence into contiguous shards: what the tracklet stitch has identities to carry across.
+    walk=None (default): the random walk above, bit for bit the output of earlier versions."""
     K, Rt, Pm = make_cameras(n_views, np.random.default_rng(seed))
-    rng = np.random.default_rng([seed if frame_seed is None else frame_seed, 1])
     F, C, Pn = n_frames, n_views, n_people
     _, side = skeleton_arrays()
-    L = chain_len if chain_len > 0 else F
-    n_chain = (F + L - 1) // L
-    root0 = np.concatenate([rng.uniform(-2, 2, size=(n_chain, Pn, 2)), rng.uniform(0.95, 1.1, size=(n_chain, Pn, 1))], -1)
-    ang0 = rng.normal(0, 0.3, size=(n_chain, Pn, 18, 3))
-    d_root = rng.normal(0, 0.02, size=(n_chain, L, Pn, 3)) * np.array([1, 1, 0.1])
-    d_ang = rng.normal(0, 0.02, size=(n_chain, L, Pn, 18, 3))
-    d_root[:, 0] = 0
-    d_ang[:, 0] = 0
-    root = (root0[:, None] + np.cumsum(d_root, axis=1)).reshape(n_chain * L, Pn, 3)[:F]
-    ang = (ang0[:, None] + np.cumsum(d_ang, axis=1)).reshape(n_chain * L, Pn, 18, 3)[:F]
-    lens = side * rng.uniform(0.9, 1.1, size=(Pn, 1)) * np.ones((Pn, 11))
+    if walk == "scene":
+        root, ang = scene_walk(F, Pn, seed, segment)
+        lens = side * np.random.default_rng([seed, 4]).uniform(0.9, 1.1, size=(Pn, 1)) * np.ones((Pn, 11))
+        frame_seed = [seed, 5, int(segment)]
+        rng = np.random.default_rng(frame_seed + [1])
+    elif walk is not None:
+        raise ValueError("generate: walk is None (random walk, restarted every chain_len frames) or 'scene'")
+    else:
+        rng = np.random.default_rng([seed if frame_seed is None else frame_seed, 1])
+        L = chain_len if chain_len > 0 else F
+        n_chain = (F + L - 1) // L
+        root0 = np.concatenate([rng.uniform(-2, 2, size=(n_chain, Pn, 2)), rng.uniform(0.95, 1.1, size=(n_chain, Pn, 1))], -1)
+        ang0 = rng.normal(0, 0.3, size=(n_chain, Pn, 18, 3))
+        d_root = rng.normal(0, 0.02, size=(n_chain, L, Pn, 3)) * np.array([1, 1, 0.1])
+        d_ang = rng.normal(0, 0.02, size=(n_chain, L, Pn, 18, 3))
+        d_root[:, 0] = 0
+        d_ang[:, 0] = 0
+        root = (root0[:, None] + np.cumsum(d_root, axis=1)).reshape(n_chain * L, Pn, 3)[:F]
+        ang = (ang0[:, None] + np.cumsum(d_ang, axis=1)).reshape(n_chain * L, Pn, 18, 3)[:F]
+        lens = side * rng.uniform(0.9, 1.1, size=(Pn, 1)) * np.ones((Pn, 11))
     joints = batched_fk(root, ang, np.broadcast_to(lens, (F, Pn, 11)))  # (F,P,18,3)
 
     # 3-D points of the OpenPose-25 layout
@@ -127,7 +169,7 @@ def generate(n_frames: int, n_views: int, n_people: int, seed: int, chain_len: i
         kps = np.take_along_axis(kps, order[..., None, None], axis=2)
     counts = np.full((F, C), Pn, dtype=np.int32)
     if occlusion > 0.0 or spurious > 0.0:
-        rng2 = np.random.default_rng([seed if frame_seed is None else frame_seed, 2])
+        rng2 = np.random.default_rng((frame_seed + [2]) if isinstance(frame_seed, list) else [seed if frame_seed is None else frame_seed, 2])
         gone = rng2.uniform(size=(F, C, Pn)) < occlusion
         ghost = gone & (rng2.uniform(size=(F, C, Pn)) < spurious)
         centre = rng2.uniform([100.0, 100.0], [900.0, 650.0], size=(F, C, Pn, 1, 2))
