@@ -15,9 +15,9 @@ data = synth.generate(F, 5, 4, 20260103, chain_len=16)
 hp = HotPath(data["K"], data["Rt"], device=d)
 kps = torch.from_numpy(data["kps25"]).to(d)
 counts = torch.from_numpy(data["counts"]).to(d)
-streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+streams = [torch.cuda.Stream() for _ in range(3)]
 outs = []
-for overlap in (1, 2):
+for overlap in (1, 2, 3):
     torch.cuda.synchronize()
     res = []
     for s in range(steps):
