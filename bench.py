@@ -958,7 +958,9 @@ def run_workload(args, rank, world, d):
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tp):
             rec = (json.load(open(tp)).get(f"{dom}:{F}x{C}x{Pn}") or {})
-            if rec.get("src_sha") == kernel_sources_sha():
+            if args.workload == "dlt" and args.dlt_out != "f32":
+                traffic_note = "no PMC record for float64 points out (profiles/pmc_traffic.json holds the float32-output pass)"
+            elif rec.get("src_sha") == kernel_sources_sha():
                 traffic, traffic_note = rec.get("bytes"), f"profiles/{rec.get('source')}"
             elif rec:
                 traffic_note = f"stale: profiles/{rec.get('source')} was measured on other kernel sources"
