@@ -199,10 +199,11 @@ def identities_carried(par, last, world):
     if last is None:
         return {}
     info = [int(v) for v in last["info"].cpu().tolist()]
-    msgs = last["messages"].cpu().numpy()
-    within = 0
-    for r in range(msgs.shape[0]):
-        within += int(par.unpack_message(msgs[r], last["b_cap"], par.T_MSG, last["row_cap"]).get("local_pairs", 0))
+    # word 1 of every message's `local` header (parallel.unpack_message's layout): only those eight words leave the device -- the
+    # gathered messages are ~1 GB at eight ranks of config 5
+    b_cap, row_cap = last["b_cap"], last["row_cap"]
+    o_local = 8 + b_cap + b_cap * 2 * par.T_MSG * 56 + row_cap * 128
+    within = int(last["messages"][:, o_local + 1].sum().item())
     return {"identities_carried_within_shard": within, "identities_carried_across_shards": info[3] - within,
             "global_identities": info[1], "shard_boundaries": world - 1}
 

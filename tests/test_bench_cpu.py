@@ -38,6 +38,12 @@ def test_als_histogram_and_the_defaults_of_the_command_line():
     assert bench.als_histogram(np.zeros(4, dtype=np.int32)) is None
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0
-    for flag in ("--force-collective", "--dlt-out", "--other-configs"):
+    for flag in ("--force-collective", "--dlt-out", "--other-configs", "--frames-total", "--walk"):
         assert flag in r.stdout
+    assert "--big-split" not in r.stdout                                    # (retired in round 6)
+    # the strong-scaling form refuses a total that does not divide into whole chains per rank
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames-total", "1000"], capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode != 0 and "--frames-total" in r.stderr
+    assert bench.OTHER_CONFIGS[-1][1][-2:] == ["--dlt-out", "f64"]           # config 2 with the reference's output dtype rides along
     assert bench.DEFAULT_NCCL_MAX_NCHANNELS == "4" and bench.OTHER_CONFIGS[1][1][:6] == ["--views", "8", "--people", "8", "--frames", "25008"]
