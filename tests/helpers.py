@@ -104,3 +104,12 @@ def twin_postopt_root(projs, poses18):
     lib.trf_check_postopt(p(pose), p(Pm), len(pose), 18, 2, p(x), p(out))
     X = x.reshape(18, 3)
     return 0.5 * (X[11] + X[12])
+
+
+def als_oracle_job(args):
+    """(S, dim) -> (X_bin, labels, iterations) of oracle_np.match_als: the unit of work of a process pool (the long ALS runs of config 5
+    take the oracle ~40 ms each; tests/test_gpu_als_cap.py has 1,563 of them).  Workers are SPAWNED, import NumPy only and never touch the GPU."""
+    S, dim = args
+    mm, xb, it = o.match_als(S, dim, return_iters=True)
+    return xb, o.cluster_labels(mm, len(S)), it
+
