@@ -580,9 +580,20 @@ def run_workload(args, rank, world, d):
             raise SystemExit("--tile-from: only with --workload dlt (independent frames), and it must divide --frames")
         F_gen = args.tile_from
     if args.walk == "continuous":
-        # one scene (the same seed everywhere), this rank's contiguous range of it: segment `rank` of `world`
-        data = synth.generate(F_gen, C, Pn, args.seed, shuffle=args.workload != "dlt", occlusion=args.occlusion, spurious=args.spurious,
-                              walk="scene", segment=rank)
+        # one scene (the same seed everywhere), this rank's contiguous range of it.  The scene is made of segments of at most 32,768
+        # frames (synth.scene_walk: a segment is a function of seed, index and length), rank r owning the segments r k .. r k + k - 1:
+        # the generator's working set stays bounded (a 200 k-frame C8 P8 range in one piece needs ~30 GB of host memory), and BASELINE
+        # config 5's strong-scaling form (--frames-total 200064) is the SAME eight segments of 25,008 frames at N = 1, 2, 4 and 8.
+        k_seg = -(-F_gen // 32768)
+        while F_gen % (k_seg * L):
+            k_seg += 1
+        parts = [synth.generate(F_gen // k_seg, C, Pn, args.seed, shuffle=args.workload != "dlt", occlusion=args.occlusion,
+                                spurious=args.spurious, walk="scene", segment=rank * k_seg + j) for j in range(k_seg)]
+        data = dict(parts[0])
+        if k_seg > 1:
+            for key in ("kps25", "counts", "gt_joints", "gt_order"):
+                data[key] = np.concatenate([p[key] for p in parts], axis=0)
+        del parts
     else:
         data = synth.generate(F_gen, C, Pn, args.seed, chain_len=L, frame_seed=args.seed + 1000 * rank,
                               shuffle=args.workload != "dlt", occlusion=args.occlusion, spurious=args.spurious)
