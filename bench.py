@@ -24,7 +24,7 @@ import sys
 import time
 
 # HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels of different streams that share a queue
-# run in order.  This program keeps three steps in flight on streams of their own beside a communication stream, a check stream and
+# run in order.  This program keeps three (since round 6: six) steps in flight on streams of their own beside a communication stream, a check stream and
 # the default stream: with four queues a step's pack kernel sat behind another step's chain kernel (1.55 ms per tail against 0.85 ms)
 # and config 4 ran at 532 k frames/s instead of 548 k (same box, three runs each; 6, 8, 12, 16, 24 queues: the same 547 - 550 k).
 # Read when the HIP runtime library is loaded, hence set before torch is imported; the environment overrides it.
@@ -471,13 +471,12 @@ def main():
                               and args.occlusion == 0.0 and args.path == "fused")
     if args.overlap is None:
         # steps in flight fill the tail of the chain kernel's launches; the memory-bound triangulation-only pass (config 2) has no
-        # such tail, and overlapped launches would only make each of them last longer.  Three since round 5 on the SMALL layout (four
-        # workgroups per CU: 1,024 slots against 10,000 workgroups per launch): 531.3 k -> 536.4 k frames/s over the 20 timed steps
-        # with four hardware queues, 530 k -> 547 - 550 k with eight (see the top of this file).  An ODD number matters more than its
-        # size: 2 and 4 in flight give 530 - 534 k, 3 / 5 / 6 give 547 - 553 k (eight or sixteen queues) -- with an even number of
-        # launches over a CU's four workgroup slots the launches' phases lock (all of a CU's workgroups in the issue-bound IK at once,
-        # then all in the latency-bound association).  Config 5 (one workgroup per CU) does not care (109.9 k / 109.7 k) and keeps two
-        args.overlap = 1 if args.workload == "dlt" else (3 if args.views * args.people <= 40 and args.workload == "full" else 2)
+        # such tail, and overlapped launches would only make each of them last longer.  SMALL layout (four workgroups per CU: 1,024
+        # slots against 10,000 workgroups per launch), eight hardware queues (see the top of this file), round 6's kernel, same box,
+        # three alternations: 3 in flight 559.9 - 561.0 k frames/s, 5: 560.3 - 560.9 k, **6: 565.8 - 566.5 k**, 7: 539.6 k, 9: 549 -
+        # 557 k (profiles/r06_ik_experiments.txt; round 5 had 2 and 4 at 530 - 534 k against 547 - 550 k at 3).  Six since round 6.
+        # Config 5 (one workgroup per CU) does not care (109.9 k / 109.7 k) and keeps two.
+        args.overlap = 1 if args.workload == "dlt" else (6 if args.views * args.people <= 40 and args.workload == "full" else 2)
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks as fresh child processes.  Nothing in this process has touched the GPU
