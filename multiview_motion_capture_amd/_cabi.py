@@ -79,8 +79,9 @@ def load():
         # .so -- built before an edit, or carried to the GPU box from another checkout -- would be measured and tested in place of the
         # code under review.  (A library named through MVMC_LIB_PATH is a deliberate A/B partner and is not checked.)
         from . import _buildinfo
-        info, want = _buildinfo.read(), _buildinfo.sources_sha()
-        if info is None or info.get("kernel_sources_sha") != want:
+        # (a deployment without the kernel sources beside the library has nothing to compare with: the check is for source trees)
+        info, want = _buildinfo.read(), (_buildinfo.sources_sha() if os.path.isdir(_buildinfo.CSRC) else None)
+        if want is not None and (info is None or info.get("kernel_sources_sha") != want):
             have = "no BUILD_INFO.json beside it" if info is None else f"built from kernel sources {info.get('kernel_sources_sha')}"
             raise MvmcError(f"{_LIB_PATH} is stale: {have}, the tree's are {want}.  Rebuild it: python -c \"import __graft_entry__ as g; "
                             "g.build()\" (or make -C multiview_motion_capture_amd/csrc)")

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Same-box A/B of library variants over the number of steps in flight:  tools/ab_overlap.sh "2 3 4 5" name1 name2 ...
+# Same-box A/B of library variants over the number of steps in flight:  [BENCH_ARGS="..."] tools/ab_overlap.sh "2 3 4 5" name1 name2 ...  (name "hip" = the shipped library)
 OV=$1; shift
 for o in $OV; do
   for n in "$@"; do
-    MVMC_LIB_PATH=$PWD/multiview_motion_capture_amd/lib/libmvmc_$n.so timeout -k 10 200 python bench.py --cpu-frames 0 --no-other-configs --sustain 0 --overlap $o 2>/dev/null > gpurun_out/ab_$n.json || exit 1
+    MVMC_LIB_PATH=$PWD/multiview_motion_capture_amd/lib/libmvmc_$n.so timeout -k 10 200 python bench.py --cpu-frames 0 --no-other-configs --sustain 0 --overlap $o $BENCH_ARGS 2>/dev/null > gpurun_out/ab_$n.json || exit 1
     python - "$n" $o <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/ab_%s.json" % sys.argv[1]))
