@@ -269,8 +269,11 @@ class MvTracker:
         self._ensure(d_frames)
         ch = self._chain
         C, P = len(d_frames), self._p_max
-        kps = np.zeros((1, C, P, 17, 3))
-        cnt = np.zeros((1, C), dtype=np.int32)
+        # (the frame's inputs are written straight into the tracker's pinned staging buffer: one asynchronous copy to the device)
+        inp = ch.frame_inputs()
+        kps, cnt = inp["kps_np"], inp["cnt_np"]
+        kps.fill(0.0)
+        cnt.fill(0)
         for c, frm in enumerate(d_frames):
             if len(frm.poses) > P:
                 raise ValueError(f"update_4d: more than p_max={P} people in view {c}")
@@ -278,14 +281,16 @@ class MvTracker:
                 kps[0, c, k, :, :2] = pose.keypoints
                 kps[0, c, k, :, 2] = np.asarray(pose.keypoints_score).ravel()
             cnt[0, c] = len(frm.poses)
-        d = ch.hp.device
-        k_d, c_d = torch.as_tensor(kps, device=d), torch.as_tensor(cnt, device=d)
+        ch.upload_inputs()
+        k_d, c_d = inp["kps_d"], inp["cnt_d"]
         n_nodes = int(cnt.sum())
-        snap = ch.snapshot()
+        # the state in front of the frame, should the frame have to be redone: the host mirror the last frame's read_back() left
+        # (restore_previous), or -- first frame of a tracker, or after a frame that did not end in read_back -- a device snapshot
+        snap = None if ch.has_previous else ch.snapshot()
         # one launch per frame (the chain kernel) when the frame's graph fits its association variants, seven otherwise
         one_launch = ch.fused_ok and (C * P > 40 or (n_nodes <= 24 and n_nodes + len(self.tracklets) <= 32))
         if one_launch:
-            ch.step_fused(k_d, c_d)
+            ch.step_fused(k_d, c_d, fold_void=False)      # (read_back() below reads the launch's void words itself)
         else:
             ch.step(k_d, c_d)
         try:
@@ -295,7 +300,10 @@ class MvTracker:
             # it with the widest tables the kernels hold (tracker.T_WIDE tracklet slots, the per-stage path); only a frame beyond
             # those raises, and then the tracker is left as it was before the frame.
             from .tracker import T_WIDE
-            ch.restore(snap)
+            if snap is not None:
+                ch.restore(snap)
+            else:
+                ch.restore_previous()
             if ch.T >= T_WIDE and not one_launch:
                 raise          # (already the widest tables, through the per-stage path: the replay below would be the same frame again)
             wide = ch if ch.T >= T_WIDE else ch.widened(T_WIDE)

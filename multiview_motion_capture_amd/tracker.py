@@ -11,6 +11,7 @@ from __future__ import annotations
 import os
 from typing import Optional
 
+import numpy as np
 import torch
 
 from . import device as dev
@@ -64,6 +65,9 @@ class ChainTracker:
         self.frame_idx = torch.arange(B, dtype=torch.int32, device=d)
         self._host = None   # pinned host mirror of _flat (+ the chain kernel's time-out words), allocated by read_back()
         self._fused = None  # workspaces of step_fused (allocated on first use)
+        self._fused_args = None   # (key, MvmcChainBuffers) of the last step_fused call: the struct is rebuilt only when a pointer changes
+        self._in = None     # pinned host staging + device buffers of one frame's inputs (frame_inputs())
+        self._void_pending = False   # step_fused(fold_void=False) left its void words for read_back()
         self.events = None  # set to a list to collect (start, end) CUDA events around every IK launch
         self.als_events = None  # same for the association (ALS) launches of the spatio-temporal graph
         self.assoc_done = None
@@ -112,10 +116,33 @@ class ChainTracker:
         return out
 
 
-    def step_fused(self, kps17: torch.Tensor, counts: torch.Tensor):
+    def frame_inputs(self):
+        """Staging for the per-frame driver (MvTracker.update_4d): ONE pinned host buffer and ONE device buffer that hold a frame's
+        keypoints (B,C,P,17,3) f64 and counts (B,C) i32 side by side -- the caller fills the NumPy views `kps_np` / `cnt_np`, calls
+        upload_inputs() (one asynchronous copy instead of two pageable ones), and hands `kps_d` / `cnt_d` to step_fused() / step().
+        The buffers are reused by the next frame: the driver synchronises at the end of every frame (read_back())."""
+        if self._in is None:
+            B, C, P = self.B, self.C, self.P
+            nk, nc = B * C * P * 17 * 3 * 8, B * C * 4
+            total = nk + ((nc + 15) & ~15)
+            host = torch.empty((total,), dtype=torch.uint8).pin_memory()
+            devb = torch.empty((total,), dtype=torch.uint8, device=self._flat.device)
+            self._in = dict(host=host, dev=devb,
+                            kps_np=host[:nk].view(torch.float64).view(B, C, P, 17, 3).numpy(),
+                            cnt_np=host[nk:nk + nc].view(torch.int32).view(B, C).numpy(),
+                            kps_d=devb[:nk].view(torch.float64).view(B, C, P, 17, 3),
+                            cnt_d=devb[nk:nk + nc].view(torch.int32).view(B, C))
+        return self._in
+
+    def upload_inputs(self) -> None:
+        self._in["dev"].copy_(self._in["host"], non_blocking=True)
+
+    def step_fused(self, kps17: torch.Tensor, counts: torch.Tensor, fold_void: bool = True):
         """The same frame update as step() in ONE launch (mvmc_chain_run with chain_len 1 on this tracker's state): what
         the per-frame call surface (MvTracker.update_4d) uses.  Sizes outside the chain kernel's arena, or a frame whose graph
-        is too large for it, are the caller's to route to step() (ChainTracker.fused_ok, check_chain_flags)."""
+        is too large for it, are the caller's to route to step() (ChainTracker.fused_ok, check_chain_flags).
+        fold_void=False: the launch's per-chain void words are NOT folded into the tracker's own (one small kernel less per frame) --
+        for a caller that ends the frame with read_back(), which then reads them where the launch left them."""
         import ctypes as C
         from . import _cabi
         B, Cn, P, T, K, V = self.B, self.C, self.P, self.T, self.K, self.V
@@ -136,21 +163,29 @@ class ChainTracker:
                 out_params=e((B, T, 68), f64), out_joints=e((B, T, 18, 3), f64), out_meta=e((B, T, 4), i32),
                 out_n_tracks=e((B,), i32), flags=z((2 * B + 8,), i32))
         w = self._fused
-        t = dict(w, kps17=kps17, counts=counts, Pmats=self.hp.P, Fmats=self.hp.F, F2=self.F2, params=self.params,
-                 joints=self.joints, meta=self.meta, n_tracks=self.n_tracks, next_id=self.next_id, n_dead=self.n_dead,
-                 slot_src=self.slot_src, out_info=None, out_als_iters=None, out_phase_cycles=None)
-        buf = _cabi.MvmcChainBuffers()
-        for name, val in dict(n_chains=B, chain_len=1, n_views=Cn, p_max=P, t_max=T, k_max=K, v_max=V,
-                              max_nfev_cold=self.nfev_cold, max_nfev_warm=self.nfev_warm, n_inits=3,
-                              seed_len=w["seed_table"].numel(), n_parts=1, force_big=0, hand_over=0).items():
-            setattr(buf, name, int(val))
-        for name in _cabi.MvmcChainBuffers._PTRS:
-            ten = t[name]
-            setattr(buf, name, None if ten is None else ten.data_ptr())
+        # the argument struct: every pointer in it but the frame's inputs belongs to this tracker, and the per-frame driver hands in
+        # the same input buffers every frame (frame_inputs()) -- built once, rebuilt when an input pointer changes
+        key = (kps17.data_ptr(), counts.data_ptr(), self.nfev_cold, self.nfev_warm)
+        if self._fused_args is None or self._fused_args[0] != key:
+            t = dict(w, kps17=kps17, counts=counts, Pmats=self.hp.P, Fmats=self.hp.F, F2=self.F2, params=self.params,
+                     joints=self.joints, meta=self.meta, n_tracks=self.n_tracks, next_id=self.next_id, n_dead=self.n_dead,
+                     slot_src=self.slot_src, out_info=None, out_als_iters=None, out_phase_cycles=None)
+            buf = _cabi.MvmcChainBuffers()
+            for name, val in dict(n_chains=B, chain_len=1, n_views=Cn, p_max=P, t_max=T, k_max=K, v_max=V,
+                                  max_nfev_cold=self.nfev_cold, max_nfev_warm=self.nfev_warm, n_inits=3,
+                                  seed_len=w["seed_table"].numel(), n_parts=1, force_big=0, hand_over=0).items():
+                setattr(buf, name, int(val))
+            for name in _cabi.MvmcChainBuffers._PTRS:
+                ten = t[name]
+                setattr(buf, name, None if ten is None else ten.data_ptr())
+            self._fused_args = (key, buf)
+        buf = self._fused_args[1]
         _cabi.check(_cabi.load().mvmc_chain_run(C.byref(self.hp.skeleton), C.byref(buf),
                                                 C.c_void_p(torch.cuda.current_stream(d).cuda_stream)), "mvmc_chain_run")
         # the launch zeroes its flag words: fold this frame's per-chain void words into the tracker's own (read by check())
-        self.overflow |= w["flags"][B + 4:2 * B + 4]
+        self._void_pending = not fold_void
+        if fold_void:
+            self.overflow |= w["flags"][B + 4:2 * B + 4]
         return dict(members=w["members"], n_members=w["n_members"], status=w["status"], n_new=w["n_new"], ik_params=w["ik_params"],
                     ik_joints=w["ik_joints"], ik_info=w["ik_info"], flags=w["flags"], void=w["flags"][B + 4:2 * B + 4], n_chains=B,
                     chain_len=1)
@@ -188,29 +223,52 @@ class ChainTracker:
         tensor reads took six round trips): dict of NumPy views (params, joints, meta, n_tracks, ..., overflow) of a pinned buffer
         that the next call overwrites, + 'timeout' (the chain kernel's hand-over word).  Clears the capacity / time-out words on the
         device like check(); raises like check()."""
-        n = self._flat.numel()
+        n, B = self._flat.numel(), self.B
+        nf = 4 * (B + 4)                 # the chain kernel's words {time-out, graph, capacity, -} + the B per-chain void words
         if self._host is None:
-            self._host = torch.empty((n + 16,), dtype=torch.uint8).pin_memory()
-        h = self._host
+            # two pinned mirrors, written alternately: the one NOT written by this call holds the state after the last frame that went
+            # through, i.e. the state in front of this one -- what restore_previous() brings back without a per-frame device snapshot
+            self._host = [torch.empty((n + nf,), dtype=torch.uint8).pin_memory() for _ in range(2)]
+            self._host_good = -1         # index of the mirror that holds the last good state (-1: none yet)
+        cur = 1 - self._host_good if self._host_good >= 0 else 0
+        h = self._host[cur]
         h[:n].copy_(self._flat, non_blocking=True)
         fl = None
         if self._fused is not None:
-            fl = self._fused["flags"][self.B:self.B + 4]
-            h[n:n + 16].view(torch.int32).copy_(fl, non_blocking=True)
-        self.overflow.zero_()            # (stream-ordered behind the copy)
-        if fl is not None:
-            fl.zero_()
+            fl = self._fused["flags"][B:2 * B + 4]
+            h[n:n + nf].view(torch.int32).copy_(fl, non_blocking=True)
         torch.cuda.current_stream(self._flat.device).synchronize()
         out = {name: h[o:o + nb].view(dt).view(shape).numpy() for name, (o, nb, shape, dt) in self._layout.items()}
-        if fl is not None and int(h[n:n + 4].view(torch.int32)[0]):
-            raise RuntimeError("mvmc_chain_run: a hand-over between the workgroups of a chain timed out; results are void")
+        words = h[n:n + nf].view(torch.int32).numpy() if fl is not None else None
         ov = int(out["overflow"].max()) if out["overflow"].size else 0
+        if words is not None and self._void_pending:
+            ov |= int(np.bitwise_or.reduce(words[4:])) if B else 0       # (step_fused(fold_void=False): read where the launch left them)
+            self._void_pending = False
+        # clear what was set -- on the device only when something WAS set (the next launch zeroes its own words anyway): the common
+        # frame ends with one transfer, one synchronisation and no further kernel
+        if ov:
+            self.overflow.zero_()
+        if words is not None and int(words[0]):
+            fl.zero_()
+            raise RuntimeError("mvmc_chain_run: a hand-over between the workgroups of a chain timed out; results are void")
         if ov:
             what = [m for bit, m in ((1, "a cluster, a member or a view block did not fit (k_max / v_max / the frame's poses)"),
                                      (2, "more than t_max live tracklets"),
                                      (4, "a graph larger than the association kernel holds")) if ov & bit]
             raise ValueError("ChainTracker: capacity exceeded (" + "; ".join(what) + "): the frame's results are void")
+        self._host_good = cur
         return out
+
+    @property
+    def has_previous(self) -> bool:
+        """Whether read_back() has left a host mirror of the state after the last good frame (restore_previous())."""
+        return self._host is not None and self._host_good >= 0
+
+    def restore_previous(self) -> None:
+        """The state after the last frame that read_back() returned for -- the state in front of a frame that has just failed --
+        back onto the device, from the pinned mirror (the per-frame driver then needs no device snapshot in front of every frame)."""
+        self._flat.copy_(self._host[self._host_good][:self._flat.numel()], non_blocking=True)
+        self.overflow.zero_()
 
     def widened(self, t_max: int) -> "ChainTracker":
         """A tracker with t_max tracklet slots (> the present number) holding this tracker's state."""
