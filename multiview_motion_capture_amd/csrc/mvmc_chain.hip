@@ -93,6 +93,8 @@ struct MvmcChainArgs {
                               // the launch; [B+4+b] the void word of chain b (bit 0 views / clusters, bit 1 tracklet table, bit 2 graph
                               // too large for the layout's association variant); [2B+4] ticket counter, [2B+5] ring tail,
                               // [2B+6 ...) ready ring of B * (parts - 1) entries (queue mode).  Zeroed by the launcher
+    int self_zero;            // 1: ONE chain run by ONE workgroup of the latency build zeroes the words itself (no memset in front of
+                              // the launch: a device operation less per frame of MvTracker.update_4d)
 };
 
 
@@ -315,6 +317,12 @@ chain_kernel(Ik1Tables tables_arg, ChainArgs A_by_value) {
     //    deadlock.  Chain and part are known at once, so the pose-pair block is made during the wait as in the static mapping, and with
     //    in-order dispatch the two mappings coincide: the static mapping's speed without its assumption, for one atomic per workgroup.
     const int tid = threadIdx.x, wave = tid >> 6;
+#ifdef MVMC_CHAIN_LAT_TU
+    if (A.self_zero) {       // (mvmc_chain_run: one chain, one workgroup -- the launcher sent no memset)
+        if (tid < 2 * A.n_chains + 8) A.flags[tid] = 0u;
+        __syncthreads();
+    }
+#endif
 #ifdef MVMC_CHAIN_WAITPROF   // diagnostic build: out_cycles[7] = cycles a chain's workgroups were resident before their frames began
     const long long t_entry = clock64();
 #endif
@@ -568,7 +576,21 @@ extern "C" int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuff
     A.queue = B.hand_over;
     if (B.n_chains >= (1 << 20) || A.parts >= (1 << 10)) return MVMC_ERR_UNSUPPORTED;   // (a ring entry is part << 20 | chain)
     A.flags = B.flags;
-    if (hipMemsetAsync(B.flags, 0, sizeof(unsigned) * ((size_t)B.n_chains * (A.parts + 1) + 8), (hipStream_t)stream) != hipSuccess)
+    A.self_zero = 0;
+    // Few workgroups (a frame at a time, short sequences): the 256-register build of the same kernel (mvmc_chain_lat.hip), see below
+    bool lat = false;
+    if (small) {
+        static const bool no_lat = getenv("MVMC_CHAIN_NO_LAT") && atoi(getenv("MVMC_CHAIN_NO_LAT")) != 0;
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        }
+        lat = !no_lat && (long long)B.n_chains * A.parts <= 2LL * cus;
+    }
+    if (lat && B.n_chains == 1 && A.parts == 1)
+        A.self_zero = 1;     // (one workgroup: it zeroes its ten words itself, the per-frame driver saves a device operation)
+    else if (hipMemsetAsync(B.flags, 0, sizeof(unsigned) * ((size_t)B.n_chains * (A.parts + 1) + 8), (hipStream_t)stream) != hipSuccess)
         return MVMC_ERR_LAUNCH;
     Ik1Tables tables_host;   // the skeleton's tables: once per call, on the host, a kernel argument of the launch
     ik1_build_tables_host(tables_host, sk);
@@ -578,13 +600,7 @@ extern "C" int mvmc_chain_run(const mvmcSkeleton* skel_host, const mvmcChainBuff
         // Few workgroups (a frame at a time, short sequences): the 256-register build of the same kernel (mvmc_chain_lat.hip) -- a
         // frame's dependent chain is ~10 % shorter with the larger batches and fewer spills of that build, and with at most two
         // workgroups per CU to place, the other slots buy nothing.  Same results bit for bit.  MVMC_CHAIN_NO_LAT=1: the 128-register build.
-        static const bool no_lat = getenv("MVMC_CHAIN_NO_LAT") && atoi(getenv("MVMC_CHAIN_NO_LAT")) != 0;
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) {
-            int v = 0;
-            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-        }
-        if (!no_lat && (long long)B.n_chains * A.parts <= 2LL * cus)
+        if (lat)
             return mvmc_chain_launch_small_lat(&tables_host, A, B.n_chains * A.parts, (hipStream_t)stream);
     }
     // (MVMC_CHAIN_EXTRA_LDS: an occupancy experiment -- bytes of LDS nobody uses, so that fewer workgroups share a CU)

@@ -51,7 +51,10 @@ class ChainTracker:
         # hold (iters < 0); accumulated on the device, read by check(): a non-zero word voids the chain's results
         layout = (("params", (B, T, 68), torch.float64), ("joints", (B, T, 18, 3), torch.float64), ("meta", (B, T, 4), torch.int32),
                   ("n_tracks", (B,), torch.int32), ("next_id", (B,), torch.int32), ("n_dead", (B,), torch.int32),
-                  ("slot_src", (B, T), torch.int32), ("overflow", (B,), torch.int32))
+                  ("slot_src", (B, T), torch.int32), ("overflow", (B,), torch.int32),
+                  # the chain kernel's flag words of step_fused (mvmc_chain_run, n_parts = 1): in the same allocation, so that
+                  # read_back() brings state and verdict to the host in ONE transfer
+                  ("cflags", (2 * B + 8,), torch.int32))
         offs, total = {}, 0
         for name, shape, dt in layout:
             nbytes = int(torch.Size(shape).numel()) * (8 if dt == torch.float64 else 4)
@@ -161,7 +164,7 @@ class ChainTracker:
                 init=e((B, NP, 68), f64), status=e((B, T), i32), n_new=e((B,), i32), ik_params=e((B, NP, 68), f64),
                 ik_joints=e((B, NP, 18, 3), f64), ik_info=e((B, NP, 8), f64), ik_scratch=_chain_scratch(B, d),
                 out_params=e((B, T, 68), f64), out_joints=e((B, T, 18, 3), f64), out_meta=e((B, T, 4), i32),
-                out_n_tracks=e((B,), i32), flags=z((2 * B + 8,), i32))
+                out_n_tracks=e((B,), i32), flags=self.cflags)
         w = self._fused
         # the argument struct: every pointer in it but the frame's inputs belongs to this tracker, and the per-frame driver hands in
         # the same input buffers every frame (frame_inputs()) -- built once, rebuilt when an input pointer changes
@@ -224,7 +227,7 @@ class ChainTracker:
         that the next call overwrites, + 'timeout' (the chain kernel's hand-over word).  Clears the capacity / time-out words on the
         device like check(); raises like check()."""
         n, B = self._flat.numel(), self.B
-        nf = 4 * (B + 4)                 # the chain kernel's words {time-out, graph, capacity, -} + the B per-chain void words
+        nf = 0
         if self._host is None:
             # two pinned mirrors, written alternately: the one NOT written by this call holds the state after the last frame that went
             # through, i.e. the state in front of this one -- what restore_previous() brings back without a per-frame device snapshot
@@ -232,14 +235,11 @@ class ChainTracker:
             self._host_good = -1         # index of the mirror that holds the last good state (-1: none yet)
         cur = 1 - self._host_good if self._host_good >= 0 else 0
         h = self._host[cur]
-        h[:n].copy_(self._flat, non_blocking=True)
-        fl = None
-        if self._fused is not None:
-            fl = self._fused["flags"][B:2 * B + 4]
-            h[n:n + nf].view(torch.int32).copy_(fl, non_blocking=True)
+        h[:n].copy_(self._flat, non_blocking=True)          # (state AND the chain kernel's flag words: `cflags` is part of _flat)
+        fl = self.cflags[B:2 * B + 4] if self._fused is not None else None
         torch.cuda.current_stream(self._flat.device).synchronize()
         out = {name: h[o:o + nb].view(dt).view(shape).numpy() for name, (o, nb, shape, dt) in self._layout.items()}
-        words = h[n:n + nf].view(torch.int32).numpy() if fl is not None else None
+        words = out["cflags"][B:2 * B + 4] if fl is not None else None
         ov = int(out["overflow"].max()) if out["overflow"].size else 0
         if words is not None and self._void_pending:
             ov |= int(np.bitwise_or.reduce(words[4:])) if B else 0       # (step_fused(fold_void=False): read where the launch left them)
