@@ -208,7 +208,8 @@ class ChainTracker:
         if ov:
             what = [m for bit, m in ((1, "a cluster, a member or a view block did not fit (k_max / v_max / the frame's poses)"),
                                      (2, "more than t_max live tracklets"),
-                                     (4, "a graph larger than the association kernel holds")) if ov & bit]
+                                     (4, "a graph larger than the association kernel holds"),
+                                     (8, "internal: a meeting of two IK waves timed out (mvmc_ik_pair.h)")) if ov & bit]
             raise ValueError("ChainTracker: capacity exceeded (" + "; ".join(what) + "): the frame's results are void")
 
     _STATE = ("params", "joints", "meta", "n_tracks", "next_id", "n_dead", "slot_src")
@@ -223,15 +224,14 @@ class ChainTracker:
 
     def read_back(self):
         """The state on the host after ONE transfer and ONE synchronisation (the per-frame driver's end of frame: check() and four
-        tensor reads took six round trips): dict of NumPy views (params, joints, meta, n_tracks, ..., overflow) of a pinned buffer
-        that the next call overwrites, + 'timeout' (the chain kernel's hand-over word).  Clears the capacity / time-out words on the
-        device like check(); raises like check()."""
+        tensor reads took six round trips): dict of NumPy views (params, joints, meta, n_tracks, ..., overflow, cflags) of one of two
+        pinned buffers (the call after next overwrites it).  Raises like check(); the words that made it raise are cleared on the device
+        (nothing is cleared on a frame that went through: the next launch zeroes its own words)."""
         n, B = self._flat.numel(), self.B
-        nf = 0
         if self._host is None:
             # two pinned mirrors, written alternately: the one NOT written by this call holds the state after the last frame that went
             # through, i.e. the state in front of this one -- what restore_previous() brings back without a per-frame device snapshot
-            self._host = [torch.empty((n + nf,), dtype=torch.uint8).pin_memory() for _ in range(2)]
+            self._host = [torch.empty((n,), dtype=torch.uint8).pin_memory() for _ in range(2)]
             self._host_good = -1         # index of the mirror that holds the last good state (-1: none yet)
         cur = 1 - self._host_good if self._host_good >= 0 else 0
         h = self._host[cur]
@@ -254,7 +254,8 @@ class ChainTracker:
         if ov:
             what = [m for bit, m in ((1, "a cluster, a member or a view block did not fit (k_max / v_max / the frame's poses)"),
                                      (2, "more than t_max live tracklets"),
-                                     (4, "a graph larger than the association kernel holds")) if ov & bit]
+                                     (4, "a graph larger than the association kernel holds"),
+                                     (8, "internal: a meeting of two IK waves timed out (mvmc_ik_pair.h)")) if ov & bit]
             raise ValueError("ChainTracker: capacity exceeded (" + "; ".join(what) + "): the frame's results are void")
         self._host_good = cur
         return out
